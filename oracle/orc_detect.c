@@ -1,0 +1,301 @@
+/*
+ * orc_detect.c -- oracle restatement of the detector behind
+ *   brisk::ScaleSpaceFeatureDetector<brisk::HarrisScoreCalculator>(
+ *       uniformityRadius, octaves, absoluteThreshold, maxNumKpt)
+ * constructed at okvis_frontend/src/Frontend.cpp:2406-2409 and invoked through
+ * cv::FeatureDetector::detect at okvis_cv/include/okvis/implementation/Frame.hpp:152.
+ *
+ * TEST INFRASTRUCTURE ONLY (see okvfe_oracle.h).  PARITY UNPINNED: the brisk
+ * submodule is absent; this restates the published BRISK2 Harris pipeline:
+ *   Scharr (3,10,3) gradients -> products scaled to 16 bit -> 3x3 binomial
+ *   (1 2 1)^2 sum -> det - trace^2/16 in int32 -> 8-neighbour non-max
+ *   suppression with absolute threshold -> score-sorted uniformity enforcement
+ *   on an occupancy grid (scaling 15/radius, 31x31 radial stamp, saturating
+ *   adds) capped at maxNumKpt -> 2-D quadratic sub-pixel refinement ->
+ *   cv::KeyPoint(pt, 12*scale, -1, score, layer).
+ * octaves: every shipped config uses 0 = single layer at full resolution
+ * (config/euroc.yaml:66, okvis_common/include/okvis/Parameters.hpp:127).
+ */
+#include "okvfe_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* arithmetic shift right with floor semantics, independent of the compiler */
+static inline int32_t asr(int32_t v, int s) {
+  return v >= 0 ? (v >> s) : -(int32_t)(((uint32_t)(-(v + 1)) >> s) + 1);
+}
+
+/* ---- K1: Harris score --------------------------------------------------------------------- */
+/* Gradient products G* live on 1..h-2 x 1..w-2 (zero on the rim), the smoothed
+ * entries S* and the score on the same range, each computed from the zero-
+ * rimmed previous stage exactly as the separate whole-image passes of the
+ * library do (GetCovarEntries -> FilterGauss3by316S x3 -> CornerHarris). */
+void orc_harris_score(const uint8_t* img, int w, int h, int stride, int32_t* score) {
+  size_t n = (size_t)w * (size_t)h;
+  int16_t* gxx = (int16_t*)calloc(n, sizeof(int16_t));
+  int16_t* gyy = (int16_t*)calloc(n, sizeof(int16_t));
+  int16_t* gxy = (int16_t*)calloc(n, sizeof(int16_t));
+  memset(score, 0, n * sizeof(int32_t));
+  for (int y = 1; y < h - 1; ++y) {
+    const uint8_t* r0 = img + (size_t)(y - 1) * stride;
+    const uint8_t* r1 = img + (size_t)y * stride;
+    const uint8_t* r2 = img + (size_t)(y + 1) * stride;
+    for (int x = 1; x < w - 1; ++x) {
+      int gx = 3 * ((int)r0[x + 1] - (int)r0[x - 1]) + 10 * ((int)r1[x + 1] - (int)r1[x - 1]) +
+               3 * ((int)r2[x + 1] - (int)r2[x - 1]);
+      int gy = 3 * ((int)r2[x - 1] - (int)r0[x - 1]) + 10 * ((int)r2[x] - (int)r0[x]) +
+               3 * ((int)r2[x + 1] - (int)r0[x + 1]);
+      /* |g| <= 4080; (8g)^2 >> 16 >> 4 == g^2 >> 14 <= 1016 */
+      gxx[(size_t)y * w + x] = (int16_t)asr(gx * gx, 14);
+      gyy[(size_t)y * w + x] = (int16_t)asr(gy * gy, 14);
+      gxy[(size_t)y * w + x] = (int16_t)asr(gx * gy, 14);
+    }
+  }
+  for (int y = 1; y < h - 1; ++y) {
+    for (int x = 1; x < w - 1; ++x) {
+      int32_t s[3];
+      const int16_t* src[3] = {gxx, gyy, gxy};
+      for (int c = 0; c < 3; ++c) {
+        const int16_t* g = src[c];
+        const int16_t* a = g + (size_t)(y - 1) * w + x;
+        const int16_t* b = g + (size_t)y * w + x;
+        const int16_t* d = g + (size_t)(y + 1) * w + x;
+        int32_t v = a[-1] + 2 * a[0] + a[1] + 2 * b[-1] + 4 * b[0] + 2 * b[1] + d[-1] + 2 * d[0] +
+                    d[1];
+        s[c] = (int16_t)v; /* 16-bit container; |v| <= 16256 so no wrap occurs */
+      }
+      int32_t det = s[0] * s[1] - s[2] * s[2];
+      int32_t tq = asr(asr(s[0], 1) + asr(s[1], 1), 1); /* trace / 4; kappa = 1/16 */
+      score[(size_t)y * w + x] = det - tq * tq;
+    }
+  }
+  free(gxx);
+  free(gyy);
+  free(gxy);
+}
+
+/* ---- K2: 8-neighbour non-max suppression -------------------------------------------------- */
+/* Raster scan of rows 2..h-3, columns 2..w-3.  A centre passes when it is >=
+ * the absolute threshold and no neighbour is strictly greater; the pixel right
+ * after an accepted maximum is skipped (so of two equal horizontal neighbours
+ * the left one wins).  Output order: y ascending, x ascending. */
+int orc_nms(const int32_t* score, int w, int h, int abs_threshold, orc_point_score* out, int cap) {
+  int n = 0;
+  for (int y = 2; y < h - 2; ++y) {
+    int last = 0;
+    for (int x = 2; x < w - 2; ++x) {
+      if (last) {
+        last = 0;
+        continue;
+      }
+      const int32_t* c = score + (size_t)y * w + x;
+      int32_t v = *c;
+      if (v < abs_threshold) continue;
+      if (c[1] > v || c[-1] > v) continue;
+      const int32_t* p1 = c + w;
+      const int32_t* p2 = c - w;
+      if (p1[0] > v || p2[0] > v) continue;
+      if (p1[1] > v || p1[-1] > v || p2[1] > v || p2[-1] > v) continue;
+      if (n < cap) {
+        out[n].x = x;
+        out[n].y = y;
+        out[n].score = v;
+      }
+      ++n;
+      last = 1;
+    }
+  }
+  return n;
+}
+
+/* ---- K3: uniformity enforcement ----------------------------------------------------------- */
+static int cmp_points(const void* pa, const void* pb) {
+  const orc_point_score* a = (const orc_point_score*)pa;
+  const orc_point_score* b = (const orc_point_score*)pb;
+  if (a->score != b->score) return a->score > b->score ? -1 : 1; /* score descending */
+  if (a->y != b->y) return a->y < b->y ? -1 : 1;                 /* total order for ties */
+  if (a->x != b->x) return a->x < b->x ? -1 : 1;
+  return 0;
+}
+
+/* Greedy selection in score order.  Each candidate reads the occupancy cell at
+ * its scaled position; it is dropped when sqrt(sqrt(score/maxScore))*255 is
+ * below that cell, otherwise a 31x31 radial patch (1 - d^2/225, clipped at 0)
+ * times 0.99 of that level is added with u8 saturation.  Stops after
+ * max_kpts accepted points.  Returns the new count; pts is rewritten in
+ * acceptance order.  radius <= 0 disables the stage (points stay in raster
+ * order and are not capped). */
+int orc_uniformity_select(orc_point_score* pts, int n, int w, int h, float radius, int max_kpts) {
+  if (n <= 0) return 0;
+  if (!(radius > 0.0f)) return n;
+  qsort(pts, (size_t)n, sizeof(orc_point_score), cmp_points);
+  float lut[31][31];
+  for (int y = 0; y < 31; ++y)
+    for (int x = 0; x < 31; ++x) {
+      double v = 1.0 - (double)((15 - x) * (15 - x) + (15 - y) * (15 - y)) / 225.0;
+      lut[y][x] = (float)(v > 0.0 ? v : 0.0);
+    }
+  const float max_score = (float)pts[0].score;
+  const float scaling = (float)(15.0 / (double)radius);
+  const int cs = (int)ceilf(scaling);
+  const int orows = h * cs + 32, ocols = w * cs + 32;
+  uint8_t* occ = (uint8_t*)calloc((size_t)orows * ocols, 1);
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (kept >= max_kpts) break;
+    const orc_point_score p = pts[i];
+    float fy = (float)p.y * scaling;
+    float fx = (float)p.x * scaling;
+    const int cy = (int)(fy + 16.0f);
+    const int cx = (int)(fx + 16.0f);
+    const float s0 = (float)occ[(size_t)cy * ocols + cx];
+    float q = (float)p.score / max_score;
+    const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+    if (nsc1 < s0) continue;
+    const float nsc = (float)(0.99 * (double)nsc1);
+    for (int y = 0; y < 31; ++y) {
+      uint8_t* row = occ + (size_t)(cy + y - 15) * ocols + (cx - 15);
+      for (int x = 0; x < 31; ++x) {
+        float m = lut[y][x] * nsc;
+        int add = (int)ceilf(m);
+        int v = (int)row[x] + add;
+        row[x] = (uint8_t)(v > 255 ? 255 : v);
+      }
+    }
+    pts[kept++] = p;
+  }
+  free(occ);
+  return kept;
+}
+
+/* ---- K4: 2-D quadratic sub-pixel refinement ------------------------------------------------ */
+/* s = 3x3 score patch, row-major: s[0]=(-1,-1) s[1]=(0,-1) s[2]=(+1,-1) s[3]=(-1,0) ...
+ * Least-squares quadratic fit of the published BRISK refinement; coefficients
+ * in 64-bit integers (Harris scores overflow 32-bit products), the Hessian
+ * determinant and the numerators in double, divisions in float. */
+void orc_subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
+  const int64_t s00 = s[0], s01 = s[1], s02 = s[2];
+  const int64_t s10 = s[3], s11 = s[4], s12 = s[5];
+  const int64_t s20 = s[6], s21 = s[7], s22 = s[8];
+  const int64_t tmp1 = s00 + s02 - 2 * s11 + s20 + s22;
+  const int64_t c1 = 3 * (tmp1 + s01 - ((s10 + s12) * 2) + s21);
+  const int64_t c2 = 3 * (tmp1 - ((s01 + s21) * 2) + s10 + s12);
+  const int64_t tmp2 = s02 - s20;
+  const int64_t tmp3 = s00 + tmp2 - s22;
+  const int64_t tmp4 = tmp3 - 2 * tmp2;
+  const int64_t c3 = -3 * (tmp3 + s01 - s21);
+  const int64_t c4 = -3 * (tmp4 + s10 - s12);
+  const int64_t c5 = (s00 - s02 - s20 + s22) * 4;
+  const int64_t c6 = -(s00 + s02 - ((s10 + s01 + s12 + s21) * 2) - 5 * s11 + s20 + s22) * 2;
+  /* |c| < 2^37, so the products need more than 64 bits: they are formed in
+   * IEEE double (each product and difference correctly rounded, no FMA). */
+  const double d1 = (double)c1, d2 = (double)c2, d3 = (double)c3, d4 = (double)c4, d5 = (double)c5;
+  double ha = 4.0 * d1; ha = ha * d2;
+  double hb = d5 * d5;
+  const double hdet = ha - hb;
+  if (hdet == 0.0) {
+    *delta_x = 0.0f;
+    *delta_y = 0.0f;
+    return;
+  }
+  if (!(hdet > 0.0 && c1 < 0)) {
+    /* maximum on one of the four patch corners */
+    int64_t best = c3 + c4 + c5;
+    float bx = 1.0f, by = 1.0f;
+    int64_t t = -c3 + c4 - c5;
+    if (t > best) { best = t; bx = -1.0f; by = 1.0f; }
+    t = c3 - c4 - c5;
+    if (t > best) { best = t; bx = 1.0f; by = -1.0f; }
+    t = -c3 - c4 + c5;
+    if (t > best) { best = t; bx = -1.0f; by = -1.0f; }
+    *delta_x = bx;
+    *delta_y = by;
+    return;
+  }
+  const float fh = -(float)hdet;
+  double na = 2.0 * d2; na = na * d3;
+  double nb = d4 * d5;
+  const float nx = (float)(na - nb);
+  na = 2.0 * d1; na = na * d4;
+  nb = d3 * d5;
+  const float ny = (float)(na - nb);
+  float dx = nx / fh;
+  float dy = ny / fh;
+  const int tx = dx > 1.0f, tx_ = dx < -1.0f, ty = dy > 1.0f, ty_ = dy < -1.0f;
+  if (tx || tx_ || ty || ty_) {
+    const float f1 = (float)c1, f2 = (float)c2, f3 = (float)c3, f4 = (float)c4, f5 = (float)c5,
+                f6 = (float)c6;
+    float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
+    if (tx) {
+      dx1 = 1.0f;
+      dy1 = -(f4 + f5) / (2.0f * f2);
+      if (dy1 > 1.0f) dy1 = 1.0f; else if (dy1 < -1.0f) dy1 = -1.0f;
+    } else if (tx_) {
+      dx1 = -1.0f;
+      dy1 = -(f4 - f5) / (2.0f * f2);
+      if (dy1 > 1.0f) dy1 = 1.0f; else if (dy1 < -1.0f) dy1 = -1.0f;
+    }
+    if (ty) {
+      dy2 = 1.0f;
+      dx2 = -(f3 + f5) / (2.0f * f1);
+      if (dx2 > 1.0f) dx2 = 1.0f; else if (dx2 < -1.0f) dx2 = -1.0f;
+    } else if (ty_) {
+      dy2 = -1.0f;
+      dx2 = -(f3 - f5) / (2.0f * f1);
+      if (dx2 > 1.0f) dx2 = 1.0f; else if (dx2 < -1.0f) dx2 = -1.0f;
+    }
+    /* evaluate both options; explicit temporaries fix the summation order */
+    float m1 = f1 * dx1; m1 = m1 * dx1;
+    float a = f2 * dy1; a = a * dy1; m1 = m1 + a;
+    a = f3 * dx1; m1 = m1 + a;
+    a = f4 * dy1; m1 = m1 + a;
+    a = f5 * dx1; a = a * dy1; m1 = m1 + a;
+    m1 = m1 + f6;
+    float m2 = f1 * dx2; m2 = m2 * dx2;
+    a = f2 * dy2; a = a * dy2; m2 = m2 + a;
+    a = f3 * dx2; m2 = m2 + a;
+    a = f4 * dy2; m2 = m2 + a;
+    a = f5 * dx2; a = a * dy2; m2 = m2 + a;
+    m2 = m2 + f6;
+    if (m1 > m2) { dx = dx1; dy = dy1; } else { dx = dx2; dy = dy2; }
+  }
+  *delta_x = dx;
+  *delta_y = dy;
+}
+
+/* ---- detect(): the whole detector for one image -------------------------------------------- */
+int orc_detect(const uint8_t* img, int w, int h, int stride, float uniformity_radius, int octaves,
+               int abs_threshold, int max_kpts, orc_keypoint* kps, int cap, int32_t* score_out) {
+  (void)octaves; /* single layer; see header */
+  size_t n = (size_t)w * (size_t)h;
+  int32_t* score = score_out ? score_out : (int32_t*)malloc(n * sizeof(int32_t));
+  orc_harris_score(img, w, h, stride, score);
+  int maxc = (w / 2 + 1) * (h - 3);
+  if (maxc < 16) maxc = 16;
+  orc_point_score* pts = (orc_point_score*)malloc((size_t)maxc * sizeof(orc_point_score));
+  int np = orc_nms(score, w, h, abs_threshold, pts, maxc);
+  np = orc_uniformity_select(pts, np, w, h, uniformity_radius, max_kpts);
+  int nout = 0;
+  for (int i = 0; i < np && nout < cap; ++i) {
+    const int u = pts[i].x, v = pts[i].y;
+    int32_t patch[9];
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        patch[(dy + 1) * 3 + (dx + 1)] = score[(size_t)(v + dy) * w + (u + dx)];
+    float ddx, ddy;
+    orc_subpixel2d(patch, &ddx, &ddy);
+    orc_keypoint* k = &kps[nout++];
+    k->x = (float)u + ddx;
+    k->y = (float)v + ddy;
+    k->size = 12.0f;
+    k->angle = -1.0f;
+    k->response = (float)pts[i].score;
+    k->octave = 0;
+    k->class_id = -1;
+  }
+  free(pts);
+  if (!score_out) free(score);
+  return nout;
+}

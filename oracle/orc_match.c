@@ -1,0 +1,333 @@
+/*
+ * orc_match.c -- oracle restatement of the brute-force Hamming matchers and
+ * their FP64 geometric gates (all of this IS in the reference tree):
+ *   brisk::Hamming::PopcntofXORed(a, b, 3)   call sites Frontend.cpp:341,1580,1661,1846,2024
+ *   triangulation::triangulateFast            okvis_frontend/src/stereo_triangulation.cpp:50-132
+ *   Frontend::matchStereo inner loops         okvis_frontend/src/Frontend.cpp:2016-2076
+ *   Frontend::matchMotionStereo inner loops   okvis_frontend/src/Frontend.cpp:1812-1905
+ *   Frontend::verifyRecognisedPlace matching  okvis_frontend/src/Frontend.cpp:330-355
+ *
+ * TEST INFRASTRUCTURE ONLY (see okvfe_oracle.h).  Vector arithmetic is written
+ * out component-wise, sums left to right, no FMA (build -ffp-contract=off).
+ * A pose is (C, r) with p_W = C p_C + r; its inverse is (C^T, -(C^T r)) as in
+ * okvis_kinematics/include/okvis/kinematics/implementation/Transformation.hpp:207-209.
+ */
+#include "okvfe_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+uint32_t orc_popcnt_xor(const uint8_t* a, const uint8_t* b, int n128) {
+  uint32_t c = 0;
+  for (int i = 0; i < 16 * n128; ++i) {
+    uint8_t x = (uint8_t)(a[i] ^ b[i]);
+    while (x) {
+      c += x & 1u;
+      x >>= 1;
+    }
+  }
+  return c;
+}
+
+static inline uint32_t popc48(const uint8_t* a, const uint8_t* b) {
+  uint64_t x[6], y[6];
+  memcpy(x, a, 48);
+  memcpy(y, b, 48);
+  uint32_t c = 0;
+  for (int i = 0; i < 6; ++i) c += (uint32_t)__builtin_popcountll(x[i] ^ y[i]);
+  return c;
+}
+
+static inline double dot3(const double a[3], const double b[3]) {
+  double s = a[0] * b[0];
+  double t = a[1] * b[1];
+  s = s + t;
+  t = a[2] * b[2];
+  s = s + t;
+  return s;
+}
+static inline void normalize3(const double v[3], double out[3]) {
+  const double n = sqrt(dot3(v, v));
+  out[0] = v[0] / n;
+  out[1] = v[1] / n;
+  out[2] = v[2] / n;
+}
+static inline void rot(const double C[9], const double v[3], double out[3]) {
+  out[0] = dot3(C, v);
+  out[1] = dot3(C + 3, v);
+  out[2] = dot3(C + 6, v);
+}
+static inline void rot_t(const double C[9], const double v[3], double out[3]) {
+  for (int i = 0; i < 3; ++i) {
+    double s = C[i] * v[0];
+    double t = C[3 + i] * v[1];
+    s = s + t;
+    t = C[6 + i] * v[2];
+    s = s + t;
+    out[i] = s;
+  }
+}
+/* hp_C = T^-1 * hp_W  (Transformation::operator*(Vector4d), Transformation.hpp:271-278) */
+static inline void inv_transform_h(const orc_pose* T, const double hp[4], double out[4]) {
+  double ri[3], cr[3], h[3];
+  rot_t(T->C, T->r, cr);
+  ri[0] = -cr[0]; ri[1] = -cr[1]; ri[2] = -cr[2];
+  rot_t(T->C, hp, h);
+  const double s = hp[3];
+  out[0] = h[0] + ri[0] * s;
+  out[1] = h[1] + ri[1] * s;
+  out[2] = h[2] + ri[2] * s;
+  out[3] = s;
+}
+
+static void midpoint_parallel(const double p1[3], const double e1[3], const double p2[3],
+                              const double e2[3], const double t12[3], double sigma, double hp[4],
+                              int* is_valid) {
+  *is_valid = 1;
+  double m[3], mid[3], d[3], dn[3];
+  const double tn = sqrt(dot3(t12, t12));
+  const double f = 40.0 * (0.01 > tn ? 0.01 : tn);
+  for (int i = 0; i < 3; ++i) {
+    m[i] = p1[i] + 0.5 * t12[i];
+    mid[i] = m[i] + f * (e1[i] + e2[i]);
+  }
+  hp[0] = mid[0]; hp[1] = mid[1]; hp[2] = mid[2]; hp[3] = 1.0;
+  const double c26 = cos(2.6 * sigma);
+  for (int i = 0; i < 3; ++i) d[i] = mid[i] - p1[i];
+  normalize3(d, dn);
+  if (dot3(e1, dn) < c26) *is_valid = 0;
+  for (int i = 0; i < 3; ++i) d[i] = mid[i] - p2[i];
+  normalize3(d, dn);
+  if (dot3(e2, dn) < c26) *is_valid = 0;
+}
+
+void orc_triangulate_fast(const double p1[3], const double e1[3], const double p2[3],
+                          const double e2[3], double sigma, double hp[4], int* is_valid,
+                          int* is_parallel) {
+  *is_parallel = 0;
+  *is_valid = 1;
+  double t12[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  const double b0 = dot3(t12, e1), b1 = dot3(t12, e2);
+  const double a00 = dot3(e1, e1);
+  const double a10 = dot3(e1, e2);
+  const double a01 = -a10;
+  const double a11 = -dot3(e2, e2);
+  /* computeInverseWithCheck(A_inverse, invertible, 1e-12) for a 2x2 */
+  const double det = a00 * a11 - a01 * a10;
+  const int invertible = fabs(det) > 1.0e-12;
+  if (!invertible) {
+    *is_parallel = 1;
+    midpoint_parallel(p1, e1, p2, e2, t12, sigma, hp, is_valid);
+    return;
+  }
+  const double invdet = 1.0 / det;
+  const double i00 = a11 * invdet, i10 = -a10 * invdet, i01 = -a01 * invdet, i11 = a00 * invdet;
+  const double l0 = i00 * b0 + i01 * b1;
+  const double l1 = i10 * b0 + i11 * b1;
+  if (l0 < 0.01 || l1 < 0.01) {
+    *is_parallel = 1;
+    midpoint_parallel(p1, e1, p2, e2, t12, sigma, hp, is_valid);
+    return;
+  }
+  double mid[3], d1[3], d2[3], n1[3], n2[3];
+  for (int i = 0; i < 3; ++i) {
+    const double xm = l0 * e1[i] + p1[i];
+    const double xn = l1 * e2[i] + p2[i];
+    mid[i] = (xm + xn) / 2.0;
+    d1[i] = mid[i] - p1[i];
+    d2[i] = mid[i] - p2[i];
+  }
+  normalize3(d1, n1);
+  normalize3(d2, n2);
+  const double c26 = cos(2.6 * sigma);
+  if (dot3(e1, n1) < c26) *is_valid = 0;
+  if (dot3(e2, n2) < c26) *is_valid = 0;
+  if (dot3(n2, n1) > cos(6.0 * sigma)) *is_parallel = 1;
+  hp[0] = mid[0]; hp[1] = mid[1]; hp[2] = mid[2]; hp[3] = 1.0;
+}
+
+/* ---- matchStereo (Frontend.cpp:2016-2076): k0 ascending, k1 ascending, strict < ------------ */
+void orc_match_stereo(const uint8_t* desc0, const orc_keypoint* kp0, const double* bp0,
+                      const uint8_t* bpv0, int n0, const uint8_t* desc1, const orc_keypoint* kp1,
+                      const double* bp1, const uint8_t* bpv1, int n1, const orc_pose* T_WC0,
+                      const orc_pose* T_WC1, double f0, double f1, double threshold,
+                      orc_stereo_match* out) {
+  for (int k0 = 0; k0 < n0; ++k0) {
+    double distances = threshold;
+    int initialisable = 0;
+    double hps_W[4] = {0, 0, 0, 0};
+    int k1_match = 0;
+    for (int k1 = 0; k1 < n1; ++k1) {
+      const uint32_t dist = popc48(desc0 + 48 * (size_t)k0, desc1 + 48 * (size_t)k1);
+      if ((double)dist < distances) {
+        const double size0 = (double)kp0[k0].size, size1 = (double)kp1[k1].size;
+        const double s0 = size0 / f0, s1 = size1 / f1;
+        const double sigma = (s0 > s1 ? s0 : s1) * 0.125; /* std::max(a,b): a<b ? b : a */
+        int is_valid = 0, is_parallel = 0;
+        if (!bpv0[k0]) continue;
+        if (!bpv1[k1]) continue;
+        double v[3], e0_W[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+        rot(T_WC0->C, bp0 + 3 * (size_t)k0, v);
+        normalize3(v, e0_W);
+        rot(T_WC1->C, bp1 + 3 * (size_t)k1, v);
+        normalize3(v, e1_W);
+        orc_triangulate_fast(T_WC0->r, e0_W, T_WC1->r, e1_W, sigma, hp_W, &is_valid,
+                             &is_parallel);
+        inv_transform_h(T_WC0, hp_W, hp_C0);
+        inv_transform_h(T_WC1, hp_W, hp_C1);
+        if (!is_parallel) {
+          const double w4 = hp_W[3];
+          hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+          if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = 0;
+          if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = 0;
+          if (dot3(e0_W, e1_W) < 0.8) is_valid = 0;
+        }
+        if (is_valid) {
+          distances = (double)dist;
+          memcpy(hps_W, hp_W, sizeof(hps_W));
+          k1_match = k1;
+          initialisable = !is_parallel;
+        }
+      }
+    }
+    orc_stereo_match* o = &out[k0];
+    memset(o, 0, sizeof(*o));
+    if (distances < threshold) {
+      o->k1 = k1_match;
+      o->dist = (int32_t)distances;
+      o->initialisable = initialisable;
+      memcpy(o->hp_W, hps_W, sizeof(hps_W));
+    } else {
+      o->k1 = -1;
+      o->dist = (int32_t)threshold;
+    }
+  }
+}
+
+/* ---- matchMotionStereo (Frontend.cpp:1789-1905) --------------------------------------------
+ * Frame 0 = older frame, frame 1 = current frame, same camera `cam`.
+ * skip0[k0] != 0 stands for the estimator-state tests at :1814-1841 (landmark
+ * already initialised / keypoint already observed): such k0 are not matched.
+ * matched1[k1] != 0 = current keypoint already carries a landmark (:1795-1798)
+ * and is left out of the packed candidate set (the packed order is k1
+ * ascending, so iterating k1 ascending and skipping is the same loop). */
+void orc_match_motion_stereo(const uint8_t* desc0, const orc_keypoint* kp0, const double* bp0,
+                             const uint8_t* bpv0, const uint8_t* skip0, int n0,
+                             const uint8_t* desc1, const orc_keypoint* kp1, const double* bp1,
+                             const uint8_t* bpv1, const uint8_t* matched1, int n1,
+                             const orc_pose* T_WC0, const orc_pose* T_WC1, const orc_camera* cam,
+                             uint32_t threshold, orc_motion_match* out) {
+  const double f0 = 0.5 * (cam->fu + cam->fv);
+  for (int k0 = 0; k0 < n0; ++k0) {
+    orc_motion_match* o = &out[k0];
+    memset(o, 0, sizeof(*o));
+    o->k1 = -1;
+    o->dist = (int32_t)threshold;
+    if (skip0 && skip0[k0]) continue;
+    uint32_t distances = threshold;
+    int initialisable = 0;
+    double quality = 0.0;
+    double hps_W[4] = {0, 0, 0, 0};
+    int k1_max = 1000;
+    if (!bpv0[k0]) continue;
+    double v[3], e0_W[3];
+    rot(T_WC0->C, bp0 + 3 * (size_t)k0, v);
+    normalize3(v, e0_W);
+    const double sigma = (double)kp0[k0].size / f0 * 0.125;
+    for (int k1 = 0; k1 < n1; ++k1) {
+      if (matched1 && matched1[k1]) continue;
+      const uint32_t dist = popc48(desc0 + 48 * (size_t)k0, desc1 + 48 * (size_t)k1);
+      if (dist < distances) {
+        int is_valid = 0, is_parallel = 0;
+        if (!bpv1[k1]) continue;
+        double e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+        rot(T_WC1->C, bp1 + 3 * (size_t)k1, v);
+        normalize3(v, e1_W);
+        const double ee = dot3(e0_W, e1_W);
+        if (ee < 0.5) continue;
+        orc_triangulate_fast(T_WC0->r, e0_W, T_WC1->r, e1_W, sigma, hp_W, &is_valid,
+                             &is_parallel);
+        if (!is_valid) continue;
+        inv_transform_h(T_WC0, hp_W, hp_C0);
+        inv_transform_h(T_WC1, hp_W, hp_C1);
+        if (ee < 0.8) is_valid = 0;
+        if (!is_parallel) {
+          const double w4 = hp_W[3];
+          hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+          if (hp_C0[2] / hp_C0[3] < 0.2) is_valid = 0;
+          if (hp_C1[2] / hp_C1[3] < 0.2) is_valid = 0;
+        }
+        if (is_valid) {
+          k1_max = k1;
+          distances = dist;
+          double a[3], b[3], an[3], bn[3];
+          for (int i = 0; i < 3; ++i) {
+            a[i] = hp_W[i] - T_WC0->r[i];
+            b[i] = hp_W[i] - T_WC1->r[i];
+          }
+          normalize3(a, an);
+          normalize3(b, bn);
+          quality = acos(dot3(an, bn));
+          memcpy(hps_W, hp_W, sizeof(hps_W));
+          initialisable = !is_parallel;
+        }
+      }
+    }
+    if (distances < threshold) {
+      o->k1 = k1_max;
+      o->dist = (int32_t)distances;
+      o->initialisable = initialisable;
+      o->quality = quality;
+      memcpy(o->hp_W, hps_W, sizeof(hps_W));
+      /* 4 px reprojection check of the winner (:1897-1905) */
+      double hp_C1[4], head[3], pt1p[2];
+      inv_transform_h(T_WC1, hps_W, hp_C1);
+      if (hp_C1[3] < 0) {
+        head[0] = -hp_C1[0]; head[1] = -hp_C1[1]; head[2] = -hp_C1[2];
+      } else {
+        head[0] = hp_C1[0]; head[1] = hp_C1[1]; head[2] = hp_C1[2];
+      }
+      const int status = orc_cam_project(cam, head, pt1p, NULL);
+      const double ex = (double)kp1[k1_max].x - pt1p[0], ey = (double)kp1[k1_max].y - pt1p[1];
+      o->accepted = (status == 0 && sqrt(ex * ex + ey * ey) < 4.0) ? 1 : 0;
+    }
+  }
+}
+
+/* ---- candidate list and ungated arg-min ----------------------------------------------------- */
+int orc_hamming_candidates(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,
+                           orc_cand* out, int cap) {
+  int n = 0;
+  for (int i = 0; i < nA; ++i)
+    for (int j = 0; j < nB; ++j) {
+      const int d = (int)popc48(A + 48 * (size_t)i, B + 48 * (size_t)j);
+      if (d < thr) {
+        if (n < cap) {
+          out[n].i = i;
+          out[n].j = j;
+          out[n].dist = d;
+        }
+        ++n;
+      }
+    }
+  return n;
+}
+
+/* For every row i of A: first-lowest j with minimal distance below thr
+ * (Frontend.cpp:337-346: uint32 distMin = threshold; strict <). */
+void orc_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
+                        int32_t* best_j, uint32_t* best_d) {
+  for (int i = 0; i < nA; ++i) {
+    uint32_t dmin = thr;
+    int32_t jmin = -1;
+    for (int j = 0; j < nB; ++j) {
+      const uint32_t d = popc48(A + 48 * (size_t)i, B + 48 * (size_t)j);
+      if (d < dmin) {
+        dmin = d;
+        jmin = j;
+      }
+    }
+    best_j[i] = jmin;
+    best_d[i] = dmin;
+  }
+}

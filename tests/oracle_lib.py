@@ -1,0 +1,265 @@
+"""ctypes binding of the CPU oracle (oracle/libokvfe_oracle.so).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package okvis2_amd never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+POINT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+CAND_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("dist", "<i4")])
+STEREO_MATCH_DTYPE = np.dtype([("k1", "<i4"), ("dist", "<i4"), ("initialisable", "<i4"),
+                               ("pad", "<i4"), ("hp_W", "<f8", (4,))])
+MOTION_MATCH_DTYPE = np.dtype([("k1", "<i4"), ("dist", "<i4"), ("initialisable", "<i4"),
+                               ("accepted", "<i4"), ("quality", "<f8"), ("hp_W", "<f8", (4,))])
+
+MODE_UPRIGHT, MODE_GRADIENT, MODE_CAMERA_AWARE = 0, 1, 2
+
+
+class Pattern(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("px", C.c_float * 60), ("py", C.c_float * 60),
+                ("sigma_half", C.c_float * 60), ("n_short", C.c_int32),
+                ("short_i", C.c_uint8 * 384), ("short_j", C.c_uint8 * 384),
+                ("n_long", C.c_int32), ("long_i", C.c_uint8 * 1100), ("long_j", C.c_uint8 * 1100),
+                ("long_wdx", C.c_int32 * 1100), ("long_wdy", C.c_int32 * 1100),
+                ("border", C.c_int32), ("rot_cos", C.c_int32 * 1024), ("rot_sin", C.c_int32 * 1024),
+                ("rot_cosf", C.c_float * 1024), ("rot_sinf", C.c_float * 1024)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("fu", C.c_double), ("fv", C.c_double),
+                ("cu", C.c_double), ("cv", C.c_double), ("dist_type", C.c_int32),
+                ("d", C.c_double * 4)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("C", C.c_double * 9), ("r", C.c_double * 3)]
+
+
+class FrontendParams(C.Structure):
+    _fields_ = [("uniformity_radius", C.c_float), ("octaves", C.c_int32),
+                ("abs_threshold", C.c_int32), ("max_kpts", C.c_int32), ("mode", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(ORACLE_DIR, "libokvfe_oracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR)
+            if f.endswith((".c", ".h")) or f == "Makefile"]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "CC=gcc"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_popcnt_xor.restype = C.c_uint32
+        _LIB.orc_smoothed_intensity.restype = C.c_int
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_camera(cam) -> Camera:
+    c = Camera()
+    c.w, c.h, c.fu, c.fv, c.cu, c.cv, c.dist_type = cam.w, cam.h, cam.fu, cam.fv, cam.cu, cam.cv, \
+        cam.dist_type
+    for i in range(4):
+        c.d[i] = cam.d[i]
+    return c
+
+
+def make_pose(Cm, r) -> Pose:
+    p = Pose()
+    for i in range(9):
+        p.C[i] = float(np.asarray(Cm).reshape(-1)[i])
+    for i in range(3):
+        p.r[i] = float(r[i])
+    return p
+
+
+_PATTERN = None
+
+
+def pattern() -> Pattern:
+    global _PATTERN
+    if _PATTERN is None:
+        _PATTERN = Pattern()
+        lib().orc_pattern_build(C.byref(_PATTERN))
+    return _PATTERN
+
+
+def harris_score(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h, w), dtype=np.int32)
+    lib().orc_harris_score(_p(img), w, h, w, _p(out))
+    return out
+
+
+def nms(score: np.ndarray, thr: int) -> np.ndarray:
+    h, w = score.shape
+    cap = (w // 2 + 1) * h
+    out = np.empty(cap, dtype=POINT_DTYPE)
+    n = lib().orc_nms(_p(np.ascontiguousarray(score)), w, h, int(thr), _p(out), cap)
+    return out[:n].copy()
+
+
+def uniformity_select(pts: np.ndarray, w: int, h: int, radius: float, max_kpts: int) -> np.ndarray:
+    pts = pts.copy()
+    n = lib().orc_uniformity_select(_p(pts), len(pts), w, h, C.c_float(radius), int(max_kpts))
+    return pts[:n].copy()
+
+
+def subpixel2d(patch) -> tuple:
+    s = np.ascontiguousarray(patch, dtype=np.int32).reshape(9)
+    dx, dy = C.c_float(), C.c_float()
+    lib().orc_subpixel2d(_p(s), C.byref(dx), C.byref(dy))
+    return dx.value, dy.value
+
+
+def detect(img, radius, octaves, thr, max_kpts, want_score=False):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    cap = max(int(max_kpts), 1) + 8
+    if not radius > 0:
+        cap = (w // 2 + 1) * h
+    kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+    score = np.empty((h, w), dtype=np.int32) if want_score else None
+    n = lib().orc_detect(_p(img), w, h, w, C.c_float(radius), int(octaves), int(thr),
+                         int(max_kpts), _p(kps), cap, _p(score))
+    return (kps[:n].copy(), score) if want_score else kps[:n].copy()
+
+
+def integral(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h + 1, w + 1), dtype=np.int32)
+    lib().orc_integral(_p(img), w, h, w, _p(out))
+    return out
+
+
+def describe(img, kps, mode, rays=None, jac=None, fu=1.0, direction=(0.0, 1.0, 0.0)):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    kps = kps.copy()
+    desc = np.zeros((max(len(kps), 1), 48), dtype=np.uint8)
+    d = (C.c_float * 3)(*[float(v) for v in direction])
+    n = lib().orc_describe(_p(img), w, h, w, C.byref(pattern()), int(mode), _p(rays), _p(jac),
+                           C.c_float(fu), d, _p(kps), len(kps), _p(desc))
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def detect_describe(img, radius, octaves, thr, max_kpts, mode, rays=None, jac=None, fu=1.0,
+                    direction=(0.0, 1.0, 0.0)):
+    kps = detect(img, radius, octaves, thr, max_kpts)
+    return describe(img, kps, mode, rays, jac, fu, direction)
+
+
+def popcnt_xor(a, b, n128=3) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return int(lib().orc_popcnt_xor(_p(a), _p(b), int(n128)))
+
+
+def awareness_maps(cam):
+    c = make_camera(cam)
+    rays = np.zeros((cam.h, cam.w, 3), dtype=np.float32)
+    jac = np.zeros((cam.h, cam.w, 6), dtype=np.float32)
+    lib().orc_cam_awareness_maps(C.byref(c), _p(rays), _p(jac))
+    return rays, jac
+
+
+def backproject_keypoints(cam, kps):
+    c = make_camera(cam)
+    n = len(kps)
+    dirs = np.zeros((max(n, 1), 3), dtype=np.float64)
+    valid = np.zeros(max(n, 1), dtype=np.uint8)
+    kps = np.ascontiguousarray(kps)
+    lib().orc_backproject_keypoints(C.byref(c), _p(kps), n, _p(dirs), _p(valid))
+    return dirs[:n], valid[:n]
+
+
+def cam_backproject(cam, pt):
+    c = make_camera(cam)
+    p = (C.c_double * 2)(*pt)
+    d = (C.c_double * 3)()
+    ok = lib().orc_cam_backproject(C.byref(c), p, d)
+    return bool(ok), np.array(d[:])
+
+
+def cam_project(cam, p3, want_jac=False):
+    c = make_camera(cam)
+    p = (C.c_double * 3)(*p3)
+    pt = (C.c_double * 2)()
+    J = (C.c_double * 6)()
+    st = lib().orc_cam_project(C.byref(c), p, pt, J if want_jac else None)
+    return st, np.array(pt[:]), (np.array(J[:]).reshape(2, 3) if want_jac else None)
+
+
+def triangulate_fast(p1, e1, p2, e2, sigma):
+    a = [(C.c_double * 3)(*v) for v in (p1, e1, p2, e2)]
+    hp = (C.c_double * 4)()
+    v, par = C.c_int(), C.c_int()
+    lib().orc_triangulate_fast(a[0], a[1], a[2], a[3], C.c_double(sigma), hp, C.byref(v),
+                               C.byref(par))
+    return np.array(hp[:]), bool(v.value), bool(par.value)
+
+
+def match_stereo(desc0, kp0, bp0, bpv0, desc1, kp1, bp1, bpv1, T0, T1, f0, f1, thr):
+    n0, n1 = len(kp0), len(kp1)
+    out = np.zeros(max(n0, 1), dtype=STEREO_MATCH_DTYPE)
+    P0, P1 = make_pose(*T0), make_pose(*T1)
+    arrs = [np.ascontiguousarray(a) for a in (desc0, kp0, bp0, bpv0, desc1, kp1, bp1, bpv1)]
+    lib().orc_match_stereo(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), n0, _p(arrs[4]),
+                           _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), n1, C.byref(P0), C.byref(P1),
+                           C.c_double(f0), C.c_double(f1), C.c_double(thr), _p(out))
+    return out[:n0]
+
+
+def match_motion_stereo(desc0, kp0, bp0, bpv0, skip0, desc1, kp1, bp1, bpv1, matched1, T0, T1, cam,
+                        thr):
+    n0, n1 = len(kp0), len(kp1)
+    out = np.zeros(max(n0, 1), dtype=MOTION_MATCH_DTYPE)
+    P0, P1 = make_pose(*T0), make_pose(*T1)
+    c = make_camera(cam)
+    arrs = [None if a is None else np.ascontiguousarray(a)
+            for a in (desc0, kp0, bp0, bpv0, skip0, desc1, kp1, bp1, bpv1, matched1)]
+    lib().orc_match_motion_stereo(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]),
+                                  n0, _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]),
+                                  _p(arrs[9]), n1, C.byref(P0), C.byref(P1), C.byref(c),
+                                  C.c_uint32(int(thr)), _p(out))
+    return out[:n0]
+
+
+def hamming_candidates(A, B, thr):
+    A = np.ascontiguousarray(A, dtype=np.uint8)
+    B = np.ascontiguousarray(B, dtype=np.uint8)
+    cap = max(len(A) * len(B), 1)
+    out = np.empty(cap, dtype=CAND_DTYPE)
+    n = lib().orc_hamming_candidates(_p(A), len(A), _p(B), len(B), int(thr), _p(out), cap)
+    return out[:n].copy()
+
+
+def hamming_argmin(A, B, thr):
+    A = np.ascontiguousarray(A, dtype=np.uint8)
+    B = np.ascontiguousarray(B, dtype=np.uint8)
+    bj = np.empty(max(len(A), 1), dtype=np.int32)
+    bd = np.empty(max(len(A), 1), dtype=np.uint32)
+    lib().orc_hamming_argmin(_p(A), len(A), _p(B), len(B), C.c_uint32(int(thr)), _p(bj), _p(bd))
+    return bj[:len(A)], bd[:len(A)]
