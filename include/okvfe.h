@@ -1,0 +1,241 @@
+/*
+ * okvfe.h -- C ABI of the MI355X (gfx950) vision front-end for OKVIS2.
+ *
+ * libokvfe.so replaces, for the front-end hot path only, the arithmetic that
+ * smartroboticslab/okvis2 reaches through three C++ seams (the reference has
+ * no C/FFI boundary of its own; citations are into the reference tree):
+ *
+ *   (1) cv::FeatureDetector::detect(image, keypoints)
+ *         okvis_cv/include/okvis/implementation/Frame.hpp:152, object built at
+ *         okvis_frontend/src/Frontend.cpp:2406-2409
+ *         (brisk::ScaleSpaceFeatureDetector<HarrisScoreCalculator>(
+ *              uniformityRadius, octaves, absoluteThreshold, maxNumKpt))
+ *       cv::DescriptorExtractor::compute(image, keypoints, descriptors)
+ *         okvis_cv/include/okvis/implementation/Frame.hpp:167, object built at
+ *         okvis_frontend/src/Frontend.cpp:2410-2412, configured by
+ *         setCameraProperties / setExtractionDirection (Frontend.cpp:239-251)
+ *   (2) okvis::Frontend::detectAndDescribe (Frontend.cpp:221-269) and the
+ *       brute-force loops of matchStereo (Frontend.cpp:2016-2076),
+ *       matchMotionStereo (:1812-1905) and verifyRecognisedPlace (:330-355)
+ *   (3) brisk::Hamming::PopcntofXORed(a, b, 3)
+ *         (Frontend.cpp:341,1580,1661,1846,2024; FBrisk.cpp:66)
+ *
+ * Conventions: plain pointers and sizes, caller-allocated outputs, integer
+ * status returns, no exceptions across the ABI.  A context is bound to one
+ * GPU and is single-threaded (the reference holds one detector/extractor per
+ * camera under one mutex per camera, Frontend.cpp:226,2405-2413); different
+ * contexts are independent.  "_device" entry points take HIP device pointers
+ * and a hipStream_t (as void*; NULL = the context's own stream) and never
+ * synchronise; the host-buffer entry points stage through pinned memory and
+ * return only when the outputs are written.
+ *
+ * There is NO CPU fallback: every compute entry point fails with
+ * OKVFE_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef OKVFE_H_
+#define OKVFE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKVFE_ABI_VERSION 1
+#define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
+
+typedef enum okvfe_status {
+  OKVFE_OK = 0,
+  OKVFE_ERR_INVALID_ARGUMENT = 1,
+  OKVFE_ERR_NO_DEVICE = 2,
+  OKVFE_ERR_OUT_OF_MEMORY = 3,
+  OKVFE_ERR_UNSUPPORTED = 4, /* e.g. octaves > 0 */
+  OKVFE_ERR_CAPACITY = 5,    /* a caller- or context-sized buffer was too small */
+  OKVFE_ERR_DEVICE = 6,      /* HIP runtime error; see okvfe_last_error */
+  OKVFE_ERR_NOT_READY = 7    /* e.g. camera-aware extraction without okvfe_set_camera */
+} okvfe_status;
+
+/* Layout-compatible with cv::KeyPoint as the reference consumes it
+ * (okvis_cv/include/okvis/implementation/Frame.hpp:253-273). */
+typedef struct okvfe_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} okvfe_keypoint;
+
+typedef enum okvfe_distortion {
+  OKVFE_DIST_NONE = 0,
+  OKVFE_DIST_RADTAN = 1,     /* okvis::cameras::RadialTangentialDistortion */
+  OKVFE_DIST_EQUIDISTANT = 2 /* okvis::cameras::EquidistantDistortion */
+} okvfe_distortion;
+
+/* okvis::cameras::PinholeCamera<DISTORTION_T> intrinsics
+ * (okvis_cv/include/okvis/cameras/PinholeCamera.hpp). */
+typedef struct okvfe_camera {
+  int32_t width, height;
+  double fu, fv, cu, cv;
+  int32_t distortion; /* okvfe_distortion */
+  double d[4];        /* k1 k2 p1 p2 | k1 k2 k3 k4 */
+} okvfe_camera;
+
+/* T_WC as rotation (row-major) and translation: p_W = C p_C + r. */
+typedef struct okvfe_pose {
+  double C[9];
+  double r[3];
+} okvfe_pose;
+
+/* Detector / extractor / matcher parameters = okvis::FrontendParameters
+ * (okvis_common/include/okvis/Parameters.hpp:123-133) plus sizes. */
+typedef struct okvfe_config {
+  int32_t abi_version;        /* OKVFE_ABI_VERSION */
+  int32_t device;             /* HIP device ordinal */
+  int32_t width, height;      /* image size, fixed per context */
+  int32_t max_batch;          /* images per batch call (>= 1) */
+  int32_t num_cameras;        /* camera slots for camera-aware extraction (>= 1) */
+  float uniformity_radius;    /* detection_threshold: uniformity radius in px */
+  int32_t octaves;            /* 0 = single scale (every shipped config) */
+  int32_t absolute_threshold; /* Harris noise floor, >= 1 */
+  int32_t max_keypoints;      /* max_num_keypoints */
+  int32_t rotation_invariant; /* Frontend.cpp:142 default true */
+  int32_t scale_invariant;    /* Frontend.cpp:143 default false; true is unsupported */
+  int32_t match_threshold;    /* matching_threshold (Hamming bits, strict <) */
+  int32_t max_candidates;     /* per-image NMS candidate capacity; 0 = worst case */
+} okvfe_config;
+
+typedef struct okvfe_ctx okvfe_ctx;
+
+/* ---- lifetime ------------------------------------------------------------ */
+okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out);
+void okvfe_destroy(okvfe_ctx* ctx);
+/* Message of the last failing call on this context ("" if none). ctx may be
+ * NULL to read the message of a failed okvfe_create on this thread. */
+const char* okvfe_last_error(const okvfe_ctx* ctx);
+int32_t okvfe_abi_version(void);
+
+/* ---- camera-aware extraction setup --------------------------------------- */
+/* = BriskDescriptorExtractor::setCameraProperties(rays, imageJacobians, fu)
+ * (Frontend.cpp:239-242): host maps, H*W*3 and H*W*6 floats; copied. */
+okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* rays_hw3,
+                                   const float* jacobians_hw6, float fu);
+/* Builds the same maps from intrinsics on the host
+ * (= PinholeCamera::initialiseCameraAwarenessMaps, PinholeCamera.hpp:180-208)
+ * and uploads them; also stores the intrinsics for back-projection. */
+okvfe_status okvfe_set_camera(okvfe_ctx* ctx, int32_t cam, const okvfe_camera* camera);
+/* Host helper: fills caller buffers with the awareness maps of a camera. */
+okvfe_status okvfe_build_awareness_maps(const okvfe_camera* camera, float* rays_hw3,
+                                        float* jacobians_hw6);
+
+/* ---- detect + describe, host buffers (cv::Feature2D-shaped) -------------- */
+/* One image: detect(), compute() and Frame::computeBackProjections in one
+ * call.  gravity_C = extraction direction (gravity in the camera frame,
+ * Frontend.cpp:247-251); NULL or cam < 0 selects the non-camera-aware mode.
+ * keypoints/descriptors: capacity `cap` rows; backproj (cap*3 doubles) and
+ * backproj_valid (cap bytes) may be NULL. */
+okvfe_status okvfe_detect_describe(okvfe_ctx* ctx, const uint8_t* image, size_t stride,
+                                   int32_t cam, const float gravity_C[3],
+                                   okvfe_keypoint* keypoints, uint8_t* descriptors,
+                                   double* backproj, uint8_t* backproj_valid, int32_t cap,
+                                   int32_t* n_out);
+/* detect() only (no descriptor-stage removal): keypoints in acceptance order. */
+okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride,
+                          okvfe_keypoint* keypoints, int32_t cap, int32_t* n_out);
+
+/* ---- detect + describe, device-resident batches -------------------------- */
+/* images_dev: n_images contiguous H*W u8 images in HBM.  cam_ids /
+ * gravity_C (n_images*3) are HOST arrays (NULL = not camera aware).
+ * Results stay in the context's device buffers (okvfe_get_device_outputs). */
+okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                                int32_t n_images, const int32_t* cam_ids,
+                                                const float* gravity_C, void* stream);
+
+typedef struct okvfe_device_outputs {
+  int32_t max_keypoints;         /* row capacity per image */
+  const int32_t* counts;         /* [max_batch] kept keypoints per image */
+  const okvfe_keypoint* keypoints; /* [max_batch][max_keypoints] */
+  const uint8_t* descriptors;    /* [max_batch][max_keypoints][48] */
+  const double* backproj;        /* [max_batch][max_keypoints][3] */
+  const uint8_t* backproj_valid; /* [max_batch][max_keypoints] */
+  const int32_t* scores;         /* [max_batch][H][W] Harris score maps */
+  const int32_t* detect_counts;  /* [max_batch] keypoints before descriptor-stage removal */
+  const int32_t* candidate_counts; /* [max_batch] NMS maxima found (may exceed capacity) */
+} okvfe_device_outputs;
+okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out);
+
+/* Copies image `index` of the last batch to host buffers (synchronises). */
+okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_keypoint* keypoints,
+                                         uint8_t* descriptors, double* backproj,
+                                         uint8_t* backproj_valid, int32_t cap, int32_t* n_out);
+
+/* ---- single stages on device buffers (parity tests, profiling) ----------- */
+/* K1: Harris score maps, n_images * H * W int32. */
+okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                       int32_t n_images, int32_t* scores_dev, void* stream);
+
+/* ---- matching ------------------------------------------------------------ */
+typedef struct okvfe_stereo_match {
+  int32_t k1;            /* index in image 1, -1 = no match */
+  int32_t dist;          /* Hamming distance of the match (match_threshold if none) */
+  int32_t initialisable; /* !isParallel */
+  int32_t pad;
+  double hp_W[4];        /* triangulated homogeneous point, world frame */
+} okvfe_stereo_match;
+
+/* One (im0, im1) pair of the last batch, = the k0 x k1 loop of
+ * Frontend::matchStereo (Frontend.cpp:2016-2076). */
+typedef struct okvfe_stereo_pair {
+  int32_t image0, image1; /* indices into the last batch */
+  okvfe_pose T_WC0, T_WC1;
+  double f0, f1;          /* 0.5*(fu+fv) of each camera */
+} okvfe_stereo_pair;
+
+/* pairs: HOST array.  matches_dev: [n_pairs][max_keypoints] device rows. */
+okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_pair* pairs,
+                                             int32_t n_pairs, okvfe_stereo_match* matches_dev,
+                                             void* stream);
+/* Host-buffer form on explicit descriptor sets (no context batch needed). */
+okvfe_status okvfe_match_stereo(okvfe_ctx* ctx, const uint8_t* desc0, const okvfe_keypoint* kp0,
+                                const double* backproj0, const uint8_t* valid0, int32_t n0,
+                                const uint8_t* desc1, const okvfe_keypoint* kp1,
+                                const double* backproj1, const uint8_t* valid1, int32_t n1,
+                                const okvfe_pose* T_WC0, const okvfe_pose* T_WC1, double f0,
+                                double f1, okvfe_stereo_match* matches /* n0 */);
+
+typedef struct okvfe_candidate {
+  int32_t i, j, dist;
+} okvfe_candidate;
+/* All (i, j) with popcnt(A[i]^B[j]) < threshold, ordered by (i, j); host buffers.
+ * n_out receives the total found even when it exceeds cap (then OKVFE_ERR_CAPACITY). */
+okvfe_status okvfe_hamming_candidates(okvfe_ctx* ctx, const uint8_t* A, int32_t nA,
+                                      const uint8_t* B, int32_t nB, int32_t threshold,
+                                      okvfe_candidate* out, int32_t cap, int32_t* n_out);
+/* Per row of A the first-lowest j with minimal distance < threshold
+ * (= the loop of verifyRecognisedPlace, Frontend.cpp:337-346); -1 if none. */
+okvfe_status okvfe_hamming_argmin(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, const uint8_t* B,
+                                  int32_t nB, uint32_t threshold, int32_t* best_j,
+                                  uint32_t* best_dist);
+
+/* = brisk::Hamming::PopcntofXORed(a, b, n128); host, no context. */
+uint32_t okvfe_popcnt_xor(const uint8_t* a, const uint8_t* b, int32_t n128);
+
+/* ---- cross-camera gather block (multi-GPU) -------------- */
+/* Fixed-size per-image record for the RCCL all-gather: {count, keypoints,
+ * descriptors, back-projections, valid flags}; size depends only on
+ * max_keypoints. */
+size_t okvfe_gather_block_bytes(const okvfe_ctx* ctx);
+/* Packs image `index` of the last batch into block_dev (device). */
+okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void* block_dev,
+                                            void* stream);
+/* Matches two gathered blocks (device), as okvfe_match_stereo_batch_device. */
+okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0_dev,
+                                              const void* block1_dev, const okvfe_pose* T_WC0,
+                                              const okvfe_pose* T_WC1, double f0, double f1,
+                                              okvfe_stereo_match* matches_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKVFE_H_ */

@@ -1,0 +1,298 @@
+"""ctypes binding of libokvfe.so (the C ABI declared in include/okvfe.h).
+
+This is the product path used by bench.py and the GPU tests: every call goes through the C ABI
+into the hand-written HIP kernels.  There is no Python or CPU implementation behind it -- if the
+library is missing or no gfx950 device is present, loading / okvfe_create fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libokvfe.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
+    ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
+ABI_VERSION = 1
+DESC_BYTES = 48
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+STEREO_MATCH_DTYPE = np.dtype([("k1", "<i4"), ("dist", "<i4"), ("initialisable", "<i4"),
+                               ("pad", "<i4"), ("hp_W", "<f8", (4,))])
+CAND_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("dist", "<i4")])
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("max_batch", C.c_int32), ("num_cameras", C.c_int32),
+                ("uniformity_radius", C.c_float), ("octaves", C.c_int32),
+                ("absolute_threshold", C.c_int32), ("max_keypoints", C.c_int32),
+                ("rotation_invariant", C.c_int32), ("scale_invariant", C.c_int32),
+                ("match_threshold", C.c_int32), ("max_candidates", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fu", C.c_double), ("fv", C.c_double),
+                ("cu", C.c_double), ("cv", C.c_double), ("distortion", C.c_int32),
+                ("d", C.c_double * 4)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("C", C.c_double * 9), ("r", C.c_double * 3)]
+
+
+class StereoPair(C.Structure):
+    _fields_ = [("image0", C.c_int32), ("image1", C.c_int32), ("T_WC0", Pose), ("T_WC1", Pose),
+                ("f0", C.c_double), ("f1", C.c_double)]
+
+
+class DeviceOutputs(C.Structure):
+    _fields_ = [("max_keypoints", C.c_int32), ("counts", C.c_void_p), ("keypoints", C.c_void_p),
+                ("descriptors", C.c_void_p), ("backproj", C.c_void_p),
+                ("backproj_valid", C.c_void_p), ("scores", C.c_void_p),
+                ("detect_counts", C.c_void_p), ("candidate_counts", C.c_void_p)]
+
+
+EXPORTS = [
+    "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
+    "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
+    "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_describe_batch_device",
+    "okvfe_get_device_outputs", "okvfe_download_image_result", "okvfe_harris_score_device",
+    "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
+    "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
+    "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
+]
+
+_LIB = None
+
+
+class OkvfeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"okvfe status {status}: {message}")
+        self.status = status
+
+
+def lib():
+    """Loads libokvfe.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.okvfe_last_error.restype = C.c_char_p
+        L.okvfe_last_error.argtypes = [C.c_void_p]
+        L.okvfe_popcnt_xor.restype = C.c_uint32
+        L.okvfe_gather_block_bytes.restype = C.c_size_t
+        L.okvfe_gather_block_bytes.argtypes = [C.c_void_p]
+        L.okvfe_destroy.argtypes = [C.c_void_p]
+        L.okvfe_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+def make_camera(cam) -> Camera:
+    c = Camera()
+    c.width, c.height, c.fu, c.fv, c.cu, c.cv = cam.w, cam.h, cam.fu, cam.fv, cam.cu, cam.cv
+    c.distortion = cam.dist_type
+    for i in range(4):
+        c.d[i] = cam.d[i]
+    return c
+
+
+def make_pose(Cm, r) -> Pose:
+    p = Pose()
+    flat = np.asarray(Cm, dtype=np.float64).reshape(-1)
+    for i in range(9):
+        p.C[i] = float(flat[i])
+    for i in range(3):
+        p.r[i] = float(r[i])
+    return p
+
+
+def popcnt_xor(a, b, n128=3) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return int(lib().okvfe_popcnt_xor(_p(a), _p(b), int(n128)))
+
+
+def build_awareness_maps(cam):
+    c = make_camera(cam)
+    rays = np.zeros((cam.h, cam.w, 3), dtype=np.float32)
+    jac = np.zeros((cam.h, cam.w, 6), dtype=np.float32)
+    st = lib().okvfe_build_awareness_maps(C.byref(c), _p(rays), _p(jac))
+    if st != OK:
+        raise OkvfeError(st, lib().okvfe_last_error(None).decode())
+    return rays, jac
+
+
+class Frontend:
+    """One okvfe context = the detector + extractor + matcher of one camera stream on one GPU.
+
+    Mirrors the reference's per-camera objects (okvis_frontend/src/Frontend.cpp:2405-2413):
+    constructor arguments are the brisk::ScaleSpaceFeatureDetector / BriskDescriptorExtractor
+    ones plus image size and batch capacity.
+    """
+
+    def __init__(self, width, height, uniformity_radius, octaves, absolute_threshold,
+                 max_keypoints, rotation_invariant=True, scale_invariant=False,
+                 match_threshold=60, max_batch=1, num_cameras=1, device=0, max_candidates=0):
+        cfg = Config(ABI_VERSION, device, width, height, max_batch, num_cameras,
+                     float(uniformity_radius), int(octaves), int(absolute_threshold),
+                     int(max_keypoints), int(bool(rotation_invariant)), int(bool(scale_invariant)),
+                     int(match_threshold), int(max_candidates))
+        self._h = C.c_void_p()
+        self.w, self.h, self.max_batch, self.max_keypoints = width, height, max_batch, max_keypoints
+        st = lib().okvfe_create(C.byref(cfg), C.byref(self._h))
+        if st != OK:
+            raise OkvfeError(st, lib().okvfe_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().okvfe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != OK:
+            raise OkvfeError(st, lib().okvfe_last_error(self._h).decode())
+
+    # -- setup ----------------------------------------------------------------------------
+    def set_camera(self, slot, cam):
+        c = make_camera(cam)
+        self._check(lib().okvfe_set_camera(self._h, int(slot), C.byref(c)))
+
+    def set_camera_maps(self, slot, rays, jac, fu):
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        jac = np.ascontiguousarray(jac, dtype=np.float32)
+        self._check(lib().okvfe_set_camera_maps(self._h, int(slot), _p(rays), _p(jac),
+                                                C.c_float(fu)))
+
+    # -- host-buffer API ------------------------------------------------------------------
+    def detect(self, image):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        cap = self.max_keypoints
+        kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        n = C.c_int32()
+        self._check(lib().okvfe_detect(self._h, _p(image), C.c_size_t(image.strides[0]), _p(kps),
+                                       cap, C.byref(n)))
+        return kps[:n.value].copy()
+
+    def detect_describe(self, image, cam=-1, gravity=None):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        cap = self.max_keypoints
+        kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((cap, DESC_BYTES), dtype=np.uint8)
+        bp = np.zeros((cap, 3), dtype=np.float64)
+        bpv = np.zeros(cap, dtype=np.uint8)
+        n = C.c_int32()
+        g = None if gravity is None else (C.c_float * 3)(*[float(v) for v in gravity])
+        self._check(lib().okvfe_detect_describe(self._h, _p(image), C.c_size_t(image.strides[0]),
+                                                int(cam), g, _p(kps), _p(desc), _p(bp), _p(bpv),
+                                                cap, C.byref(n)))
+        k = n.value
+        return kps[:k].copy(), desc[:k].copy(), bp[:k].copy(), bpv[:k].copy()
+
+    # -- device-resident API --------------------------------------------------------------
+    def harris_score_device(self, images_ptr, n_images, scores_ptr, stream=None):
+        self._check(lib().okvfe_harris_score_device(self._h, _p(images_ptr), int(n_images),
+                                                    _p(scores_ptr), _p(stream)))
+
+    def detect_describe_batch_device(self, images_ptr, n_images, cam_ids=None, gravity=None,
+                                     stream=None):
+        ids = None if cam_ids is None else np.ascontiguousarray(cam_ids, dtype=np.int32)
+        g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float32)
+        self._check(lib().okvfe_detect_describe_batch_device(self._h, _p(images_ptr),
+                                                             int(n_images), _p(ids), _p(g),
+                                                             _p(stream)))
+
+    def device_outputs(self) -> DeviceOutputs:
+        out = DeviceOutputs()
+        self._check(lib().okvfe_get_device_outputs(self._h, C.byref(out)))
+        return out
+
+    def download(self, index):
+        cap = self.max_keypoints
+        kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((cap, DESC_BYTES), dtype=np.uint8)
+        bp = np.zeros((cap, 3), dtype=np.float64)
+        bpv = np.zeros(cap, dtype=np.uint8)
+        n = C.c_int32()
+        self._check(lib().okvfe_download_image_result(self._h, int(index), _p(kps), _p(desc),
+                                                      _p(bp), _p(bpv), cap, C.byref(n)))
+        k = n.value
+        return kps[:k].copy(), desc[:k].copy(), bp[:k].copy(), bpv[:k].copy()
+
+    def match_stereo_batch_device(self, pairs, matches_ptr, stream=None):
+        arr = (StereoPair * len(pairs))(*pairs)
+        self._check(lib().okvfe_match_stereo_batch_device(self._h, arr, len(pairs),
+                                                          _p(matches_ptr), _p(stream)))
+
+    # -- matching, host buffers -----------------------------------------------------------
+    def match_stereo(self, desc0, kp0, bp0, bpv0, desc1, kp1, bp1, bpv1, T0, T1, f0, f1):
+        n0, n1 = len(kp0), len(kp1)
+        out = np.zeros(max(n0, 1), dtype=STEREO_MATCH_DTYPE)
+        arrs = [np.ascontiguousarray(a) for a in (desc0, kp0, bp0, bpv0, desc1, kp1, bp1, bpv1)]
+        P0, P1 = make_pose(*T0), make_pose(*T1)
+        self._check(lib().okvfe_match_stereo(self._h, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]),
+                                             _p(arrs[3]), n0, _p(arrs[4]), _p(arrs[5]),
+                                             _p(arrs[6]), _p(arrs[7]), n1, C.byref(P0),
+                                             C.byref(P1), C.c_double(f0), C.c_double(f1),
+                                             _p(out)))
+        return out[:n0]
+
+    def hamming_candidates(self, A, B, thr, cap=None):
+        A = np.ascontiguousarray(A, dtype=np.uint8)
+        B = np.ascontiguousarray(B, dtype=np.uint8)
+        cap = len(A) * len(B) if cap is None else cap
+        out = np.zeros(max(cap, 1), dtype=CAND_DTYPE)
+        n = C.c_int32()
+        st = lib().okvfe_hamming_candidates(self._h, _p(A), len(A), _p(B), len(B), int(thr),
+                                            _p(out), int(cap), C.byref(n))
+        if st == ERR_CAPACITY:
+            return out[:cap].copy(), n.value
+        self._check(st)
+        return out[:n.value].copy(), n.value
+
+    def hamming_argmin(self, A, B, thr):
+        A = np.ascontiguousarray(A, dtype=np.uint8)
+        B = np.ascontiguousarray(B, dtype=np.uint8)
+        bj = np.zeros(max(len(A), 1), dtype=np.int32)
+        bd = np.zeros(max(len(A), 1), dtype=np.uint32)
+        self._check(lib().okvfe_hamming_argmin(self._h, _p(A), len(A), _p(B), len(B),
+                                               C.c_uint32(int(thr)), _p(bj), _p(bd)))
+        return bj[:len(A)], bd[:len(A)]
+
+    # -- gather blocks --------------------------------------------------------------------
+    def gather_block_bytes(self) -> int:
+        return int(lib().okvfe_gather_block_bytes(self._h))
+
+    def pack_gather_block_device(self, index, block_ptr, stream=None):
+        self._check(lib().okvfe_pack_gather_block_device(self._h, int(index), _p(block_ptr),
+                                                         _p(stream)))
+
+    def match_stereo_blocks_device(self, block0_ptr, block1_ptr, T0, T1, f0, f1, matches_ptr,
+                                   stream=None):
+        P0, P1 = make_pose(*T0), make_pose(*T1)
+        self._check(lib().okvfe_match_stereo_blocks_device(self._h, _p(block0_ptr), _p(block1_ptr),
+                                                           C.byref(P0), C.byref(P1),
+                                                           C.c_double(f0), C.c_double(f1),
+                                                           _p(matches_ptr), _p(stream)))

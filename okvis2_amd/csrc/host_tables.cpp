@@ -1,0 +1,255 @@
+// host_tables.cpp -- host-side tables and camera input preparation of libokvfe.so (product code).
+//
+//   build_pattern          BRISK2-style sampling pattern (data consumed by k_describe.hip).
+//   build_uniformity_lut   31x31 radial stamp of the uniformity enforcement (k_select.hip).
+//   build_awareness_maps   = okvis::cameras::PinholeCamera<D>::initialiseCameraAwarenessMaps
+//                            (okvis_cv/include/okvis/cameras/implementation/PinholeCamera.hpp:180-208):
+//                            per-pixel unit ray (CV_32FC3) and 2x3 image Jacobian (CV_32FC6).
+//   host_backproject       = PinholeCamera<D>::backProject (PinholeCamera.hpp:574-593) with the
+//                            Gauss-Newton undistortion of RadialTangentialDistortion.hpp:214-252 /
+//                            EquidistantDistortion.hpp:319-351.
+// FP64, explicit evaluation order, compiled with -ffp-contract=off.
+#include <cmath>
+#include <cstring>
+
+#include "okvfe_internal.h"
+
+namespace okvfe {
+
+void build_pattern(Pattern* p) {
+  // published BRISK geometry: rings of radius {0,2.9,4.9,7.4,10.8}*0.85 with {1,10,14,15,20}
+  // points, smoothing sigma 1.3 * (ring spacing), at the fixed scale of the non-scale-invariant
+  // extractor; the 383 pairs closer than 5.10 make the 384-bit row (bit 383 stays 0); pairs
+  // further apart than 8.2 feed the gradient orientation.
+  const double ring_radius[5] = {0.0, 2.9, 4.9, 7.4, 10.8};
+  const int ring_points[5] = {1, 10, 14, 15, 20};
+  const double lb_range = std::log(30.0) / std::log(2.0);
+  const int scale_index = static_cast<int>(64.0 / lb_range * (std::log(1.45 / 0.6) / std::log(2.0)) + 0.5);
+  const double scale = std::pow(2.0, static_cast<double>(scale_index) * (lb_range / 64.0));
+  std::memset(p, 0, sizeof(*p));
+  double ux[kPatternPoints], uy[kPatternPoints];
+  int n = 0;
+  double reach = 0.0;
+  for (int ring = 0; ring < 5; ++ring) {
+    const double r = ring_radius[ring] * 0.85;
+    for (int j = 0; j < ring_points[ring]; ++j, ++n) {
+      const double alpha = static_cast<double>(j) * 2.0 * M_PI / static_cast<double>(ring_points[ring]);
+      ux[n] = r * std::cos(alpha);
+      uy[n] = r * std::sin(alpha);
+      p->px[n] = static_cast<float>(scale * ux[n]);
+      p->py[n] = static_cast<float>(scale * uy[n]);
+      const double sigma = ring == 0 ? 1.3 * scale * 0.5
+                                     : 1.3 * scale * r * std::sin(M_PI / static_cast<double>(ring_points[ring]));
+      p->sigma_half[n] = static_cast<float>(sigma);
+      reach = std::fmax(reach, scale * r + sigma);
+    }
+  }
+  p->n_points = n;
+  p->border = static_cast<int>(std::ceil(reach)) + 1;
+  for (int i = 1; i < n; ++i) {
+    for (int j = 0; j < i; ++j) {
+      const double dx = ux[j] - ux[i], dy = uy[j] - uy[i];
+      const double norm_sq = dx * dx + dy * dy;
+      const double d = std::sqrt(norm_sq);
+      if (d < 5.10 && p->n_short < 384) {
+        p->short_i[p->n_short] = static_cast<uint8_t>(i);
+        p->short_j[p->n_short] = static_cast<uint8_t>(j);
+        ++p->n_short;
+      } else if (d > 8.2 && p->n_long < kMaxLongPairs) {
+        p->long_i[p->n_long] = static_cast<uint8_t>(i);
+        p->long_j[p->n_long] = static_cast<uint8_t>(j);
+        p->long_wdx[p->n_long] = static_cast<int32_t>(std::floor((dx / norm_sq) * 2048.0 + 0.5));
+        p->long_wdy[p->n_long] = static_cast<int32_t>(std::floor((dy / norm_sq) * 2048.0 + 0.5));
+        ++p->n_long;
+      }
+    }
+  }
+  for (int k = 0; k < kRot; ++k) {
+    const double a = static_cast<double>(k) * 2.0 * M_PI / 1024.0;
+    p->rot_cos[k] = static_cast<int32_t>(std::lround(32768.0 * std::cos(a)));
+    p->rot_sin[k] = static_cast<int32_t>(std::lround(32768.0 * std::sin(a)));
+    p->rot_cosf[k] = static_cast<float>(std::cos(a));
+    p->rot_sinf[k] = static_cast<float>(std::sin(a));
+  }
+}
+
+void build_uniformity_lut(float lut[31 * 31]) {
+  for (int y = 0; y < 31; ++y)
+    for (int x = 0; x < 31; ++x) {
+      const int d2 = (15 - x) * (15 - x) + (15 - y) * (15 - y);
+      const double v = 1.0 - static_cast<double>(d2) / 225.0;
+      lut[y * 31 + x] = static_cast<float>(v > 0.0 ? v : 0.0);
+    }
+}
+
+namespace {
+
+struct Vec2 {
+  double x, y;
+};
+struct Mat2 {
+  double a, b, c, d;  // [a b; c d]
+};
+
+void distort(const okvfe_camera& cam, Vec2 u, Vec2* out, Mat2* J) {
+  if (cam.distortion == OKVFE_DIST_NONE) {
+    *out = u;
+    if (J) *J = {1.0, 0.0, 0.0, 1.0};
+    return;
+  }
+  const double u0 = u.x, u1 = u.y;
+  if (cam.distortion == OKVFE_DIST_RADTAN) {
+    const double k1 = cam.d[0], k2 = cam.d[1], p1 = cam.d[2], p2 = cam.d[3];
+    const double mx_u = u0 * u0;
+    const double my_u = u1 * u1;
+    const double mxy_u = u0 * u1;
+    const double rho_u = mx_u + my_u;
+    const double rad_dist_u = k1 * rho_u + k2 * rho_u * rho_u;
+    out->x = u0 + u0 * rad_dist_u + 2.0 * p1 * mxy_u + p2 * (rho_u + 2.0 * mx_u);
+    out->y = u1 + u1 * rad_dist_u + 2.0 * p2 * mxy_u + p1 * (rho_u + 2.0 * my_u);
+    if (J) {
+      J->a = 1 + rad_dist_u + k1 * 2.0 * mx_u + k2 * rho_u * 4 * mx_u + 2.0 * p1 * u1 + 6 * p2 * u0;
+      J->c = k1 * 2.0 * u0 * u1 + k2 * 4 * rho_u * u0 * u1 + p1 * 2.0 * u0 + 2.0 * p2 * u1;
+      J->b = J->c;
+      J->d = 1 + rad_dist_u + k1 * 2.0 * my_u + k2 * rho_u * 4 * my_u + 6 * p1 * u1 + 2.0 * p2 * u0;
+    }
+    return;
+  }
+  const double k1 = cam.d[0], k2 = cam.d[1], k3 = cam.d[2], k4 = cam.d[3];
+  const double r = std::sqrt(u0 * u0 + u1 * u1);
+  const double theta = std::atan(r);
+  const double theta2 = theta * theta;
+  const double theta4 = theta2 * theta2;
+  const double theta6 = theta4 * theta2;
+  const double theta8 = theta4 * theta4;
+  const double thetad = theta * (1.0 + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
+  const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+  out->x = scaling * u0;
+  out->y = scaling * u1;
+  if (!J) return;
+  if (r > 1e-8) {
+    // generated expression of the reference (EquidistantDistortion.hpp:128-171); the operation
+    // order is kept because it fixes the rounding
+    const double t2 = u0 * u0;
+    const double t3 = u1 * u1;
+    double t4 = t2 + t3;
+    const double t6 = std::atan(std::sqrt(t4));
+    double t7 = t6 * t6;
+    const double t8 = 1.0 / std::sqrt(t4);
+    const double t9 = t7 * t7;
+    const double t11 = 1.0 / ((t2 + t3) + 1.0);
+    const double t17 = (((k1 * t7 + k2 * t9) + k3 * t7 * t9) + k4 * (t9 * t9)) + 1.0;
+    const double t18 = 1.0 / t4;
+    const double t19 = 1.0 / std::sqrt(t4 * t4 * t4);
+    const double t20 = t6 * t8 * t17;
+    const double t25 = ((k2 * t6 * t7 * t8 * t11 * u1 * 4.0 + k3 * t6 * t8 * t9 * t11 * u1 * 6.0) +
+                        k4 * t6 * t7 * t8 * t9 * t11 * u1 * 8.0) +
+                       k1 * t6 * t8 * t11 * u1 * 2.0;
+    t4 = ((k2 * t6 * t7 * t8 * t11 * u0 * 4.0 + k3 * t6 * t8 * t9 * t11 * u0 * 6.0) +
+          k4 * t6 * t7 * t8 * t9 * t11 * u0 * 8.0) +
+         k1 * t6 * t8 * t11 * u0 * 2.0;
+    t7 = t11 * t17 * t18 * u0 * u1;
+    J->b = (t7 + t6 * t8 * t25 * u0) - t6 * t17 * t19 * u0 * u1;
+    J->d = ((t20 - t3 * t6 * t17 * t19) + t3 * t11 * t17 * t18) + t6 * t8 * t25 * u1;
+    J->a = ((t20 - t2 * t6 * t17 * t19) + t2 * t11 * t17 * t18) + t6 * t8 * t4 * u0;
+    J->c = (t7 + t6 * t8 * t4 * u1) - t6 * t17 * t19 * u0 * u1;
+  } else {
+    *J = {1.0, 0.0, 0.0, 1.0};
+  }
+}
+
+bool undistort(const okvfe_camera& cam, Vec2 pd, Vec2* out) {
+  if (cam.distortion == OKVFE_DIST_NONE) {
+    *out = pd;
+    return true;
+  }
+  const int iterations = cam.distortion == OKVFE_DIST_RADTAN ? 5 : 20;
+  Vec2 x_bar = pd;
+  bool success = false;
+  for (int it = 0; it < iterations; ++it) {
+    Vec2 x_tmp;
+    Mat2 E;
+    distort(cam, x_bar, &x_tmp, &E);
+    const double e0 = pd.x - x_tmp.x, e1 = pd.y - x_tmp.y;
+    // E2 = E^T E ; du = (inv(E2) * E^T) * e
+    const double a = E.a * E.a + E.c * E.c;
+    const double b = E.a * E.b + E.c * E.d;
+    const double c = E.b * E.a + E.d * E.c;
+    const double d = E.b * E.b + E.d * E.d;
+    const double det = a * d - b * c;
+    const double invdet = 1.0 / det;
+    const double i00 = d * invdet, i01 = -b * invdet, i10 = -c * invdet, i11 = a * invdet;
+    const double b00 = i00 * E.a + i01 * E.b;
+    const double b01 = i00 * E.c + i01 * E.d;
+    const double b10 = i10 * E.a + i11 * E.b;
+    const double b11 = i10 * E.c + i11 * E.d;
+    x_bar.x += b00 * e0 + b01 * e1;
+    x_bar.y += b10 * e0 + b11 * e1;
+    const double chi2 = e0 * e0 + e1 * e1;
+    if (chi2 < 1e-6) success = true;
+    if (chi2 < 1e-15) {
+      success = true;
+      break;
+    }
+  }
+  *out = x_bar;
+  return success;
+}
+
+// status 0 = Successful (only that one matters here)
+int project(const okvfe_camera& cam, const double p[3], double J23[6]) {
+  if (std::fabs(p[2]) < 1.0e-12) return 4;
+  const double rz = 1.0 / p[2];
+  const double rz2 = rz * rz;
+  Vec2 und{p[0] * rz, p[1] * rz}, dist;
+  Mat2 D;
+  distort(cam, und, &dist, &D);
+  J23[0] = cam.fu * D.a * rz;
+  J23[1] = cam.fu * D.b * rz;
+  J23[2] = -cam.fu * (p[0] * D.a + p[1] * D.b) * rz2;
+  J23[3] = cam.fv * D.c * rz;
+  J23[4] = cam.fv * D.d * rz;
+  J23[5] = -cam.fv * (p[0] * D.c + p[1] * D.d) * rz2;
+  const double px = cam.fu * dist.x + cam.cu;
+  const double py = cam.fv * dist.y + cam.cv;
+  if (px < 0.0 || py < 0.0) return 1;
+  if (px >= static_cast<double>(cam.width) || py >= static_cast<double>(cam.height)) return 1;
+  return p[2] > 0.0 ? 0 : 3;
+}
+
+}  // namespace
+
+bool host_backproject(const okvfe_camera& cam, double px, double py, double dir[3]) {
+  const double one_over_fu = 1.0 / cam.fu, one_over_fv = 1.0 / cam.fv;
+  Vec2 p2{(px - cam.cu) * one_over_fu, (py - cam.cv) * one_over_fv}, und;
+  const bool ok = undistort(cam, p2, &und);
+  dir[0] = und.x;
+  dir[1] = und.y;
+  dir[2] = 1.0;
+  return ok;
+}
+
+void build_awareness_maps(const okvfe_camera& cam, float* rays, float* jac) {
+  for (int v = 0; v < cam.height; ++v) {
+    for (int u = 0; u < cam.width; ++u) {
+      double ray[3];
+      if (host_backproject(cam, static_cast<double>(u), static_cast<double>(v), ray)) {
+        const double n = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+        ray[0] /= n;
+        ray[1] /= n;
+        ray[2] /= n;
+      } else {
+        ray[0] = ray[1] = ray[2] = 0.0;
+      }
+      const size_t px = static_cast<size_t>(v) * cam.width + u;
+      for (int i = 0; i < 3; ++i) rays[px * 3 + i] = static_cast<float>(ray[i]);
+      double J[6];
+      const bool ok = project(cam, ray, J) == 0;
+      // the reference leaves failed entries uninitialised; they are defined as zero here and
+      // never read for a kept keypoint (a zero ray removes the keypoint)
+      for (int i = 0; i < 6; ++i) jac[px * 6 + i] = ok ? static_cast<float>(J[i]) : 0.0f;
+    }
+  }
+}
+
+}  // namespace okvfe

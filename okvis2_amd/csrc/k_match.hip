@@ -1,0 +1,354 @@
+// k_match.hip -- K7: brute-force 384-bit Hamming matching with the reference's FP64 gates.
+//
+//   match_stereo_kernel   the k0 x k1 loop of okvis::Frontend::matchStereo
+//                         (okvis_frontend/src/Frontend.cpp:2016-2076) including
+//                         triangulation::triangulateFast
+//                         (okvis_frontend/src/stereo_triangulation.cpp:50-132).
+//   hamming_argmin_kernel the ungated running minimum of verifyRecognisedPlace
+//                         (Frontend.cpp:337-346).
+//   hamming_count/emit    all pairs below a threshold in (i, j) order (host replay of the
+//                         other gated loops: Frontend.cpp:1566-1587, 1651-1716, 1844-1893).
+//   popcount primitive    = brisk::Hamming::PopcntofXORed(a, b, 3) (Frontend.cpp:2024).
+//
+// Mapping: lane = one k0 with its 48-byte descriptor in 12 VGPRs; the k1 loop is wave-uniform,
+// so descriptor k1 arrives through scalar loads (SGPR broadcast) and each lane keeps the
+// reference's running minimum ("dist < best", k1 ascending, first-lowest wins) -- literally
+// the reference loop per lane, no cross-lane reduction.  The FP64 gate runs only in lanes
+// whose distance beats their running best, exactly when the reference evaluates it.
+// Integer-ALU bound (v_xor + v_bcnt_u32_b32, 24 VALU per pair); inputs are 2 x 33.6 KB per
+// EuRoC stereo frame, so HBM is not the limit.
+#include "okvfe_internal.h"
+
+namespace okvfe {
+namespace {
+
+struct Desc12 {
+  uint32_t w[12];
+};
+
+__device__ __forceinline__ Desc12 load_desc(const uint8_t* p) {
+  Desc12 d;
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1], c = q[2];
+  d.w[0] = a.x; d.w[1] = a.y; d.w[2] = a.z; d.w[3] = a.w;
+  d.w[4] = b.x; d.w[5] = b.y; d.w[6] = b.z; d.w[7] = b.w;
+  d.w[8] = c.x; d.w[9] = c.y; d.w[10] = c.z; d.w[11] = c.w;
+  return d;
+}
+
+__device__ __forceinline__ int hamming(const Desc12& a, const uint32_t* __restrict__ b) {
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) c += __popc(a.w[i] ^ b[i]);
+  return c;
+}
+
+__device__ __forceinline__ double dot3(const double a[3], const double b[3]) {
+  double s = a[0] * b[0];
+  double t = a[1] * b[1];
+  s = s + t;
+  t = a[2] * b[2];
+  s = s + t;
+  return s;
+}
+__device__ __forceinline__ void normalize3(const double v[3], double out[3]) {
+  const double n = sqrt(dot3(v, v));
+  out[0] = v[0] / n;
+  out[1] = v[1] / n;
+  out[2] = v[2] / n;
+}
+__device__ __forceinline__ void rot(const double C[9], const double v[3], double out[3]) {
+  out[0] = dot3(C, v);
+  out[1] = dot3(C + 3, v);
+  out[2] = dot3(C + 6, v);
+}
+__device__ __forceinline__ void rot_t(const double C[9], const double v[3], double out[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double s = C[i] * v[0];
+    double t = C[3 + i] * v[1];
+    s = s + t;
+    t = C[6 + i] * v[2];
+    s = s + t;
+    out[i] = s;
+  }
+}
+__device__ __forceinline__ void inv_transform_h(const double C[9], const double r[3],
+                                                const double hp[4], double out[4]) {
+  double cr[3], h[3];
+  rot_t(C, r, cr);
+  rot_t(C, hp, h);
+  const double s = hp[3];
+  out[0] = h[0] + (-cr[0]) * s;
+  out[1] = h[1] + (-cr[1]) * s;
+  out[2] = h[2] + (-cr[2]) * s;
+  out[3] = s;
+}
+
+__device__ void midpoint_parallel(const double p1[3], const double e1[3], const double p2[3],
+                                  const double e2[3], const double t12[3], double c26,
+                                  double hp[4], bool* is_valid) {
+  *is_valid = true;
+  double mid[3], d[3], dn[3];
+  const double tn = sqrt(dot3(t12, t12));
+  const double f = 40.0 * (0.01 > tn ? 0.01 : tn);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double m = p1[i] + 0.5 * t12[i];
+    mid[i] = m + f * (e1[i] + e2[i]);
+  }
+  hp[0] = mid[0]; hp[1] = mid[1]; hp[2] = mid[2]; hp[3] = 1.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d[i] = mid[i] - p1[i];
+  normalize3(d, dn);
+  if (dot3(e1, dn) < c26) *is_valid = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d[i] = mid[i] - p2[i];
+  normalize3(d, dn);
+  if (dot3(e2, dn) < c26) *is_valid = false;
+}
+
+// stereo_triangulation.cpp:50-132 with cos(2.6 sigma), cos(6 sigma) supplied by the host
+__device__ void triangulate_fast(const double p1[3], const double e1[3], const double p2[3],
+                                 const double e2[3], double c26, double c6, double hp[4],
+                                 bool* is_valid, bool* is_parallel) {
+  *is_parallel = false;
+  *is_valid = true;
+  const double t12[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  const double b0 = dot3(t12, e1), b1 = dot3(t12, e2);
+  const double a00 = dot3(e1, e1);
+  const double a10 = dot3(e1, e2);
+  const double a01 = -a10;
+  const double a11 = -dot3(e2, e2);
+  const double det = a00 * a11 - a01 * a10;
+  if (!(fabs(det) > 1.0e-12)) {
+    *is_parallel = true;
+    midpoint_parallel(p1, e1, p2, e2, t12, c26, hp, is_valid);
+    return;
+  }
+  const double invdet = 1.0 / det;
+  const double i00 = a11 * invdet, i10 = -a10 * invdet, i01 = -a01 * invdet, i11 = a00 * invdet;
+  const double l0 = i00 * b0 + i01 * b1;
+  const double l1 = i10 * b0 + i11 * b1;
+  if (l0 < 0.01 || l1 < 0.01) {
+    *is_parallel = true;
+    midpoint_parallel(p1, e1, p2, e2, t12, c26, hp, is_valid);
+    return;
+  }
+  double mid[3], d1[3], d2[3], n1[3], n2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double xm = l0 * e1[i] + p1[i];
+    const double xn = l1 * e2[i] + p2[i];
+    mid[i] = (xm + xn) / 2.0;
+    d1[i] = mid[i] - p1[i];
+    d2[i] = mid[i] - p2[i];
+  }
+  normalize3(d1, n1);
+  normalize3(d2, n2);
+  if (dot3(e1, n1) < c26) *is_valid = false;
+  if (dot3(e2, n2) < c26) *is_valid = false;
+  if (dot3(n2, n1) > c6) *is_parallel = true;
+  hp[0] = mid[0]; hp[1] = mid[1]; hp[2] = mid[2]; hp[3] = 1.0;
+}
+
+struct BlockView {  // per-image arrays as the matcher sees them
+  const uint8_t* desc;
+  const double* bp;
+  const uint8_t* bpv;
+  int n;
+};
+
+__device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
+                                  int threshold, okvfe_stereo_match* __restrict__ out) {
+  const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = k0 < I0.n;
+  Desc12 d0;
+  if (active) d0 = load_desc(I0.desc + (size_t)k0 * OKVFE_DESC_BYTES);
+  double e0_W[3] = {0, 0, 0};
+  const bool v0 = active && I0.bpv[k0] != 0;
+  if (v0) {
+    double v[3];
+    rot(P.C0, I0.bp + 3 * (size_t)k0, v);
+    normalize3(v, e0_W);
+  }
+  int best = threshold;  // running "distances"
+  int k1_match = 0;
+  bool initialisable = false;
+  double hps[4] = {0, 0, 0, 0};
+  for (int k1 = 0; k1 < I1.n; ++k1) {
+    const uint32_t* d1 = reinterpret_cast<const uint32_t*>(I1.desc + (size_t)k1 * OKVFE_DESC_BYTES);
+    if (!active) continue;
+    const int dist = hamming(d0, d1);
+    if (dist < best) {
+      if (!v0) continue;
+      if (!I1.bpv[k1]) continue;
+      double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+      rot(P.C1, I1.bp + 3 * (size_t)k1, v);
+      normalize3(v, e1_W);
+      bool is_valid, is_parallel;
+      triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
+      inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+      inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+      if (!is_parallel) {
+        const double w4 = hp_W[3];
+        hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+        if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
+        if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
+        if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
+      }
+      if (is_valid) {
+        best = dist;
+        hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
+        k1_match = k1;
+        initialisable = !is_parallel;
+      }
+    }
+  }
+  if (active) {
+    okvfe_stereo_match m;
+    const bool hit = best < threshold;
+    m.k1 = hit ? k1_match : -1;
+    m.dist = hit ? best : threshold;
+    m.initialisable = hit ? (initialisable ? 1 : 0) : 0;
+    m.pad = 0;
+    m.hp_W[0] = hit ? hps[0] : 0.0;
+    m.hp_W[1] = hit ? hps[1] : 0.0;
+    m.hp_W[2] = hit ? hps[2] : 0.0;
+    m.hp_W[3] = hit ? hps[3] : 0.0;
+    out[k0] = m;
+  }
+}
+
+__global__ __launch_bounds__(64) void match_stereo_kernel(
+    const PairParams* __restrict__ pairs, const okvfe_keypoint* __restrict__ kps,
+    const uint8_t* __restrict__ desc, const double* __restrict__ bp,
+    const uint8_t* __restrict__ bpv, const int32_t* __restrict__ counts, int kp_cap,
+    int threshold, okvfe_stereo_match* __restrict__ out) {
+  (void)kps;
+  const PairParams& P = pairs[blockIdx.y];
+  BlockView I0, I1;
+  const size_t o0 = (size_t)P.image0 * kp_cap, o1 = (size_t)P.image1 * kp_cap;
+  I0.desc = desc + o0 * OKVFE_DESC_BYTES; I0.bp = bp + o0 * 3; I0.bpv = bpv + o0;
+  I0.n = counts[P.image0];
+  I1.desc = desc + o1 * OKVFE_DESC_BYTES; I1.bp = bp + o1 * 3; I1.bpv = bpv + o1;
+  I1.n = counts[P.image1];
+  match_stereo_rows(P, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
+}
+
+// explicit arrays (host-buffer API and gathered blocks)
+__global__ __launch_bounds__(64) void match_stereo_arrays_kernel(
+    const PairParams* __restrict__ pair, const uint8_t* __restrict__ desc0,
+    const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0, const int32_t* n0p, int n0,
+    const uint8_t* __restrict__ desc1, const double* __restrict__ bp1,
+    const uint8_t* __restrict__ bpv1, const int32_t* n1p, int n1, int threshold,
+    okvfe_stereo_match* __restrict__ out) {
+  BlockView I0, I1;
+  I0.desc = desc0; I0.bp = bp0; I0.bpv = bpv0; I0.n = n0p ? *n0p : n0;
+  I1.desc = desc1; I1.bp = bp1; I1.bpv = bpv1; I1.n = n1p ? *n1p : n1;
+  match_stereo_rows(*pair, I0, I1, threshold, out);
+}
+
+__global__ __launch_bounds__(64) void hamming_argmin_kernel(const uint8_t* __restrict__ A, int nA,
+                                                            const uint8_t* __restrict__ B, int nB,
+                                                            uint32_t thr,
+                                                            int32_t* __restrict__ best_j,
+                                                            uint32_t* __restrict__ best_d) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nA) return;
+  const Desc12 a = load_desc(A + (size_t)i * OKVFE_DESC_BYTES);
+  uint32_t dmin = thr;
+  int jmin = -1;
+  for (int j = 0; j < nB; ++j) {
+    const uint32_t d =
+        (uint32_t)hamming(a, reinterpret_cast<const uint32_t*>(B + (size_t)j * OKVFE_DESC_BYTES));
+    if (d < dmin) {
+      dmin = d;
+      jmin = j;
+    }
+  }
+  best_j[i] = jmin;
+  best_d[i] = dmin;
+}
+
+__global__ __launch_bounds__(64) void hamming_count_kernel(const uint8_t* __restrict__ A, int nA,
+                                                           const uint8_t* __restrict__ B, int nB,
+                                                           int thr, int32_t* __restrict__ rows) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nA) return;
+  const Desc12 a = load_desc(A + (size_t)i * OKVFE_DESC_BYTES);
+  int c = 0;
+  for (int j = 0; j < nB; ++j)
+    c += hamming(a, reinterpret_cast<const uint32_t*>(B + (size_t)j * OKVFE_DESC_BYTES)) < thr;
+  rows[i] = c;
+}
+
+__global__ __launch_bounds__(64) void hamming_emit_kernel(const uint8_t* __restrict__ A, int nA,
+                                                          const uint8_t* __restrict__ B, int nB,
+                                                          int thr,
+                                                          const int32_t* __restrict__ offsets,
+                                                          okvfe_candidate* __restrict__ out,
+                                                          int cap) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nA) return;
+  const Desc12 a = load_desc(A + (size_t)i * OKVFE_DESC_BYTES);
+  int pos = offsets[i];
+  for (int j = 0; j < nB; ++j) {
+    const int d = hamming(a, reinterpret_cast<const uint32_t*>(B + (size_t)j * OKVFE_DESC_BYTES));
+    if (d < thr) {
+      if (pos < cap) {
+        okvfe_candidate c;
+        c.i = i;
+        c.j = j;
+        c.dist = d;
+        out[pos] = c;
+      }
+      ++pos;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_match_stereo(const PairParams* pairs, int n_pairs, const okvfe_keypoint* kps,
+                         const uint8_t* desc, const double* bp, const uint8_t* bpv,
+                         const int32_t* counts, int kp_cap, int threshold,
+                         okvfe_stereo_match* out, hipStream_t stream) {
+  if (n_pairs <= 0) return;
+  hipLaunchKernelGGL(match_stereo_kernel, dim3((kp_cap + 63) / 64, n_pairs), dim3(64), 0, stream,
+                     pairs, kps, desc, bp, bpv, counts, kp_cap, threshold, out);
+}
+
+void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, const double* bp0,
+                                const uint8_t* bpv0, const int32_t* n0p, int n0,
+                                const uint8_t* desc1, const double* bp1, const uint8_t* bpv1,
+                                const int32_t* n1p, int n1, int max_rows, int threshold,
+                                okvfe_stereo_match* out, hipStream_t stream) {
+  if (max_rows <= 0) return;
+  hipLaunchKernelGGL(match_stereo_arrays_kernel, dim3((max_rows + 63) / 64), dim3(64), 0, stream,
+                     pair, desc0, bp0, bpv0, n0p, n0, desc1, bp1, bpv1, n1p, n1, threshold, out);
+}
+
+void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
+                           int32_t* best_j, uint32_t* best_d, hipStream_t stream) {
+  if (nA <= 0) return;
+  hipLaunchKernelGGL(hamming_argmin_kernel, dim3((nA + 63) / 64), dim3(64), 0, stream, A, nA, B,
+                     nB, thr, best_j, best_d);
+}
+
+void launch_hamming_count(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,
+                          int32_t* row_counts, hipStream_t stream) {
+  if (nA <= 0) return;
+  hipLaunchKernelGGL(hamming_count_kernel, dim3((nA + 63) / 64), dim3(64), 0, stream, A, nA, B,
+                     nB, thr, row_counts);
+}
+
+void launch_hamming_emit(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,
+                         const int32_t* row_offsets, okvfe_candidate* out, int cap,
+                         hipStream_t stream) {
+  if (nA <= 0) return;
+  hipLaunchKernelGGL(hamming_emit_kernel, dim3((nA + 63) / 64), dim3(64), 0, stream, A, nA, B, nB,
+                     thr, row_offsets, out, cap);
+}
+
+}  // namespace okvfe

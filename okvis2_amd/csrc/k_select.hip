@@ -1,0 +1,344 @@
+// k_select.hip -- K3/K4: score-ordered uniformity enforcement, cap, sub-pixel refinement.
+//
+// Replaces the tail of brisk::ScaleSpaceLayer::DetectScaleSpaceMaxima (sort by score,
+// EnforceKeypointUniformity on an occupancy grid, stop at maxNumKpt, Subpixel2D, emit
+// cv::KeyPoint(pt, 12*scale, -1, score, layer)) behind cv::FeatureDetector::detect
+// (okvis_cv/include/okvis/implementation/Frame.hpp:152; parameters
+// okvis_frontend/src/Frontend.cpp:2406-2409 = uniformityRadius, octaves, absoluteThreshold,
+// maxNumKpt).
+//
+// Two kernels, one workgroup (1024 threads = 16 waves) per image:
+//   sort_kernel    bitonic sort of 64-bit keys (score descending, y, x ascending -- a total
+//                  order, so the result does not depend on the append order of K2) in LDS
+//                  (<= 8192 keys) or in the global workspace (larger candidate sets).
+//   select_kernel  the greedy is serial in its accepted points only: occupancy only grows, so a
+//                  candidate that fails its test once is dead for good.  Each round all 1024
+//                  threads test the next 1024 candidates against the current occupancy, the
+//                  first one that passes is accepted (everything before it is rejected for
+//                  good), its 31x31 stamp is added by 961 threads, and the window restarts
+//                  behind it.  Rounds = accepted points + empty windows.  The occupancy grid
+//                  lives in LDS when it fits (EuRoC: 222x330 B), else in the HBM workspace.
+// Bound: latency / LDS (no HBM roofline); batches keep all CUs busy with independent images.
+#include "okvfe_internal.h"
+
+namespace okvfe {
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kLdsSortKeys = 8192;
+constexpr int kMaxKp = 4096;  // okvfe_create enforces max_keypoints <= 4096
+
+__device__ __forceinline__ uint64_t make_key(const Candidate& c) {
+  return ((uint64_t)(uint32_t)(0x7FFFFFFF - c.score) << 32) | ((uint32_t)c.y << 16) |
+         (uint32_t)c.x;
+}
+
+__global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restrict__ cand,
+                                                        int cand_cap,
+                                                        const int32_t* __restrict__ cand_count,
+                                                        uint64_t* __restrict__ sort_ws,
+                                                        int ws_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
+  const int img = blockIdx.x;
+  int n = cand_count[img];
+  n = n > cand_cap ? cand_cap : n;
+  const Candidate* c = cand + (size_t)img * cand_cap;
+  uint64_t* ws = sort_ws + (size_t)img * ws_stride;
+  int np = 1;
+  while (np < n) np <<= 1;
+  const int tid = threadIdx.x;
+  if (np <= kLdsSortKeys) {
+    for (int i = tid; i < np; i += kThreads) lds[i] = i < n ? make_key(c[i]) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (np >> 1); t += kThreads) {
+          const int lo = ((t / j) * (j << 1)) + (t % j);  // j is a power of two
+          const int hi = lo + j;
+          const bool up = ((lo & k) == 0);
+          const uint64_t a = lds[lo], b = lds[hi];
+          if ((a > b) == up) {
+            lds[lo] = b;
+            lds[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < n; i += kThreads) ws[i] = lds[i];
+  } else {
+    for (int i = tid; i < np; i += kThreads) ws[i] = i < n ? make_key(c[i]) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (np >> 1); t += kThreads) {
+          const int lo = ((t / j) * (j << 1)) + (t % j);
+          const int hi = lo + j;
+          const bool up = ((lo & k) == 0);
+          const uint64_t a = ws[lo], b = ws[hi];
+          if ((a > b) == up) {
+            ws[lo] = b;
+            ws[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// 2-D quadratic sub-pixel refinement; mirrors the published BRISK Subpixel2D with 64-bit
+// coefficients (Harris scores overflow 32-bit products) and double Hessian terms.
+__device__ void subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
+  const int64_t s00 = s[0], s01 = s[1], s02 = s[2];
+  const int64_t s10 = s[3], s11 = s[4], s12 = s[5];
+  const int64_t s20 = s[6], s21 = s[7], s22 = s[8];
+  const int64_t tmp1 = s00 + s02 - 2 * s11 + s20 + s22;
+  const int64_t c1 = 3 * (tmp1 + s01 - ((s10 + s12) * 2) + s21);
+  const int64_t c2 = 3 * (tmp1 - ((s01 + s21) * 2) + s10 + s12);
+  const int64_t tmp2 = s02 - s20;
+  const int64_t tmp3 = s00 + tmp2 - s22;
+  const int64_t tmp4 = tmp3 - 2 * tmp2;
+  const int64_t c3 = -3 * (tmp3 + s01 - s21);
+  const int64_t c4 = -3 * (tmp4 + s10 - s12);
+  const int64_t c5 = (s00 - s02 - s20 + s22) * 4;
+  const int64_t c6 = -(s00 + s02 - ((s10 + s01 + s12 + s21) * 2) - 5 * s11 + s20 + s22) * 2;
+  const double d1 = (double)c1, d2 = (double)c2, d3 = (double)c3, d4 = (double)c4, d5 = (double)c5;
+  double ha = 4.0 * d1;
+  ha = ha * d2;
+  double hb = d5 * d5;
+  const double hdet = ha - hb;
+  if (hdet == 0.0) {
+    *delta_x = 0.0f;
+    *delta_y = 0.0f;
+    return;
+  }
+  if (!(hdet > 0.0 && c1 < 0)) {
+    int64_t best = c3 + c4 + c5;
+    float bx = 1.0f, by = 1.0f;
+    int64_t t = -c3 + c4 - c5;
+    if (t > best) { best = t; bx = -1.0f; by = 1.0f; }
+    t = c3 - c4 - c5;
+    if (t > best) { best = t; bx = 1.0f; by = -1.0f; }
+    t = -c3 - c4 + c5;
+    if (t > best) { best = t; bx = -1.0f; by = -1.0f; }
+    *delta_x = bx;
+    *delta_y = by;
+    return;
+  }
+  const float fh = -(float)hdet;
+  double na = 2.0 * d2;
+  na = na * d3;
+  double nb = d4 * d5;
+  const float nx = (float)(na - nb);
+  na = 2.0 * d1;
+  na = na * d4;
+  nb = d3 * d5;
+  const float ny = (float)(na - nb);
+  float dx = nx / fh;
+  float dy = ny / fh;
+  const bool tx = dx > 1.0f, tx_ = dx < -1.0f, ty = dy > 1.0f, ty_ = dy < -1.0f;
+  if (tx || tx_ || ty || ty_) {
+    const float f1 = (float)c1, f2 = (float)c2, f3 = (float)c3, f4 = (float)c4, f5 = (float)c5,
+                f6 = (float)c6;
+    float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
+    if (tx) {
+      dx1 = 1.0f;
+      dy1 = -(f4 + f5) / (2.0f * f2);
+      if (dy1 > 1.0f) dy1 = 1.0f; else if (dy1 < -1.0f) dy1 = -1.0f;
+    } else if (tx_) {
+      dx1 = -1.0f;
+      dy1 = -(f4 - f5) / (2.0f * f2);
+      if (dy1 > 1.0f) dy1 = 1.0f; else if (dy1 < -1.0f) dy1 = -1.0f;
+    }
+    if (ty) {
+      dy2 = 1.0f;
+      dx2 = -(f3 + f5) / (2.0f * f1);
+      if (dx2 > 1.0f) dx2 = 1.0f; else if (dx2 < -1.0f) dx2 = -1.0f;
+    } else if (ty_) {
+      dy2 = -1.0f;
+      dx2 = -(f3 - f5) / (2.0f * f1);
+      if (dx2 > 1.0f) dx2 = 1.0f; else if (dx2 < -1.0f) dx2 = -1.0f;
+    }
+    float m1 = f1 * dx1; m1 = m1 * dx1;
+    float a = f2 * dy1; a = a * dy1; m1 = m1 + a;
+    a = f3 * dx1; m1 = m1 + a;
+    a = f4 * dy1; m1 = m1 + a;
+    a = f5 * dx1; a = a * dy1; m1 = m1 + a;
+    m1 = m1 + f6;
+    float m2 = f1 * dx2; m2 = m2 * dx2;
+    a = f2 * dy2; a = a * dy2; m2 = m2 + a;
+    a = f3 * dx2; m2 = m2 + a;
+    a = f4 * dy2; m2 = m2 + a;
+    a = f5 * dx2; a = a * dy2; m2 = m2 + a;
+    m2 = m2 + f6;
+    if (m1 > m2) { dx = dx1; dy = dy1; } else { dx = dx2; dy = dy2; }
+  }
+  *delta_x = dx;
+  *delta_y = dy;
+}
+
+template <bool OCC_LDS>
+__global__ __launch_bounds__(kThreads) void select_kernel(
+    const int32_t* __restrict__ scores, int w, int h, const Candidate* __restrict__ cand,
+    int cand_cap, const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws,
+    int ws_stride, float radius, int max_kpts, const float* __restrict__ lut,
+    uint8_t* __restrict__ occ_ws, size_t occ_image_bytes, int occ_rows, int occ_cols,
+    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int wave_first[16];
+  __shared__ uint32_t accepted_xy[kMaxKp];  // (y << 16) | x of accepted points, <= kp_cap
+  __shared__ int32_t accepted_score[kMaxKp];
+  const int img = blockIdx.x;
+  const int tid = threadIdx.x;
+  int n = cand_count[img];
+  n = n > cand_cap ? cand_cap : n;
+  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
+  const int32_t* sc = scores + (size_t)img * w * h;
+  okvfe_keypoint* out = kps + (size_t)img * kp_cap;
+  int kept = 0;
+
+  if (!(radius > 0.0f)) {
+    // uniformity disabled: every maximum is a keypoint, in raster order, not capped by max_kpts
+    // (sorted by (y, x) here: keys carry score in the high half, so re-sort is avoided by
+    // ranking each candidate directly -- O(n^2/threads), only for this rarely used mode)
+    const Candidate* c = cand + (size_t)img * cand_cap;
+    for (int i = tid; i < n; i += kThreads) {
+      const uint32_t me = ((uint32_t)c[i].y << 16) | (uint32_t)c[i].x;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += ((((uint32_t)c[j].y << 16) | (uint32_t)c[j].x) < me);
+      if (rank < kp_cap && rank < kMaxKp) {
+        accepted_xy[rank] = me;
+        accepted_score[rank] = c[i].score;
+      }
+    }
+    kept = n < kp_cap ? n : kp_cap;
+    kept = kept < kMaxKp ? kept : kMaxKp;
+    __syncthreads();
+  } else if (n > 0) {
+    uint8_t* occ = OCC_LDS ? smem_raw : occ_ws + (size_t)img * occ_image_bytes;
+    if (OCC_LDS) {
+      uint32_t* z = reinterpret_cast<uint32_t*>(smem_raw);
+      const int nz = (occ_rows * occ_cols + 3) >> 2;
+      for (int i = tid; i < nz; i += kThreads) z[i] = 0u;
+    }
+    const float scaling = (float)(15.0 / (double)radius);
+    const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
+    const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
+    __syncthreads();
+    int pos = 0;
+    while (pos < n && kept < limit) {
+      // ---- test the window [pos, pos + 1024) against the current occupancy
+      const int idx = pos + tid;
+      bool pass = false;
+      if (idx < n) {
+        const uint64_t k = keys[idx];
+        const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+        const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
+        const float fy = (float)y * scaling;
+        const float fx = (float)x * scaling;
+        const int cy = (int)(fy + 16.0f);
+        const int cx = (int)(fx + 16.0f);
+        const float s0 = (float)occ[(size_t)cy * occ_cols + cx];
+        const float q = (float)score / max_score;
+        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+        pass = !(nsc1 < s0);
+      }
+      const unsigned long long b = __ballot(pass);
+      if ((tid & 63) == 0) wave_first[tid >> 6] = b ? (int)__ffsll((long long)b) - 1 : -1;
+      __syncthreads();
+      int first = -1;
+#pragma unroll
+      for (int wv = 15; wv >= 0; --wv)
+        if (wave_first[wv] >= 0) first = wv * 64 + wave_first[wv];
+      if (first < 0) {
+        pos += kThreads;
+        __syncthreads();
+        continue;
+      }
+      // ---- accept candidate pos + first: stamp its 31x31 patch
+      const uint64_t k = keys[pos + first];
+      const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+      const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
+      if (tid < 961) {
+        const float fy = (float)y * scaling;
+        const float fx = (float)x * scaling;
+        const int cy = (int)(fy + 16.0f);
+        const int cx = (int)(fx + 16.0f);
+        const float q = (float)score / max_score;
+        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+        const float nsc = (float)(0.99 * (double)nsc1);
+        const int ry = tid / 31, rx = tid - ry * 31;
+        const float m = lut[tid] * nsc;
+        const int add = (int)ceilf(m);
+        uint8_t* cell = occ + (size_t)(cy + ry - 15) * occ_cols + (cx + rx - 15);
+        const int v = (int)(*cell) + add;
+        *cell = (uint8_t)(v > 255 ? 255 : v);
+      }
+      if (tid == 0) {
+        accepted_xy[kept] = (uint32_t)(k & 0xFFFFFFFFu);
+        accepted_score[kept] = score;
+      }
+      ++kept;
+      pos += first + 1;
+      __syncthreads();
+    }
+  }
+
+  // ---- K4: sub-pixel refinement and keypoint emission
+  for (int i = tid; i < kept; i += kThreads) {
+    const int u = (int)(accepted_xy[i] & 0xFFFF), v = (int)(accepted_xy[i] >> 16);
+    int32_t patch[9];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        patch[(dy + 1) * 3 + (dx + 1)] = sc[(size_t)(v + dy) * w + (u + dx)];
+    float ddx, ddy;
+    subpixel2d(patch, &ddx, &ddy);
+    okvfe_keypoint kp;
+    kp.x = (float)u + ddx;
+    kp.y = (float)v + ddy;
+    kp.size = 12.0f;
+    kp.angle = -1.0f;
+    kp.response = (float)accepted_score[i];
+    kp.octave = 0;
+    kp.class_id = -1;
+    out[i] = kp;
+  }
+  if (tid == 0) kp_count[img] = kept;
+}
+
+}  // namespace
+
+void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
+                   int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
+                   const float* lut, uint8_t* occupancy, size_t occ_image_bytes, int occ_rows,
+                   int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
+                   uint64_t* sort_ws, hipStream_t stream) {
+  if (n_images <= 0) return;
+  int ws_stride = 1;
+  while (ws_stride < cand_cap) ws_stride <<= 1;
+  if (radius > 0.0f) {
+    const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
+    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
+                       cand, cand_cap, cand_count, sort_ws, ws_stride);
+  }
+  const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
+  const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
+  if (occ_lds) {
+    hipLaunchKernelGGL(select_kernel<true>, dim3(n_images), dim3(kThreads), occ_bytes, stream,
+                       score, w, h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius,
+                       max_kpts, lut, occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap,
+                       kp_count);
+  } else {
+    if (radius > 0.0f)
+      hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
+    hipLaunchKernelGGL(select_kernel<false>, dim3(n_images), dim3(kThreads), 0, stream, score, w,
+                       h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
+                       occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap, kp_count);
+  }
+}
+
+}  // namespace okvfe

@@ -1,0 +1,794 @@
+// okvfe_capi.cpp -- C-ABI runtime of libokvfe.so: contexts, HBM workspaces, stream plumbing.
+// Entry points and the reference interfaces they replace are documented in include/okvfe.h.
+// There is no CPU fallback anywhere in this file: without a gfx950 device okvfe_create fails.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "okvfe_internal.h"
+
+using namespace okvfe;
+
+namespace {
+thread_local std::string g_create_error;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+struct okvfe_ctx {
+  okvfe_config cfg{};
+  hipStream_t stream = nullptr;
+  std::string err;
+  int w = 0, h = 0, B = 0, kp_cap = 0, cand_cap = 0, ws_stride = 0;
+  int occ_rows = 0, occ_cols = 0;
+  size_t occ_image_bytes = 0;
+  int mode_default = kUpright;
+  Pattern host_pattern{};
+
+  std::vector<void*> allocs;
+  int32_t* d_scores = nullptr;
+  Candidate* d_cand = nullptr;
+  int32_t* d_cand_count = nullptr;
+  uint64_t* d_sort_ws = nullptr;
+  uint8_t* d_occ = nullptr;
+  float* d_lut = nullptr;
+  Pattern* d_pattern = nullptr;
+  okvfe_keypoint* d_kps_det = nullptr;
+  int32_t* d_det_count = nullptr;
+  int32_t* d_integral = nullptr;
+  okvfe_keypoint* d_kps_tmp = nullptr;
+  uint8_t* d_desc_tmp = nullptr;
+  uint8_t* d_valid_tmp = nullptr;
+  okvfe_keypoint* d_kps = nullptr;
+  uint8_t* d_desc = nullptr;
+  double* d_bp = nullptr;
+  uint8_t* d_bpv = nullptr;
+  int32_t* d_count = nullptr;
+  ImageParams* d_prm = nullptr;
+  DeviceCamera* d_cams = nullptr;
+  const float** d_rays_ptrs = nullptr;
+  const float** d_jac_ptrs = nullptr;
+  PairParams* d_pairs = nullptr;
+  uint8_t* d_img_stage = nullptr;
+  okvfe_stereo_match* d_match_stage = nullptr;
+
+  std::vector<ImageParams> h_prm_last;  // what d_prm currently holds
+  std::vector<PairParams> h_pairs_last;
+  std::vector<float*> cam_rays, cam_jac;  // device maps per camera slot (nullptr = not set)
+  std::vector<float> cam_fu;
+  std::vector<DeviceCamera> h_cams;
+  std::vector<bool> cam_has_intrinsics;
+  int pair_cap = 0;
+  int last_n_images = 0;
+  hipStream_t last_stream = nullptr;
+
+  // scratch for the explicit-array matchers (grown on demand)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  uint8_t* h_pinned = nullptr;  // pinned staging for the host-buffer API
+  size_t h_pinned_bytes = 0;
+};
+
+namespace {
+
+okvfe_status fail(okvfe_ctx* ctx, okvfe_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx)
+    ctx->err = buf;
+  else
+    g_create_error = buf;
+  return st;
+}
+
+#define HIP_TRY(ctx, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail((ctx), e__ == hipErrorOutOfMemory ? OKVFE_ERR_OUT_OF_MEMORY               \
+                                                    : OKVFE_ERR_DEVICE,                     \
+                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+okvfe_status dev_alloc(okvfe_ctx* ctx, T** p, size_t count) {
+  void* q = nullptr;
+  HIP_TRY(ctx, hipMalloc(&q, std::max<size_t>(count * sizeof(T), 256)));
+  ctx->allocs.push_back(q);
+  *p = static_cast<T*>(q);
+  return OKVFE_OK;
+}
+
+okvfe_status ensure_scratch(okvfe_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return OKVFE_OK;
+  if (ctx->scratch) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return OKVFE_OK;
+}
+
+okvfe_status ensure_pinned(okvfe_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->h_pinned_bytes) return OKVFE_OK;
+  if (ctx->h_pinned) {
+    HIP_TRY(ctx, hipHostFree(ctx->h_pinned));
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_bytes = 0;
+  }
+  void* p = nullptr;
+  HIP_TRY(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  ctx->h_pinned = static_cast<uint8_t*>(p);
+  ctx->h_pinned_bytes = bytes;
+  return OKVFE_OK;
+}
+
+DeviceCamera to_device_camera(const okvfe_camera& c) {
+  DeviceCamera d{};
+  d.fu = c.fu; d.fv = c.fv; d.cu = c.cu; d.cv = c.cv;
+  d.one_over_fu = 1.0 / c.fu;
+  d.one_over_fv = 1.0 / c.fv;
+  for (int i = 0; i < 4; ++i) d.d[i] = c.d[i];
+  d.distortion = c.distortion;
+  return d;
+}
+
+PairParams to_pair_params(const okvfe_stereo_pair& p) {
+  PairParams q{};
+  q.image0 = p.image0;
+  q.image1 = p.image1;
+  std::memcpy(q.C0, p.T_WC0.C, sizeof(q.C0));
+  std::memcpy(q.r0, p.T_WC0.r, sizeof(q.r0));
+  std::memcpy(q.C1, p.T_WC1.C, sizeof(q.C1));
+  std::memcpy(q.r1, p.T_WC1.r, sizeof(q.r1));
+  q.f0 = p.f0;
+  q.f1 = p.f1;
+  // sigma = max(size0/f0, size1/f1) * 0.125 with size = 12 (single scale): Frontend.cpp:2035
+  const double s0 = 12.0 / p.f0, s1 = 12.0 / p.f1;
+  const double sigma = std::max(s0, s1) * 0.125;
+  q.cos26 = std::cos(2.6 * sigma);  // stereo_triangulation.cpp:86,121
+  q.cos6 = std::cos(6.0 * sigma);   // stereo_triangulation.cpp:127
+  return q;
+}
+
+hipStream_t pick_stream(okvfe_ctx* ctx, void* stream) {
+  return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t okvfe_abi_version(void) { return OKVFE_ABI_VERSION; }
+
+const char* okvfe_last_error(const okvfe_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+uint32_t okvfe_popcnt_xor(const uint8_t* a, const uint8_t* b, int32_t n128) {
+  uint32_t c = 0;
+  for (int i = 0; i < 2 * n128; ++i) {
+    uint64_t x, y;
+    std::memcpy(&x, a + 8 * i, 8);
+    std::memcpy(&y, b + 8 * i, 8);
+    c += static_cast<uint32_t>(__builtin_popcountll(x ^ y));
+  }
+  return c;
+}
+
+okvfe_status okvfe_build_awareness_maps(const okvfe_camera* camera, float* rays_hw3,
+                                        float* jacobians_hw6) {
+  if (!camera || !rays_hw3 || !jacobians_hw6 || camera->width <= 0 || camera->height <= 0)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_build_awareness_maps: bad argument");
+  build_awareness_maps(*camera, rays_hw3, jacobians_hw6);
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != OKVFE_ABI_VERSION)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: abi_version %d != %d",
+                cfg->abi_version, OKVFE_ABI_VERSION);
+  if (cfg->width < 64 || cfg->height < 64 || cfg->width > 4096 || cfg->height > 4096 ||
+      (int64_t)cfg->width * cfg->height * 255 >= (int64_t)INT32_MAX)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT,
+                "okvfe_create: image size %dx%d out of range (64..4096, w*h*255 < 2^31)", cfg->width,
+                cfg->height);
+  if (cfg->max_batch < 1 || cfg->num_cameras < 1 || cfg->num_cameras > 64)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: max_batch/num_cameras out of range");
+  if (cfg->max_keypoints < 1 || cfg->max_keypoints > 4096)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: max_keypoints must be in 1..4096");
+  if (cfg->absolute_threshold < 1)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: absolute_threshold must be >= 1");
+  if (cfg->match_threshold < 0 || cfg->match_threshold > 385)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: match_threshold out of range");
+  if (cfg->octaves != 0)
+    return fail(nullptr, OKVFE_ERR_UNSUPPORTED,
+                "okvfe_create: octaves=%d unsupported (every shipped OKVIS2 config uses 0)", cfg->octaves);
+  if (cfg->scale_invariant)
+    return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: scale_invariant extraction unsupported");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, OKVFE_ERR_NO_DEVICE, "okvfe_create: no HIP device visible (no CPU fallback exists)");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, OKVFE_ERR_NO_DEVICE, "okvfe_create: device %d of %d not available", cfg->device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, OKVFE_ERR_NO_DEVICE, "okvfe_create: cannot query device %d", cfg->device);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, OKVFE_ERR_NO_DEVICE, "okvfe_create: device %d is %s; this library carries gfx950 code only",
+                cfg->device, prop.gcnArchName);
+
+  std::unique_ptr<okvfe_ctx> ctx(new okvfe_ctx());
+  ctx->cfg = *cfg;
+  ctx->w = cfg->width;
+  ctx->h = cfg->height;
+  ctx->B = cfg->max_batch;
+  ctx->kp_cap = cfg->max_keypoints;
+  const int worst = (cfg->width / 2 + 1) * (cfg->height - 4);
+  ctx->cand_cap = cfg->max_candidates > 0 ? std::min(cfg->max_candidates, worst) : worst;
+  ctx->cand_cap = std::max(ctx->cand_cap, 64);
+  ctx->ws_stride = 1;
+  while (ctx->ws_stride < ctx->cand_cap) ctx->ws_stride <<= 1;
+  ctx->mode_default = cfg->rotation_invariant ? kGradient : kUpright;
+  if (cfg->uniformity_radius > 0.0f) {
+    const float scaling = (float)(15.0 / (double)cfg->uniformity_radius);
+    ctx->occ_rows = (int)((float)(ctx->h - 1) * scaling + 16.0f) + 17;
+    ctx->occ_cols = (int)((float)(ctx->w - 1) * scaling + 16.0f) + 17;
+  } else {
+    ctx->occ_rows = ctx->occ_cols = 1;
+  }
+  ctx->occ_image_bytes = align_up((size_t)ctx->occ_rows * ctx->occ_cols, 256);
+
+  okvfe_ctx* c = ctx.get();
+  okvfe_status st = OKVFE_OK;
+  auto run = [&]() -> okvfe_status {
+    HIP_TRY(c, hipSetDevice(cfg->device));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t P = (size_t)c->w * c->h, B = (size_t)c->B, K = (size_t)c->kp_cap;
+    okvfe_status s;
+#define A(ptr, n) if ((s = dev_alloc(c, &c->ptr, (n))) != OKVFE_OK) return s
+    A(d_scores, P * B);
+    A(d_integral, P * B);
+    A(d_cand, (size_t)c->cand_cap * B);
+    A(d_cand_count, B);
+    A(d_sort_ws, (size_t)c->ws_stride * B);
+    A(d_occ, c->occ_image_bytes * B);
+    A(d_lut, 31 * 31);
+    A(d_pattern, 1);
+    A(d_kps_det, K * B);
+    A(d_det_count, B);
+    A(d_kps_tmp, K * B);
+    A(d_desc_tmp, K * B * OKVFE_DESC_BYTES);
+    A(d_valid_tmp, K * B);
+    A(d_kps, K * B);
+    A(d_desc, K * B * OKVFE_DESC_BYTES);
+    A(d_bp, K * B * 3);
+    A(d_bpv, K * B);
+    A(d_count, B);
+    A(d_prm, B);
+    A(d_cams, (size_t)cfg->num_cameras);
+    A(d_rays_ptrs, (size_t)cfg->num_cameras);
+    A(d_jac_ptrs, (size_t)cfg->num_cameras);
+    A(d_img_stage, P);
+    A(d_match_stage, K);
+#undef A
+    c->pair_cap = std::max(1, c->B);
+    if ((s = dev_alloc(c, &c->d_pairs, (size_t)c->pair_cap)) != OKVFE_OK) return s;
+    float lut[31 * 31];
+    build_uniformity_lut(lut);
+    build_pattern(&c->host_pattern);
+    HIP_TRY(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_pattern, &c->host_pattern, sizeof(Pattern), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_count, 0, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->d_det_count, 0, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->d_cand_count, 0, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->d_cams, 0, cfg->num_cameras * sizeof(DeviceCamera)));
+    HIP_TRY(c, hipMemset(c->d_rays_ptrs, 0, cfg->num_cameras * sizeof(float*)));
+    HIP_TRY(c, hipMemset(c->d_jac_ptrs, 0, cfg->num_cameras * sizeof(float*)));
+    c->cam_rays.assign(cfg->num_cameras, nullptr);
+    c->cam_jac.assign(cfg->num_cameras, nullptr);
+    c->cam_fu.assign(cfg->num_cameras, 0.0f);
+    c->h_cams.assign(cfg->num_cameras, DeviceCamera{});
+    c->cam_has_intrinsics.assign(cfg->num_cameras, false);
+    return OKVFE_OK;
+  };
+  st = run();
+  if (st != OKVFE_OK) {
+    g_create_error = c->err;
+    okvfe_destroy(ctx.release());
+    return st;
+  }
+  *out = ctx.release();
+  return OKVFE_OK;
+}
+
+void okvfe_destroy(okvfe_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->cfg.device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (void* p : ctx->allocs) (void)hipFree(p);
+  for (float* p : ctx->cam_rays)
+    if (p) (void)hipFree(p);
+  for (float* p : ctx->cam_jac)
+    if (p) (void)hipFree(p);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* rays_hw3,
+                                   const float* jacobians_hw6, float fu) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (cam < 0 || cam >= ctx->cfg.num_cameras || !rays_hw3 || !jacobians_hw6 || !(fu > 0.0f))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_camera_maps: bad argument (cam=%d)", cam);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  const size_t P = (size_t)ctx->w * ctx->h;
+  if (!ctx->cam_rays[cam]) {
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, P * 3 * sizeof(float)));
+    ctx->cam_rays[cam] = static_cast<float*>(p);
+    HIP_TRY(ctx, hipMalloc(&p, P * 6 * sizeof(float)));
+    ctx->cam_jac[cam] = static_cast<float*>(p);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(ctx->cam_rays[cam], rays_hw3, P * 3 * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->cam_jac[cam], jacobians_hw6, P * 6 * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_rays_ptrs + cam, &ctx->cam_rays[cam], sizeof(float*), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_jac_ptrs + cam, &ctx->cam_jac[cam], sizeof(float*), hipMemcpyHostToDevice));
+  ctx->cam_fu[cam] = fu;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_set_camera(okvfe_ctx* ctx, int32_t cam, const okvfe_camera* camera) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!camera || cam < 0 || cam >= ctx->cfg.num_cameras || camera->width != ctx->w ||
+      camera->height != ctx->h || !(camera->fu > 0.0) || !(camera->fv > 0.0) ||
+      camera->distortion < 0 || camera->distortion > 2)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_camera: bad argument (cam=%d)", cam);
+  const size_t P = (size_t)ctx->w * ctx->h;
+  std::vector<float> rays(P * 3), jac(P * 6);
+  build_awareness_maps(*camera, rays.data(), jac.data());
+  okvfe_status st = okvfe_set_camera_maps(ctx, cam, rays.data(), jac.data(), (float)camera->fu);
+  if (st != OKVFE_OK) return st;
+  ctx->h_cams[cam] = to_device_camera(*camera);
+  ctx->cam_has_intrinsics[cam] = true;
+  HIP_TRY(ctx, hipMemcpy(ctx->d_cams + cam, &ctx->h_cams[cam], sizeof(DeviceCamera), hipMemcpyHostToDevice));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                       int32_t* scores_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || !scores_dev || n_images < 0)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_harris_score_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, pick_stream(ctx, stream));
+  HIP_TRY(ctx, hipGetLastError());
+  return OKVFE_OK;
+}
+
+static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int32_t* cam_ids,
+                                        const float* gravity, hipStream_t s) {
+  std::vector<ImageParams> prm(n_images);
+  for (int i = 0; i < n_images; ++i) {
+    ImageParams& p = prm[i];
+    p.cam = cam_ids ? cam_ids[i] : -1;
+    if (p.cam >= ctx->cfg.num_cameras)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "camera id %d out of range", p.cam);
+    const bool aware = gravity != nullptr && p.cam >= 0;
+    if (aware) {
+      if (!ctx->cam_rays[p.cam])
+        return fail(ctx, OKVFE_ERR_NOT_READY,
+                    "camera-aware extraction requested for camera %d before okvfe_set_camera[_maps]", p.cam);
+      p.mode = kCameraAware;
+      p.dir[0] = gravity[3 * i];
+      p.dir[1] = gravity[3 * i + 1];
+      p.dir[2] = gravity[3 * i + 2];
+      p.fu = ctx->cam_fu[p.cam];
+    } else {
+      p.mode = ctx->mode_default;
+      p.dir[0] = 0.0f; p.dir[1] = 1.0f; p.dir[2] = 0.0f;
+      p.fu = 1.0f;
+    }
+    if (p.cam >= 0 && !ctx->cam_has_intrinsics[p.cam]) p.cam = aware ? p.cam : -1;
+  }
+  // intrinsics are needed for back-projection; a slot with maps only (set_camera_maps) keeps its
+  // cam id for the maps and gets invalid back-projections (DeviceCamera zeroed -> fu = 0)
+  const bool same = ctx->h_prm_last.size() >= (size_t)n_images &&
+                    std::memcmp(ctx->h_prm_last.data(), prm.data(), n_images * sizeof(ImageParams)) == 0;
+  if (!same) {
+    if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prm, prm.data(), n_images * sizeof(ImageParams), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->h_prm_last = prm;
+  }
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                                int32_t n_images, const int32_t* cam_ids,
+                                                const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_device: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  if (st != OKVFE_OK) return st;
+  const int w = ctx->w, h = ctx->h;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, n_images * sizeof(int32_t), s));
+  launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
+  launch_nms(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap,
+             ctx->d_cand_count, s);
+  launch_select(ctx->d_scores, w, h, n_images, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count,
+                ctx->cfg.uniformity_radius, ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ,
+                ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols, ctx->d_kps_det, ctx->kp_cap,
+                ctx->d_det_count, ctx->d_sort_ws, s);
+  launch_integral(images_dev, w, h, n_images, ctx->d_integral, s);
+  launch_describe(images_dev, ctx->d_integral, w, h, n_images, ctx->d_pattern, ctx->d_prm,
+                  ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
+                  ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
+  launch_compact(n_images, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp,
+                 ctx->d_det_count, ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv,
+                 ctx->d_count, s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_n_images = n_images;
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out) {
+  if (!ctx || !out) return OKVFE_ERR_INVALID_ARGUMENT;
+  out->max_keypoints = ctx->kp_cap;
+  out->counts = ctx->d_count;
+  out->keypoints = ctx->d_kps;
+  out->descriptors = ctx->d_desc;
+  out->backproj = ctx->d_bp;
+  out->backproj_valid = ctx->d_bpv;
+  out->scores = ctx->d_scores;
+  out->detect_counts = ctx->d_det_count;
+  out->candidate_counts = ctx->d_cand_count;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_keypoint* keypoints,
+                                         uint8_t* descriptors, double* backproj,
+                                         uint8_t* backproj_valid, int32_t cap, int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (index < 0 || index >= ctx->last_n_images || !n_out || cap < 0)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_download_image_result: index %d of %d", index,
+                ctx->last_n_images);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  int32_t counts[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpy(&counts[0], ctx->d_count + index, sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(&counts[1], ctx->d_cand_count + index, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (counts[1] > ctx->cand_cap)
+    return fail(ctx, OKVFE_ERR_CAPACITY, "image %d produced %d NMS maxima, candidate capacity is %d", index,
+                counts[1], ctx->cand_cap);
+  const int n = counts[0];
+  *n_out = n;
+  if (n > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+  const size_t off = (size_t)index * ctx->kp_cap;
+  if (n > 0) {
+    if (keypoints)
+      HIP_TRY(ctx, hipMemcpy(keypoints, ctx->d_kps + off, n * sizeof(okvfe_keypoint), hipMemcpyDeviceToHost));
+    if (descriptors)
+      HIP_TRY(ctx, hipMemcpy(descriptors, ctx->d_desc + off * OKVFE_DESC_BYTES, (size_t)n * OKVFE_DESC_BYTES,
+                             hipMemcpyDeviceToHost));
+    if (backproj)
+      HIP_TRY(ctx, hipMemcpy(backproj, ctx->d_bp + off * 3, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (backproj_valid)
+      HIP_TRY(ctx, hipMemcpy(backproj_valid, ctx->d_bpv + off, n, hipMemcpyDeviceToHost));
+  }
+  return OKVFE_OK;
+}
+
+static okvfe_status stage_image(okvfe_ctx* ctx, const uint8_t* image, size_t stride) {
+  const size_t P = (size_t)ctx->w * ctx->h;
+  if (stride < (size_t)ctx->w) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "stride %zu < width %d", stride, ctx->w);
+  okvfe_status st = ensure_pinned(ctx, P);
+  if (st != OKVFE_OK) return st;
+  for (int y = 0; y < ctx->h; ++y) std::memcpy(ctx->h_pinned + (size_t)y * ctx->w, image + (size_t)y * stride, ctx->w);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_img_stage, ctx->h_pinned, P, hipMemcpyHostToDevice, ctx->stream));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_detect_describe(okvfe_ctx* ctx, const uint8_t* image, size_t stride, int32_t cam,
+                                   const float gravity_C[3], okvfe_keypoint* keypoints,
+                                   uint8_t* descriptors, double* backproj, uint8_t* backproj_valid,
+                                   int32_t cap, int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!image || !n_out) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  okvfe_status st = stage_image(ctx, image, stride);
+  if (st != OKVFE_OK) return st;
+  const int32_t cam_id = cam;
+  st = okvfe_detect_describe_batch_device(ctx, ctx->d_img_stage, 1, &cam_id, (cam >= 0) ? gravity_C : nullptr,
+                                          ctx->stream);
+  if (st != OKVFE_OK) return st;
+  return okvfe_download_image_result(ctx, 0, keypoints, descriptors, backproj, backproj_valid, cap, n_out);
+}
+
+okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride, okvfe_keypoint* keypoints,
+                          int32_t cap, int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!image || !n_out) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  okvfe_status st = stage_image(ctx, image, stride);
+  if (st != OKVFE_OK) return st;
+  hipStream_t s = ctx->stream;
+  const int w = ctx->w, h = ctx->h;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, sizeof(int32_t), s));
+  launch_harris(ctx->d_img_stage, w, h, 1, ctx->d_scores, s);
+  launch_nms(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, s);
+  launch_select(ctx->d_scores, w, h, 1, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, ctx->cfg.uniformity_radius,
+                ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ, ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols,
+                ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_sort_ws, s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  ctx->last_stream = s;
+  int32_t n = 0, nc = 0;
+  HIP_TRY(ctx, hipMemcpy(&n, ctx->d_det_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(&nc, ctx->d_cand_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (nc > ctx->cand_cap)
+    return fail(ctx, OKVFE_ERR_CAPACITY, "%d NMS maxima, candidate capacity is %d", nc, ctx->cand_cap);
+  *n_out = n;
+  if (n > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+  if (n > 0 && keypoints)
+    HIP_TRY(ctx, hipMemcpy(keypoints, ctx->d_kps_det, n * sizeof(okvfe_keypoint), hipMemcpyDeviceToHost));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_pair* pairs,
+                                             int32_t n_pairs, okvfe_stereo_match* matches_dev,
+                                             void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!pairs || !matches_dev || n_pairs < 1)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo_batch_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  std::vector<PairParams> pp(n_pairs);
+  for (int i = 0; i < n_pairs; ++i) {
+    if (pairs[i].image0 < 0 || pairs[i].image0 >= ctx->B || pairs[i].image1 < 0 || pairs[i].image1 >= ctx->B ||
+        !(pairs[i].f0 > 0.0) || !(pairs[i].f1 > 0.0))
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "pair %d: image index or focal length out of range", i);
+    pp[i] = to_pair_params(pairs[i]);
+  }
+  if (n_pairs > ctx->pair_cap) {
+    if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    void* q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, (size_t)n_pairs * sizeof(PairParams)));
+    ctx->allocs.push_back(q);
+    ctx->d_pairs = static_cast<PairParams*>(q);
+    ctx->pair_cap = n_pairs;
+    ctx->h_pairs_last.clear();
+  }
+  const bool same = ctx->h_pairs_last.size() == (size_t)n_pairs &&
+                    std::memcmp(ctx->h_pairs_last.data(), pp.data(), n_pairs * sizeof(PairParams)) == 0;
+  if (!same) {
+    if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs, pp.data(), n_pairs * sizeof(PairParams), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->h_pairs_last = pp;
+  }
+  launch_match_stereo(ctx->d_pairs, n_pairs, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count,
+                      ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_match_stereo(okvfe_ctx* ctx, const uint8_t* desc0, const okvfe_keypoint* kp0,
+                                const double* backproj0, const uint8_t* valid0, int32_t n0,
+                                const uint8_t* desc1, const okvfe_keypoint* kp1, const double* backproj1,
+                                const uint8_t* valid1, int32_t n1, const okvfe_pose* T_WC0,
+                                const okvfe_pose* T_WC1, double f0, double f1, okvfe_stereo_match* matches) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n0 < 0 || n1 < 0 || !T_WC0 || !T_WC1 || !(f0 > 0.0) || !(f1 > 0.0) ||
+      (n0 > 0 && (!desc0 || !backproj0 || !valid0 || !matches)) || (n1 > 0 && (!desc1 || !backproj1 || !valid1)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo: bad argument");
+  // single-scale contract: every keypoint carries size 12 (cos tables are per size class)
+  for (int i = 0; kp0 && i < n0; ++i)
+    if (kp0[i].size != 12.0f) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint size %f != 12 (multi-scale unsupported)", kp0[i].size);
+  for (int i = 0; kp1 && i < n1; ++i)
+    if (kp1[i].size != 12.0f) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint size %f != 12 (multi-scale unsupported)", kp1[i].size);
+  if (n0 == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  const size_t a = 256;
+  const size_t o_pair = 0;
+  const size_t o_d0 = align_up(o_pair + sizeof(PairParams), a);
+  const size_t o_b0 = align_up(o_d0 + (size_t)n0 * 48, a);
+  const size_t o_v0 = align_up(o_b0 + (size_t)n0 * 24, a);
+  const size_t o_d1 = align_up(o_v0 + (size_t)n0, a);
+  const size_t o_b1 = align_up(o_d1 + (size_t)n1 * 48, a);
+  const size_t o_v1 = align_up(o_b1 + (size_t)n1 * 24, a);
+  const size_t o_out = align_up(o_v1 + (size_t)n1, a);
+  const size_t total = o_out + (size_t)n0 * sizeof(okvfe_stereo_match);
+  okvfe_status st = ensure_scratch(ctx, total);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  okvfe_stereo_pair sp{};
+  sp.image0 = 0; sp.image1 = 0; sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
+  const PairParams pp = to_pair_params(sp);
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_pair, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_d0, desc0, (size_t)n0 * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_b0, backproj0, (size_t)n0 * 24, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_v0, valid0, (size_t)n0, hipMemcpyHostToDevice, s));
+  if (n1 > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_d1, desc1, (size_t)n1 * 48, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_b1, backproj1, (size_t)n1 * 24, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_v1, valid1, (size_t)n1, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources must stay valid until copied
+  launch_match_stereo_arrays(reinterpret_cast<PairParams*>(base + o_pair), base + o_d0,
+                             reinterpret_cast<double*>(base + o_b0), base + o_v0, nullptr, n0, base + o_d1,
+                             reinterpret_cast<double*>(base + o_b1), base + o_v1, nullptr, n1, n0,
+                             ctx->cfg.match_threshold, reinterpret_cast<okvfe_stereo_match*>(base + o_out), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(matches, base + o_out, (size_t)n0 * sizeof(okvfe_stereo_match), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_hamming_candidates(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, const uint8_t* B,
+                                      int32_t nB, int32_t threshold, okvfe_candidate* out, int32_t cap,
+                                      int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (nA < 0 || nB < 0 || !n_out || cap < 0 || (nA > 0 && !A) || (nB > 0 && !B) || (cap > 0 && !out))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_hamming_candidates: bad argument");
+  *n_out = 0;
+  if (nA == 0 || nB == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  const size_t a = 256;
+  const size_t o_A = 0;
+  const size_t o_B = align_up(o_A + (size_t)nA * 48, a);
+  const size_t o_rows = align_up(o_B + (size_t)nB * 48, a);
+  const size_t o_out = align_up(o_rows + (size_t)nA * 4, a);
+  const size_t total = o_out + (size_t)std::max(cap, 1) * sizeof(okvfe_candidate);
+  okvfe_status st = ensure_scratch(ctx, total);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_A, A, (size_t)nA * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_B, B, (size_t)nB * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  int32_t* d_rows = reinterpret_cast<int32_t*>(base + o_rows);
+  launch_hamming_count(base + o_A, nA, base + o_B, nB, threshold, d_rows, s);
+  std::vector<int32_t> rows(nA);
+  HIP_TRY(ctx, hipMemcpyAsync(rows.data(), d_rows, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  int64_t total_c = 0;
+  for (int i = 0; i < nA; ++i) {
+    const int32_t c = rows[i];
+    rows[i] = (int32_t)std::min<int64_t>(total_c, INT32_MAX);
+    total_c += c;
+  }
+  *n_out = (int32_t)std::min<int64_t>(total_c, INT32_MAX);
+  HIP_TRY(ctx, hipMemcpyAsync(d_rows, rows.data(), (size_t)nA * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_hamming_emit(base + o_A, nA, base + o_B, nB, threshold, d_rows,
+                      reinterpret_cast<okvfe_candidate*>(base + o_out), cap, s);
+  HIP_TRY(ctx, hipGetLastError());
+  const int32_t ncopy = (int32_t)std::min<int64_t>(total_c, cap);
+  if (ncopy > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(out, base + o_out, (size_t)ncopy * sizeof(okvfe_candidate), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  if (total_c > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%lld candidates, caller capacity %d", (long long)total_c, cap);
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_hamming_argmin(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, const uint8_t* B, int32_t nB,
+                                  uint32_t threshold, int32_t* best_j, uint32_t* best_dist) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (nA < 0 || nB < 0 || (nA > 0 && (!A || !best_j || !best_dist)) || (nB > 0 && !B))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_hamming_argmin: bad argument");
+  if (nA == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  const size_t a = 256;
+  const size_t o_A = 0;
+  const size_t o_B = align_up(o_A + (size_t)nA * 48, a);
+  const size_t o_j = align_up(o_B + (size_t)std::max(nB, 1) * 48, a);
+  const size_t o_d = align_up(o_j + (size_t)nA * 4, a);
+  const size_t total = o_d + (size_t)nA * 4;
+  okvfe_status st = ensure_scratch(ctx, total);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_A, A, (size_t)nA * 48, hipMemcpyHostToDevice, s));
+  if (nB > 0) HIP_TRY(ctx, hipMemcpyAsync(base + o_B, B, (size_t)nB * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_hamming_argmin(base + o_A, nA, base + o_B, nB, threshold, reinterpret_cast<int32_t*>(base + o_j),
+                        reinterpret_cast<uint32_t*>(base + o_d), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(best_j, base + o_j, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(best_dist, base + o_d, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
+// ---- gather blocks ---------------------------------------------------------------------------
+namespace {
+struct BlockLayout {
+  size_t o_count, o_kps, o_desc, o_bp, o_bpv, total;
+};
+BlockLayout block_layout(int kp_cap) {
+  BlockLayout L;
+  L.o_count = 0;
+  L.o_kps = 16;
+  L.o_desc = align_up(L.o_kps + (size_t)kp_cap * sizeof(okvfe_keypoint), 16);
+  L.o_bp = align_up(L.o_desc + (size_t)kp_cap * OKVFE_DESC_BYTES, 16);
+  L.o_bpv = align_up(L.o_bp + (size_t)kp_cap * 3 * sizeof(double), 16);
+  L.total = align_up(L.o_bpv + (size_t)kp_cap, 256);
+  return L;
+}
+}  // namespace
+
+size_t okvfe_gather_block_bytes(const okvfe_ctx* ctx) { return ctx ? block_layout(ctx->kp_cap).total : 0; }
+
+okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void* block_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (index < 0 || index >= ctx->B || !block_dev)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_pack_gather_block_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  uint8_t* b = static_cast<uint8_t*>(block_dev);
+  const size_t off = (size_t)index * ctx->kp_cap;
+  const size_t K = (size_t)ctx->kp_cap;
+  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_count, ctx->d_count + index, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_kps, ctx->d_kps + off, K * sizeof(okvfe_keypoint), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_desc, ctx->d_desc + off * OKVFE_DESC_BYTES, K * OKVFE_DESC_BYTES,
+                             hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_bp, ctx->d_bp + off * 3, K * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_bpv, ctx->d_bpv + off, K, hipMemcpyDeviceToDevice, s));
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0_dev, const void* block1_dev,
+                                              const okvfe_pose* T_WC0, const okvfe_pose* T_WC1, double f0,
+                                              double f1, okvfe_stereo_match* matches_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!block0_dev || !block1_dev || !T_WC0 || !T_WC1 || !matches_dev || !(f0 > 0.0) || !(f1 > 0.0))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo_blocks_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  okvfe_stereo_pair sp{};
+  sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
+  const PairParams pp = to_pair_params(sp);
+  // the pair record rides in the scratch buffer; block matching is a setup-light path (Hilti rig)
+  okvfe_status st = ensure_scratch(ctx, sizeof(PairParams));
+  if (st != OKVFE_OK) return st;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  const uint8_t* b0 = static_cast<const uint8_t*>(block0_dev);
+  const uint8_t* b1 = static_cast<const uint8_t*>(block1_dev);
+  launch_match_stereo_arrays(static_cast<PairParams*>(ctx->scratch), b0 + L.o_desc,
+                             reinterpret_cast<const double*>(b0 + L.o_bp), b0 + L.o_bpv,
+                             reinterpret_cast<const int32_t*>(b0 + L.o_count), 0, b1 + L.o_desc,
+                             reinterpret_cast<const double*>(b1 + L.o_bp), b1 + L.o_bpv,
+                             reinterpret_cast<const int32_t*>(b1 + L.o_count), 0, ctx->kp_cap,
+                             ctx->cfg.match_threshold, matches_dev, s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// okvfe_internal.h -- shared declarations of the libokvfe.so runtime (host + HIP kernels).
+// Product code; never includes or links anything under oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/okvfe.h"
+
+namespace okvfe {
+
+constexpr int kPatternPoints = 60;
+constexpr int kMaxLongPairs = 1100;
+constexpr int kRot = 1024;
+
+// BRISK2-style sampling pattern, host-built (host_tables.cpp), uploaded once per context.
+struct Pattern {
+  int32_t n_points;
+  float px[kPatternPoints];
+  float py[kPatternPoints];
+  float sigma_half[kPatternPoints];
+  int32_t n_short;
+  uint8_t short_i[384], short_j[384];
+  int32_t n_long;
+  uint8_t long_i[kMaxLongPairs], long_j[kMaxLongPairs];
+  int32_t long_wdx[kMaxLongPairs], long_wdy[kMaxLongPairs];
+  int32_t border;
+  int32_t rot_cos[kRot], rot_sin[kRot];
+  float rot_cosf[kRot], rot_sinf[kRot];
+};
+void build_pattern(Pattern* p);
+void build_uniformity_lut(float lut[31 * 31]);
+void build_awareness_maps(const okvfe_camera& cam, float* rays_hw3, float* jac_hw6);
+bool host_backproject(const okvfe_camera& cam, double px, double py, double dir[3]);
+
+struct Candidate {  // NMS maximum
+  int32_t x, y, score;
+};
+
+struct DeviceCamera {  // intrinsics for on-device back-projection
+  double fu, fv, cu, cv;
+  double one_over_fu, one_over_fv;
+  double d[4];
+  int32_t distortion;
+  int32_t pad;
+};
+
+enum ExtractMode : int32_t { kUpright = 0, kGradient = 1, kCameraAware = 2 };
+
+// per-image launch parameters of one batch (host-filled, uploaded per call)
+struct ImageParams {
+  int32_t cam;     // camera slot or -1
+  int32_t mode;    // ExtractMode
+  float dir[3];    // extraction direction
+  float fu;
+};
+
+struct PairParams {  // one stereo pair on device
+  int32_t image0, image1;
+  double C0[9], r0[3], C1[9], r1[3];
+  double f0, f1;
+  double cos26, cos6;  // cos(2.6 sigma), cos(6 sigma) for the (single) size class
+};
+
+}  // namespace okvfe
+
+// ---- kernel launchers (defined in the .hip files) ----------------------------------------------
+namespace okvfe {
+
+void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                   hipStream_t stream);
+void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
+                Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
+void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
+                   int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
+                   const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
+                   int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
+                   uint64_t* sort_ws, hipStream_t stream);
+void launch_integral(const uint8_t* img, int w, int h, int n_images, int32_t* integral,
+                     hipStream_t stream);
+void launch_describe(const uint8_t* img, const int32_t* integral, int w, int h, int n_images,
+                     const Pattern* pat, const ImageParams* prm, const float* const* rays,
+                     const float* const* jac, const okvfe_keypoint* kps_in, int kp_cap,
+                     const int32_t* kp_count_in, okvfe_keypoint* kps_tmp, uint8_t* desc_tmp,
+                     uint8_t* valid_tmp, hipStream_t stream);
+void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
+                    const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
+                    const uint8_t* valid_tmp, const int32_t* kp_count_in, int kp_cap,
+                    okvfe_keypoint* kps, uint8_t* desc, double* bp, uint8_t* bpv,
+                    int32_t* kp_count, hipStream_t stream);
+void launch_match_stereo(const PairParams* pairs, int n_pairs, const okvfe_keypoint* kps,
+                         const uint8_t* desc, const double* bp, const uint8_t* bpv,
+                         const int32_t* counts, int kp_cap, int threshold,
+                         okvfe_stereo_match* out, hipStream_t stream);
+void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, const double* bp0,
+                                const uint8_t* bpv0, const int32_t* n0p, int n0,
+                                const uint8_t* desc1, const double* bp1, const uint8_t* bpv1,
+                                const int32_t* n1p, int n1, int max_rows, int threshold,
+                                okvfe_stereo_match* out, hipStream_t stream);
+void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
+                           int32_t* best_j, uint32_t* best_d, hipStream_t stream);
+void launch_hamming_count(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,
+                          int32_t* row_counts, hipStream_t stream);
+void launch_hamming_emit(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,
+                         const int32_t* row_offsets, okvfe_candidate* out, int cap,
+                         hipStream_t stream);
+
+}  // namespace okvfe

@@ -1,0 +1,252 @@
+"""GPU parity: every stage of the HIP path, called through the C ABI (libokvfe.so), against the
+CPU oracle on the same seeded inputs.  Bit-exact for all integer outputs, for the float32
+keypoint fields (compared as bit patterns) and for the FP64 back-projections / triangulated
+points of radial-tangential and undistorted cameras."""
+import numpy as np
+import pytest
+
+from okvis2_amd import capi, synth
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("w,h,kind,nimg", [(752, 480, "corners", 3), (640, 480, "noise", 2),
+                                           (720, 540, "corners", 1), (1024, 1024, "corners", 1),
+                                           (750, 481, "corners", 2), (333, 97, "noise", 1)])
+def test_harris_score_map(oracle, w, h, kind, nimg):
+    fe = capi.Frontend(w, h, 38.0, 0, 150, 700, max_batch=nimg)
+    imgs = np.stack([synth.noise_image(w, h, 11 + i) if kind == "noise" else
+                     synth.corners_image(w, h, 11 + i) for i in range(nimg)])
+    d_img = _dev(imgs)
+    d_sc = torch.empty((nimg, h, w), dtype=torch.int32, device="cuda")
+    fe.harris_score_device(d_img.data_ptr(), nimg, d_sc.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_sc.cpu().numpy()
+    for i in range(nimg):
+        ref = oracle.harris_score(imgs[i])
+        assert np.array_equal(got[i], ref), (i, np.argwhere(got[i] != ref)[:5])
+
+
+def test_harris_extremes(oracle):
+    w, h = 256, 128
+    fe = capi.Frontend(w, h, 38.0, 0, 150, 700, max_batch=4)
+    chk = (np.indices((h, w)).sum(0) % 2 * 255).astype(np.uint8)
+    imgs = np.stack([np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8), chk,
+                     np.tile(np.arange(w, dtype=np.uint8), (h, 1))])
+    d_img = _dev(imgs)
+    d_sc = torch.empty((4, h, w), dtype=torch.int32, device="cuda")
+    fe.harris_score_device(d_img.data_ptr(), 4, d_sc.data_ptr(), None)
+    torch.cuda.synchronize()
+    got = d_sc.cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], oracle.harris_score(imgs[i]))
+
+
+CONFIGS = [("euroc", synth.euroc_config, "corners"), ("euroc", synth.euroc_config, "noise"),
+           ("mono640", synth.mono640_config, "corners"), ("mono640", synth.mono640_config, "noise"),
+           ("hilti", synth.hilti_config, "corners")]
+
+
+@pytest.mark.parametrize("name,mk,kind", CONFIGS)
+def test_detect(oracle, name, mk, kind):
+    cfg = mk()
+    fe = G.make_frontend(cfg)
+    for seed in (1, 2):
+        img = G.image_for(cfg, seed, kind)
+        ref = oracle.detect(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts)
+        got = fe.detect(img)
+        G.assert_keypoints_equal(got, ref)
+        assert len(got) > 50
+
+
+def test_detect_plateaus(oracle):
+    """Blocky image (every pixel doubled) creates equal-score horizontal neighbours."""
+    cfg = synth.mono640_config()
+    small = synth.corners_image(cfg.w // 2, cfg.h // 2, 5, cell=8)
+    img = np.repeat(np.repeat(small, 2, axis=0), 2, axis=1)
+    fe = G.make_frontend(cfg)
+    ref = oracle.detect(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts)
+    G.assert_keypoints_equal(fe.detect(img), ref)
+
+
+@pytest.mark.parametrize("rot", [True, False])
+def test_describe_not_camera_aware(oracle, rot):
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg, rotation_invariant=rot)
+    img = G.image_for(cfg, 3)
+    mode = oracle.MODE_GRADIENT if rot else oracle.MODE_UPRIGHT
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    mode)
+    kps, desc, bp, bpv = fe.detect_describe(img)
+    G.assert_keypoints_equal(kps, rk)
+    assert np.array_equal(desc, rd)
+    assert not bpv.any()
+
+
+@pytest.mark.parametrize("name,mk", [("euroc", synth.euroc_config), ("mono640", synth.mono640_config)])
+def test_describe_camera_aware_and_backprojection(oracle, name, mk):
+    cfg = mk()
+    fe = G.make_frontend(cfg)
+    for ci, cam in enumerate(cfg.cams):
+        fe.set_camera(ci, cam)
+    for ci, cam in enumerate(cfg.cams):
+        rays, jac = oracle.awareness_maps(cam)
+        for seed, grav in ((4, (0.0, 1.0, 0.0)), (5, (0.3, 0.9, -0.2)), (6, (-1.0, 0.05, 0.1))):
+            img = G.image_for(cfg, seed, cam=ci)
+            rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold,
+                                            cfg.max_kpts, oracle.MODE_CAMERA_AWARE, rays, jac,
+                                            np.float32(cam.fu), grav)
+            kps, desc, bp, bpv = fe.detect_describe(img, cam=ci, gravity=grav)
+            G.assert_keypoints_equal(kps, rk)
+            assert np.array_equal(desc, rd)
+            rbp, rv = oracle.backproject_keypoints(cam, rk)
+            assert np.array_equal(bpv, rv)
+            assert np.array_equal(bp.view(np.uint64), rbp.view(np.uint64))
+            assert len(kps) > 50
+
+
+def test_awareness_maps_host_builder(oracle):
+    for cam in synth.euroc_config().cams[:1] + synth.hilti_config().cams[:1]:
+        rays, jac = capi.build_awareness_maps(cam)
+        rr, rj = oracle.awareness_maps(cam)
+        assert np.array_equal(rays.view(np.uint32), rr.view(np.uint32))
+        assert np.array_equal(jac.view(np.uint32), rj.view(np.uint32))
+
+
+def test_equidistant_backprojection_tolerance(oracle):
+    """Equidistant undistortion calls atan() in FP64: device libm vs glibc may differ in the last
+    ulp, so this one is checked to 1e-12 instead of bit-exact."""
+    cfg = synth.hilti_config()
+    fe = G.make_frontend(cfg)
+    fe.set_camera(0, cfg.cams[0])
+    img = G.image_for(cfg, 9)
+    kps, desc, bp, bpv = fe.detect_describe(img, cam=0, gravity=(0.0, 1.0, 0.0))
+    rbp, rv = oracle.backproject_keypoints(cfg.cams[0], kps)
+    assert np.array_equal(bpv, rv)
+    assert np.allclose(bp, rbp, rtol=0, atol=1e-12)
+
+
+def _stereo_inputs(oracle, cfg, seed):
+    L, R, _ = synth.stereo_pair(cfg.w, cfg.h, seed)
+    out = []
+    for ci, img in enumerate((L, R)):
+        cam = cfg.cams[ci]
+        rays, jac = oracle.awareness_maps(cam)
+        k, d = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold,
+                                      cfg.max_kpts, oracle.MODE_CAMERA_AWARE, rays, jac,
+                                      np.float32(cam.fu), (0.0, 1.0, 0.0))
+        bp, bv = oracle.backproject_keypoints(cam, k)
+        out.append((k, d, bp, bv))
+    return L, R, out
+
+
+def test_match_stereo_host_buffers(oracle):
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    nmatch = 0
+    for seed in (21, 22):
+        _, _, ((k0, d0, b0, v0), (k1, d1, b1, v1)) = _stereo_inputs(oracle, cfg, seed)
+        v0 = v0.copy()
+        v0[::7] = 0  # some invalid back-projections
+        ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1,
+                                  cfg.match_threshold)
+        got = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1)
+        assert np.array_equal(got["k1"], ref["k1"])
+        assert np.array_equal(got["dist"], ref["dist"])
+        assert np.array_equal(got["initialisable"], ref["initialisable"])
+        assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
+        nmatch += int((ref["k1"] >= 0).sum())
+    assert nmatch > 20
+
+
+def test_stereo_pipeline_device_resident(oracle):
+    """detect+describe of a stereo batch and matchStereo, all outputs resident in HBM."""
+    cfg = synth.euroc_config()
+    nfr = 3
+    fe = G.make_frontend(cfg, max_batch=2 * nfr)
+    for ci, cam in enumerate(cfg.cams):
+        fe.set_camera(ci, cam)
+    frames = [_stereo_inputs(oracle, cfg, 30 + i) for i in range(nfr)]
+    imgs = np.stack([im for (L, R, _) in frames for im in (L, R)])
+    d_img = _dev(imgs)
+    cam_ids = np.array([0, 1] * nfr, dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (2 * nfr, 1))
+    stream = torch.cuda.current_stream().cuda_stream
+    fe.detect_describe_batch_device(d_img.data_ptr(), 2 * nfr, cam_ids, grav, stream)
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    pairs = []
+    for i in range(nfr):
+        sp = capi.StereoPair()
+        sp.image0, sp.image1 = 2 * i, 2 * i + 1
+        sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
+        sp.f0, sp.f1 = f0, f1
+        pairs.append(sp)
+    d_m = torch.zeros((nfr, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8,
+                      device="cuda")
+    fe.match_stereo_batch_device(pairs, d_m.data_ptr(), stream)
+    torch.cuda.synchronize()
+    m = d_m.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(nfr, cfg.max_kpts)
+    for i, (_, _, ((k0, d0, b0, v0), (k1, d1, b1, v1))) in enumerate(frames):
+        g0 = fe.download(2 * i)
+        g1 = fe.download(2 * i + 1)
+        G.assert_keypoints_equal(g0[0], k0)
+        G.assert_keypoints_equal(g1[0], k1)
+        assert np.array_equal(g0[1], d0) and np.array_equal(g1[1], d1)
+        ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1,
+                                  cfg.match_threshold)
+        got = m[i, :len(k0)]
+        assert np.array_equal(got["k1"], ref["k1"])
+        assert np.array_equal(got["dist"], ref["dist"])
+        assert np.array_equal(got["initialisable"], ref["initialisable"])
+        assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
+
+
+def test_hamming_candidates_and_argmin(oracle):
+    rng = np.random.default_rng(5)
+    fe = capi.Frontend(752, 480, 38.0, 0, 150, 700)
+    voc = np.fromfile(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden",
+                                                 "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+    A = voc[:400]
+    B = np.concatenate([voc[300:], voc[:50] ^ (rng.random((50, 48)) < 0.02).astype(np.uint8)])
+    ref = oracle.hamming_candidates(A, B, 60)
+    got, n = fe.hamming_candidates(A, B, 60)
+    assert n == len(ref) and np.array_equal(got, ref)
+    rj, rd = oracle.hamming_argmin(A, B, 60)
+    gj, gd = fe.hamming_argmin(A, B, 60)
+    assert np.array_equal(gj, rj) and np.array_equal(gd, rd)
+    # empty and ragged inputs
+    got, n = fe.hamming_candidates(A[:0], B, 60)
+    assert n == 0
+    gj, gd = fe.hamming_argmin(A[:3], B[:0], 60)
+    assert np.array_equal(gj, [-1, -1, -1]) and np.array_equal(gd, [60, 60, 60])
+    # capacity overflow is reported, not silently truncated
+    got, n = fe.hamming_candidates(A, B, 60, cap=5)
+    assert n == len(ref) and np.array_equal(got, ref[:5])
+
+
+def test_error_paths():
+    with pytest.raises(capi.OkvfeError) as e:
+        capi.Frontend(752, 480, 38.0, 2, 150, 700)
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.OkvfeError) as e:
+        capi.Frontend(752, 480, 38.0, 0, 0, 700)
+    assert e.value.status == capi.ERR_INVALID_ARGUMENT
+    fe = capi.Frontend(752, 480, 38.0, 0, 150, 700)
+    img = synth.corners_image(752, 480, 1)
+    with pytest.raises(capi.OkvfeError) as e:
+        fe.detect_describe(img, cam=0, gravity=(0, 1, 0))  # camera-aware before set_camera
+    assert e.value.status == capi.ERR_NOT_READY
