@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- front-end throughput on MI355X: stereo-frames/s (detect + describe + match).
+
+Workload (BASELINE.json metric, configs[2]): synthetic EuRoC-shaped stereo, 752x480 x 2 cameras,
+front-end parameters of config/euroc.yaml:63-67 (uniformity radius 38, Harris threshold 150,
+<= 700 keypoints, Hamming threshold 60), camera-aware gravity-aligned BRISK2 extraction,
+matchStereo with the FP64 triangulation gate.  One "step" = one batch of `--batch` stereo frames
+through the whole hot path (K1 harris -> K2 nms -> K3 sort/select -> K5 integral -> K6 describe ->
+compaction + back-projection -> K7 gated stereo match), inputs resident in HBM.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+N > 1 is launched by torch.distributed.run (one rank per GPU); stereo frames are independent
+units, so ranks shard batches with no data-path collective ("scaling": "weak").
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def make_inputs(cfg, n_frames, n_distinct, seed0):
+    from okvis2_amd import synth
+    base = []
+    for i in range(n_distinct):
+        L, R, _ = synth.stereo_pair(cfg.w, cfg.h, seed0 + i)
+        base.append(L)
+        base.append(R)
+    base = np.stack(base)  # [2*n_distinct, H, W]
+    reps = (n_frames + n_distinct - 1) // n_distinct
+    return np.concatenate([base] * reps)[: 2 * n_frames], base
+
+
+def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
+    """Times the CPU oracle (a port of the algorithm, NOT the reference binary, which cannot be
+    built here) with the reference's threading shape: one thread per camera for detect+describe
+    (ThreadedSlam.cpp:434-448), matchStereo single-threaded (Frontend.cpp:2016).  Also compares
+    the oracle's outputs with the GPU's for the same frames (the oracle acting as checker)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from okvis2_amd import synth
+    maps = [O.awareness_maps(c) for c in cfg.cams]
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f = [0.5 * (c.fu + c.fv) for c in cfg.cams]
+    grav = (0.0, 1.0, 0.0)
+    n_distinct = len(base_imgs) // 2
+    out = [None, None]
+
+    def work(ci, img):
+        cam = cfg.cams[ci]
+        k, d = O.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                 O.MODE_CAMERA_AWARE, maps[ci][0], maps[ci][1], np.float32(cam.fu),
+                                 grav)
+        bp, bv = O.backproject_keypoints(cam, k)
+        out[ci] = (k, d, bp, bv)
+
+    done, checked, mismatches = 0, 0, 0
+    t0 = time.perf_counter()
+    while True:
+        i = done % n_distinct
+        th = threading.Thread(target=work, args=(1, base_imgs[2 * i + 1]))
+        th.start()
+        work(0, base_imgs[2 * i])
+        th.join()
+        (k0, d0, b0, v0), (k1, d1, b1, v1) = out
+        m = O.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[0], f[1], cfg.match_threshold)
+        done += 1
+        elapsed = time.perf_counter() - t0
+        if done <= n_distinct and fe is not None:  # checker leg, outside the measured work
+            t_chk = time.perf_counter()
+            g0, g1 = fe.download(2 * i), fe.download(2 * i + 1)
+            ok = (np.array_equal(g0[0].view(np.uint8), k0.view(np.uint8)) and
+                  np.array_equal(g1[0].view(np.uint8), k1.view(np.uint8)) and
+                  np.array_equal(g0[1], d0) and np.array_equal(g1[1], d1) and
+                  np.array_equal(fe._bench_matches[i, :len(k0)]["k1"], m["k1"]))
+            checked += 1
+            mismatches += 0 if ok else 1
+            t0 += time.perf_counter() - t_chk
+        if elapsed >= budget_s and done >= 8:
+            break
+    elapsed = time.perf_counter() - t0
+    return {"value": done / elapsed, "unit": "stereo-frames/s", "cores": 2, "kind": "port",
+            "sample": f"{done} stereo frames of the bench workload ({n_distinct} distinct), "
+                      f"{elapsed:.1f} s; 1 thread per camera for detect+describe, match serial; "
+                      f"host has {os.cpu_count()} logical cores",
+            "parity_checked_frames": checked, "parity_mismatches": mismatches}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="stereo frames per step per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
+    ap.add_argument("--max-candidates", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from okvis2_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = synth.euroc_config()
+    B = args.batch
+    n_img = 2 * B
+    distinct = min(args.distinct, B)
+    imgs, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank)
+    d_img = torch.from_numpy(imgs).to(dev)
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold,
+                       cfg.max_kpts, match_threshold=cfg.match_threshold, max_batch=n_img,
+                       num_cameras=2, device=local_rank, max_candidates=args.max_candidates)
+    for ci, cam in enumerate(cfg.cams):
+        fe.set_camera(ci, cam)
+    cam_ids = np.array([0, 1] * B, dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (n_img, 1))
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    pairs = []
+    for i in range(B):
+        sp = capi.StereoPair()
+        sp.image0, sp.image1 = 2 * i, 2 * i + 1
+        sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
+        sp.f0, sp.f1 = f0, f1
+        pairs.append(sp)
+    pairs_arr = (capi.StereoPair * B)(*pairs)
+    d_match = torch.zeros((B, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8,
+                          device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    img_ptr, match_ptr = d_img.data_ptr(), d_match.data_ptr()
+
+    def step():
+        fe.detect_describe_batch_device(img_ptr, n_img, cam_ids, grav, stream)
+        fe.match_stereo_batch_device(pairs_arr, match_ptr, stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # capacity check (outside the timed region): download() raises OKVFE_ERR_CAPACITY if any NMS
+    # candidate list of the checked images overflowed its buffer
+    kp_total = 0
+    for i in range(min(n_img, 2 * distinct)):
+        k, _, _, _ = fe.download(i)
+        kp_total += len(k)
+
+    fe.profile_enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = fe.profile_read()
+    fe.profile_enable(False)
+
+    if rank == 0:
+        P = cfg.w * cfg.h
+        stage_ms = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
+        harris_ms = stage_ms["harris"]
+        achieved = 5.0 * P * n_img / (harris_ms * 1e-3) / 1e9
+        m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
+        fe._bench_matches = m
+        result = {
+            "metric": "front-end stereo-frames/s (detect+describe+match), 752x480 stereo",
+            "value": world * B * args.steps / elapsed,
+            "unit": "stereo-frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int32 (detect, describe, Hamming) + f64 (match gate)",
+            "data": "synthetic",
+            "config": {"workload": "EuRoC-shaped 752x480 stereo, euroc.yaml front-end params "
+                                   "(radius 38, thr 150, <=700 kpts, match thr 60)",
+                       "stereo_frames_per_step_per_gpu": B, "distinct_frames": distinct,
+                       "mean_keypoints_per_image": kp_total / max(1, min(n_img, 2 * distinct)),
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+            "roofline": {"kernel": "harris_kernel (K1 score map)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": 5 * P * n_img,
+                         "avg_launch_ms": harris_ms},
+            "stage_ms_per_step": stage_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, base, fe)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

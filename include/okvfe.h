@@ -175,6 +175,26 @@ okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_ke
 okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev,
                                        int32_t n_images, int32_t* scores_dev, void* stream);
 
+/* ---- stage profiling ----------------------------------------------------- */
+/* When enabled, every stage launch of the batch entry points is bracketed by a
+ * HIP event pair on the launch stream (no synchronisation is added).
+ * okvfe_profile_read synchronises and returns, per stage, the summed elapsed
+ * milliseconds and the number of launches since okvfe_profile_enable. */
+typedef enum okvfe_stage {
+  OKVFE_STAGE_HARRIS = 0,   /* K1 score map */
+  OKVFE_STAGE_NMS = 1,      /* K2 */
+  OKVFE_STAGE_SORT = 2,     /* K3 sort */
+  OKVFE_STAGE_SELECT = 3,   /* K3 uniformity + K4 sub-pixel */
+  OKVFE_STAGE_INTEGRAL = 4, /* K5 */
+  OKVFE_STAGE_DESCRIBE = 5, /* K6 */
+  OKVFE_STAGE_COMPACT = 6,  /* compaction + back-projection */
+  OKVFE_STAGE_MATCH = 7,    /* K7 gated stereo match */
+  OKVFE_STAGE_COUNT = 8
+} okvfe_stage;
+okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable);
+okvfe_status okvfe_profile_read(okvfe_ctx* ctx, double total_ms[OKVFE_STAGE_COUNT],
+                                int32_t launches[OKVFE_STAGE_COUNT]);
+
 /* ---- matching ------------------------------------------------------------ */
 typedef struct okvfe_stereo_match {
   int32_t k1;            /* index in image 1, -1 = no match */

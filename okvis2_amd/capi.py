@@ -66,7 +66,10 @@ EXPORTS = [
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
+    "okvfe_profile_enable", "okvfe_profile_read",
 ]
+
+STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
 
 _LIB = None
 
@@ -242,7 +245,7 @@ class Frontend:
         return kps[:k].copy(), desc[:k].copy(), bp[:k].copy(), bpv[:k].copy()
 
     def match_stereo_batch_device(self, pairs, matches_ptr, stream=None):
-        arr = (StereoPair * len(pairs))(*pairs)
+        arr = pairs if isinstance(pairs, C.Array) else (StereoPair * len(pairs))(*pairs)
         self._check(lib().okvfe_match_stereo_batch_device(self._h, arr, len(pairs),
                                                           _p(matches_ptr), _p(stream)))
 
@@ -280,6 +283,16 @@ class Frontend:
         self._check(lib().okvfe_hamming_argmin(self._h, _p(A), len(A), _p(B), len(B),
                                                C.c_uint32(int(thr)), _p(bj), _p(bd)))
         return bj[:len(A)], bd[:len(A)]
+
+    # -- stage profiling (HIP events on the launch stream) --------------------------------
+    def profile_enable(self, on=True):
+        self._check(lib().okvfe_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        ms = (C.c_double * len(STAGES))()
+        n = (C.c_int32 * len(STAGES))()
+        self._check(lib().okvfe_profile_read(self._h, ms, n))
+        return {STAGES[i]: (ms[i], n[i]) for i in range(len(STAGES))}
 
     # -- gather blocks --------------------------------------------------------------------
     def gather_block_bytes(self) -> int:

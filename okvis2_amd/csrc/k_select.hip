@@ -312,6 +312,16 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
 
 }  // namespace
 
+void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
+                 float radius, uint64_t* sort_ws, hipStream_t stream) {
+  if (n_images <= 0 || !(radius > 0.0f)) return;
+  int ws_stride = 1;
+  while (ws_stride < cand_cap) ws_stride <<= 1;
+  const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
+  hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
+                     cand, cand_cap, cand_count, sort_ws, ws_stride);
+}
+
 void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_image_bytes, int occ_rows,
@@ -320,11 +330,6 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
   if (n_images <= 0) return;
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
-  if (radius > 0.0f) {
-    const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
-    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
-                       cand, cand_cap, cand_count, sort_ws, ws_stride);
-  }
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
   const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
   if (occ_lds) {
@@ -334,7 +339,7 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
                        kp_count);
   } else {
     if (radius > 0.0f)
-      hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
+      (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
     hipLaunchKernelGGL(select_kernel<false>, dim3(n_images), dim3(kThreads), 0, stream, score, w,
                        h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
                        occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap, kp_count);

@@ -70,6 +70,15 @@ struct okvfe_ctx {
   size_t scratch_bytes = 0;
   uint8_t* h_pinned = nullptr;  // pinned staging for the host-buffer API
   size_t h_pinned_bytes = 0;
+
+  // stage profiling (okvfe_profile_*): event pairs per recorded stage launch
+  bool profiling = false;
+  struct StageEvents {
+    int stage;
+    hipEvent_t a, b;
+  };
+  std::vector<StageEvents> prof_events;
+  std::vector<hipEvent_t> event_pool;
 };
 
 namespace {
@@ -159,6 +168,31 @@ PairParams to_pair_params(const okvfe_stereo_pair& p) {
   q.cos6 = std::cos(6.0 * sigma);   // stereo_triangulation.cpp:127
   return q;
 }
+
+// RAII-free stage timer: records an event pair around a launch when profiling is on
+struct StageTimer {
+  okvfe_ctx* ctx;
+  hipStream_t s;
+  int idx = -1;
+  StageTimer(okvfe_ctx* c, int stage, hipStream_t st) : ctx(c), s(st) {
+    if (!c->profiling || c->prof_events.size() >= 65536) return;
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+      if (!c->event_pool.empty()) {
+        e[i] = c->event_pool.back();
+        c->event_pool.pop_back();
+      } else if (hipEventCreate(&e[i]) != hipSuccess) {
+        return;
+      }
+    }
+    c->prof_events.push_back({stage, e[0], e[1]});
+    idx = (int)c->prof_events.size() - 1;
+    (void)hipEventRecord(e[0], s);
+  }
+  ~StageTimer() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof_events[idx].b, s);
+  }
+};
 
 hipStream_t pick_stream(okvfe_ctx* ctx, void* stream) {
   return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
@@ -325,6 +359,11 @@ void okvfe_destroy(okvfe_ctx* ctx) {
     if (p) (void)hipFree(p);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  for (auto& e : ctx->prof_events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -375,7 +414,11 @@ okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev
   if (!images_dev || !scores_dev || n_images < 0)
     return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_harris_score_device: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, pick_stream(ctx, stream));
+  {
+    hipStream_t s = pick_stream(ctx, stream);
+    StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+    launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return OKVFE_OK;
 }
@@ -431,20 +474,43 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
   if (st != OKVFE_OK) return st;
   const int w = ctx->w, h = ctx->h;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, n_images * sizeof(int32_t), s));
-  launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
-  launch_nms(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap,
-             ctx->d_cand_count, s);
-  launch_select(ctx->d_scores, w, h, n_images, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count,
-                ctx->cfg.uniformity_radius, ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ,
-                ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols, ctx->d_kps_det, ctx->kp_cap,
-                ctx->d_det_count, ctx->d_sort_ws, s);
-  launch_integral(images_dev, w, h, n_images, ctx->d_integral, s);
-  launch_describe(images_dev, ctx->d_integral, w, h, n_images, ctx->d_pattern, ctx->d_prm,
-                  ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
-                  ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
-  launch_compact(n_images, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp,
-                 ctx->d_det_count, ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv,
-                 ctx->d_count, s);
+  {
+    StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+    launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
+  }
+  {
+    StageTimer t(ctx, OKVFE_STAGE_NMS, s);
+    launch_nms(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap,
+               ctx->d_cand_count, s);
+  }
+  {
+    StageTimer t(ctx, OKVFE_STAGE_SORT, s);
+    launch_sort(ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, n_images, ctx->cfg.uniformity_radius,
+                ctx->d_sort_ws, s);
+  }
+  {
+    StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
+    launch_select(ctx->d_scores, w, h, n_images, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count,
+                  ctx->cfg.uniformity_radius, ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ,
+                  ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols, ctx->d_kps_det, ctx->kp_cap,
+                  ctx->d_det_count, ctx->d_sort_ws, s);
+  }
+  {
+    StageTimer t(ctx, OKVFE_STAGE_INTEGRAL, s);
+    launch_integral(images_dev, w, h, n_images, ctx->d_integral, s);
+  }
+  {
+    StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
+    launch_describe(images_dev, ctx->d_integral, w, h, n_images, ctx->d_pattern, ctx->d_prm,
+                    ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
+  }
+  {
+    StageTimer t(ctx, OKVFE_STAGE_COMPACT, s);
+    launch_compact(n_images, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp,
+                   ctx->d_det_count, ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv,
+                   ctx->d_count, s);
+  }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_n_images = n_images;
   ctx->last_stream = s;
@@ -536,6 +602,7 @@ okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride, o
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, sizeof(int32_t), s));
   launch_harris(ctx->d_img_stage, w, h, 1, ctx->d_scores, s);
   launch_nms(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, s);
+  launch_sort(ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, 1, ctx->cfg.uniformity_radius, ctx->d_sort_ws, s);
   launch_select(ctx->d_scores, w, h, 1, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, ctx->cfg.uniformity_radius,
                 ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ, ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols,
                 ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_sort_ws, s);
@@ -586,8 +653,11 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
     HIP_TRY(ctx, hipStreamSynchronize(s));
     ctx->h_pairs_last = pp;
   }
-  launch_match_stereo(ctx->d_pairs, n_pairs, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count,
-                      ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
+  {
+    StageTimer t(ctx, OKVFE_STAGE_MATCH, s);
+    launch_match_stereo(ctx->d_pairs, n_pairs, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count,
+                        ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
+  }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
   return OKVFE_OK;
@@ -719,6 +789,40 @@ okvfe_status okvfe_hamming_argmin(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, 
   HIP_TRY(ctx, hipMemcpyAsync(best_j, base + o_j, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(best_dist, base + o_d, (size_t)nA * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
+// ---- stage profiling -------------------------------------------------------------------------
+okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& e : ctx->prof_events) {
+    ctx->event_pool.push_back(e.a);
+    ctx->event_pool.push_back(e.b);
+  }
+  ctx->prof_events.clear();
+  ctx->profiling = enable != 0;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_profile_read(okvfe_ctx* ctx, double total_ms[OKVFE_STAGE_COUNT],
+                                int32_t launches[OKVFE_STAGE_COUNT]) {
+  if (!ctx || !total_ms || !launches) return OKVFE_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < OKVFE_STAGE_COUNT; ++i) {
+    total_ms[i] = 0.0;
+    launches[i] = 0;
+  }
+  for (auto& e : ctx->prof_events) {
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e.a, e.b));
+    total_ms[e.stage] += (double)ms;
+    launches[e.stage] += 1;
+  }
   return OKVFE_OK;
 }
 

@@ -74,6 +74,8 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
                    hipStream_t stream);
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
+void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
+                 float radius, uint64_t* sort_ws, hipStream_t stream);
 void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
