@@ -129,6 +129,14 @@ okvfe_status okvfe_set_camera(okvfe_ctx* ctx, int32_t cam, const okvfe_camera* c
 okvfe_status okvfe_build_awareness_maps(const okvfe_camera* camera, float* rays_hw3,
                                         float* jacobians_hw6);
 
+/* Host helper: field-of-view overlap of `camera` as seen by `other`
+ * (= NCameraSystem::computeOverlaps, okvis_cv/src/NCameraSystem.cpp:48-119; decides which
+ * camera pairs matchStereo visits, Frontend.cpp:1998).  R_other_cam = rotation part of
+ * T_Cother_C, row-major.  mask_hw (H*W of `camera`, 1 = visible) may be NULL. */
+okvfe_status okvfe_camera_overlap(const okvfe_camera* camera, const okvfe_camera* other,
+                                  const double R_other_cam[9], uint8_t* mask_hw,
+                                  int32_t* has_overlap);
+
 /* ---- detect + describe, host buffers (cv::Feature2D-shaped) -------------- */
 /* One image: detect(), compute() and Frame::computeBackProjections in one
  * call.  gravity_C = extraction direction (gravity in the camera frame,

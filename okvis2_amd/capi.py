@@ -66,7 +66,7 @@ EXPORTS = [
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
-    "okvfe_profile_enable", "okvfe_profile_read",
+    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -140,6 +140,17 @@ def build_awareness_maps(cam):
     if st != OK:
         raise OkvfeError(st, lib().okvfe_last_error(None).decode())
     return rays, jac
+
+
+def camera_overlap(cam, other, R_other_cam, want_mask=False):
+    c, o = make_camera(cam), make_camera(other)
+    R = (C.c_double * 9)(*[float(v) for v in np.asarray(R_other_cam).reshape(-1)])
+    mask = np.zeros((cam.h, cam.w), dtype=np.uint8) if want_mask else None
+    has = C.c_int32()
+    st = lib().okvfe_camera_overlap(C.byref(c), C.byref(o), R, _p(mask), C.byref(has))
+    if st != OK:
+        raise OkvfeError(st, lib().okvfe_last_error(None).decode())
+    return (bool(has.value), mask) if want_mask else bool(has.value)
 
 
 class Frontend:

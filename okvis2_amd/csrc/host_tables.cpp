@@ -197,7 +197,7 @@ bool undistort(const okvfe_camera& cam, Vec2 pd, Vec2* out) {
 }
 
 // status 0 = Successful (only that one matters here)
-int project(const okvfe_camera& cam, const double p[3], double J23[6]) {
+int project_point(const okvfe_camera& cam, const double p[3], double* out_x, double* out_y, double J23[6]) {
   if (std::fabs(p[2]) < 1.0e-12) return 4;
   const double rz = 1.0 / p[2];
   const double rz2 = rz * rz;
@@ -212,6 +212,8 @@ int project(const okvfe_camera& cam, const double p[3], double J23[6]) {
   J23[5] = -cam.fv * (p[0] * D.c + p[1] * D.d) * rz2;
   const double px = cam.fu * dist.x + cam.cu;
   const double py = cam.fv * dist.y + cam.cv;
+  *out_x = px;
+  *out_y = py;
   if (px < 0.0 || py < 0.0) return 1;
   if (px >= static_cast<double>(cam.width) || py >= static_cast<double>(cam.height)) return 1;
   return p[2] > 0.0 ? 0 : 3;
@@ -229,6 +231,30 @@ bool host_backproject(const okvfe_camera& cam, double px, double py, double dir[
   return ok;
 }
 
+// = NCameraSystem::computeOverlaps for one ordered camera pair (okvis_cv/src/NCameraSystem.cpp:48-119)
+bool camera_overlap(const okvfe_camera& cam, const okvfe_camera& other, const double R[9], uint8_t* mask) {
+  bool any = false;
+  for (int u = 0; u < cam.width; ++u) {
+    for (int v = 0; v < cam.height; ++v) {
+      double ray[3], ro[3], ver[3], J[6];
+      host_backproject(cam, static_cast<double>(u), static_cast<double>(v), ray);
+      for (int i = 0; i < 3; ++i) ro[i] = R[3 * i] * ray[0] + R[3 * i + 1] * ray[1] + R[3 * i + 2] * ray[2];
+      bool hit = false;
+      double px = 0.0, py = 0.0;
+      if (project_point(other, ro, &px, &py, J) == 0) {
+        host_backproject(other, px, py, ver);
+        const double na = std::sqrt(ro[0] * ro[0] + ro[1] * ro[1] + ro[2] * ro[2]);
+        const double nb = std::sqrt(ver[0] * ver[0] + ver[1] * ver[1] + ver[2] * ver[2]);
+        const double dot = (ro[0] / na) * (ver[0] / nb) + (ro[1] / na) * (ver[1] / nb) + (ro[2] / na) * (ver[2] / nb);
+        hit = std::fabs(dot - 1.0) < 1.0e-10;
+      }
+      if (mask) mask[static_cast<size_t>(v) * cam.width + u] = hit ? 1 : 0;
+      any = any || hit;
+    }
+  }
+  return any;
+}
+
 void build_awareness_maps(const okvfe_camera& cam, float* rays, float* jac) {
   for (int v = 0; v < cam.height; ++v) {
     for (int u = 0; u < cam.width; ++u) {
@@ -244,7 +270,8 @@ void build_awareness_maps(const okvfe_camera& cam, float* rays, float* jac) {
       const size_t px = static_cast<size_t>(v) * cam.width + u;
       for (int i = 0; i < 3; ++i) rays[px * 3 + i] = static_cast<float>(ray[i]);
       double J[6];
-      const bool ok = project(cam, ray, J) == 0;
+      double qx, qy;
+      const bool ok = project_point(cam, ray, &qx, &qy, J) == 0;
       // the reference leaves failed entries uninitialised; they are defined as zero here and
       // never read for a kept keypoint (a zero ray removes the keypoint)
       for (int i = 0; i < 6; ++i) jac[px * 6 + i] = ok ? static_cast<float>(J[i]) : 0.0f;

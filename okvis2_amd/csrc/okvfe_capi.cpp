@@ -227,6 +227,14 @@ okvfe_status okvfe_build_awareness_maps(const okvfe_camera* camera, float* rays_
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_camera_overlap(const okvfe_camera* camera, const okvfe_camera* other,
+                                  const double R_other_cam[9], uint8_t* mask_hw, int32_t* has_overlap) {
+  if (!camera || !other || !R_other_cam || !has_overlap || camera->width <= 0 || camera->height <= 0)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_camera_overlap: bad argument");
+  *has_overlap = camera_overlap(*camera, *other, R_other_cam, mask_hw) ? 1 : 0;
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
   if (!cfg || !out) return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: null argument");
   *out = nullptr;

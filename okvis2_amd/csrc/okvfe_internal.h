@@ -34,6 +34,8 @@ struct Pattern {
 void build_pattern(Pattern* p);
 void build_uniformity_lut(float lut[31 * 31]);
 void build_awareness_maps(const okvfe_camera& cam, float* rays_hw3, float* jac_hw6);
+bool camera_overlap(const okvfe_camera& cam, const okvfe_camera& other, const double R_other_cam[9],
+                    uint8_t* mask_hw);
 bool host_backproject(const okvfe_camera& cam, double px, double py, double dir[3]);
 
 struct Candidate {  // NMS maximum

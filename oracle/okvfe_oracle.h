@@ -125,6 +125,8 @@ int orc_cam_backproject(const orc_camera* c, const double pt[2], double dir[3]);
 /* status: 0 Successful, 1 OutsideImage, 2 Masked, 3 Behind, 4 Invalid */
 int orc_cam_project(const orc_camera* c, const double p[3], double pt[2], double J23[6]);
 void orc_cam_awareness_maps(const orc_camera* c, float* rays_hw3, float* jac_hw6);
+int orc_cam_overlap(const orc_camera* c, const orc_camera* o, const double R_other_c[9],
+                    uint8_t* mask_hw);
 int orc_backproject_keypoints(const orc_camera* c, const orc_keypoint* kps, int n,
                               double* dirs_n3, uint8_t* valid);
 

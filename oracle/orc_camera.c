@@ -215,3 +215,32 @@ int orc_backproject_keypoints(const orc_camera* c, const orc_keypoint* kps, int 
   }
   return ctr;
 }
+
+/* Field-of-view overlap of camera `c` as seen by camera `o` (NCameraSystem::computeOverlaps,
+ * okvis_cv/src/NCameraSystem.cpp:48-119): every pixel of c is back-projected, rotated by
+ * R = C(T_Cother_C) (points at infinity), projected into o, and counted when the projection is
+ * Successful and back-projects onto the same direction (|cos - 1| < 1e-10).  mask (h*w of c) may
+ * be NULL.  Returns hasOverlap. */
+int orc_cam_overlap(const orc_camera* c, const orc_camera* o, const double R[9], uint8_t* mask) {
+  int has = 0;
+  for (int u = 0; u < c->w; ++u) {
+    for (int v = 0; v < c->h; ++v) {
+      double ray[3], ro[3], pt[2], ver[3];
+      const double p[2] = {(double)u, (double)v};
+      orc_cam_backproject(c, p, ray);
+      for (int i = 0; i < 3; ++i) ro[i] = R[3 * i] * ray[0] + R[3 * i + 1] * ray[1] + R[3 * i + 2] * ray[2];
+      int hit = 0;
+      if (orc_cam_project(o, ro, pt, NULL) == 0) {
+        orc_cam_backproject(o, pt, ver);
+        const double na = sqrt(ro[0] * ro[0] + ro[1] * ro[1] + ro[2] * ro[2]);
+        const double nb = sqrt(ver[0] * ver[0] + ver[1] * ver[1] + ver[2] * ver[2]);
+        const double dot = (ro[0] / na) * (ver[0] / nb) + (ro[1] / na) * (ver[1] / nb) +
+                           (ro[2] / na) * (ver[2] / nb);
+        if (fabs(dot - 1.0) < 1.0e-10) hit = 1;
+      }
+      if (mask) mask[(size_t)v * c->w + u] = (uint8_t)hit;
+      has |= hit;
+    }
+  }
+  return has;
+}

@@ -176,9 +176,10 @@ int orc_uniformity_select(orc_point_score* pts, int n, int w, int h, float radiu
  * in 64-bit integers (Harris scores overflow 32-bit products), the Hessian
  * determinant and the numerators in double, divisions in float. */
 void orc_subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
-  const int64_t s00 = s[0], s01 = s[1], s02 = s[2];
-  const int64_t s10 = s[3], s11 = s[4], s12 = s[5];
-  const int64_t s20 = s[6], s21 = s[7], s22 = s[8];
+  /* s_i_j of the published formula = score(x-1+i, y-1+j): first index along x */
+  const int64_t s00 = s[0], s01 = s[3], s02 = s[6];
+  const int64_t s10 = s[1], s11 = s[4], s12 = s[7];
+  const int64_t s20 = s[2], s21 = s[5], s22 = s[8];
   const int64_t tmp1 = s00 + s02 - 2 * s11 + s20 + s22;
   const int64_t c1 = 3 * (tmp1 + s01 - ((s10 + s12) * 2) + s21);
   const int64_t c2 = 3 * (tmp1 - ((s01 + s21) * 2) + s10 + s12);

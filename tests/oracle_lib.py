@@ -185,6 +185,14 @@ def awareness_maps(cam):
     return rays, jac
 
 
+def cam_overlap(cam, other, R_other_cam, want_mask=False):
+    c, o = make_camera(cam), make_camera(other)
+    R = (C.c_double * 9)(*[float(v) for v in np.asarray(R_other_cam).reshape(-1)])
+    mask = np.zeros((cam.h, cam.w), dtype=np.uint8) if want_mask else None
+    has = lib().orc_cam_overlap(C.byref(c), C.byref(o), R, _p(mask))
+    return (bool(has), mask) if want_mask else bool(has)
+
+
 def backproject_keypoints(cam, kps):
     c = make_camera(cam)
     n = len(kps)

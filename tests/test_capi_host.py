@@ -1,0 +1,99 @@
+"""No-GPU checks of the drop-in boundary: libokvfe.so loads, exports every symbol that
+include/okvfe.h declares, its struct layouts match the ctypes mirror, and -- without a GPU --
+the compute entry points fail loudly instead of falling back to any CPU path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from okvis2_amd import capi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "okvfe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(okvfe_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = C.CDLL(capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the Python mirror knows all of them
+    assert sorted(capi.EXPORTS) == names
+
+
+def test_abi_version_and_struct_layouts():
+    lib = capi.lib()
+    assert lib.okvfe_abi_version() == capi.ABI_VERSION
+    assert C.sizeof(capi.Config) == 14 * 4
+    assert capi.KEYPOINT_DTYPE.itemsize == 28            # cv::KeyPoint: 5 floats + 2 ints
+    assert capi.STEREO_MATCH_DTYPE.itemsize == 48
+    assert C.sizeof(capi.Pose) == 96 and C.sizeof(capi.Camera) == 80
+    assert C.sizeof(capi.StereoPair) == 8 + 2 * 96 + 16
+
+
+def test_no_silent_cpu_fallback():
+    """On a machine without a usable gfx950 device okvfe_create must fail with
+    OKVFE_ERR_NO_DEVICE (the GPU box runs the -m gpu tests instead)."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(capi.OkvfeError) as e:
+        capi.Frontend(752, 480, 38.0, 0, 150, 700)
+    assert e.value.status == capi.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value) or "device" in str(e.value)
+
+
+def test_argument_validation_precedes_device_probe():
+    for kw, status in ((dict(octaves=2), capi.ERR_UNSUPPORTED),
+                       (dict(scale_invariant=True), capi.ERR_UNSUPPORTED),
+                       (dict(absolute_threshold=0), capi.ERR_INVALID_ARGUMENT),
+                       (dict(max_keypoints=5000), capi.ERR_INVALID_ARGUMENT),
+                       (dict(width=32), capi.ERR_INVALID_ARGUMENT)):
+        args = dict(width=752, height=480, uniformity_radius=38.0, octaves=0, absolute_threshold=150,
+                    max_keypoints=700)
+        args.update(kw)
+        with pytest.raises(capi.OkvfeError) as e:
+            capi.Frontend(**args)
+        assert e.value.status == status, kw
+
+
+def test_product_never_imports_the_oracle():
+    """The package and the native sources must not reference oracle/ (checked textually)."""
+    pkg = os.path.join(ROOT, "okvis2_amd")
+    bad = []
+    for dp, _, files in os.walk(pkg):
+        if "build" in dp:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"oracle_lib|okvfe_oracle|liboracle|orc_[a-z]+\(", t):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_synthetic_inputs_are_deterministic():
+    a = synth.corners_image(752, 480, 5)
+    b = synth.corners_image(752, 480, 5)
+    assert np.array_equal(a, b) and a.dtype == np.uint8 and a.shape == (480, 752)
+    assert not np.array_equal(a, synth.corners_image(752, 480, 6))
+    L, R, d = synth.stereo_pair(752, 480, 9)
+    assert 4 <= d <= 40
+    # the right image is the left content shifted by the disparity (up to +-2 sensor noise)
+    diff = np.abs(L[:, d:].astype(int) - R[:, :752 - d].astype(int))
+    assert diff.max() <= 2
+    for mk in (synth.euroc_config, synth.mono640_config, synth.tumvi1024_config, synth.hilti_config):
+        cfg = mk()
+        assert all(c.w == cfg.w and c.h == cfg.h for c in cfg.cams)

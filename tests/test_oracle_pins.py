@@ -1,0 +1,176 @@
+"""Pins the CPU oracle against every known answer the reference tree offers for the path
+ -- these run without a GPU.
+
+ * Hamming: popcnt(x^x)=0, popcnt(x^~x)=384 and the statistics of the 819 REAL BRISK2 descriptors
+   of the reference's vocabulary resources/small_voc.yml.gz (fixture tests/golden/small_voc_desc.bin,
+   extracted by tools/make_voc_fixture.py).
+ * Camera model: the tolerances of okvis_cv/test/TestPinholeCamera.cpp:52-140 on the reference's
+   createTestObject() cameras (PinholeCamera.hpp:389-393, distortion testObject()s).
+ * FoV overlap truth table of okvis_cv/test/TestNCameraSystem.cpp:55-112.
+ * triangulateFast (okvis_frontend/src/stereo_triangulation.cpp:50-132): intersecting, parallel,
+   diverging rays.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from okvis2_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def voc():
+    return np.fromfile(os.path.join(GOLDEN, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+
+
+def test_popcnt_known_answers(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        x = rng.integers(0, 256, 48, dtype=np.uint8)
+        assert oracle.popcnt_xor(x, x) == 0
+        assert oracle.popcnt_xor(x, ~x) == 384
+        y = rng.integers(0, 256, 48, dtype=np.uint8)
+        assert oracle.popcnt_xor(x, y) == int(np.unpackbits(x ^ y).sum())
+        assert oracle.popcnt_xor(x, y, 1) == int(np.unpackbits((x ^ y)[:16]).sum())
+
+
+def test_vocabulary_descriptor_statistics(oracle):
+    """Values measured on the reference's own data file."""
+    d = voc()
+    assert d.shape == (819, 48)
+    bits = np.unpackbits(d, axis=1).astype(np.int32)
+    assert abs(bits.mean() - 0.498) < 0.002
+    dist = bits @ (1 - bits).T
+    dist = dist + dist.T  # pairwise Hamming
+    iu = np.triu_indices(819, 1)
+    pd = dist[iu]
+    assert pd.min() == 8 and pd.max() == 372
+    assert abs(pd.mean() - 191.9) < 0.1
+    assert abs((pd < 60).mean() - 0.0027) < 0.0003
+    # the oracle's popcount and its matchers agree with the numpy bit count on the real data
+    rng = np.random.default_rng(1)
+    for i, j in rng.integers(0, 819, (50, 2)):
+        assert oracle.popcnt_xor(d[i], d[j]) == dist[i, j]
+    cand = oracle.hamming_candidates(d[:200], d[200:500], 60)
+    ii, jj = np.nonzero(dist[:200, 200:500] < 60)
+    assert np.array_equal(cand["i"], ii) and np.array_equal(cand["j"], jj)
+    assert np.array_equal(cand["dist"], dist[:200, 200:500][ii, jj])
+    bj, bd = oracle.hamming_argmin(d[:200], d[200:500], 60)
+    sub = dist[:200, 200:500]
+    want_d = np.minimum(sub.min(1), 60)
+    want_j = np.where(sub.min(1) < 60, sub.argmin(1), -1)
+    assert np.array_equal(bd, want_d) and np.array_equal(bj, want_j)
+
+
+def test_host_popcnt_of_product_library_matches(oracle):
+    """okvfe_popcnt_xor is a host function of libokvfe.so (no GPU needed)."""
+    from okvis2_amd import capi
+    d = voc()
+    for i in range(0, 800, 37):
+        assert capi.popcnt_xor(d[i], d[i + 1]) == oracle.popcnt_xor(d[i], d[i + 1])
+        assert capi.popcnt_xor(d[i], d[i + 1], 1) == oracle.popcnt_xor(d[i], d[i + 1], 1)
+
+
+def _test_cameras():
+    # createTestObject(): 752x480, f=(350,360), c=(378,238); distortion testObject() values
+    return [synth.Camera(752, 480, 350.0, 360.0, 378.0, 238.0, 0, (0.0, 0.0, 0.0, 0.0)),
+            synth.Camera(752, 480, 350.0, 360.0, 378.0, 238.0, 1, (-0.16, 0.15, 0.0003, 0.0002)),
+            synth.Camera(752, 480, 350.0, 360.0, 378.0, 238.0, 2, (-0.21, 0.14, 0.0006, 0.0003))]
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_pinhole_roundtrip_and_jacobian(oracle, ci):
+    cam = _test_cameras()[ci]
+    rng = np.random.default_rng(42 + ci)
+    for _ in range(100):
+        # createRandomImagePoint(): uniform inside the image with a margin
+        pt = np.array([rng.uniform(0.1 * cam.w, 0.9 * cam.w), rng.uniform(0.1 * cam.h, 0.9 * cam.h)])
+        ok, ray = oracle.cam_backproject(cam, pt)
+        assert ok
+        ray = ray / np.linalg.norm(ray) * (0.2 + 8 * (rng.uniform(-1, 1) + 1.0))
+        st, pt2, J = oracle.cam_project(cam, ray, want_jac=True)
+        assert st == 0
+        assert np.linalg.norm(pt2 - pt) < 0.01
+        dp = 1.0e-7
+        Jn = np.zeros((2, 3))
+        for d in range(3):
+            e = np.zeros(3)
+            e[d] = dp
+            _, pp, _ = oracle.cam_project(cam, ray + e)
+            _, pm, _ = oracle.cam_project(cam, ray - e)
+            Jn[:, d] = (pp - pm) / (2 * dp)
+        assert np.linalg.norm(Jn - J) < 1e-4
+
+
+def test_projection_status_codes(oracle):
+    cam = _test_cameras()[1]
+    assert oracle.cam_project(cam, (0.0, 0.0, 1.0))[0] == 0       # Successful
+    assert oracle.cam_project(cam, (0.0, 0.0, 1e-13))[0] == 4     # Invalid
+    assert oracle.cam_project(cam, (5.0, 0.0, 1.0))[0] == 1       # OutsideImage
+    assert oracle.cam_project(cam, (0.0, 0.0, -1.0))[0] == 3      # Behind
+
+
+def test_fov_overlap_truth_table(oracle):
+    """TestNCameraSystem.cpp:73-112: cameras 0/1 look the same way, camera 2 the opposite way
+    (quaternion (w,x,y,z) = (0,0,1,0) = 180 deg about y)."""
+    cams = _test_cameras()
+    # the test cameras are subsampled 4x for speed; intrinsics scaled accordingly
+    small = [synth.Camera(c.w // 4, c.h // 4, c.fu / 4, c.fv / 4, c.cu / 4, c.cv / 4, c.dist_type, c.d)
+             for c in cams]
+    eye = np.eye(3)
+    flip = np.diag([-1.0, 1.0, -1.0])
+    C_SC = [eye, eye, flip]
+    expect = {(0, 1): True, (1, 0): True, (1, 2): False, (2, 1): False, (0, 2): False, (2, 0): False}
+    for (seen_by, idx), want in expect.items():
+        R = C_SC[seen_by].T @ C_SC[idx]  # rotation of T_Cother_C = T_SC[seen_by]^-1 * T_SC[idx]
+        assert oracle.cam_overlap(small[idx], small[seen_by], R) == want, (seen_by, idx)
+    # the product's host helper computes the same masks (host code, no GPU needed)
+    from okvis2_amd import capi
+    has, mask = capi.camera_overlap(small[1], small[0], eye, want_mask=True)
+    has_o, mask_o = oracle.cam_overlap(small[1], small[0], eye, want_mask=True)
+    assert has == has_o and np.array_equal(mask, mask_o) and mask.mean() > 0.5
+
+
+def test_awareness_maps_product_host_vs_oracle(oracle):
+    """Input preparation is host code on both sides and must agree bit for bit."""
+    from okvis2_amd import capi
+    for cam in (_test_cameras()[1], synth.Camera(160, 120, 80.0, 82.0, 81.0, 59.0, 2,
+                                                 (-0.0369, -0.0089, 0.0089, -0.0037))):
+        if cam.w > 200:
+            cam = synth.Camera(188, 120, cam.fu / 4, cam.fv / 4, cam.cu / 4, cam.cv / 4,
+                               cam.dist_type, cam.d)
+        r0, j0 = oracle.awareness_maps(cam)
+        r1, j1 = capi.build_awareness_maps(cam)
+        assert np.array_equal(r0.view(np.uint32), r1.view(np.uint32))
+        assert np.array_equal(j0.view(np.uint32), j1.view(np.uint32))
+        c = r0[cam.h // 2, cam.w // 2]
+        assert abs(np.linalg.norm(c) - 1.0) < 1e-6 and c[2] > 0.99
+
+
+def test_triangulate_fast_cases(oracle):
+    sigma = 12.0 / 458.0 * 0.125
+    p1, p2 = np.zeros(3), np.array([0.11, 0.0, 0.0])
+    X = np.array([0.3, -0.2, 4.0])
+    e1, e2 = (X - p1) / np.linalg.norm(X - p1), (X - p2) / np.linalg.norm(X - p2)
+    hp, valid, par = oracle.triangulate_fast(p1, e1, p2, e2, sigma)
+    assert valid and not par and np.allclose(hp[:3] / hp[3], X, atol=1e-9)
+    # identical directions: A not invertible -> parallel, valid, point far along the ray
+    hp, valid, par = oracle.triangulate_fast(p1, e1, p2, e1, sigma)
+    assert par and valid and hp[3] == 1.0 and np.linalg.norm(hp[:3]) > 0.3
+    # far point (1 km): rays intersect but nearly parallel -> flagged parallel, still valid
+    Xf = np.array([10.0, 5.0, 1000.0])
+    f1, f2 = (Xf - p1) / np.linalg.norm(Xf - p1), (Xf - p2) / np.linalg.norm(Xf - p2)
+    hp, valid, par = oracle.triangulate_fast(p1, f1, p2, f2, sigma)
+    assert valid and par
+    # diverging rays (intersection behind the cameras): lambda < 0.01 -> parallel branch, and the
+    # mid-ray check fails -> invalid
+    d1 = np.array([-0.3, 0.0, 1.0]) / np.linalg.norm([-0.3, 0.0, 1.0])
+    d2 = np.array([0.3, 0.0, 1.0]) / np.linalg.norm([0.3, 0.0, 1.0])
+    hp, valid, par = oracle.triangulate_fast(p1, d1, p2, d2, sigma)
+    assert par and not valid
+    # skew rays that miss each other by much more than sigma -> invalid
+    s2 = np.array([0.3, 0.4, 4.0]) - p2
+    s2 /= np.linalg.norm(s2)
+    hp, valid, par = oracle.triangulate_fast(p1, e1, p2, s2, sigma)
+    assert not valid
