@@ -1,0 +1,102 @@
+"""GPU: (1) the HIP path against the COMMITTED golden vectors (tests/golden/frontend_golden.npz),
+(2) the cross-camera gather path: device-side block packing, an RCCL all-gather (nccl backend,
+world size 1 on the single-GPU box) and matching on gathered blocks, against the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from okvis2_amd import capi, multigpu, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "frontend_golden.npz")
+
+
+def _gold():
+    g = np.load(GOLDEN)
+    W, H, radius, thr, maxk, mthr = g["params"]
+    cams = [synth.Camera(int(W), int(H), c[0], c[1], c[2], c[3], int(c[4]), tuple(c[5:9]))
+            for c in g["cams"]]
+    return g, int(W), int(H), float(radius), int(thr), int(maxk), int(mthr), cams
+
+
+def test_hip_path_reproduces_golden_vectors():
+    g, W, H, radius, thr, maxk, mthr, cams = _gold()
+    for rot, name in ((False, "upright"), (True, "gradient")):
+        fe = capi.Frontend(W, H, radius, 0, thr, maxk, rotation_invariant=rot, match_threshold=mthr)
+        for ci, key in enumerate(("left", "right")):
+            assert np.array_equal(fe.detect(g[key]).view(np.uint8), g[f"kp_detect_{ci}"].view(np.uint8))
+            k, d, _, _ = fe.detect_describe(g[key])
+            assert np.array_equal(k.view(np.uint8), g[f"kp_{name}_{ci}"].view(np.uint8))
+            assert np.array_equal(d, g[f"desc_{name}_{ci}"])
+    fe = capi.Frontend(W, H, radius, 0, thr, maxk, match_threshold=mthr, num_cameras=2)
+    res = []
+    for ci, key in enumerate(("left", "right")):
+        fe.set_camera(ci, cams[ci])
+        k, d, bp, bv = fe.detect_describe(g[key], cam=ci, gravity=(0.1, 0.98, -0.05))
+        assert np.array_equal(k.view(np.uint8), g[f"kp_aware_{ci}"].view(np.uint8))
+        assert np.array_equal(d, g[f"desc_aware_{ci}"])
+        assert np.array_equal(bp.view(np.uint64), g[f"bp_{ci}"].view(np.uint64))
+        assert np.array_equal(bv, g[f"bpv_{ci}"])
+        res.append((k, d, bp, bv))
+    T0, T1 = synth.stereo_poses(0.11)
+    f0, f1 = 0.5 * (cams[0].fu + cams[0].fv), 0.5 * (cams[1].fu + cams[1].fv)
+    (k0, d0, b0, v0), (k1, d1, b1, v1) = res
+    m = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1)
+    assert np.array_equal(m.view(np.uint8), g["match_stereo"].view(np.uint8))
+    # noise frame with the reference's smoke-test detector parameters (TestFrame.cpp:75-77)
+    fe2 = capi.Frontend(W, H, 34.0, 0, 800, 450)
+    assert np.array_equal(fe2.detect(g["noise"]).view(np.uint8), g["kp_noise"].view(np.uint8))
+    # score map
+    d_img = torch.from_numpy(g["left"]).cuda()
+    d_sc = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    fe.harris_score_device(d_img.data_ptr(), 1, d_sc.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_sc.cpu().numpy(), g["score_left"])
+
+
+def test_gather_blocks_rccl_and_block_matching(oracle):
+    import torch.distributed as dist
+    g, W, H, radius, thr, maxk, mthr, cams = _gold()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        fe = capi.Frontend(W, H, radius, 0, thr, maxk, match_threshold=mthr, num_cameras=2, max_batch=2)
+        for ci in range(2):
+            fe.set_camera(ci, cams[ci])
+        imgs = torch.from_numpy(np.stack([g["left"], g["right"]])).cuda()
+        grav = np.tile(np.array([0.1, 0.98, -0.05], dtype=np.float32), (2, 1))
+        stream = torch.cuda.current_stream().cuda_stream
+        fe.detect_describe_batch_device(imgs.data_ptr(), 2, np.array([0, 1], dtype=np.int32), grav, stream)
+        nb = fe.gather_block_bytes()
+        assert nb == multigpu.block_layout(maxk)["total"]
+        local = torch.zeros((2, nb), dtype=torch.uint8, device="cuda")
+        for i in range(2):
+            fe.pack_gather_block_device(i, local[i].data_ptr(), stream)
+        allb = multigpu.all_gather_blocks(local)  # RCCL all-gather, world size 1
+        assert allb.shape == (1, 2, nb)
+        host = allb.cpu().numpy()
+        for ci in range(2):
+            k, d, bp, bv = multigpu.unpack_block_host(host[0, ci], maxk)
+            assert np.array_equal(k.view(np.uint8), g[f"kp_aware_{ci}"].view(np.uint8))
+            assert np.array_equal(d, g[f"desc_aware_{ci}"])
+            assert np.array_equal(bp.view(np.uint64), g[f"bp_{ci}"].view(np.uint64))
+            assert np.array_equal(bv, g[f"bpv_{ci}"])
+        T0, T1 = synth.stereo_poses(0.11)
+        f0, f1 = 0.5 * (cams[0].fu + cams[0].fv), 0.5 * (cams[1].fu + cams[1].fv)
+        d_m = torch.zeros((maxk, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+        fe.match_stereo_blocks_device(allb[0, 0].data_ptr(), allb[0, 1].data_ptr(), T0, T1, f0, f1,
+                                      d_m.data_ptr(), stream)
+        torch.cuda.synchronize()
+        n0 = len(g["kp_aware_0"])
+        m = d_m.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(-1)[:n0]
+        assert np.array_equal(m.view(np.uint8), g["match_stereo"].view(np.uint8))
+    finally:
+        dist.destroy_process_group()
