@@ -152,6 +152,15 @@ okvfe_status okvfe_detect_describe(okvfe_ctx* ctx, const uint8_t* image, size_t 
 okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride,
                           okvfe_keypoint* keypoints, int32_t cap, int32_t* n_out);
 
+/* compute() only = cv::DescriptorExtractor::compute(image, keypoints, descriptors)
+ * (Frame.hpp:167): describes the n_in caller keypoints (in/out: the extractor
+ * removes keypoints too close to the rim, order preserved) and back-projects
+ * the survivors.  n_in <= max_keypoints. */
+okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, int32_t cam,
+                           const float gravity_C[3], okvfe_keypoint* keypoints, int32_t n_in,
+                           uint8_t* descriptors, double* backproj, uint8_t* backproj_valid,
+                           int32_t* n_out);
+
 /* ---- detect + describe, device-resident batches -------------------------- */
 /* images_dev: n_images contiguous H*W u8 images in HBM.  cam_ids /
  * gravity_C (n_images*3) are HOST arrays (NULL = not camera aware).

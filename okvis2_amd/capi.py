@@ -66,7 +66,7 @@ EXPORTS = [
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
-    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap",
+    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap", "okvfe_compute",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -222,6 +222,23 @@ class Frontend:
         self._check(lib().okvfe_detect_describe(self._h, _p(image), C.c_size_t(image.strides[0]),
                                                 int(cam), g, _p(kps), _p(desc), _p(bp), _p(bpv),
                                                 cap, C.byref(n)))
+        k = n.value
+        return kps[:k].copy(), desc[:k].copy(), bp[:k].copy(), bpv[:k].copy()
+
+    def compute(self, image, keypoints, cam=-1, gravity=None):
+        """cv::DescriptorExtractor::compute: describe the given keypoints (some may be removed)."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        kps = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE).copy()
+        n_in = len(kps)
+        if n_in == 0:
+            kps = np.zeros(1, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((max(n_in, 1), DESC_BYTES), dtype=np.uint8)
+        bp = np.zeros((max(n_in, 1), 3), dtype=np.float64)
+        bpv = np.zeros(max(n_in, 1), dtype=np.uint8)
+        n = C.c_int32()
+        g = None if gravity is None else (C.c_float * 3)(*[float(v) for v in gravity])
+        self._check(lib().okvfe_compute(self._h, _p(image), C.c_size_t(image.strides[0]), int(cam),
+                                        g, _p(kps), n_in, _p(desc), _p(bp), _p(bpv), C.byref(n)))
         k = n.value
         return kps[:k].copy(), desc[:k].copy(), bp[:k].copy(), bpv[:k].copy()
 

@@ -9,37 +9,78 @@
 // Roofline: HBM.  Algorithmic bytes per pixel = 1 (u8 in) + 4 (int32 out) = 5.
 // Mapping: one wave = a 256-pixel-wide column strip (4 px per lane, one aligned dword load per
 // lane per row = 256 B coalesced per wave, one 16 B store per lane per row = 1 KiB per wave);
-// the wave walks TH rows down the strip keeping a rolling 3-row window of pixels and of
+// the wave walks kTH rows down the strip keeping a rolling 3-row window of pixels and of
 // horizontally smoothed covariance entries in registers, so every pixel is fetched once per
-// strip (+4 halo rows per TH) and nothing is staged through LDS.  All products fit 24 bits
-// (|g| <= 4080, entries <= 16256), so the multiplies are full-rate v_mul_i32_i24 / v_mad_i32_i24.
+// strip (+4 halo rows per kTH) and nothing is staged through LDS.  The inner loop is branch-free:
+// rim handling is an AND with per-lane column masks and a wave-uniform row mask.  All products
+// fit 24 bits (|g| <= 4080, entries <= 16256), so the multiplies are the full-rate
+// v_mul_i32_i24 / v_mad_i32_i24 (emitted explicitly: the compiler otherwise falls back to the
+// quarter-rate v_mul_lo_u32 for loop-carried values whose range it cannot prove).
+#include <cstdlib>
+
 #include "okvfe_internal.h"
 
 namespace okvfe {
 
 namespace {
 
-constexpr int kTH = 32;          // output rows per wave
+constexpr int kTH = 32;  // output rows per wave
 constexpr int kWavesPerBlock = 4;
 
-__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ int mul24(int a, int b) {
+  int d;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int mad24_10(int a, int c) {  // a * 10 + c
+  int d;
+  asm("v_mad_i32_i24 %0, %1, 10, %2" : "=v"(d) : "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ int mul24_3(int a) {
+  int d;
+  asm("v_mul_i32_i24 %0, 3, %1" : "=v"(d) : "v"(a));
+  return d;
+}
 
-// pixels of columns x0-2 .. x0+5 of one row into p[0..7]
+// raw pixels of one row: ALIGNED = the three aligned dwords covering columns x0-4 .. x0+7,
+// otherwise 8 clamped byte loads packed into two dwords (columns x0-2 .. x0+5)
 template <bool ALIGNED>
-__device__ __forceinline__ void load_row(const uint8_t* __restrict__ img, int w, int h, int row,
-                                         int x0, int p[8]) {
-  row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
-  const uint8_t* rp = img + (size_t)row * w;
+__device__ __forceinline__ void load_raw(const uint8_t* __restrict__ img, int w, int h, int row,
+                                         int x0, int dl, int dc, int dr, uint32_t raw[3]) {
+  row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);  // wave-uniform
   if (ALIGNED) {
-    // w % 4 == 0 and the image base is 4-byte aligned: three aligned dwords, indices clamped
-    // (clamped lanes only feed masked rim entries)
-    const uint32_t* rq = reinterpret_cast<const uint32_t*>(rp);
-    const int nd = w >> 2;
-    int dc = x0 >> 2;
-    dc = dc > nd - 1 ? nd - 1 : dc;
-    const int dl = dc > 0 ? dc - 1 : 0;
-    const int dr = dc < nd - 1 ? dc + 1 : nd - 1;
-    const uint32_t L = rq[dl], C = rq[dc], R = rq[dr];
+    const uint32_t* rq = reinterpret_cast<const uint32_t*>(img + (size_t)row * (size_t)w);
+    raw[0] = rq[dl];
+    raw[1] = rq[dc];
+    raw[2] = rq[dr];
+  } else {
+    const uint8_t* rp = img + (size_t)row * (size_t)w;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c0 = x0 - 2 + i, c1 = x0 + 2 + i;
+      c0 = c0 < 0 ? 0 : (c0 > w - 1 ? w - 1 : c0);
+      c1 = c1 < 0 ? 0 : (c1 > w - 1 ? w - 1 : c1);
+      lo |= (uint32_t)rp[c0] << (8 * i);
+      hi |= (uint32_t)rp[c1] << (8 * i);
+    }
+    raw[0] = lo;
+    raw[1] = hi;
+    raw[2] = 0;
+  }
+}
+
+// raw -> pixels of columns x0-2 .. x0+5
+template <bool ALIGNED>
+__device__ __forceinline__ void unpack(const uint32_t raw[3], int p[8]) {
+  if (ALIGNED) {
+    const uint32_t L = raw[0], C = raw[1], R = raw[2];
     p[0] = (L >> 16) & 255;
     p[1] = (L >> 24);
     p[2] = C & 255;
@@ -50,35 +91,33 @@ __device__ __forceinline__ void load_row(const uint8_t* __restrict__ img, int w,
     p[7] = (R >> 8) & 255;
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int c = x0 - 2 + i;
-      c = c < 0 ? 0 : (c > w - 1 ? w - 1 : c);
-      p[i] = rp[c];
+    for (int i = 0; i < 4; ++i) {
+      p[i] = (raw[0] >> (8 * i)) & 255;
+      p[4 + i] = (raw[1] >> (8 * i)) & 255;
     }
   }
 }
 
 // Covariance entries of row g at columns x0-1 .. x0+4 from pixel rows a (g-1), b (g), c (g+1),
 // then the horizontal binomial [1 2 1] for the 4 output columns -> hs[3][4].
-__device__ __forceinline__ void cov_row(const int a[8], const int b[8], const int c[8], int g, int x0,
-                                        int w, int h, int hs[3][4]) {
+// cmask[i] = -1 where column x0-1+i is inside 1..w-2 (else 0); rmask = -1 for 1 <= g <= h-2.
+__device__ __forceinline__ void cov_row(const int a[8], const int b[8], const int c[8],
+                                        const int cmask[6], int rmask, int hs[3][4]) {
   int vs[8], vd[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    vs[i] = 3 * (a[i] + c[i]) + 10 * b[i];  // vertical (3,10,3)
-    vd[i] = c[i] - a[i];                     // vertical difference
+    vs[i] = mad24_10(b[i], mul24_3(a[i] + c[i]));  // vertical (3,10,3)
+    vd[i] = c[i] - a[i];                           // vertical difference
   }
   int gxx[6], gyy[6], gxy[6];
-  const bool row_ok = (g >= 1) && (g <= h - 2);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const int col = x0 - 1 + i;
-    const int gx = vs[i + 2] - vs[i];
-    const int gy = 3 * (vd[i] + vd[i + 2]) + 10 * vd[i + 1];
-    const bool ok = row_ok && (col >= 1) && (col <= w - 2);
-    gxx[i] = ok ? (mul24(gx, gx) >> 14) : 0;
-    gyy[i] = ok ? (mul24(gy, gy) >> 14) : 0;
-    gxy[i] = ok ? (mul24(gx, gy) >> 14) : 0;  // arithmetic shift = floor
+    const int m = cmask[i] & rmask;
+    const int gx = (vs[i + 2] - vs[i]) & m;
+    const int gy = mad24_10(vd[i + 1], mul24_3(vd[i] + vd[i + 2])) & m;
+    gxx[i] = mul24(gx, gx) >> 14;
+    gyy[i] = mul24(gy, gy) >> 14;
+    gxy[i] = mul24(gx, gy) >> 14;  // arithmetic shift = floor
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -89,67 +128,262 @@ __device__ __forceinline__ void cov_row(const int a[8], const int b[8], const in
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) void harris_generic_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores) {
   const int lane = threadIdx.x;
   const int x0 = (blockIdx.x * 64 + lane) * 4;
-  const int ys = (blockIdx.y * kWavesPerBlock + threadIdx.y) * kTH;
-  if (ys >= h) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int ys = (blockIdx.y * kWavesPerBlock + wave) * kTH;
+  if (ys >= h || x0 >= w) return;
   const int ye = ys + kTH < h ? ys + kTH : h;
   const size_t img_off = (size_t)blockIdx.z * (size_t)w * (size_t)h;
   const uint8_t* img = images + img_off;
-  int32_t* out = scores + img_off;
+  int32_t* out = scores + img_off + x0;
 
-  int pr[3][8];      // rolling pixel rows, slot = row mod 3 (relative)
-  int hsr[3][3][4];  // rolling horizontally smoothed entries, slot = row mod 3 (relative)
+  // per-lane constants: clamped dword indices and rim masks
+  const int nd = w >> 2;
+  int dc = x0 >> 2;
+  dc = dc > nd - 1 ? nd - 1 : dc;
+  const int dl = dc > 0 ? dc - 1 : 0;
+  const int dr = dc < nd - 1 ? dc + 1 : nd - 1;
+  int cmask[6], smask[4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int col = x0 - 1 + i;
+    cmask[i] = (col >= 1 && col <= w - 2) ? -1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) smask[i] = cmask[i + 1];  // same predicate for output column x0+i
 
-  // prologue: pixel rows ys-2, ys-1 -> slots 0, 1 ; the loop loads row r = ys-2+k into slot k%3
-  load_row<ALIGNED>(img, w, h, ys - 2, x0, pr[0]);
-  load_row<ALIGNED>(img, w, h, ys - 1, x0, pr[1]);
+  int pr[3][8];        // rolling pixel rows
+  int hsr[3][3][4];    // rolling horizontally smoothed entries
+  uint32_t raw[3][3];  // pixel rows in flight: loads are issued two steps ahead of their use
+  {
+    uint32_t t0[3], t1[3];
+    load_raw<ALIGNED>(img, w, h, ys - 2, x0, dl, dc, dr, t0);
+    load_raw<ALIGNED>(img, w, h, ys - 1, x0, dl, dc, dr, t1);
+    load_raw<ALIGNED>(img, w, h, ys, x0, dl, dc, dr, raw[0]);
+    load_raw<ALIGNED>(img, w, h, ys + 1, x0, dl, dc, dr, raw[1]);
+    unpack<ALIGNED>(t0, pr[0]);
+    unpack<ALIGNED>(t1, pr[1]);
+  }
 
-  // iteration k (k = 2, 3, ...): load pixel row r = ys-2+k, produce covariance row g = r-1
-  // into hs slot (k-2)%3... relative numbering j = k-2 = 0,1,2,...: g = ys-1+j ; once j >= 2 the
-  // score row y = g-1 = ys+j-2 is complete.
+  // step j: consume pixel row ys+j (loaded two steps ago), prefetch row ys+j+2, produce covariance
+  // row g = ys+j-1; from j >= 2 on the score row y = g-1 is complete.  Unrolled by 3 so that all
+  // rolling-buffer slots are compile-time.
   auto step = [&](int j, int s_new, int s_a, int s_b, int h_new, int h_a, int h_b) {
-    const int r = ys + j;  // pixel row loaded this step
-    load_row<ALIGNED>(img, w, h, r, x0, pr[s_new]);
+    const int r = ys + j;
+    load_raw<ALIGNED>(img, w, h, r + 2, x0, dl, dc, dr, raw[s_new]);  // raw slot (j+2)%3: free
+    unpack<ALIGNED>(raw[s_a], pr[s_new]);                           // raw slot of row r   == j%3
     const int g = r - 1;
-    cov_row(pr[s_a], pr[s_b], pr[s_new], g, x0, w, h, hsr[h_new]);
-    if (j >= 2) {
-      const int y = g - 1;
-      if (y < ye) {
-        int sc[4];
-        const bool yrow = (y >= 1) && (y <= h - 2);
+    const int rmask = (g >= 1 && g <= h - 2) ? -1 : 0;  // wave-uniform
+    cov_row(pr[s_a], pr[s_b], pr[s_new], cmask, rmask, hsr[h_new]);
+    const int y = g - 1;
+    if (j >= 2 && y < ye) {  // wave-uniform
+      const int ymask = (y >= 1 && y <= h - 2) ? -1 : 0;
+      int sc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int A = hsr[h_a][0][i] + 2 * hsr[h_b][0][i] + hsr[h_new][0][i];
-          const int B = hsr[h_a][1][i] + 2 * hsr[h_b][1][i] + hsr[h_new][1][i];
-          const int Cc = hsr[h_a][2][i] + 2 * hsr[h_b][2][i] + hsr[h_new][2][i];
-          const int det = mul24(A, B) - mul24(Cc, Cc);
-          const int tq = ((A >> 1) + (B >> 1)) >> 1;
-          const int x = x0 + i;
-          const bool ok = yrow && (x >= 1) && (x <= w - 2);
-          sc[i] = ok ? det - mul24(tq, tq) : 0;
-        }
-        int32_t* op = out + (size_t)y * w + x0;
-        if (ALIGNED && x0 + 3 < w) {
-          *reinterpret_cast<int4*>(op) = make_int4(sc[0], sc[1], sc[2], sc[3]);
-        } else {
+      for (int i = 0; i < 4; ++i) {
+        const int A = hsr[h_a][0][i] + 2 * hsr[h_b][0][i] + hsr[h_new][0][i];
+        const int B = hsr[h_a][1][i] + 2 * hsr[h_b][1][i] + hsr[h_new][1][i];
+        const int Cc = hsr[h_a][2][i] + 2 * hsr[h_b][2][i] + hsr[h_new][2][i];
+        const int tq = ((A >> 1) + (B >> 1)) >> 1;
+        const int det = mul24(A, B) - mul24(Cc, Cc);
+        sc[i] = (det - mul24(tq, tq)) & (smask[i] & ymask);
+      }
+      int32_t* op = out + (size_t)y * (size_t)w;
+      if (ALIGNED) {
+        *reinterpret_cast<int4*>(op) = make_int4(sc[0], sc[1], sc[2], sc[3]);
+      } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (x0 + i < w) op[i] = sc[i];
-        }
+        for (int i = 0; i < 4; ++i)
+          if (x0 + i < w) op[i] = sc[i];
       }
     }
   };
 
-  // j = 0 .. (ye-ys)+1 ; unrolled by 3 so that all rolling-buffer slots are compile-time
+  // slots: pixel row ys+j lives in pr slot (j+2)%3 and its raw dwords in raw slot j%3
   const int jn = (ye - ys) + 2;
   for (int j = 0; j < jn; j += 3) {
-    // slots: pixel row ys+j lives in slot (j+2)%3 ; with j % 3 == 0: new=2, a=0, b=1
     step(j, 2, 0, 1, 0, 1, 2);
     if (j + 1 < jn) step(j + 1, 0, 1, 2, 1, 2, 0);
     if (j + 2 < jn) step(j + 2, 1, 2, 0, 2, 0, 1);
+  }
+}
+
+
+// ---- fast path (w % 4 == 0): no redundant halo columns ------------------------------------------
+// Lane l of strip s owns dword d = 62*s + l of every row (4 pixels).  Horizontal neighbours come
+// from the adjacent lanes through DPP wave shifts, so each lane computes the vertical filters and
+// the covariance entries of its own 4 columns only.  Lane 0 / lane 63 of interior strip borders
+// have no neighbour on one side: they are halo lanes (strips overlap by 2 dwords) and do not
+// store; at the image border no halo is needed (the rim is zero by definition).  752 px = 188
+// dwords = 63 + 62 + 63 valid lanes in 3 waves.
+__device__ __forceinline__ int mulhi24(int a, int b) {  // (a * b) >> 32 of the 48-bit product
+  int d;
+  asm("v_mul_hi_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// DPP reads of a VGPR written by a VALU op need 2 wait states; the compiler inserts them for
+// its own instructions but cannot see through inline asm, so values produced by mulhi24 pass
+// through this fence before they are shifted across lanes.
+__device__ __forceinline__ void dpp_fence(int& a, int& b, int& c, int& d, int& e, int& f) {
+  asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+__device__ __forceinline__ int from_left(int v) {   // value of lane-1
+  return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int from_right(int v) {  // value of lane+1
+  return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
+}
+
+constexpr int kStripLanes = 62;
+
+template <int kTHF>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
+    const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores) {
+  const int lane = threadIdx.x;
+  const int strip = blockIdx.x;
+  const int nd = w >> 2;
+  const int d = strip * kStripLanes + lane;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int ys = (blockIdx.y * kWavesPerBlock + wave) * kTHF;
+  if (ys >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
+  const int ye = ys + kTHF < h ? ys + kTHF : h;
+  const bool last_strip = strip * kStripLanes + 64 >= nd;
+  const bool store = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
+  const int dcl = d < nd ? d : nd - 1;  // clamped dword index for loads
+  const size_t img_off = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+  const uint32_t* img = reinterpret_cast<const uint32_t*>(images + img_off) + dcl;
+  int32_t* out = scores + img_off + (size_t)dcl * 4;
+  const int m0 = d == 0 ? 0 : -1;        // column 0 is rim
+  const int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
+  const int k3 = 3 << 9, k10 = 10 << 9;  // gradients carry a factor 2^9: mulhi24 then yields >> 14
+
+  auto load_row = [&](int row) -> uint32_t {
+    row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
+    return img[(size_t)row * (size_t)nd];
+  };
+  auto unpack4 = [](uint32_t c, int p[4]) {
+    p[0] = c & 255;
+    p[1] = (c >> 8) & 255;
+    p[2] = (c >> 16) & 255;
+    p[3] = c >> 24;
+  };
+
+  int pr[3][4];      // rolling pixel rows (own 4 columns)
+  int hs[2][3][4];   // horizontally smoothed entries: current / previous row
+  int vp[2][3][4];   // vertical pair sums hs[g-1] + hs[g]
+  uint32_t raw[3];   // pixel rows in flight (loaded two steps ahead)
+  {
+    const uint32_t t0 = load_row(ys - 2), t1 = load_row(ys - 1);
+    raw[0] = load_row(ys);
+    raw[1] = load_row(ys + 1);
+    unpack4(t0, pr[0]);
+    unpack4(t1, pr[1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hs[q][c][i] = vp[q][c][i] = 0;
+
+  // step j: consume pixel row r = ys+j, covariance row g = r-1, score row y = g-1 (from j >= 2)
+  auto step = [&](int j, int s_new, int s_a, int s_b, int q) {
+    const int r = ys + j;
+    raw[s_new] = load_row(r + 2);   // raw slot (j+2)%3 is free
+    unpack4(raw[s_a], pr[s_new]);   // raw slot j%3 holds row r
+    const int g = r - 1;
+    const int* a = pr[s_a];
+    const int* b = pr[s_b];
+    const int* c = pr[s_new];
+    int (*H)[4] = hs[q];
+    int (*Hp)[4] = hs[q ^ 1];
+    int (*V)[4] = vp[q];
+    int (*Vp)[4] = vp[q ^ 1];
+    if (g >= 1 && g <= h - 2) {  // wave-uniform
+      int vs[4], vd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vs[i] = b[i] * k10 + (a[i] + c[i]) * k3;
+        vd[i] = c[i] - a[i];
+      }
+      // NOTE: the subtrahend of gx[0] is shifted in NEGATED form and added: hipcc folds
+      // "x - dpp(y)" into v_subrev_u32_dpp wave_shr:1, which does not shift on gfx950
+      // (tools/ubench/dpp_test.hip); v_add_u32_dpp / v_sub_u32_dpp(dpp - x) are fine.
+      const int vs_l_neg = from_left(-vs[3]), vs_r = from_right(vs[0]);
+      const int vd_l = from_left(vd[3]), vd_r = from_right(vd[0]);
+      int gx[4], gy[4];
+      gx[0] = (vs[1] + vs_l_neg) & m0;
+      gx[1] = vs[2] - vs[0];
+      gx[2] = vs[3] - vs[1];
+      gx[3] = (vs_r - vs[2]) & m3;
+      gy[0] = (vd[0] * k10 + (vd_l + vd[1]) * k3) & m0;
+      gy[1] = vd[1] * k10 + (vd[0] + vd[2]) * k3;
+      gy[2] = vd[2] * k10 + (vd[1] + vd[3]) * k3;
+      gy[3] = (vd[3] * k10 + (vd[2] + vd_r) * k3) & m3;
+      int G[3][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        G[0][i] = mulhi24(gx[i], gx[i]);
+        G[1][i] = mulhi24(gy[i], gy[i]);
+        G[2][i] = mulhi24(gx[i], gy[i]);
+      }
+      dpp_fence(G[0][0], G[0][3], G[1][0], G[1][3], G[2][0], G[2][3]);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const int gl = from_left(G[ch][3]), gr = from_right(G[ch][0]);
+        const int pm = gl + G[ch][0];
+        const int p0 = G[ch][0] + G[ch][1];
+        const int p1 = G[ch][1] + G[ch][2];
+        const int p2 = G[ch][2] + G[ch][3];
+        const int p3 = G[ch][3] + gr;
+        H[ch][0] = pm + p0;
+        H[ch][1] = p0 + p1;
+        H[ch][2] = p1 + p2;
+        H[ch][3] = p2 + p3;
+      }
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) H[ch][i] = 0;
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) V[ch][i] = Hp[ch][i] + H[ch][i];
+    const int y = g - 1;
+    if (j >= 2 && y < ye) {  // wave-uniform
+      int sc[4];
+      if (y >= 1 && y <= h - 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int A = Vp[0][i] + V[0][i];
+          const int B = Vp[1][i] + V[1][i];
+          const int Cc = Vp[2][i] + V[2][i];
+          const int tq = ((A >> 1) + (B >> 1)) >> 1;
+          sc[i] = mul24(A, B) - mad24(tq, tq, mul24(Cc, Cc));
+        }
+        sc[0] &= m0;
+        sc[3] &= m3;
+      } else {
+        sc[0] = sc[1] = sc[2] = sc[3] = 0;
+      }
+      if (store) *reinterpret_cast<int4*>(out + (size_t)y * (size_t)w) = make_int4(sc[0], sc[1], sc[2], sc[3]);
+    }
+  };
+
+  // pixel slots have period 3, the hs/vp ping-pong period 2 -> unroll by 6
+  const int jn = (ye - ys) + 2;
+  for (int j = 0; j < jn; j += 6) {
+    step(j, 2, 0, 1, 0);
+    if (j + 1 < jn) step(j + 1, 0, 1, 2, 1);
+    if (j + 2 < jn) step(j + 2, 1, 2, 0, 0);
+    if (j + 3 < jn) step(j + 3, 2, 0, 1, 1);
+    if (j + 4 < jn) step(j + 4, 0, 1, 2, 0);
+    if (j + 5 < jn) step(j + 5, 1, 2, 0, 1);
   }
 }
 
@@ -159,14 +393,34 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
                    hipStream_t stream) {
   if (n_images <= 0) return;
   const dim3 block(64, kWavesPerBlock, 1);
-  const dim3 grid((w + 255) / 256, (h + kTH * kWavesPerBlock - 1) / (kTH * kWavesPerBlock),
-                  n_images);
   const bool aligned = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) &&
                        ((reinterpret_cast<uintptr_t>(score) & 15) == 0);
-  if (aligned)
-    hipLaunchKernelGGL(harris_kernel<true>, grid, block, 0, stream, img, w, h, score);
-  else
-    hipLaunchKernelGGL(harris_kernel<false>, grid, block, 0, stream, img, w, h, score);
+  if (aligned) {
+    const int nd = w >> 2;
+    int strips = 1;
+    while ((strips - 1) * kStripLanes + 64 < nd) ++strips;  // last strip must reach dword nd-1
+    static const int th_env = [] {
+      const char* e = getenv("OKVFE_K1_TH");  // tuning knob: output rows per wave
+      return e ? atoi(e) : 0;
+    }();
+#define OKVFE_K1_LAUNCH(TH)                                                                   \
+  hipLaunchKernelGGL(harris_kernel<TH>,                                                       \
+                     dim3(strips, (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock), n_images), \
+                     block, 0, stream, img, w, h, score)
+    switch (th_env ? th_env : (h % 30 == 0 ? 30 : 32)) {
+      case 16: OKVFE_K1_LAUNCH(16); break;
+      case 24: OKVFE_K1_LAUNCH(24); break;
+      case 30: OKVFE_K1_LAUNCH(30); break;
+      case 40: OKVFE_K1_LAUNCH(40); break;
+      case 60: OKVFE_K1_LAUNCH(60); break;
+      default: OKVFE_K1_LAUNCH(32); break;
+    }
+#undef OKVFE_K1_LAUNCH
+  } else {
+    const dim3 grid((w + 255) / 256, (h + kTH * kWavesPerBlock - 1) / (kTH * kWavesPerBlock),
+                    n_images);
+    hipLaunchKernelGGL(harris_generic_kernel<false>, grid, block, 0, stream, img, w, h, score);
+  }
 }
 
 }  // namespace okvfe

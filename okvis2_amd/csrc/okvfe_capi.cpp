@@ -629,6 +629,40 @@ okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride, o
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, int32_t cam,
+                           const float gravity_C[3], okvfe_keypoint* keypoints, int32_t n_in,
+                           uint8_t* descriptors, double* backproj, uint8_t* backproj_valid,
+                           int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!image || !n_out || n_in < 0 || (n_in > 0 && !keypoints))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_compute: bad argument");
+  if (n_in > ctx->kp_cap)
+    return fail(ctx, OKVFE_ERR_CAPACITY, "okvfe_compute: %d keypoints exceed max_keypoints %d", n_in, ctx->kp_cap);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  okvfe_status st = stage_image(ctx, image, stride);
+  if (st != OKVFE_OK) return st;
+  hipStream_t s = ctx->stream;
+  const int32_t cam_id = cam;
+  st = upload_image_params(ctx, 1, &cam_id, (cam >= 0) ? gravity_C : nullptr, s);
+  if (st != OKVFE_OK) return st;
+  const int w = ctx->w, h = ctx->h;
+  if (n_in > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_kps_det, keypoints, n_in * sizeof(okvfe_keypoint), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_det_count, &n_in, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, sizeof(int32_t), s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources
+  launch_integral(ctx->d_img_stage, w, h, 1, ctx->d_integral, s);
+  launch_describe(ctx->d_img_stage, ctx->d_integral, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
+                  ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
+                  ctx->d_desc_tmp, ctx->d_valid_tmp, s);
+  launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
+                 ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_n_images = 1;
+  ctx->last_stream = s;
+  return okvfe_download_image_result(ctx, 0, keypoints, descriptors, backproj, backproj_valid, n_in, n_out);
+}
+
 okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_pair* pairs,
                                              int32_t n_pairs, okvfe_stereo_match* matches_dev,
                                              void* stream) {

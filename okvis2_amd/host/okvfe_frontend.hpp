@@ -1,0 +1,234 @@
+// okvfe_frontend.hpp -- C++ host mirror of the reference's front-end interfaces over the C ABI.
+//
+// Dependency-free (no OpenCV / Eigen): the types are layout-compatible stand-ins, so the classes
+// keep the reference's names, argument meaning and error behaviour and can be dropped behind
+//   cv::FeatureDetector::detect / cv::DescriptorExtractor::compute
+//     (okvis_cv/include/okvis/implementation/Frame.hpp:152,167)
+//   brisk::BriskDescriptorExtractor::isCameraAware / setCameraProperties / setExtractionDirection
+//     (okvis_frontend/src/Frontend.cpp:232-251)
+//   okvis::Frontend::detectAndDescribe            (okvis_frontend/src/Frontend.cpp:221-269)
+//   okvis::Frontend::matchStereo inner loops      (okvis_frontend/src/Frontend.cpp:2016-2076)
+// okvfe_opencv_adapters.hpp wraps these in the real cv:: base classes when OpenCV is available.
+//
+// Every call goes to libokvfe.so (HIP kernels).  Failures throw okvfe::Exception, the analogue of
+// okvis::Frontend::Exception (okvis_util/include/okvis/assert_macros.hpp:49-113).
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/okvfe.h"
+
+namespace okvfe {
+
+class Exception : public std::runtime_error {
+ public:
+  Exception(okvfe_status st, const std::string& what)
+      : std::runtime_error("okvfe status " + std::to_string(int(st)) + ": " + what), status(st) {}
+  okvfe_status status;
+};
+
+struct ImageView {  // cv::Mat CV_8UC1 view
+  const uint8_t* data;
+  int width, height;
+  size_t stride;
+};
+
+using KeyPoint = okvfe_keypoint;  // cv::KeyPoint layout
+struct Descriptors {              // cv::Mat CV_8UC1, N x 48
+  std::vector<uint8_t> data;
+  int rows = 0;
+  static constexpr int cols = OKVFE_DESC_BYTES;
+  const uint8_t* row(int k) const { return data.data() + size_t(k) * cols; }
+};
+
+// shared handle: detector and extractor of one camera share one context (one HIP stream)
+class Context {
+ public:
+  explicit Context(const okvfe_config& cfg) {
+    okvfe_ctx* c = nullptr;
+    const okvfe_status st = okvfe_create(&cfg, &c);
+    if (st != OKVFE_OK) throw Exception(st, okvfe_last_error(nullptr));
+    ctx_ = c;
+    max_keypoints_ = cfg.max_keypoints;
+  }
+  ~Context() { okvfe_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  okvfe_ctx* get() const { return ctx_; }
+  int maxKeypoints() const { return max_keypoints_; }
+  void check(okvfe_status st) const {
+    if (st != OKVFE_OK) throw Exception(st, okvfe_last_error(ctx_));
+  }
+
+ private:
+  okvfe_ctx* ctx_ = nullptr;
+  int max_keypoints_ = 0;
+};
+
+// = brisk::ScaleSpaceFeatureDetector<brisk::HarrisScoreCalculator>(uniformityRadius, octaves,
+//   absoluteThreshold, maxNumKpt) as a cv::FeatureDetector (Frontend.cpp:2406-2409)
+class HipBriskDetector {
+ public:
+  explicit HipBriskDetector(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) {}
+  void detect(const ImageView& image, std::vector<KeyPoint>& keypoints) const {
+    keypoints.resize(size_t(ctx_->maxKeypoints()));
+    int32_t n = 0;
+    ctx_->check(okvfe_detect(ctx_->get(), image.data, image.stride, keypoints.data(),
+                             int32_t(keypoints.size()), &n));
+    keypoints.resize(size_t(n));
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+};
+
+// = brisk::BriskDescriptorExtractor(rotationInvariant, scaleInvariant) as a
+//   cv::DescriptorExtractor with the camera-aware extras (Frontend.cpp:2410-2412, 232-251)
+class HipBriskExtractor {
+ public:
+  HipBriskExtractor(std::shared_ptr<Context> ctx, int cameraSlot)
+      : ctx_(std::move(ctx)), cam_(cameraSlot) {}
+  bool isCameraAware() const { return aware_; }
+  // rays: H*W*3 f32, imageJacobians: H*W*6 f32 (PinholeCamera.hpp:180-208)
+  void setCameraProperties(const float* rays, const float* imageJacobians, float fu) {
+    ctx_->check(okvfe_set_camera_maps(ctx_->get(), cam_, rays, imageJacobians, fu));
+    aware_ = true;
+  }
+  // full intrinsics: also enables back-projection of the kept keypoints on the GPU
+  void setCamera(const okvfe_camera& camera) {
+    ctx_->check(okvfe_set_camera(ctx_->get(), cam_, &camera));
+    aware_ = true;
+  }
+  void setExtractionDirection(const std::array<float, 3>& dir) { dir_ = dir; }
+  // keypoints in/out: keypoints too close to the rim are removed (Frame.hpp:146)
+  void compute(const ImageView& image, std::vector<KeyPoint>& keypoints, Descriptors& descriptors,
+               std::vector<std::array<double, 3>>* backProjections = nullptr,
+               std::vector<uint8_t>* backProjectionsValid = nullptr) const {
+    const int32_t n_in = int32_t(keypoints.size());
+    descriptors.data.assign(size_t(std::max(n_in, 1)) * OKVFE_DESC_BYTES, 0);
+    std::vector<double> bp(size_t(std::max(n_in, 1)) * 3);
+    std::vector<uint8_t> bv(size_t(std::max(n_in, 1)));
+    if (keypoints.empty()) keypoints.resize(1);
+    int32_t n = 0;
+    ctx_->check(okvfe_compute(ctx_->get(), image.data, image.stride, aware_ ? cam_ : -1,
+                              aware_ ? dir_.data() : nullptr, keypoints.data(), n_in,
+                              descriptors.data.data(), bp.data(), bv.data(), &n));
+    keypoints.resize(size_t(n));
+    descriptors.rows = n;
+    descriptors.data.resize(size_t(n) * OKVFE_DESC_BYTES);
+    if (backProjections) {
+      backProjections->resize(size_t(n));
+      for (int k = 0; k < n; ++k) (*backProjections)[size_t(k)] = {bp[3 * k], bp[3 * k + 1], bp[3 * k + 2]};
+    }
+    if (backProjectionsValid) backProjectionsValid->assign(bv.begin(), bv.begin() + n);
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  int cam_;
+  bool aware_ = false;
+  std::array<float, 3> dir_{{0.0f, 1.0f, 0.0f}};
+};
+
+// per-camera slice of okvis::MultiFrame that the front-end fills (okvis_cv/include/okvis/Frame.hpp:248-264)
+struct FrameData {
+  std::vector<KeyPoint> keypoints;
+  Descriptors descriptors;
+  std::vector<uint64_t> landmarkIds;  // zero-filled (Frame.hpp:170-173)
+  std::vector<std::array<double, 3>> backProjections;
+  std::vector<uint8_t> backProjectionsValid;
+};
+
+struct FrontendParameters {  // okvis_common/include/okvis/Parameters.hpp:123-133; Frontend.cpp:138-145
+  float detection_threshold = 40.0f;  // uniformity radius in px
+  int absolute_threshold = 200;
+  int matching_threshold = 60;
+  int octaves = 0;
+  int max_num_keypoints = 450;
+  bool rotation_invariance = true;
+  bool scale_invariance = false;
+};
+
+// = the detect/describe/matchStereo part of okvis::Frontend (one GPU, all cameras of one rig)
+class HipFrontend {
+ public:
+  HipFrontend(const std::vector<okvfe_camera>& cameras, const FrontendParameters& p, int device = 0)
+      : cameras_(cameras), mutexes_(cameras.size()) {
+    if (cameras.empty()) throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "no cameras");
+    for (size_t i = 0; i < cameras.size(); ++i) {
+      okvfe_config cfg{};
+      cfg.abi_version = OKVFE_ABI_VERSION;
+      cfg.device = device;
+      cfg.width = cameras[i].width;
+      cfg.height = cameras[i].height;
+      cfg.max_batch = 1;
+      cfg.num_cameras = 1;
+      cfg.uniformity_radius = p.detection_threshold;
+      cfg.octaves = p.octaves;
+      cfg.absolute_threshold = p.absolute_threshold;
+      cfg.max_keypoints = p.max_num_keypoints;
+      cfg.rotation_invariant = p.rotation_invariance;
+      cfg.scale_invariant = p.scale_invariance;
+      cfg.match_threshold = p.matching_threshold;
+      auto ctx = std::make_shared<Context>(cfg);
+      contexts_.push_back(ctx);
+      detectors_.emplace_back(ctx);
+      extractors_.emplace_back(ctx, 0);
+    }
+  }
+  size_t numCameras() const { return cameras_.size(); }
+
+  // Frontend::detectAndDescribe(cameraIndex, frameOut, T_WC): thread-safe per camera.
+  bool detectAndDescribe(size_t cameraIndex, const ImageView& image, const okvfe_pose& T_WC,
+                         FrameData& frameOut) {
+    if (cameraIndex >= cameras_.size())
+      throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "Camera index exceeds number of cameras.");
+    std::lock_guard<std::mutex> lock(mutexes_[cameraIndex]);
+    HipBriskExtractor& ex = extractors_[cameraIndex];
+    if (!ex.isCameraAware()) ex.setCamera(cameras_[cameraIndex]);  // Frontend.cpp:232-244
+    // extraction direction = gravity in the camera frame: T_WC.inverse().C() * (0,0,-1)
+    std::array<float, 3> dir;
+    for (int i = 0; i < 3; ++i) dir[size_t(i)] = float(-T_WC.C[6 + i]);  // C^T * (0,0,-1)
+    ex.setExtractionDirection(dir);
+    detectors_[cameraIndex].detect(image, frameOut.keypoints);
+    ex.compute(image, frameOut.keypoints, frameOut.descriptors, &frameOut.backProjections,
+               &frameOut.backProjectionsValid);
+    frameOut.landmarkIds.assign(frameOut.keypoints.size(), 0);
+    return true;
+  }
+
+  // the k0 x k1 loop of Frontend::matchStereo for one camera pair (Frontend.cpp:2016-2076)
+  std::vector<okvfe_stereo_match> matchStereo(size_t im0, const FrameData& f0, const okvfe_pose& T_WC0,
+                                              size_t im1, const FrameData& f1, const okvfe_pose& T_WC1) {
+    std::lock_guard<std::mutex> lock(mutexes_[im0]);
+    std::vector<okvfe_stereo_match> out(f0.keypoints.size());
+    const double fa = 0.5 * (cameras_[im0].fu + cameras_[im0].fv);
+    const double fb = 0.5 * (cameras_[im1].fu + cameras_[im1].fv);
+    std::vector<double> b0(f0.backProjections.size() * 3 + 3), b1(f1.backProjections.size() * 3 + 3);
+    for (size_t k = 0; k < f0.backProjections.size(); ++k)
+      for (int i = 0; i < 3; ++i) b0[3 * k + size_t(i)] = f0.backProjections[k][size_t(i)];
+    for (size_t k = 0; k < f1.backProjections.size(); ++k)
+      for (int i = 0; i < 3; ++i) b1[3 * k + size_t(i)] = f1.backProjections[k][size_t(i)];
+    contexts_[im0]->check(okvfe_match_stereo(
+        contexts_[im0]->get(), f0.descriptors.data.data(), f0.keypoints.data(), b0.data(),
+        f0.backProjectionsValid.data(), int32_t(f0.keypoints.size()), f1.descriptors.data.data(),
+        f1.keypoints.data(), b1.data(), f1.backProjectionsValid.data(), int32_t(f1.keypoints.size()),
+        &T_WC0, &T_WC1, fa, fb, out.data()));
+    return out;
+  }
+
+ private:
+  std::vector<okvfe_camera> cameras_;
+  std::vector<std::mutex> mutexes_;
+  std::vector<std::shared_ptr<Context>> contexts_;
+  std::vector<HipBriskDetector> detectors_;
+  std::vector<HipBriskExtractor> extractors_;
+};
+
+}  // namespace okvfe

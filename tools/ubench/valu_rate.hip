@@ -1,0 +1,92 @@
+// VALU issue-rate micro-benchmark for gfx950: cycles per wave64 instruction of the ops K1 uses.
+// Build: hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 64
+#define ITERS 2000
+
+#define KERNEL(name, decl, body)                                            \
+  __global__ void name(int* out, int seed) {                                \
+    decl;                                                                   \
+    for (int it = 0; it < ITERS; ++it) {                                    \
+      _Pragma("unroll") for (int r = 0; r < REP / 8; ++r) { body }          \
+    }                                                                       \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; \
+  }
+
+#define DECL_I int a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7, b = threadIdx.x | 1
+#define OP8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
+
+#define ADD(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MUL24(x) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MAD24(x) asm volatile("v_mad_i32_i24 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MULHI24(x) asm volatile("v_mul_hi_i32_i24 %0, %0, %1" : "+v"(x) : "v"(b));
+#define ASHR(x) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(x));
+#define ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(b));
+#define PKADD(x) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define PKMAD(x) asm volatile("v_pk_mad_u16 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define PKMUL(x) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MADI16(x) asm volatile("v_mad_i32_i16 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define DOT2(x) asm volatile("v_dot2_i32_i16 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define DOT4(x) asm volatile("v_dot4_u32_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define ALIGNBIT(x) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(x) : "v"(b));
+#define FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define AND(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define DPPMOV(x) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+#define SUBSDWA(x) asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_0" : "+v"(x) : "v"(b));
+
+KERNEL(k_add, DECL_I, OP8(ADD))
+KERNEL(k_mul24, DECL_I, OP8(MUL24))
+KERNEL(k_mad24, DECL_I, OP8(MAD24))
+KERNEL(k_mullo, DECL_I, OP8(MULLO))
+KERNEL(k_mulhi24, DECL_I, OP8(MULHI24))
+KERNEL(k_ashr, DECL_I, OP8(ASHR))
+KERNEL(k_add3, DECL_I, OP8(ADD3))
+KERNEL(k_lshladd, DECL_I, OP8(LSHLADD))
+KERNEL(k_pkadd, DECL_I, OP8(PKADD))
+KERNEL(k_pkmad, DECL_I, OP8(PKMAD))
+KERNEL(k_pkmul, DECL_I, OP8(PKMUL))
+KERNEL(k_madi16, DECL_I, OP8(MADI16))
+KERNEL(k_dot2, DECL_I, OP8(DOT2))
+KERNEL(k_dot4, DECL_I, OP8(DOT4))
+KERNEL(k_perm, DECL_I, OP8(PERM))
+KERNEL(k_alignbit, DECL_I, OP8(ALIGNBIT))
+KERNEL(k_fma, DECL_I, OP8(FMA))
+KERNEL(k_and, DECL_I, OP8(AND))
+KERNEL(k_dppmov, DECL_I, OP8(DPPMOV))
+KERNEL(k_subsdwa, DECL_I, OP8(SUBSDWA))
+
+int main() {
+  int* d;
+  const int blocks = 256 * 8, threads = 256;  // 8 waves per SIMD
+  hipMalloc(&d, blocks * threads * sizeof(int));
+  hipDeviceProp_t p;
+  hipGetDeviceProperties(&p, 0);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+#define RUN(k)                                                                              \
+  {                                                                                         \
+    k<<<blocks, threads>>>(d, 1);                                                           \
+    hipDeviceSynchronize();                                                                 \
+    hipEventRecord(a);                                                                      \
+    k<<<blocks, threads>>>(d, 1);                                                           \
+    hipEventRecord(b);                                                                      \
+    hipEventSynchronize(b);                                                                 \
+    float ms;                                                                               \
+    hipEventElapsedTime(&ms, a, b);                                                         \
+    const double instr = (double)blocks * (threads / 64) * ITERS * REP;                     \
+    const double per_simd = instr / (p.multiProcessorCount * 4);                            \
+    printf("%-10s %.3f ms  -> %.2f ns per wave-instr per SIMD (= %.2f cycles @2.4GHz)\n", #k, ms, \
+           ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);                                 \
+  }
+  RUN(k_add) RUN(k_mul24) RUN(k_mad24) RUN(k_mullo) RUN(k_mulhi24) RUN(k_ashr) RUN(k_add3) RUN(k_lshladd)
+  RUN(k_pkadd) RUN(k_pkmad) RUN(k_pkmul) RUN(k_madi16) RUN(k_dot2) RUN(k_dot4) RUN(k_perm) RUN(k_alignbit)
+  RUN(k_fma) RUN(k_and) RUN(k_dppmov) RUN(k_subsdwa)
+  return 0;
+}
