@@ -1,4 +1,4 @@
-// k_describe.hip -- K5 integral image, K6 BRISK2 descriptor, compaction + back-projection.
+// k_describe.hip -- K6 BRISK2 descriptor, compaction + back-projection.
 //
 // Replaces brisk::BriskDescriptorExtractor::compute (behind cv::DescriptorExtractor::compute,
 // okvis_cv/include/okvis/implementation/Frame.hpp:167; extractor built at
@@ -7,14 +7,13 @@
 // (okvis_cv/include/okvis/implementation/Frame.hpp:178-193 ->
 // cameras/implementation/PinholeCamera.hpp:574-593).
 //
-//   integral_kernel  inclusive integral image J[y][x] = sum_{r<=y, c<=x} img, int32.  One
-//                    workgroup per image walks the rows (4 px per lane, wave scan + LDS carry,
-//                    column accumulators in registers): every pixel is read once and every J
-//                    written once (5 B/px, HBM-bound in large batches).
-//   describe_kernel  one wave per keypoint, lane i = pattern point i (60 of 64 lanes): sample
-//                    position kp + M p_i, box-smoothed intensity from J (13 taps) and 4 rim
-//                    pixels, 383 pair comparisons as 6 wave ballots -> 6 x u64 = 48 bytes.
-//                    L2-resident gathers; ALU/latency-bound, no HBM roofline.
+//   describe_kernel  one wave per keypoint, lane i = pattern point i (60 of 64 lanes).  The
+//                    pixels under the keypoint's pattern are staged ONCE in LDS with coalesced
+//                    dword loads (<= 80 x 96 B per wave); every sample is a box sum with
+//                    sub-pixel rim weights read from LDS; 383 pair comparisons become 6 wave
+//                    ballots -> 6 x u64 = 48 bytes.  No integral image: the 4 B/px integral
+//                    pass of the classic CPU formulation (5 B/px of HBM traffic) is gone.
+//                    LDS / ALU bound, HBM traffic ~ 3.5 KB in + 76 B out per keypoint.
 //   compact_kernel   removes the keypoints the extractor dropped (order preserved) and
 //                    back-projects the survivors in FP64 (Gauss-Newton undistortion).
 #include <limits.h>
@@ -24,98 +23,44 @@
 namespace okvfe {
 namespace {
 
-// ---- K5 -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void integral_kernel(const uint8_t* __restrict__ images, int w,
-                                                       int h, int32_t* __restrict__ integral) {
-  __shared__ int wave_tot[2][4];
-  const int img = blockIdx.x;
-  const uint8_t* src = images + (size_t)img * w * h;
-  int32_t* dst = integral + (size_t)img * w * h;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(integral) & 15) == 0);
-  const int nseg = (w + 1023) / 1024;
-  // column accumulators: up to 4 segments of 1024 columns (w <= 4096), 4 columns per lane each
-  int acc[4][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[s][i] = 0;
-  int buf = 0;
-  for (int y = 0; y < h; ++y) {
-    int carry = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s < nseg) {
-        const int x0 = s * 1024 + tid * 4;
-        int p[4] = {0, 0, 0, 0};
-        if (vec) {
-          if (x0 < w) {
-            const uint32_t d = *reinterpret_cast<const uint32_t*>(src + (size_t)y * w + x0);
-            p[0] = d & 255; p[1] = (d >> 8) & 255; p[2] = (d >> 16) & 255; p[3] = d >> 24;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (x0 + i < w) p[i] = src[(size_t)y * w + x0 + i];
-        }
-        p[1] += p[0]; p[2] += p[1]; p[3] += p[2];
-        // inclusive wave scan of the lane totals
-        int t = p[3];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o = __shfl_up(t, d);
-          if (lane >= d) t += o;
-        }
-        if (lane == 63) wave_tot[buf][wv] = t;
-        __syncthreads();
-        int base = carry + t - p[3];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int wt = wave_tot[buf][k];
-          if (k < wv) base += wt;
-          carry += wt;
-        }
-        buf ^= 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[s][i] += base + p[i];
-        if (vec) {
-          if (x0 < w)
-            *reinterpret_cast<int4*>(dst + (size_t)y * w + x0) =
-                make_int4(acc[s][0], acc[s][1], acc[s][2], acc[s][3]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (x0 + i < w) dst[(size_t)y * w + x0 + i] = acc[s][i];
-        }
-      }
-    }
-  }
-}
-
 // ---- K6 -----------------------------------------------------------------------------------
-__device__ __forceinline__ int isum(const int32_t* __restrict__ J, int w, int y, int x) {
-  // exclusive integral I[y][x] = sum rows < y, cols < x
-  return (x > 0 && y > 0) ? J[(size_t)(y - 1) * w + (x - 1)] : 0;
-}
-#define RECT(xa, ya, xb, yb) \
-  (isum(J, w, (yb), (xb)) - isum(J, w, (ya), (xb)) - isum(J, w, (yb), (xa)) + isum(J, w, (ya), (xa)))
-
 // Box of half-side sigma_half centred at (xf, yf); returns 1024 * mean intensity.  Same integer /
-// float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights).
-__device__ __forceinline__ int smoothed_intensity(const uint8_t* __restrict__ img,
-                                                  const int32_t* __restrict__ J, int w, float xf,
-                                                  float yf, float sigma_half) {
+// float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
+// interior / edge sums are taken directly over the pixels (identical to integral-image sums).
+constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
+struct Box {
+  int x_left, x_right, y_top, y_bottom;
+};
+__device__ __forceinline__ Box sample_box(float xf, float yf, float sigma_half) {
+  Box b;
+  if (sigma_half < 0.5f) {
+    b.x_left = (int)xf;
+    b.y_top = (int)yf;
+    b.x_right = b.x_left + 1;
+    b.y_bottom = b.y_top + 1;
+  } else {
+    const float x_1 = xf - sigma_half, x1 = xf + sigma_half;
+    const float y_1 = yf - sigma_half, y1 = yf + sigma_half;
+    b.x_left = (int)(x_1 + 0.5f);
+    b.y_top = (int)(y_1 + 0.5f);
+    b.x_right = (int)(x1 + 0.5f);
+    b.y_bottom = (int)(y1 + 0.5f);
+  }
+  return b;
+}
+
+template <typename PX>
+__device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
+                                                  float sigma_half) {
   if (sigma_half < 0.5f) {
     const int x = (int)xf, y = (int)yf;
     const int r_x = (int)((xf - (float)x) * 1024.0f);
     const int r_y = (int)((yf - (float)y) * 1024.0f);
     const int r_x_1 = 1024 - r_x, r_y_1 = 1024 - r_y;
-    const uint8_t* ptr = img + (size_t)y * w + x;
-    int ret = r_x_1 * r_y_1 * (int)ptr[0];
-    ret += r_x * r_y_1 * (int)ptr[1];
-    ret += r_x * r_y * (int)ptr[w + 1];
-    ret += r_x_1 * r_y * (int)ptr[w];
+    int ret = r_x_1 * r_y_1 * px(y, x);
+    ret += r_x * r_y_1 * px(y, x + 1);
+    ret += r_x * r_y * px(y + 1, x + 1);
+    ret += r_x_1 * r_y * px(y + 1, x);
     return (ret + 512) / 1024;
   }
   float area = 4.0f * sigma_half;
@@ -139,19 +84,52 @@ __device__ __forceinline__ int smoothed_intensity(const uint8_t* __restrict__ im
   t = r_x_1 * r_y1;  const int D = (int)(t * fs);
   const int r_x_1_i = (int)(r_x_1 * fs), r_y_1_i = (int)(r_y_1 * fs);
   const int r_x1_i = (int)(r_x1 * fs), r_y1_i = (int)(r_y1 * fs);
-  int ret = A * (int)img[(size_t)y_top * w + x_left];
-  ret += B * (int)img[(size_t)y_top * w + x_right];
-  ret += C * (int)img[(size_t)y_bottom * w + x_right];
-  ret += D * (int)img[(size_t)y_bottom * w + x_left];
-  const int upper = RECT(x_left + 1, y_top, x_right, y_top + 1);
-  const int middle = RECT(x_left + 1, y_top + 1, x_right, y_bottom);
-  const int left = RECT(x_left, y_top + 1, x_left + 1, y_bottom);
-  const int right = RECT(x_right, y_top + 1, x_right + 1, y_bottom);
-  const int bottom = RECT(x_left + 1, y_bottom, x_right, y_bottom + 1);
+  int ret = A * px(y_top, x_left);
+  ret += B * px(y_top, x_right);
+  ret += C * px(y_bottom, x_right);
+  ret += D * px(y_bottom, x_left);
+  int upper = 0, middle = 0, left = 0, right = 0, bottom = 0;
+  const int bw = x_right - x_left, bh = y_bottom - y_top;  // >= 1 for sigma_half >= 0.5
+  if (PX::kFixedTrip && __all(bw <= kMaxBox && bh <= kMaxBox)) {
+    // fixed trip counts (fully unrolled, reads clamped into the box and masked) so that the LDS
+    // reads of a sample are issued back to back instead of one dependent read per loop trip
+    ret = 0;
+#pragma unroll
+    for (int dy = 0; dy <= kMaxBox; ++dy) {
+      const int y = y_top + (dy < bh ? dy : bh);
+      const int pl = px(y, x_left), pr = px(y, x_right);
+      int mid = 0;
+#pragma unroll
+      for (int dx = 1; dx < kMaxBox; ++dx) {
+        const int v = px(y, x_left + (dx < bw ? dx : bw));
+        mid += dx < bw ? v : 0;
+      }
+      if (dy == 0) {
+        ret = A * pl + B * pr;
+        upper = mid;
+      } else {
+        const bool is_bottom = dy == bh, is_mid = dy < bh;
+        ret += is_bottom ? D * pl + C * pr : 0;
+        bottom += is_bottom ? mid : 0;
+        left += is_mid ? pl : 0;
+        right += is_mid ? pr : 0;
+        middle += is_mid ? mid : 0;
+      }
+    }
+  } else {
+    for (int x = x_left + 1; x < x_right; ++x) {
+      upper += px(y_top, x);
+      bottom += px(y_bottom, x);
+    }
+    for (int y = y_top + 1; y < y_bottom; ++y) {
+      left += px(y, x_left);
+      right += px(y, x_right);
+      for (int x = x_left + 1; x < x_right; ++x) middle += px(y, x);
+    }
+  }
   ret += upper * r_y_1_i + middle * scaling + left * r_x_1_i + right * r_x1_i + bottom * r_y1_i;
   return (ret + scaling2 / 2) / scaling2;
 }
-#undef RECT
 
 // sample position of this lane's pattern point under M; ok = box inside the image (NaN-safe)
 __device__ __forceinline__ bool sample_pos(const float M[4], float kx, float ky, float px, float py,
@@ -217,14 +195,44 @@ __device__ __forceinline__ bool camera_aware_matrix(const float* __restrict__ ra
 }
 
 constexpr int kDescWaves = 4;
+constexpr int kPatchPitch = 96;  // bytes per patch row in LDS (multiple of 4)
+constexpr int kPatchRows = 80;
 
+struct GlobalPx {  // direct reads from the image (fallback when the patch does not fit in LDS)
+  static constexpr bool kFixedTrip = false;
+  const uint8_t* img;
+  int w;
+  __device__ __forceinline__ int operator()(int y, int x) const { return img[(size_t)y * w + x]; }
+};
+struct PatchPx {   // reads from the keypoint's patch staged in LDS
+  static constexpr bool kFixedTrip = true;
+  const uint8_t* patch;
+  int x0, y0;
+  __device__ __forceinline__ int operator()(int y, int x) const {
+    return patch[(y - y0) * kPatchPitch + (x - x0)];
+  }
+};
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+  return v;
+}
+
+// One wave per keypoint, lane i = pattern point i.  The pixels under the keypoint's pattern
+// (<= 80 x 96) are staged once in LDS with coalesced dword loads; all box sums then read LDS.
 __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
-    const uint8_t* __restrict__ images, const int32_t* __restrict__ integral, int w, int h,
-    const Pattern* __restrict__ pat, const ImageParams* __restrict__ prm,
-    const float* const* __restrict__ rays, const float* const* __restrict__ jac,
-    const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
-    okvfe_keypoint* __restrict__ kps_tmp, uint8_t* __restrict__ desc_tmp,
-    uint8_t* __restrict__ valid_tmp) {
+    const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
+    const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
+    const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
+    const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
+    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
+  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchRows * kPatchPitch];
   __shared__ int values[kDescWaves][64];
   const int img = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -232,27 +240,91 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
   const int n = kp_count_in[img];
   if (k >= n) return;  // whole wave exits; no block-wide barriers below
   const uint8_t* im = images + (size_t)img * w * h;
-  const int32_t* J = integral + (size_t)img * w * h;
   const size_t slot = (size_t)img * kp_cap + k;
   okvfe_keypoint kp = kps_in[slot];
   const ImageParams ip = prm[img];
   const int border = pat->border;
   bool valid = !(kp.x < (float)border || kp.x >= (float)(w - border) || kp.y < (float)border ||
                  kp.y >= (float)(h - border));
-  const int li = lane < kPatternPoints ? lane : 0;
+  const bool active = lane < kPatternPoints;
+  const int li = active ? lane : 0;
   const float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
   float M[4] = {1.0f, 0.0f, 0.0f, 1.0f};
   float xf, yf;
   int* vals = values[wv];
+  uint8_t* patch = patches[wv];
+  const bool dword_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0);
+
+  // stages the pixels [bx0..bx1] x [by0..by1] (inside the image) into LDS; false if too large
+  auto stage_patch = [&](int bx0, int bx1, int by0, int by1, PatchPx* ppx) -> bool {
+    const int px0 = bx0 & ~3;
+    const int pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
+    if (pw > kPatchPitch || ph > kPatchRows) return false;  // wave-uniform
+    __builtin_amdgcn_wave_barrier();
+    if (dword_ok) {
+      const int ndw = (pw + 3) >> 2;  // <= 24 dwords per row
+      const int total = ndw * ph;     // <= 1920 dwords = 30 per lane
+      uint32_t tmp[30];
+      int off[30];
+#pragma unroll
+      for (int it = 0; it < 30; ++it) {  // every global load is in flight before the first use
+        const int idx = it * 64 + lane;
+        const int r = idx / ndw, c = idx - r * ndw;
+        off[it] = idx < total ? r * kPatchPitch + c * 4 : -1;
+        tmp[it] = 0;
+        if (idx < total)
+          tmp[it] = reinterpret_cast<const uint32_t*>(im + (size_t)(by0 + r) * w + px0)[c];
+      }
+#pragma unroll
+      for (int it = 0; it < 30; ++it)
+        if (off[it] >= 0) *reinterpret_cast<uint32_t*>(patch + off[it]) = tmp[it];
+    } else {
+      for (int r = 0; r < ph; ++r)
+        for (int c = lane; c < pw; c += 64) patch[r * kPatchPitch + c] = im[(size_t)(by0 + r) * w + px0 + c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    ppx->patch = patch;
+    ppx->x0 = px0;
+    ppx->y0 = by0;
+    return true;
+  };
+  // values of all 60 samples under the current M; false when a box leaves the image
+  auto sample_all = [&](bool fixed_box) -> bool {
+    const bool ok = sample_pos(M, kp.x, kp.y, px, py, sg, w, h, &xf, &yf);
+    if (!__all(ok || !active)) return false;
+    int bx0, bx1, by0, by1;
+    if (fixed_box) {  // circle of the pattern: covers every rotation (upright / gradient modes)
+      const int cx = (int)kp.x, cy = (int)kp.y;
+      bx0 = cx - border; bx1 = cx + border + 1; by0 = cy - border; by1 = cy + border + 1;
+      bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+      bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
+    } else {
+      const Box b = sample_box(xf, yf, sg);
+      bx0 = wave_min(active ? b.x_left : 0x7fffffff);
+      by0 = wave_min(active ? b.y_top : 0x7fffffff);
+      bx1 = wave_max(active ? b.x_right : -1);
+      by1 = wave_max(active ? b.y_bottom : -1);
+    }
+    PatchPx ppx;
+    int v = 0;
+    if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
+      if (active) v = smoothed_intensity(ppx, xf, yf, sg);
+    } else {
+      const GlobalPx gpx{im, w};
+      if (active) v = smoothed_intensity(gpx, xf, yf, sg);
+    }
+    __builtin_amdgcn_wave_barrier();
+    vals[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+    return true;
+  };
+
   if (valid && ip.mode == kCameraAware) {
     const float dir[3] = {ip.dir[0], ip.dir[1], ip.dir[2]};
     valid = camera_aware_matrix(rays[ip.cam], jac[ip.cam], w, ip.fu, dir, kp.x, kp.y, M);
   } else if (valid && ip.mode == kGradient) {
-    bool ok = sample_pos(M, kp.x, kp.y, px, py, sg, w, h, &xf, &yf);
-    valid = __all(ok || lane >= kPatternPoints);
+    valid = sample_all(true);
     if (valid) {
-      vals[lane] = lane < kPatternPoints ? smoothed_intensity(im, J, w, xf, yf, sg) : 0;
-      __builtin_amdgcn_wave_barrier();
       int d0 = 0, d1 = 0;
       for (int l = lane; l < pat->n_long; l += 64) {
         const int delta_t = vals[pat->long_i[l]] - vals[pat->long_j[l]];
@@ -291,16 +363,10 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
       M[1] = -pat->rot_sinf[best_k];
       M[2] = pat->rot_sinf[best_k];
       M[3] = pat->rot_cosf[best_k];
-      __builtin_amdgcn_wave_barrier();
     }
   }
+  if (valid) valid = sample_all(ip.mode != kCameraAware);
   if (valid) {
-    const bool ok = sample_pos(M, kp.x, kp.y, px, py, sg, w, h, &xf, &yf);
-    valid = __all(ok || lane >= kPatternPoints);
-  }
-  if (valid) {
-    vals[lane] = lane < kPatternPoints ? smoothed_intensity(im, J, w, xf, yf, sg) : 0;
-    __builtin_amdgcn_wave_barrier();
     unsigned long long words[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -479,22 +545,15 @@ __global__ __launch_bounds__(256) void compact_kernel(
 
 }  // namespace
 
-void launch_integral(const uint8_t* img, int w, int h, int n_images, int32_t* integral,
+void launch_describe(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
+                     const ImageParams* prm, const float* const* rays, const float* const* jac,
+                     const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
+                     okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      hipStream_t stream) {
   if (n_images <= 0) return;
-  hipLaunchKernelGGL(integral_kernel, dim3(n_images), dim3(256), 0, stream, img, w, h, integral);
-}
-
-void launch_describe(const uint8_t* img, const int32_t* integral, int w, int h, int n_images,
-                     const Pattern* pat, const ImageParams* prm, const float* const* rays,
-                     const float* const* jac, const okvfe_keypoint* kps_in, int kp_cap,
-                     const int32_t* kp_count_in, okvfe_keypoint* kps_tmp, uint8_t* desc_tmp,
-                     uint8_t* valid_tmp, hipStream_t stream) {
-  if (n_images <= 0) return;
   const dim3 grid((kp_cap + kDescWaves - 1) / kDescWaves, n_images);
-  hipLaunchKernelGGL(describe_kernel, grid, dim3(64 * kDescWaves), 0, stream, img, integral, w, h,
-                     pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                     valid_tmp);
+  hipLaunchKernelGGL(describe_kernel, grid, dim3(64 * kDescWaves), 0, stream, img, w, h, pat, prm,
+                     rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp);
 }
 
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,

@@ -38,7 +38,6 @@ struct okvfe_ctx {
   Pattern* d_pattern = nullptr;
   okvfe_keypoint* d_kps_det = nullptr;
   int32_t* d_det_count = nullptr;
-  int32_t* d_integral = nullptr;
   okvfe_keypoint* d_kps_tmp = nullptr;
   uint8_t* d_desc_tmp = nullptr;
   uint8_t* d_valid_tmp = nullptr;
@@ -302,7 +301,6 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     okvfe_status s;
 #define A(ptr, n) if ((s = dev_alloc(c, &c->ptr, (n))) != OKVFE_OK) return s
     A(d_scores, P * B);
-    A(d_integral, P * B);
     A(d_cand, (size_t)c->cand_cap * B);
     A(d_cand_count, B);
     A(d_sort_ws, (size_t)c->ws_stride * B);
@@ -504,12 +502,8 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
                   ctx->d_det_count, ctx->d_sort_ws, s);
   }
   {
-    StageTimer t(ctx, OKVFE_STAGE_INTEGRAL, s);
-    launch_integral(images_dev, w, h, n_images, ctx->d_integral, s);
-  }
-  {
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
-    launch_describe(images_dev, ctx->d_integral, w, h, n_images, ctx->d_pattern, ctx->d_prm,
+    launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
   }
@@ -651,8 +645,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_det_count, &n_in, sizeof(int32_t), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, sizeof(int32_t), s));
   HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources
-  launch_integral(ctx->d_img_stage, w, h, 1, ctx->d_integral, s);
-  launch_describe(ctx->d_img_stage, ctx->d_integral, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
+  launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
                   ctx->d_desc_tmp, ctx->d_valid_tmp, s);
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,

@@ -83,13 +83,11 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
                    uint64_t* sort_ws, hipStream_t stream);
-void launch_integral(const uint8_t* img, int w, int h, int n_images, int32_t* integral,
+void launch_describe(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
+                     const ImageParams* prm, const float* const* rays, const float* const* jac,
+                     const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
+                     okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      hipStream_t stream);
-void launch_describe(const uint8_t* img, const int32_t* integral, int w, int h, int n_images,
-                     const Pattern* pat, const ImageParams* prm, const float* const* rays,
-                     const float* const* jac, const okvfe_keypoint* kps_in, int kp_cap,
-                     const int32_t* kp_count_in, okvfe_keypoint* kps_tmp, uint8_t* desc_tmp,
-                     uint8_t* valid_tmp, hipStream_t stream);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
                     const uint8_t* valid_tmp, const int32_t* kp_count_in, int kp_cap,
