@@ -311,6 +311,125 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
   if (tid == 0) kp_count[img] = kept;
 }
 
+// ---- single-wave greedy (the production path when the occupancy grid fits in LDS) ---------------
+// One WAVE per image: no workgroup barriers at all.  LDS holds the occupancy grid, a per-candidate
+// record {cell (cy << 16 | cx), level nsc1 (float)} for the first `pre_cap` candidates (the rest
+// lives in the dead Candidate array in HBM) and the indices of the accepted candidates.  Each
+// round tests 64 consecutive candidates, accepts the first that passes (all before it are dead
+// for good, occupancy only grows), and stamps its 31x31 patch: 16 cells per lane, all reads
+// issued before the writes.  Sub-pixel refinement of the accepted points runs at the end.
+__global__ __launch_bounds__(64) void select_wave_kernel(
+    const int32_t* __restrict__ scores, int w, int h, Candidate* __restrict__ cand, int cand_cap,
+    const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
+    float radius, int max_kpts, const float* __restrict__ lut, int occ_rows, int occ_cols,
+    int occ_bytes16, int pre_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
+    int32_t* __restrict__ kp_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint8_t* occ = smem_raw;
+  int* acc_idx = reinterpret_cast<int*>(smem_raw + occ_bytes16);
+  uint2* pre_lds = reinterpret_cast<uint2*>(smem_raw + occ_bytes16 + ((kp_cap * 4 + 15) & ~15));
+  const int img = blockIdx.x;
+  const int lane = threadIdx.x;
+  int n = cand_count[img];
+  n = n > cand_cap ? cand_cap : n;
+  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
+  uint2* pre_glb = reinterpret_cast<uint2*>(cand + (size_t)img * cand_cap);  // Candidate is dead after the sort
+  const int32_t* sc = scores + (size_t)img * w * h;
+  okvfe_keypoint* out = kps + (size_t)img * kp_cap;
+  int kept = 0;
+  if (n > 0) {
+    {
+      uint4* z = reinterpret_cast<uint4*>(smem_raw);
+      const uint4 zero = make_uint4(0, 0, 0, 0);
+      for (int i = lane; i < (occ_bytes16 >> 4); i += 64) z[i] = zero;
+    }
+    const float scaling = (float)(15.0 / (double)radius);
+    const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
+    for (int i = lane; i < n; i += 64) {
+      const uint64_t k = keys[i];
+      const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+      const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
+      const float fy = (float)y * scaling;
+      const float fx = (float)x * scaling;
+      const int cy = (int)(fy + 16.0f);
+      const int cx = (int)(fx + 16.0f);
+      const float q = (float)score / max_score;
+      const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+      const uint2 rec = make_uint2(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1));
+      if (i < pre_cap) pre_lds[i] = rec; else pre_glb[i] = rec;
+    }
+    // per-lane stamp geometry: cells t = it*64 + lane of the 31x31 patch
+    float lutv[16];
+    int off[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int t = it * 64 + lane;
+      const int tt = t < 961 ? t : 0;
+      const int ry = tt / 31, rx = tt - ry * 31;
+      lutv[it] = t < 961 ? lut[tt] : 0.0f;   // add = ceil(0 * nsc) = 0 for the padding lanes
+      off[it] = (ry - 15) * occ_cols + (rx - 15);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
+    int pos = 0;
+    while (pos < n && kept < limit) {
+      const int idx = pos + lane;
+      uint2 rec = make_uint2(0, 0);
+      if (idx < n) rec = idx < pre_cap ? pre_lds[idx] : pre_glb[idx];
+      const int cell = (int)(rec.x >> 16) * occ_cols + (int)(rec.x & 0xFFFF);
+      const float s0 = (float)occ[idx < n ? cell : 0];
+      const bool pass = idx < n && !(__uint_as_float(rec.y) < s0);
+      const unsigned long long b = __ballot(pass);
+      if (b == 0) {
+        pos += 64;
+        continue;
+      }
+      const int first = (int)__ffsll((long long)b) - 1;
+      const int wcell = __builtin_amdgcn_readlane(cell, first);
+      const float wnsc1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)rec.y, first));
+      const float nsc = (float)(0.99 * (double)wnsc1);
+      int v[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) v[it] = occ[wcell + off[it]];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const float m = lutv[it] * nsc;
+        const int nv = v[it] + (int)ceilf(m);
+        if (it < 15 || lane == 0) occ[wcell + off[it]] = (uint8_t)(nv > 255 ? 255 : nv);
+      }
+      if (lane == 0) acc_idx[kept] = pos + first;
+      ++kept;
+      pos += first + 1;
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i < kept; i += 64) {
+    const uint64_t k = keys[acc_idx[i]];
+    const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+    const int v = (int)((k >> 16) & 0xFFFF), u = (int)(k & 0xFFFF);
+    int32_t patch[9];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        patch[(dy + 1) * 3 + (dx + 1)] = sc[(size_t)(v + dy) * w + (u + dx)];
+    float ddx, ddy;
+    subpixel2d(patch, &ddx, &ddy);
+    okvfe_keypoint kp;
+    kp.x = (float)u + ddx;
+    kp.y = (float)v + ddy;
+    kp.size = 12.0f;
+    kp.angle = -1.0f;
+    kp.response = (float)score;
+    kp.octave = 0;
+    kp.class_id = -1;
+    out[i] = kp;
+  }
+  if (lane == 0) kp_count[img] = kept;
+}
+
 }  // namespace
 
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
@@ -333,6 +452,19 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
   const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
+  // single-wave kernel: occupancy + accepted indices + as many candidate records as fit in LDS
+  const size_t acc_bytes = ((size_t)kp_cap * 4 + 15) & ~(size_t)15;
+  const size_t lds_budget = 152 * 1024;
+  if (occ_lds && occ_bytes + acc_bytes + 64 * 8 <= lds_budget && (cand_cap % 2) == 0) {
+    size_t pre_cap = (lds_budget - occ_bytes - acc_bytes) / 8;
+    if (pre_cap > (size_t)cand_cap) pre_cap = (size_t)cand_cap;
+    // keep two waves per CU resident when the candidate records allow it
+    const size_t lds = occ_bytes + acc_bytes + pre_cap * 8;
+    hipLaunchKernelGGL(select_wave_kernel, dim3(n_images), dim3(64), lds, stream, score, w, h, cand,
+                       cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, occ_rows,
+                       occ_cols, (int)occ_bytes, (int)pre_cap, kps, kp_cap, kp_count);
+    return;
+  }
   if (occ_lds) {
     hipLaunchKernelGGL(select_kernel<true>, dim3(n_images), dim3(kThreads), occ_bytes, stream,
                        score, w, h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius,

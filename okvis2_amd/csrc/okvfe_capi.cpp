@@ -279,7 +279,7 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
   ctx->kp_cap = cfg->max_keypoints;
   const int worst = (cfg->width / 2 + 1) * (cfg->height - 4);
   ctx->cand_cap = cfg->max_candidates > 0 ? std::min(cfg->max_candidates, worst) : worst;
-  ctx->cand_cap = std::max(ctx->cand_cap, 64);
+  ctx->cand_cap = (std::max(ctx->cand_cap, 64) + 1) & ~1;  // even: the array doubles as 8-byte records
   ctx->ws_stride = 1;
   while (ctx->ws_stride < ctx->cand_cap) ctx->ws_stride <<= 1;
   ctx->mode_default = cfg->rotation_invariant ? kGradient : kUpright;
