@@ -193,6 +193,14 @@ def main():
         stage_ms = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
         harris_ms = stage_ms["harris"]
         achieved = 5.0 * P * n_img / (harris_ms * 1e-3) / 1e9
+        # HBM traffic of the K1 launch from the PMC passes committed under profiles/ (rocprofv3
+        # cannot run inside this process); only valid for the launch shape it was measured on
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "round1_k1_pmc.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("algorithmic_bytes_per_launch") == 5 * P * n_img:
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/round1_k1_pmc.json"
         m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
         fe._bench_matches = m
         result = {
@@ -215,7 +223,8 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"kernel": "harris_kernel (K1 score map)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": 5 * P * n_img,
                          "avg_launch_ms": harris_ms},
             "stage_ms_per_step": stage_ms,
