@@ -241,6 +241,42 @@ okvfe_status okvfe_match_stereo(okvfe_ctx* ctx, const uint8_t* desc0, const okvf
                                 const okvfe_pose* T_WC0, const okvfe_pose* T_WC1, double f0,
                                 double f1, okvfe_stereo_match* matches /* n0 */);
 
+typedef struct okvfe_motion_match {
+  int32_t k1;            /* index in the current frame, -1 = no match */
+  int32_t dist;
+  int32_t initialisable; /* !isParallel */
+  int32_t accepted;      /* winner re-projects within 4 px (Frontend.cpp:1897-1905) */
+  double cos_quality;    /* quality = acos(cos_quality) (Frontend.cpp:1887-1889) */
+  double hp_W[4];
+} okvfe_motion_match;
+
+/* = the k0 x k1 loop of Frontend::matchMotionStereo for one (older frame, current frame, camera)
+ * triple (Frontend.cpp:1789-1905).  Frame 0 = older frame.  skip0[k0] != 0: k0 is not matched
+ * (landmark already initialised / already observed, :1814-1841); matched1[k1] != 0: current
+ * keypoint already carries a landmark and is left out (:1795-1798).  Either may be NULL.
+ * Host buffers; `camera` is the shared camera of both frames. */
+okvfe_status okvfe_match_motion_stereo(okvfe_ctx* ctx, const okvfe_camera* camera,
+                                       const uint8_t* desc0, const okvfe_keypoint* kp0,
+                                       const double* backproj0, const uint8_t* valid0,
+                                       const uint8_t* skip0, int32_t n0, const uint8_t* desc1,
+                                       const okvfe_keypoint* kp1, const double* backproj1,
+                                       const uint8_t* valid1, const uint8_t* matched1, int32_t n1,
+                                       const okvfe_pose* T_WC0, const okvfe_pose* T_WC1,
+                                       okvfe_motion_match* matches /* n0 */);
+
+/* = Frontend::matchToMapByThread for the 3-D landmarks (Frontend.cpp:1552-1589), all keypoints
+ * in one call.  Landmarks in the caller's order (ascending LandmarkId in the reference);
+ * landmark l owns pool rows desc_begin[l] .. desc_begin[l+1]-1 (<= 3 descriptors each,
+ * :1220-1222) and the projection (2 doubles).  use[k] == 0 skips keypoint k (:1541-1547).
+ * reprojection_threshold: 20 px with IMU, 150 without (:1530).  Outputs per keypoint: landmark
+ * INDEX (-1 = none) and distance (match_threshold if none). */
+okvfe_status okvfe_match_to_map(okvfe_ctx* ctx, const uint8_t* desc, const okvfe_keypoint* kps,
+                                const uint8_t* use, int32_t n_kps, const double* projections_l2,
+                                const int32_t* desc_begin /* n_landmarks + 1 */,
+                                int32_t n_landmarks, const uint8_t* pool,
+                                double reprojection_threshold, int32_t* best_landmark,
+                                int32_t* best_dist);
+
 typedef struct okvfe_candidate {
   int32_t i, j, dist;
 } okvfe_candidate;

@@ -25,6 +25,8 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
 STEREO_MATCH_DTYPE = np.dtype([("k1", "<i4"), ("dist", "<i4"), ("initialisable", "<i4"),
                                ("pad", "<i4"), ("hp_W", "<f8", (4,))])
 CAND_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("dist", "<i4")])
+MOTION_MATCH_DTYPE = np.dtype([("k1", "<i4"), ("dist", "<i4"), ("initialisable", "<i4"),
+                               ("accepted", "<i4"), ("cos_quality", "<f8"), ("hp_W", "<f8", (4,))])
 
 
 class Config(C.Structure):
@@ -67,6 +69,7 @@ EXPORTS = [
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
     "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap", "okvfe_compute",
+    "okvfe_match_motion_stereo", "okvfe_match_to_map",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -289,6 +292,33 @@ class Frontend:
                                              C.byref(P1), C.c_double(f0), C.c_double(f1),
                                              _p(out)))
         return out[:n0]
+
+    def match_motion_stereo(self, cam, desc0, kp0, bp0, bpv0, skip0, desc1, kp1, bp1, bpv1, matched1,
+                            T0, T1):
+        n0, n1 = len(kp0), len(kp1)
+        out = np.zeros(max(n0, 1), dtype=MOTION_MATCH_DTYPE)
+        arrs = [None if a is None else np.ascontiguousarray(a)
+                for a in (desc0, kp0, bp0, bpv0, skip0, desc1, kp1, bp1, bpv1, matched1)]
+        c = make_camera(cam)
+        P0, P1 = make_pose(*T0), make_pose(*T1)
+        self._check(lib().okvfe_match_motion_stereo(
+            self._h, C.byref(c), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]), n0,
+            _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), _p(arrs[8]), _p(arrs[9]), n1, C.byref(P0),
+            C.byref(P1), _p(out)))
+        return out[:n0]
+
+    def match_to_map(self, desc, kps, use, proj, desc_begin, pool, repr_thr):
+        n, nl = len(kps), len(desc_begin) - 1
+        bl = np.zeros(max(n, 1), dtype=np.int32)
+        bd = np.zeros(max(n, 1), dtype=np.int32)
+        arrs = [np.ascontiguousarray(a) for a in (desc, kps, np.asarray(use, dtype=np.uint8),
+                                                 np.asarray(proj, dtype=np.float64),
+                                                 np.asarray(desc_begin, dtype=np.int32),
+                                                 np.asarray(pool, dtype=np.uint8))]
+        self._check(lib().okvfe_match_to_map(self._h, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), n,
+                                             _p(arrs[3]), _p(arrs[4]), nl, _p(arrs[5]),
+                                             C.c_double(repr_thr), _p(bl), _p(bd)))
+        return bl[:n], bd[:n]
 
     def hamming_candidates(self, A, B, thr, cap=None):
         A = np.ascontiguousarray(A, dtype=np.uint8)

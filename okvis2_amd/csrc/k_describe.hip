@@ -18,6 +18,7 @@
 //                    back-projects the survivors in FP64 (Gauss-Newton undistortion).
 #include <limits.h>
 
+#include "camera_dev.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -390,111 +391,6 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
 }
 
 // ---- compaction + back-projection -----------------------------------------------------------
-__device__ void distort(const DeviceCamera& c, double u0, double u1, double out[2], double J[4]) {
-  if (c.distortion == OKVFE_DIST_NONE) {
-    out[0] = u0; out[1] = u1;
-    J[0] = 1.0; J[1] = 0.0; J[2] = 0.0; J[3] = 1.0;
-    return;
-  }
-  if (c.distortion == OKVFE_DIST_RADTAN) {
-    const double k1 = c.d[0], k2 = c.d[1], p1 = c.d[2], p2 = c.d[3];
-    const double mx_u = u0 * u0;
-    const double my_u = u1 * u1;
-    const double mxy_u = u0 * u1;
-    const double rho_u = mx_u + my_u;
-    const double rad_dist_u = k1 * rho_u + k2 * rho_u * rho_u;
-    out[0] = u0 + u0 * rad_dist_u + 2.0 * p1 * mxy_u + p2 * (rho_u + 2.0 * mx_u);
-    out[1] = u1 + u1 * rad_dist_u + 2.0 * p2 * mxy_u + p1 * (rho_u + 2.0 * my_u);
-    J[0] = 1 + rad_dist_u + k1 * 2.0 * mx_u + k2 * rho_u * 4 * mx_u + 2.0 * p1 * u1 + 6 * p2 * u0;
-    J[2] = k1 * 2.0 * u0 * u1 + k2 * 4 * rho_u * u0 * u1 + p1 * 2.0 * u0 + 2.0 * p2 * u1;
-    J[1] = J[2];
-    J[3] = 1 + rad_dist_u + k1 * 2.0 * my_u + k2 * rho_u * 4 * my_u + 6 * p1 * u1 + 2.0 * p2 * u0;
-    return;
-  }
-  // equidistant (device atan; see DESIGN.md on its last-ulp caveat)
-  const double k1 = c.d[0], k2 = c.d[1], k3 = c.d[2], k4 = c.d[3];
-  const double r = sqrt(u0 * u0 + u1 * u1);
-  const double theta = atan(r);
-  const double theta2 = theta * theta;
-  const double theta4 = theta2 * theta2;
-  const double theta6 = theta4 * theta2;
-  const double theta8 = theta4 * theta4;
-  const double thetad = theta * (1.0 + k1 * theta2 + k2 * theta4 + k3 * theta6 + k4 * theta8);
-  const double scaling = (r > 1e-8) ? thetad / r : 1.0;
-  out[0] = scaling * u0;
-  out[1] = scaling * u1;
-  if (r > 1e-8) {
-    double t2, t3, t4, t6, t7, t8, t9, t11, t17, t18, t19, t20, t25;
-    t2 = u0 * u0;
-    t3 = u1 * u1;
-    t4 = t2 + t3;
-    t6 = atan(sqrt(t4));
-    t7 = t6 * t6;
-    t8 = 1.0 / sqrt(t4);
-    t9 = t7 * t7;
-    t11 = 1.0 / ((t2 + t3) + 1.0);
-    t17 = (((k1 * t7 + k2 * t9) + k3 * t7 * t9) + k4 * (t9 * t9)) + 1.0;
-    t18 = 1.0 / t4;
-    t19 = 1.0 / sqrt(t4 * t4 * t4);
-    t20 = t6 * t8 * t17;
-    t25 = ((k2 * t6 * t7 * t8 * t11 * u1 * 4.0 + k3 * t6 * t8 * t9 * t11 * u1 * 6.0) +
-           k4 * t6 * t7 * t8 * t9 * t11 * u1 * 8.0) +
-          k1 * t6 * t8 * t11 * u1 * 2.0;
-    t4 = ((k2 * t6 * t7 * t8 * t11 * u0 * 4.0 + k3 * t6 * t8 * t9 * t11 * u0 * 6.0) +
-          k4 * t6 * t7 * t8 * t9 * t11 * u0 * 8.0) +
-         k1 * t6 * t8 * t11 * u0 * 2.0;
-    t7 = t11 * t17 * t18 * u0 * u1;
-    J[1] = (t7 + t6 * t8 * t25 * u0) - t6 * t17 * t19 * u0 * u1;
-    J[3] = ((t20 - t3 * t6 * t17 * t19) + t3 * t11 * t17 * t18) + t6 * t8 * t25 * u1;
-    J[0] = ((t20 - t2 * t6 * t17 * t19) + t2 * t11 * t17 * t18) + t6 * t8 * t4 * u0;
-    J[2] = (t7 + t6 * t8 * t4 * u1) - t6 * t17 * t19 * u0 * u1;
-  } else {
-    J[0] = 1.0; J[1] = 0.0; J[2] = 0.0; J[3] = 1.0;
-  }
-}
-
-__device__ bool backproject(const DeviceCamera& c, double px, double py, double dir[3]) {
-  const double pd0 = (px - c.cu) * c.one_over_fu;
-  const double pd1 = (py - c.cv) * c.one_over_fv;
-  bool success = false;
-  double x0 = pd0, x1 = pd1;
-  if (c.distortion == OKVFE_DIST_NONE) {
-    success = true;
-  } else {
-    const int n = c.distortion == OKVFE_DIST_RADTAN ? 5 : 20;
-    for (int i = 0; i < n; ++i) {
-      double xt[2], E[4];
-      distort(c, x0, x1, xt, E);
-      const double e0 = pd0 - xt[0], e1 = pd1 - xt[1];
-      const double a = E[0] * E[0] + E[2] * E[2];
-      const double b = E[0] * E[1] + E[2] * E[3];
-      const double cc = E[1] * E[0] + E[3] * E[2];
-      const double d = E[1] * E[1] + E[3] * E[3];
-      const double det = a * d - b * cc;
-      const double invdet = 1.0 / det;
-      const double i00 = d * invdet, i01 = -b * invdet, i10 = -cc * invdet, i11 = a * invdet;
-      const double b00 = i00 * E[0] + i01 * E[1];
-      const double b01 = i00 * E[2] + i01 * E[3];
-      const double b10 = i10 * E[0] + i11 * E[1];
-      const double b11 = i10 * E[2] + i11 * E[3];
-      const double du0 = b00 * e0 + b01 * e1;
-      const double du1 = b10 * e0 + b11 * e1;
-      x0 += du0;
-      x1 += du1;
-      const double chi2 = e0 * e0 + e1 * e1;
-      if (chi2 < 1e-6) success = true;
-      if (chi2 < 1e-15) {
-        success = true;
-        break;
-      }
-    }
-  }
-  dir[0] = x0;
-  dir[1] = x1;
-  dir[2] = 1.0;
-  return success;
-}
-
 __global__ __launch_bounds__(256) void compact_kernel(
     const DeviceCamera* __restrict__ cams, const ImageParams* __restrict__ prm,
     const okvfe_keypoint* __restrict__ kps_tmp, const uint8_t* __restrict__ desc_tmp,
@@ -530,7 +426,7 @@ __global__ __launch_bounds__(256) void compact_kernel(
       d[2] = s[2];
       double dir[3] = {0.0, 0.0, 0.0};
       bool ok = false;
-      if (cam >= 0 && cams[cam].fu > 0.0) ok = backproject(cams[cam], (double)kp.x, (double)kp.y, dir);
+      if (cam >= 0 && cams[cam].fu > 0.0) ok = cam::backproject(cams[cam], (double)kp.x, (double)kp.y, dir);
       bp[(off + pos) * 3 + 0] = dir[0];
       bp[(off + pos) * 3 + 1] = dir[1];
       bp[(off + pos) * 3 + 2] = dir[2];

@@ -17,6 +17,7 @@
 // whose distance beats their running best, exactly when the reference evaluates it.
 // Integer-ALU bound (v_xor + v_bcnt_u32_b32, 24 VALU per pair); inputs are 2 x 33.6 KB per
 // EuRoC stereo frame, so HBM is not the limit.
+#include "camera_dev.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -308,7 +309,174 @@ __global__ __launch_bounds__(64) void hamming_emit_kernel(const uint8_t* __restr
   }
 }
 
+// ---- matchMotionStereo (Frontend.cpp:1812-1905) -------------------------------------------------
+// Frame 0 = older frame, frame 1 = current frame, same camera.  Lane = k0; k1 ascending over the
+// current keypoints that do not carry a landmark yet (matched1[k1] == 0, the packed set of
+// :1789-1802); skip0[k0] stands for the estimator-state tests at :1814-1841.  Gate order as in the
+// reference: back-projection valid -> e0.e1 >= 0.5 -> triangulateFast valid -> e0.e1 >= 0.8 ->
+// depths >= 0.2 unless parallel.  The winner is re-projected into the current camera and must
+// land within 4 px (:1897-1905).  `cos_quality` is the cosine whose acos the reference stores
+// as match quality (:1887-1889); the host takes the acos.
+__global__ __launch_bounds__(64) void match_motion_kernel(
+    const PairParams* __restrict__ pair, const DeviceCamera* __restrict__ camera, int w, int h,
+    const uint8_t* __restrict__ desc0, const okvfe_keypoint* __restrict__ kp0,
+    const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0,
+    const uint8_t* __restrict__ skip0, int n0, const uint8_t* __restrict__ desc1,
+    const okvfe_keypoint* __restrict__ kp1, const double* __restrict__ bp1,
+    const uint8_t* __restrict__ bpv1, const uint8_t* __restrict__ matched1, int n1, int threshold,
+    okvfe_motion_match* __restrict__ out) {
+  const PairParams& P = *pair;
+  const int k0 = blockIdx.x * 64 + threadIdx.x;
+  const bool in_range = k0 < n0;
+  bool active = in_range && !(skip0 && skip0[k0]) && bpv0[k0] != 0;
+  Desc12 d0;
+  double e0_W[3] = {0, 0, 0};
+  if (active) {
+    d0 = load_desc(desc0 + (size_t)k0 * OKVFE_DESC_BYTES);
+    double v[3];
+    rot(P.C0, bp0 + 3 * (size_t)k0, v);
+    normalize3(v, e0_W);
+  }
+  int best = threshold;
+  int k1_max = 1000;
+  bool initialisable = false;
+  double cosq = 1.0;
+  double hps[4] = {0, 0, 0, 0};
+  for (int k1 = 0; k1 < n1; ++k1) {
+    if (matched1 && matched1[k1]) continue;  // wave-uniform
+    const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc1 + (size_t)k1 * OKVFE_DESC_BYTES);
+    if (!active) continue;
+    const int dist = hamming(d0, d1);
+    if (dist < best) {
+      if (!bpv1[k1]) continue;
+      double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+      rot(P.C1, bp1 + 3 * (size_t)k1, v);
+      normalize3(v, e1_W);
+      const double ee = dot3(e0_W, e1_W);
+      if (ee < 0.5) continue;
+      bool is_valid, is_parallel;
+      triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
+      if (!is_valid) continue;
+      inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+      inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+      if (ee < 0.8) is_valid = false;
+      if (!is_parallel) {
+        const double w4 = hp_W[3];
+        hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+        if (hp_C0[2] / hp_C0[3] < 0.2) is_valid = false;
+        if (hp_C1[2] / hp_C1[3] < 0.2) is_valid = false;
+      }
+      if (is_valid) {
+        k1_max = k1;
+        best = dist;
+        double a[3], b[3], an[3], bn[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          a[i] = hp_W[i] - P.r0[i];
+          b[i] = hp_W[i] - P.r1[i];
+        }
+        normalize3(a, an);
+        normalize3(b, bn);
+        cosq = dot3(an, bn);
+        hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
+        initialisable = !is_parallel;
+      }
+    }
+  }
+  if (in_range) {
+    okvfe_motion_match m;
+    const bool hit = active && best < threshold;
+    m.k1 = hit ? k1_max : -1;
+    m.dist = hit ? best : threshold;
+    m.initialisable = hit && initialisable ? 1 : 0;
+    m.accepted = 0;
+    m.cos_quality = hit ? cosq : 1.0;
+    m.hp_W[0] = hit ? hps[0] : 0.0;
+    m.hp_W[1] = hit ? hps[1] : 0.0;
+    m.hp_W[2] = hit ? hps[2] : 0.0;
+    m.hp_W[3] = hit ? hps[3] : 0.0;
+    if (hit) {
+      double hp_C1[4], head[3], pt1p[2];
+      inv_transform_h(P.C1, P.r1, hps, hp_C1);
+      const double sgn = hp_C1[3] < 0 ? -1.0 : 1.0;  // projectHomogeneous: PinholeCamera.hpp:493-503
+      head[0] = hp_C1[3] < 0 ? -hp_C1[0] : hp_C1[0];
+      head[1] = hp_C1[3] < 0 ? -hp_C1[1] : hp_C1[1];
+      head[2] = hp_C1[3] < 0 ? -hp_C1[2] : hp_C1[2];
+      (void)sgn;
+      const int status = cam::project(*camera, w, h, head, pt1p);
+      const double ex = (double)kp1[k1_max].x - pt1p[0], ey = (double)kp1[k1_max].y - pt1p[1];
+      m.accepted = (status == 0 && sqrt(ex * ex + ey * ey) < 4.0) ? 1 : 0;
+    }
+    out[k0] = m;
+  }
+  (void)kp0;
+}
+
+// ---- matchToMapByThread, 3-D landmarks (Frontend.cpp:1552-1589) ----------------------------------
+// Lane = keypoint k; landmarks in the caller's order (ascending LandmarkId in the reference's
+// std::map); per landmark the image-distance gate |projection - keypoint|^2 <= thr^2, then its
+// <= 3 descriptors in order with the running minimum "dist < distances[k]" (strict, first-lowest
+// wins).  Returns per keypoint the distance and the landmark INDEX (or -1).
+__global__ __launch_bounds__(64) void match_to_map_kernel(
+    const uint8_t* __restrict__ desc_k, const okvfe_keypoint* __restrict__ kps,
+    const uint8_t* __restrict__ use, int n_k, const double* __restrict__ projections,
+    const int32_t* __restrict__ desc_begin, int n_lm, const uint8_t* __restrict__ pool,
+    double thr_sq, int threshold, int32_t* __restrict__ best_lm, int32_t* __restrict__ best_d) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const bool in_range = k < n_k;
+  const bool active = in_range && use[k] != 0;
+  Desc12 dk;
+  double kx = 0.0, ky = 0.0;
+  if (active) {
+    dk = load_desc(desc_k + (size_t)k * OKVFE_DESC_BYTES);
+    kx = (double)kps[k].x;
+    ky = (double)kps[k].y;
+  }
+  int best = threshold, lm = -1;
+  for (int l = 0; l < n_lm; ++l) {
+    const double px = projections[2 * l], py = projections[2 * l + 1];
+    const int b = desc_begin[l], e = desc_begin[l + 1];
+    if (!active) continue;
+    const double dx = px - kx, dy = py - ky;
+    const double dd = dx * dx + dy * dy;
+    if (dd > thr_sq) continue;
+    for (int d = b; d < e; ++d) {
+      const int dist = hamming(dk, reinterpret_cast<const uint32_t*>(pool + (size_t)d * OKVFE_DESC_BYTES));
+      if (dist < best) {
+        best = dist;
+        lm = l;
+      }
+    }
+  }
+  if (in_range) {
+    best_lm[k] = lm;
+    best_d[k] = best;
+  }
+}
+
 }  // namespace
+
+void launch_match_motion(const PairParams* pair, const DeviceCamera* camera, int w, int h,
+                         const uint8_t* desc0, const okvfe_keypoint* kp0, const double* bp0,
+                         const uint8_t* bpv0, const uint8_t* skip0, int n0, const uint8_t* desc1,
+                         const okvfe_keypoint* kp1, const double* bp1, const uint8_t* bpv1,
+                         const uint8_t* matched1, int n1, int threshold, okvfe_motion_match* out,
+                         hipStream_t stream) {
+  if (n0 <= 0) return;
+  hipLaunchKernelGGL(match_motion_kernel, dim3((n0 + 63) / 64), dim3(64), 0, stream, pair, camera, w,
+                     h, desc0, kp0, bp0, bpv0, skip0, n0, desc1, kp1, bp1, bpv1, matched1, n1,
+                     threshold, out);
+}
+
+void launch_match_to_map(const uint8_t* desc_k, const okvfe_keypoint* kps, const uint8_t* use, int n_k,
+                         const double* projections, const int32_t* desc_begin, int n_lm,
+                         const uint8_t* pool, double thr_sq, int threshold, int32_t* best_lm,
+                         int32_t* best_d, hipStream_t stream) {
+  if (n_k <= 0) return;
+  hipLaunchKernelGGL(match_to_map_kernel, dim3((n_k + 63) / 64), dim3(64), 0, stream, desc_k, kps,
+                     use, n_k, projections, desc_begin, n_lm, pool, thr_sq, threshold, best_lm,
+                     best_d);
+}
 
 void launch_match_stereo(const PairParams* pairs, int n_pairs, const okvfe_keypoint* kps,
                          const uint8_t* desc, const double* bp, const uint8_t* bpv,

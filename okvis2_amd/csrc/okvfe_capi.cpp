@@ -751,6 +751,112 @@ okvfe_status okvfe_match_stereo(okvfe_ctx* ctx, const uint8_t* desc0, const okvf
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_match_motion_stereo(okvfe_ctx* ctx, const okvfe_camera* camera, const uint8_t* desc0,
+                                       const okvfe_keypoint* kp0, const double* backproj0, const uint8_t* valid0,
+                                       const uint8_t* skip0, int32_t n0, const uint8_t* desc1,
+                                       const okvfe_keypoint* kp1, const double* backproj1, const uint8_t* valid1,
+                                       const uint8_t* matched1, int32_t n1, const okvfe_pose* T_WC0,
+                                       const okvfe_pose* T_WC1, okvfe_motion_match* matches) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!camera || n0 < 0 || n1 < 0 || !T_WC0 || !T_WC1 ||
+      (n0 > 0 && (!desc0 || !kp0 || !backproj0 || !valid0 || !matches)) ||
+      (n1 > 0 && (!desc1 || !kp1 || !backproj1 || !valid1)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_motion_stereo: bad argument");
+  for (int i = 0; i < n0; ++i)
+    if (kp0[i].size != 12.0f) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint size %f != 12 (multi-scale unsupported)", kp0[i].size);
+  if (n0 == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  const size_t a = 256;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), a); return o; };
+  const size_t o_pair = take(sizeof(PairParams)), o_cam = take(sizeof(DeviceCamera));
+  const size_t o_d0 = take((size_t)n0 * 48), o_k0 = take((size_t)n0 * sizeof(okvfe_keypoint)), o_b0 = take((size_t)n0 * 24),
+               o_v0 = take(n0), o_s0 = take(n0);
+  const size_t o_d1 = take((size_t)n1 * 48), o_k1 = take((size_t)n1 * sizeof(okvfe_keypoint)), o_b1 = take((size_t)n1 * 24),
+               o_v1 = take(n1), o_m1 = take(n1);
+  const size_t o_out = take((size_t)n0 * sizeof(okvfe_motion_match));
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  okvfe_stereo_pair sp{};
+  sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1;
+  sp.f0 = sp.f1 = 0.5 * (camera->fu + camera->fv);  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834)
+  const PairParams pp = to_pair_params(sp);
+  const DeviceCamera dc = to_device_camera(*camera);
+  auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRY(ctx, up(o_pair, &pp, sizeof(pp)));
+  HIP_TRY(ctx, up(o_cam, &dc, sizeof(dc)));
+  HIP_TRY(ctx, up(o_d0, desc0, (size_t)n0 * 48));
+  HIP_TRY(ctx, up(o_k0, kp0, (size_t)n0 * sizeof(okvfe_keypoint)));
+  HIP_TRY(ctx, up(o_b0, backproj0, (size_t)n0 * 24));
+  HIP_TRY(ctx, up(o_v0, valid0, n0));
+  if (skip0) HIP_TRY(ctx, up(o_s0, skip0, n0));
+  HIP_TRY(ctx, up(o_d1, desc1, (size_t)n1 * 48));
+  HIP_TRY(ctx, up(o_k1, kp1, (size_t)n1 * sizeof(okvfe_keypoint)));
+  HIP_TRY(ctx, up(o_b1, backproj1, (size_t)n1 * 24));
+  HIP_TRY(ctx, up(o_v1, valid1, n1));
+  if (matched1) HIP_TRY(ctx, up(o_m1, matched1, n1));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_match_motion(reinterpret_cast<PairParams*>(base + o_pair), reinterpret_cast<DeviceCamera*>(base + o_cam),
+                      camera->width, camera->height, base + o_d0, reinterpret_cast<okvfe_keypoint*>(base + o_k0),
+                      reinterpret_cast<double*>(base + o_b0), base + o_v0, skip0 ? base + o_s0 : nullptr, n0,
+                      base + o_d1, reinterpret_cast<okvfe_keypoint*>(base + o_k1),
+                      reinterpret_cast<double*>(base + o_b1), base + o_v1, matched1 ? base + o_m1 : nullptr, n1,
+                      ctx->cfg.match_threshold, reinterpret_cast<okvfe_motion_match*>(base + o_out), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(matches, base + o_out, (size_t)n0 * sizeof(okvfe_motion_match), hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_match_to_map(okvfe_ctx* ctx, const uint8_t* desc, const okvfe_keypoint* kps, const uint8_t* use,
+                                int32_t n_kps, const double* projections_l2, const int32_t* desc_begin,
+                                int32_t n_landmarks, const uint8_t* pool, double reprojection_threshold,
+                                int32_t* best_landmark, int32_t* best_dist) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n_kps < 0 || n_landmarks < 0 || !desc_begin || !(reprojection_threshold >= 0.0) ||
+      (n_kps > 0 && (!desc || !kps || !use || !best_landmark || !best_dist)) ||
+      (n_landmarks > 0 && (!projections_l2 || !pool)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map: bad argument");
+  for (int l = 0; l < n_landmarks; ++l)
+    if (desc_begin[l + 1] < desc_begin[l] || desc_begin[l] < 0)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map: desc_begin not monotone at %d", l);
+  if (n_kps == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  const int n_pool = desc_begin[n_landmarks];
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  const size_t o_d = take((size_t)n_kps * 48), o_k = take((size_t)n_kps * sizeof(okvfe_keypoint)), o_u = take(n_kps);
+  const size_t o_p = take((size_t)n_landmarks * 16), o_b = take((size_t)(n_landmarks + 1) * 4), o_pool = take((size_t)n_pool * 48);
+  const size_t o_lm = take((size_t)n_kps * 4), o_bd = take((size_t)n_kps * 4);
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRY(ctx, up(o_d, desc, (size_t)n_kps * 48));
+  HIP_TRY(ctx, up(o_k, kps, (size_t)n_kps * sizeof(okvfe_keypoint)));
+  HIP_TRY(ctx, up(o_u, use, n_kps));
+  HIP_TRY(ctx, up(o_p, projections_l2, (size_t)n_landmarks * 16));
+  HIP_TRY(ctx, up(o_b, desc_begin, (size_t)(n_landmarks + 1) * 4));
+  HIP_TRY(ctx, up(o_pool, pool, (size_t)n_pool * 48));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_match_to_map(base + o_d, reinterpret_cast<okvfe_keypoint*>(base + o_k), base + o_u, n_kps,
+                      reinterpret_cast<double*>(base + o_p), reinterpret_cast<int32_t*>(base + o_b), n_landmarks,
+                      base + o_pool, reprojection_threshold * reprojection_threshold, ctx->cfg.match_threshold,
+                      reinterpret_cast<int32_t*>(base + o_lm), reinterpret_cast<int32_t*>(base + o_bd), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(best_landmark, base + o_lm, (size_t)n_kps * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(best_dist, base + o_bd, (size_t)n_kps * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_hamming_candidates(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, const uint8_t* B,
                                       int32_t nB, int32_t threshold, okvfe_candidate* out, int32_t cap,
                                       int32_t* n_out) {

@@ -102,6 +102,16 @@ void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, co
                                 const uint8_t* desc1, const double* bp1, const uint8_t* bpv1,
                                 const int32_t* n1p, int n1, int max_rows, int threshold,
                                 okvfe_stereo_match* out, hipStream_t stream);
+void launch_match_motion(const PairParams* pair, const DeviceCamera* camera, int w, int h,
+                         const uint8_t* desc0, const okvfe_keypoint* kp0, const double* bp0,
+                         const uint8_t* bpv0, const uint8_t* skip0, int n0, const uint8_t* desc1,
+                         const okvfe_keypoint* kp1, const double* bp1, const uint8_t* bpv1,
+                         const uint8_t* matched1, int n1, int threshold, okvfe_motion_match* out,
+                         hipStream_t stream);
+void launch_match_to_map(const uint8_t* desc_k, const okvfe_keypoint* kps, const uint8_t* use, int n_k,
+                         const double* projections, const int32_t* desc_begin, int n_lm,
+                         const uint8_t* pool, double thr_sq, int threshold, int32_t* best_lm,
+                         int32_t* best_d, hipStream_t stream);
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
                            int32_t* best_j, uint32_t* best_d, hipStream_t stream);
 void launch_hamming_count(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,

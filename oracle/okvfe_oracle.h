@@ -170,6 +170,11 @@ void orc_match_motion_stereo(const uint8_t* desc0, const orc_keypoint* kp0, cons
                              const orc_pose* T_WC0, const orc_pose* T_WC1, const orc_camera* cam,
                              uint32_t threshold, orc_motion_match* out /* n0 */);
 
+void orc_match_to_map(const uint8_t* desc, const orc_keypoint* kps, const uint8_t* use, int n_k,
+                      const double* proj, const int32_t* desc_begin, int n_lm, const uint8_t* pool,
+                      double reprojection_threshold, double threshold, int32_t* best_lm,
+                      int32_t* best_d);
+
 /* candidates: all (i, j) with popcnt(A[i]^B[j]) < thr in (i, j) order */
 typedef struct orc_cand {
   int32_t i, j, dist;

@@ -331,3 +331,32 @@ void orc_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint
     best_d[i] = dmin;
   }
 }
+
+/* ---- matchToMapByThread, 3-D landmarks (Frontend.cpp:1552-1589) ----------------------------------
+ * Landmarks in the given order (the reference iterates a std::map by ascending LandmarkId);
+ * landmark l owns pool rows desc_begin[l] .. desc_begin[l+1]-1.  distances[k] starts at the
+ * threshold (double, fresh vector at Frontend.cpp:1365) and is updated with strict '<'. */
+void orc_match_to_map(const uint8_t* desc, const orc_keypoint* kps, const uint8_t* use, int n_k,
+                      const double* proj, const int32_t* desc_begin, int n_lm, const uint8_t* pool,
+                      double reprojection_threshold, double threshold, int32_t* best_lm,
+                      int32_t* best_d) {
+  const double thr_sq = reprojection_threshold * reprojection_threshold;
+  for (int k = 0; k < n_k; ++k) {
+    best_lm[k] = -1;
+    best_d[k] = (int32_t)threshold;
+  }
+  for (int l = 0; l < n_lm; ++l) {
+    for (int k = 0; k < n_k; ++k) {
+      if (!use[k]) continue;
+      const double dx = proj[2 * l] - (double)kps[k].x, dy = proj[2 * l + 1] - (double)kps[k].y;
+      if (dx * dx + dy * dy > thr_sq) continue;
+      for (int d = desc_begin[l]; d < desc_begin[l + 1]; ++d) {
+        const double dist = (double)popc48(desc + 48 * (size_t)k, pool + 48 * (size_t)d);
+        if (dist < (double)best_d[k]) {
+          best_d[k] = (int32_t)dist;
+          best_lm[k] = l;
+        }
+      }
+    }
+  }
+}

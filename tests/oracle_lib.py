@@ -271,3 +271,15 @@ def hamming_argmin(A, B, thr):
     bd = np.empty(max(len(A), 1), dtype=np.uint32)
     lib().orc_hamming_argmin(_p(A), len(A), _p(B), len(B), C.c_uint32(int(thr)), _p(bj), _p(bd))
     return bj[:len(A)], bd[:len(A)]
+
+
+def match_to_map(desc, kps, use, proj, desc_begin, pool, repr_thr, thr):
+    n, nl = len(kps), len(desc_begin) - 1
+    bl = np.zeros(max(n, 1), dtype=np.int32)
+    bd = np.zeros(max(n, 1), dtype=np.int32)
+    arrs = [np.ascontiguousarray(a) for a in (desc, kps, np.asarray(use, dtype=np.uint8),
+                                             np.asarray(proj, dtype=np.float64),
+                                             np.asarray(desc_begin, dtype=np.int32), pool)]
+    lib().orc_match_to_map(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), n, _p(arrs[3]), _p(arrs[4]), nl,
+                           _p(arrs[5]), C.c_double(repr_thr), C.c_double(thr), _p(bl), _p(bd))
+    return bl[:n], bd[:n]

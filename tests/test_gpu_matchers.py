@@ -1,0 +1,188 @@
+"""GPU parity of the gated matchers beyond matchStereo, and of the remaining BASELINE configs.
+
+ * matchMotionStereo (okvis_frontend/src/Frontend.cpp:1812-1905) -- FP64 gates + 4 px check
+ * matchToMapByThread for 3-D landmarks (Frontend.cpp:1552-1589) -- reprojection gate + <=3
+   descriptors per landmark
+ * TUM-VI 1024x1024 (equidistant) and Hilti 720x540 x 5 cameras: detect + describe (+ FoV-overlap
+   driven cross-camera matching) against the oracle.
+"""
+import numpy as np
+import pytest
+
+from okvis2_amd import capi, synth
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(oracle, cam, n, seed, T):
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-0.8, 0.8, n), rng.uniform(2.5, 9, n)], 1)
+    Xc = X - np.asarray(T[1])
+    kp = np.zeros(n, dtype=oracle.KEYPOINT_DTYPE)
+    kp["size"] = 12.0
+    keep = np.zeros(n, bool)
+    for i in range(n):
+        st, pt, _ = oracle.cam_project(cam, Xc[i])
+        if st == 0:
+            kp["x"][i], kp["y"][i] = pt
+            keep[i] = True
+    return X, kp, keep
+
+
+def test_match_motion_stereo(oracle):
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    fe = G.make_frontend(cfg)
+    rng = np.random.default_rng(3)
+    n = 400
+    T0 = (np.eye(3).reshape(-1), np.zeros(3))
+    th = 0.05
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    T1 = (Rz.reshape(-1), np.array([0.35, 0.04, 0.02]))
+    X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-0.8, 0.8, n), rng.uniform(2.5, 9, n)], 1)
+
+    def observe(T, noise):
+        Cm = np.asarray(T[0]).reshape(3, 3)
+        Xc = (X - np.asarray(T[1])) @ Cm  # C^T (X - r)
+        kp = np.zeros(n, dtype=oracle.KEYPOINT_DTYPE)
+        kp["size"] = 12.0
+        for i in range(n):
+            st, pt, _ = oracle.cam_project(cam, Xc[i])
+            kp["x"][i], kp["y"][i] = pt if st == 0 else (5.0, 5.0)
+        kp["x"] += rng.normal(0, noise, n).astype(np.float32)
+        kp["y"] += rng.normal(0, noise, n).astype(np.float32)
+        bp, bv = oracle.backproject_keypoints(cam, kp)
+        return kp, bp, bv
+
+    kp0, bp0, bv0 = observe(T0, 0.3)
+    kp1, bp1, bv1 = observe(T1, 0.3)
+    d0 = rng.integers(0, 256, (n, 48), dtype=np.uint8)
+    d1 = d0 ^ (rng.random((n, 48)) < 0.03).astype(np.uint8) * rng.integers(0, 256, (n, 48), dtype=np.uint8)
+    perm = rng.permutation(n)
+    d1, kp1, bp1, bv1 = d1[perm], kp1[perm], bp1[perm], bv1[perm]
+    skip0 = (rng.random(n) < 0.1).astype(np.uint8)
+    matched1 = (rng.random(n) < 0.1).astype(np.uint8)
+    bv0 = bv0.copy()
+    bv0[::11] = 0
+    for s0, m1 in ((skip0, matched1), (None, None)):
+        ref = oracle.match_motion_stereo(d0, kp0, bp0, bv0, s0, d1, kp1, bp1, bv1, m1, T0, T1, cam,
+                                         cfg.match_threshold)
+        got = fe.match_motion_stereo(cam, d0, kp0, bp0, bv0, s0, d1, kp1, bp1, bv1, m1, T0, T1)
+        for f in ("k1", "dist", "initialisable", "accepted"):
+            assert np.array_equal(got[f], ref[f]), f
+        assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
+        hit = ref["k1"] >= 0
+        # the reference stores acos(cos_quality); the host adaptor takes the acos
+        import math
+        q = np.array([math.acos(c) for c in got["cos_quality"][hit]])  # libm acos, as the C++ host does
+        assert np.array_equal(q, ref["quality"][hit])
+        assert hit.sum() > 100 and ref["accepted"].sum() > 50
+    # empty inputs
+    assert len(fe.match_motion_stereo(cam, d0[:0], kp0[:0], bp0[:0], bv0[:0], None, d1, kp1, bp1, bv1,
+                                      None, T0, T1)) == 0
+    e = fe.match_motion_stereo(cam, d0, kp0, bp0, bv0, None, d1[:0], kp1[:0], bp1[:0], bv1[:0], None,
+                               T0, T1)
+    assert np.all(e["k1"] == -1)
+
+
+def test_match_to_map_3d(oracle):
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    rng = np.random.default_rng(8)
+    n_k, n_lm = 650, 1800
+    kps = np.zeros(n_k, dtype=oracle.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(30, 720, n_k)
+    kps["y"] = rng.uniform(30, 450, n_k)
+    desc = rng.integers(0, 256, (n_k, 48), dtype=np.uint8)
+    use = (rng.random(n_k) > 0.15).astype(np.uint8)
+    counts = rng.integers(1, 4, n_lm)
+    counts[::17] = 0  # landmarks without descriptors
+    desc_begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    pool = rng.integers(0, 256, (desc_begin[-1], 48), dtype=np.uint8)
+    proj = np.stack([rng.uniform(0, 752, n_lm), rng.uniform(0, 480, n_lm)], 1)
+    # plant true matches: landmark l observes keypoint l (near its projection, few flipped bits)
+    for l in range(0, min(n_k, n_lm), 2):
+        if counts[l] == 0:
+            continue
+        proj[l] = (kps["x"][l] + rng.normal(0, 3), kps["y"][l] + rng.normal(0, 3))
+        d = desc_begin[l] + rng.integers(0, counts[l])
+        flips = (rng.random(48) < 0.05).astype(np.uint8) * rng.integers(0, 256, 48, dtype=np.uint8)
+        pool[d] = desc[l] ^ flips
+    # duplicates: two landmarks with the same best distance -> the first (lower index) wins
+    pool[desc_begin[3]] = pool[desc_begin[1]] if counts[1] and counts[3] else pool[desc_begin[3]]
+    for thr in (20.0, 150.0):
+        rl, rd = oracle.match_to_map(desc, kps, use, proj, desc_begin, pool, thr, cfg.match_threshold)
+        gl, gd = fe.match_to_map(desc, kps, use, proj, desc_begin, pool, thr)
+        assert np.array_equal(gl, rl) and np.array_equal(gd, rd)
+        assert (rl >= 0).sum() > 100
+        assert np.all(rl[use == 0] == -1)
+    gl, gd = fe.match_to_map(desc, kps, use, proj[:0], np.zeros(1, np.int32), pool[:0], 20.0)
+    assert np.all(gl == -1) and np.all(gd == cfg.match_threshold)
+
+
+def test_tumvi_1024_equidistant(oracle):
+    """config/tumvi_slam_1024.yaml: 1024x1024, radius 50, threshold 5, <= 1000 keypoints.
+    Detect + describe are bit-exact; back-projection of an equidistant camera uses atan() and is
+    compared to 1e-12."""
+    cfg = synth.tumvi1024_config()
+    fe = G.make_frontend(cfg)
+    cam = cfg.cams[0]
+    fe.set_camera(0, cam)
+    rays, jac = oracle.awareness_maps(cam)
+    img = synth.corners_image(cfg.w, cfg.h, 77)
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu),
+                                    (0.0, 1.0, 0.0))
+    kps, desc, bp, bpv = fe.detect_describe(img, cam=0, gravity=(0.0, 1.0, 0.0))
+    G.assert_keypoints_equal(kps, rk)
+    assert np.array_equal(desc, rd) and len(kps) > 200
+    rbp, rv = oracle.backproject_keypoints(cam, rk)
+    # fisheye rim: tangent values up to ~65, so the tolerance is relative (measured: 2e-14 rel.)
+    assert np.array_equal(bpv, rv) and np.allclose(bp, rbp, rtol=1e-12, atol=1e-12)
+    # the noise frame has ~50k NMS maxima: exercises the global-memory sort path
+    noise = synth.noise_image(cfg.w, cfg.h, 78)
+    G.assert_keypoints_equal(fe.detect(noise),
+                             oracle.detect(noise, cfg.uniformity_radius, 0, cfg.abs_threshold,
+                                           cfg.max_kpts))
+
+
+def test_hilti_five_cameras_overlap_driven_matching(oracle):
+    """config/hilti_challenge_2022.yaml shape: 5 equidistant 720x540 cameras.  Camera pairs are
+    matched only where the fields of view overlap (Frontend.cpp:1998); here cameras 0/1 look
+    forward, 2 looks backward: pairs (0,1) visited, (0,2), (1,2) skipped."""
+    cfg = synth.hilti_config()
+    # the forward pair shares one set of intrinsics so that the synthetic disparity is epipolar-consistent
+    cams = [cfg.cams[0], cfg.cams[0], cfg.cams[2]]
+    fe = G.make_frontend(cfg, num_cameras=3)
+    eye, flip = np.eye(3), np.diag([-1.0, 1.0, -1.0])
+    C_SC = [eye, eye, flip]
+    small = [synth.Camera(c.w // 4, c.h // 4, c.fu / 4, c.fv / 4, c.cu / 4, c.cv / 4, c.dist_type, c.d)
+             for c in cams]
+    visit = [(i, j) for i in range(3) for j in range(i + 1, 3)
+             if capi.camera_overlap(small[j], small[i], C_SC[i].T @ C_SC[j])]
+    assert visit == [(0, 1)]
+    L, R, _ = synth.stereo_pair(cfg.w, cfg.h, 55)
+    imgs = [L, R, synth.corners_image(cfg.w, cfg.h, 56)]
+    res = []
+    for ci, cam in enumerate(cams):
+        fe.set_camera(ci, cam)
+        rays, jac = oracle.awareness_maps(cam)
+        rk, rd = oracle.detect_describe(imgs[ci], cfg.uniformity_radius, 0, cfg.abs_threshold,
+                                        cfg.max_kpts, oracle.MODE_CAMERA_AWARE, rays, jac,
+                                        np.float32(cam.fu), (0.0, 1.0, 0.0))
+        k, d, bp, bv = fe.detect_describe(imgs[ci], cam=ci, gravity=(0.0, 1.0, 0.0))
+        G.assert_keypoints_equal(k, rk)
+        assert np.array_equal(d, rd) and len(k) > 50
+        res.append((k, d, bp, bv))
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f = [0.5 * (c.fu + c.fv) for c in cams]
+    for (i, j) in visit:
+        (k0, d0, b0, v0), (k1, d1, b1, v1) = res[i], res[j]
+        # both sides consume the GPU's back-projections (equidistant: atan last-ulp caveat)
+        ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[i], f[j],
+                                  cfg.match_threshold)
+        got = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[i], f[j])
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert (ref["k1"] >= 0).sum() > 10
