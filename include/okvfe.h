@@ -294,6 +294,26 @@ okvfe_status okvfe_hamming_argmin(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, 
 /* = brisk::Hamming::PopcntofXORed(a, b, n128); host, no context. */
 uint32_t okvfe_popcnt_xor(const uint8_t* a, const uint8_t* b, int32_t n128);
 
+/* ---- data formats either side of the path (host, no context) ------------- */
+/* Text records of OKVIS2 map files, one line per keypoint:
+ *   "FRAME:KEYPOINT <stateId> <cameraIdx> <x> <y> <size> BRISK2 <96 hex digits>\n"
+ * (okvis::Component::save, okvis_ceres/src/Component.cpp:448-460, precision 17 from :409).
+ * out == NULL queries the size; *written always receives the bytes needed. */
+okvfe_status okvfe_format_keypoint_lines(uint64_t state_id, uint64_t camera_idx,
+                                         const okvfe_keypoint* keypoints,
+                                         const uint8_t* descriptors, int32_t n, char* out,
+                                         size_t cap, size_t* written);
+/* Reads one block of such lines (same stateId / cameraIdx; stops at the first other line), as
+ * okvis::Component::load does before MultiFrame::resetKeypoints / resetDescriptors
+ * (Component.cpp:235-266).  Descriptor kinds other than BRISK2 -> OKVFE_ERR_UNSUPPORTED. */
+okvfe_status okvfe_parse_keypoint_lines(const char* text, size_t len, uint64_t* state_id,
+                                        uint64_t* camera_idx, okvfe_keypoint* keypoints,
+                                        uint8_t* descriptors, int32_t cap, int32_t* n_out,
+                                        size_t* consumed);
+/* = DBoW2::FBrisk::meanValue (okvis_frontend/src/FBrisk.cpp:25-58): bitwise majority of n
+ * 48-byte descriptors (bit set iff more than n/2 descriptors have it). */
+okvfe_status okvfe_fbrisk_mean(const uint8_t* descriptors, int32_t n, uint8_t* mean48);
+
 /* ---- cross-camera gather block (multi-GPU) -------------- */
 /* Fixed-size per-image record for the RCCL all-gather: {count, keypoints,
  * descriptors, back-projections, valid flags}; size depends only on

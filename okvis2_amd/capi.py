@@ -70,6 +70,7 @@ EXPORTS = [
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
     "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap", "okvfe_compute",
     "okvfe_match_motion_stereo", "okvfe_match_to_map",
+    "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -143,6 +144,45 @@ def build_awareness_maps(cam):
     if st != OK:
         raise OkvfeError(st, lib().okvfe_last_error(None).decode())
     return rays, jac
+
+
+def format_keypoint_lines(state_id, camera_idx, keypoints, descriptors) -> bytes:
+    """Map-file text records (okvis::Component::save format)."""
+    kps = np.ascontiguousarray(keypoints, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(descriptors, dtype=np.uint8)
+    need = C.c_size_t()
+    st = lib().okvfe_format_keypoint_lines(C.c_uint64(state_id), C.c_uint64(camera_idx), _p(kps),
+                                           _p(desc), len(kps), None, C.c_size_t(0), C.byref(need))
+    if st != OK:
+        raise OkvfeError(st, "okvfe_format_keypoint_lines")
+    buf = C.create_string_buffer(max(need.value, 1))
+    st = lib().okvfe_format_keypoint_lines(C.c_uint64(state_id), C.c_uint64(camera_idx), _p(kps),
+                                           _p(desc), len(kps), buf, C.c_size_t(need.value),
+                                           C.byref(need))
+    if st != OK:
+        raise OkvfeError(st, "okvfe_format_keypoint_lines")
+    return buf.raw[:need.value]
+
+
+def parse_keypoint_lines(text: bytes, cap=4096):
+    """Returns (state_id, camera_idx, keypoints, descriptors, bytes_consumed)."""
+    kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+    desc = np.zeros((cap, DESC_BYTES), dtype=np.uint8)
+    sid, cam, n, used = C.c_uint64(), C.c_uint64(), C.c_int32(), C.c_size_t()
+    st = lib().okvfe_parse_keypoint_lines(text, C.c_size_t(len(text)), C.byref(sid), C.byref(cam),
+                                          _p(kps), _p(desc), cap, C.byref(n), C.byref(used))
+    if st != OK:
+        raise OkvfeError(st, "okvfe_parse_keypoint_lines")
+    return sid.value, cam.value, kps[:n.value].copy(), desc[:n.value].copy(), used.value
+
+
+def fbrisk_mean(descriptors) -> np.ndarray:
+    d = np.ascontiguousarray(descriptors, dtype=np.uint8).reshape(-1, DESC_BYTES)
+    out = np.zeros(DESC_BYTES, dtype=np.uint8)
+    st = lib().okvfe_fbrisk_mean(_p(d), len(d), _p(out))
+    if st != OK:
+        raise OkvfeError(st, "okvfe_fbrisk_mean")
+    return out
 
 
 def camera_overlap(cam, other, R_other_cam, want_mask=False):
