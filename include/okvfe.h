@@ -277,6 +277,24 @@ okvfe_status okvfe_match_to_map(okvfe_ctx* ctx, const uint8_t* desc, const okvfe
                                 double reprojection_threshold, int32_t* best_landmark,
                                 int32_t* best_dist);
 
+/* = Frontend::matchToMapByThreadUnitialised (Frontend.cpp:1616-1719), all keypoints in one call:
+ * landmarks that are not 3-D yet.  Pool row d carries its observing unit ray e0_W[d] and camera
+ * centre r0_W[d] (3 doubles each, LandmarkToMatch::e_W / r_W).  backproj = the current frame's
+ * cached back-projections (normalised inside, :1625); use[k] != 0 as computed at :1621-1635;
+ * previous_landmark[k] = index of the landmark keypoint k already carries or -1 (:1701-1704).
+ * Outputs: landmark index / distance per keypoint, hps_W (4 doubles, written when hp_set[k]:
+ * only non-parallel triangulations are stored, :1708-1710) and the count of already-correct
+ * matches (ctrs, :1702). */
+okvfe_status okvfe_match_to_map_uninitialised(okvfe_ctx* ctx, const uint8_t* desc,
+                                              const double* backproj, const uint8_t* use,
+                                              const int32_t* previous_landmark, int32_t n_kps,
+                                              const int32_t* desc_begin, int32_t n_landmarks,
+                                              const uint8_t* pool, const double* e0_W,
+                                              const double* r0_W, const okvfe_pose* T_WC1,
+                                              double focal_length, int32_t* best_landmark,
+                                              int32_t* best_dist, double* hps_W, uint8_t* hp_set,
+                                              int32_t* already_matched);
+
 typedef struct okvfe_candidate {
   int32_t i, j, dist;
 } okvfe_candidate;

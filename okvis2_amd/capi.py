@@ -71,6 +71,7 @@ EXPORTS = [
     "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap", "okvfe_compute",
     "okvfe_match_motion_stereo", "okvfe_match_to_map",
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
+    "okvfe_match_to_map_uninitialised",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -359,6 +360,25 @@ class Frontend:
                                              _p(arrs[3]), _p(arrs[4]), nl, _p(arrs[5]),
                                              C.c_double(repr_thr), _p(bl), _p(bd)))
         return bl[:n], bd[:n]
+
+    def match_to_map_uninitialised(self, desc, bp, use, previous, desc_begin, pool, e0_W, r0_W, T1,
+                                   focal):
+        n, nl = len(desc), len(desc_begin) - 1
+        bl = np.zeros(max(n, 1), dtype=np.int32)
+        bd = np.zeros(max(n, 1), dtype=np.int32)
+        hp = np.zeros((max(n, 1), 4), dtype=np.float64)
+        hs = np.zeros(max(n, 1), dtype=np.uint8)
+        ctr = C.c_int32()
+        arrs = [np.ascontiguousarray(desc, dtype=np.uint8), np.ascontiguousarray(bp, dtype=np.float64),
+                np.ascontiguousarray(use, dtype=np.uint8), np.ascontiguousarray(previous, dtype=np.int32),
+                np.ascontiguousarray(desc_begin, dtype=np.int32), np.ascontiguousarray(pool, dtype=np.uint8),
+                np.ascontiguousarray(e0_W, dtype=np.float64), np.ascontiguousarray(r0_W, dtype=np.float64)]
+        P1 = make_pose(*T1)
+        self._check(lib().okvfe_match_to_map_uninitialised(
+            self._h, _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), n, _p(arrs[4]), nl,
+            _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), C.byref(P1), C.c_double(focal), _p(bl), _p(bd),
+            _p(hp), _p(hs), C.byref(ctr)))
+        return bl[:n], bd[:n], hp[:n], hs[:n], ctr.value
 
     def hamming_candidates(self, A, B, thr, cap=None):
         A = np.ascontiguousarray(A, dtype=np.uint8)

@@ -454,7 +454,129 @@ __global__ __launch_bounds__(64) void match_to_map_kernel(
   }
 }
 
+// ---- matchToMapByThreadUnitialised (Frontend.cpp:1616-1719) --------------------------------------
+// Landmarks that are not 3-D yet: pooled descriptor d carries the observing ray e0_W[d] and camera
+// centre r0_W[d].  Lane = keypoint k; landmark / descriptor loops are wave-uniform.  Gates in the
+// reference's order: epipolar plane + divergence (unless nearly parallel) -> triangulateFast with
+// sigma = 1/f -> not within 0.2 m of either centre; a hit on the landmark the keypoint already
+// carries is counted and ends that landmark's descriptor loop; hp is only stored when the
+// triangulation is not parallel.
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double out[3]) {
+  double t1, t2;
+  t1 = a[1] * b[2]; t2 = a[2] * b[1]; out[0] = t1 - t2;
+  t1 = a[2] * b[0]; t2 = a[0] * b[2]; out[1] = t1 - t2;
+  t1 = a[0] * b[1]; t2 = a[1] * b[0]; out[2] = t1 - t2;
+}
+
+__global__ __launch_bounds__(64) void match_to_map_uninit_kernel(
+    const PairParams* __restrict__ pair, const uint8_t* __restrict__ desc_k,
+    const double* __restrict__ bp, const uint8_t* __restrict__ use,
+    const int32_t* __restrict__ previous, int n_k, const int32_t* __restrict__ desc_begin, int n_lm,
+    const uint8_t* __restrict__ pool, const double* __restrict__ e0_W,
+    const double* __restrict__ r0_W, int threshold, int32_t* __restrict__ best_lm,
+    int32_t* __restrict__ best_d, double* __restrict__ hps_W, uint8_t* __restrict__ hp_set,
+    int32_t* __restrict__ ctr_total) {
+  const PairParams& P = *pair;  // C1/r1 = T_WC1; cos26/cos6 for sigma = 1/f
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const bool in_range = k < n_k;
+  const bool active = in_range && use[k] != 0;
+  Desc12 dk;
+  double e1_W[3] = {0, 0, 0};
+  int prev = -1;
+  if (active) {
+    dk = load_desc(desc_k + (size_t)k * OKVFE_DESC_BYTES);
+    double en[3];
+    normalize3(bp + 3 * (size_t)k, en);
+    rot(P.C1, en, e1_W);
+    prev = previous[k];
+  }
+  int best = threshold, lm = -1, ctr = 0;
+  bool have_hp = false;
+  double hps[4] = {0, 0, 0, 0};
+  for (int l = 0; l < n_lm; ++l) {
+    const int b = desc_begin[l], e = desc_begin[l + 1];
+    bool done = !active;  // per-lane "break" out of this landmark's descriptor loop
+    for (int d = b; d < e; ++d) {
+      const uint32_t* dd = reinterpret_cast<const uint32_t*>(pool + (size_t)d * OKVFE_DESC_BYTES);
+      if (done) continue;
+      const int dist = hamming(dk, dd);
+      if (dist < best) {
+        const double* e0 = e0_W + 3 * (size_t)d;
+        const double* r0 = r0_W + 3 * (size_t)d;
+        const double e0v[3] = {e0[0], e0[1], e0[2]}, r0v[3] = {r0[0], r0[1], r0[2]};
+        if (dot3(e0v, e1_W) < P.cos6) {
+          double t[3], et[3], c0[3], c1[3], n0[3], n1[3], cx[3], nn[3], nnn[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) t[i] = P.r1[i] - r0v[i];
+          normalize3(t, et);
+          cross3(e0v, et, c0);
+          normalize3(c0, n0);
+          cross3(e1_W, et, c1);
+          normalize3(c1, n1);
+          if (dot3(n0, n1) < P.cos6) continue;
+          cross3(e0v, e1_W, cx);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) nn[i] = n0[i] + n0[i];
+          normalize3(nn, nnn);
+          if (dot3(cx, nnn) > 0.0) continue;
+        }
+        double hp[4];
+        bool is_valid, is_parallel;
+        triangulate_fast(r0v, e0v, P.r1, e1_W, P.cos26, P.cos6, hp, &is_valid, &is_parallel);
+        if (!is_valid) continue;
+        if (!is_parallel) {
+          double a[3], bb[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double p = hp[i] / hp[3];
+            a[i] = p - r0v[i];
+            bb[i] = p - P.r1[i];
+          }
+          if (sqrt(dot3(a, a)) < 0.2) is_valid = false;
+          if (sqrt(dot3(bb, bb)) < 0.2) is_valid = false;
+        }
+        if (!is_valid) continue;
+        if (l == prev) {
+          ++ctr;
+          done = true;
+          continue;
+        }
+        best = dist;
+        lm = l;
+        if (!is_parallel) {
+          hps[0] = hp[0]; hps[1] = hp[1]; hps[2] = hp[2]; hps[3] = hp[3];
+          have_hp = true;
+        }
+      }
+    }
+  }
+  if (in_range) {
+    best_lm[k] = lm;
+    best_d[k] = best;
+    hp_set[k] = have_hp ? 1 : 0;
+    hps_W[4 * (size_t)k + 0] = hps[0];
+    hps_W[4 * (size_t)k + 1] = hps[1];
+    hps_W[4 * (size_t)k + 2] = hps[2];
+    hps_W[4 * (size_t)k + 3] = hps[3];
+  }
+#pragma unroll
+  for (int dlt = 32; dlt > 0; dlt >>= 1) ctr += __shfl_xor(ctr, dlt);
+  if (threadIdx.x == 0 && ctr) atomicAdd(ctr_total, ctr);
+}
+
 }  // namespace
+
+void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, const double* bp,
+                                const uint8_t* use, const int32_t* previous, int n_k,
+                                const int32_t* desc_begin, int n_lm, const uint8_t* pool,
+                                const double* e0_W, const double* r0_W, int threshold,
+                                int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
+                                int32_t* ctr_total, hipStream_t stream) {
+  if (n_k <= 0) return;
+  hipLaunchKernelGGL(match_to_map_uninit_kernel, dim3((n_k + 63) / 64), dim3(64), 0, stream, pair,
+                     desc_k, bp, use, previous, n_k, desc_begin, n_lm, pool, e0_W, r0_W, threshold,
+                     best_lm, best_d, hps_W, hp_set, ctr_total);
+}
 
 void launch_match_motion(const PairParams* pair, const DeviceCamera* camera, int w, int h,
                          const uint8_t* desc0, const okvfe_keypoint* kp0, const double* bp0,

@@ -857,6 +857,75 @@ okvfe_status okvfe_match_to_map(okvfe_ctx* ctx, const uint8_t* desc, const okvfe
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_match_to_map_uninitialised(okvfe_ctx* ctx, const uint8_t* desc, const double* backproj,
+                                              const uint8_t* use, const int32_t* previous_landmark,
+                                              int32_t n_kps, const int32_t* desc_begin, int32_t n_landmarks,
+                                              const uint8_t* pool, const double* e0_W, const double* r0_W,
+                                              const okvfe_pose* T_WC1, double focal_length,
+                                              int32_t* best_landmark, int32_t* best_dist, double* hps_W,
+                                              uint8_t* hp_set, int32_t* already_matched) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n_kps < 0 || n_landmarks < 0 || !desc_begin || !T_WC1 || !(focal_length > 0.0) || !already_matched ||
+      (n_kps > 0 && (!desc || !backproj || !use || !previous_landmark || !best_landmark || !best_dist || !hps_W || !hp_set)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_uninitialised: bad argument");
+  for (int l = 0; l < n_landmarks; ++l)
+    if (desc_begin[l + 1] < desc_begin[l] || desc_begin[l] < 0)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_uninitialised: desc_begin not monotone at %d", l);
+  *already_matched = 0;
+  if (n_kps == 0) return OKVFE_OK;
+  const int n_pool = desc_begin[n_landmarks];
+  if (n_pool > 0 && (!pool || !e0_W || !r0_W))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_uninitialised: null pool");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  const size_t o_pair = take(sizeof(PairParams)), o_d = take((size_t)n_kps * 48), o_bp = take((size_t)n_kps * 24),
+               o_u = take(n_kps), o_prev = take((size_t)n_kps * 4), o_b = take((size_t)(n_landmarks + 1) * 4),
+               o_pool = take((size_t)n_pool * 48), o_e = take((size_t)n_pool * 24), o_r = take((size_t)n_pool * 24),
+               o_lm = take((size_t)n_kps * 4), o_bd = take((size_t)n_kps * 4), o_hp = take((size_t)n_kps * 32),
+               o_hs = take(n_kps), o_ctr = take(4);
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  PairParams pp{};
+  std::memcpy(pp.C1, T_WC1->C, sizeof(pp.C1));
+  std::memcpy(pp.r1, T_WC1->r, sizeof(pp.r1));
+  const double sigma = 1.0 / focal_length;  // Frontend.cpp:1636
+  pp.cos26 = std::cos(2.6 * sigma);
+  pp.cos6 = std::cos(6.0 * sigma);
+  auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRY(ctx, up(o_pair, &pp, sizeof(pp)));
+  HIP_TRY(ctx, up(o_d, desc, (size_t)n_kps * 48));
+  HIP_TRY(ctx, up(o_bp, backproj, (size_t)n_kps * 24));
+  HIP_TRY(ctx, up(o_u, use, n_kps));
+  HIP_TRY(ctx, up(o_prev, previous_landmark, (size_t)n_kps * 4));
+  HIP_TRY(ctx, up(o_b, desc_begin, (size_t)(n_landmarks + 1) * 4));
+  HIP_TRY(ctx, up(o_pool, pool, (size_t)n_pool * 48));
+  HIP_TRY(ctx, up(o_e, e0_W, (size_t)n_pool * 24));
+  HIP_TRY(ctx, up(o_r, r0_W, (size_t)n_pool * 24));
+  HIP_TRY(ctx, hipMemsetAsync(base + o_ctr, 0, 4, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_match_to_map_uninit(reinterpret_cast<PairParams*>(base + o_pair), base + o_d,
+                             reinterpret_cast<double*>(base + o_bp), base + o_u,
+                             reinterpret_cast<int32_t*>(base + o_prev), n_kps, reinterpret_cast<int32_t*>(base + o_b),
+                             n_landmarks, base + o_pool, reinterpret_cast<double*>(base + o_e),
+                             reinterpret_cast<double*>(base + o_r), ctx->cfg.match_threshold,
+                             reinterpret_cast<int32_t*>(base + o_lm), reinterpret_cast<int32_t*>(base + o_bd),
+                             reinterpret_cast<double*>(base + o_hp), base + o_hs,
+                             reinterpret_cast<int32_t*>(base + o_ctr), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(best_landmark, base + o_lm, (size_t)n_kps * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(best_dist, base + o_bd, (size_t)n_kps * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(hps_W, base + o_hp, (size_t)n_kps * 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(hp_set, base + o_hs, n_kps, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(already_matched, base + o_ctr, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_hamming_candidates(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, const uint8_t* B,
                                       int32_t nB, int32_t threshold, okvfe_candidate* out, int32_t cap,
                                       int32_t* n_out) {

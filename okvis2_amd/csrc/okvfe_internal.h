@@ -112,6 +112,12 @@ void launch_match_to_map(const uint8_t* desc_k, const okvfe_keypoint* kps, const
                          const double* projections, const int32_t* desc_begin, int n_lm,
                          const uint8_t* pool, double thr_sq, int threshold, int32_t* best_lm,
                          int32_t* best_d, hipStream_t stream);
+void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, const double* bp,
+                                const uint8_t* use, const int32_t* previous, int n_k,
+                                const int32_t* desc_begin, int n_lm, const uint8_t* pool,
+                                const double* e0_W, const double* r0_W, int threshold,
+                                int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
+                                int32_t* ctr_total, hipStream_t stream);
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
                            int32_t* best_j, uint32_t* best_d, hipStream_t stream);
 void launch_hamming_count(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,

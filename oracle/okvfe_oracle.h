@@ -175,6 +175,13 @@ void orc_match_to_map(const uint8_t* desc, const orc_keypoint* kps, const uint8_
                       double reprojection_threshold, double threshold, int32_t* best_lm,
                       int32_t* best_d);
 
+void orc_match_to_map_uninit(const uint8_t* desc, const double* bp, const uint8_t* use,
+                             const int32_t* previous, int n_k, const int32_t* desc_begin, int n_lm,
+                             const uint8_t* pool, const double* e0_W, const double* r0_W,
+                             const orc_pose* T_WC1, double focal, double threshold,
+                             int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
+                             int32_t* ctr_out);
+
 /* candidates: all (i, j) with popcnt(A[i]^B[j]) < thr in (i, j) order */
 typedef struct orc_cand {
   int32_t i, j, dist;

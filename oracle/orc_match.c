@@ -360,3 +360,89 @@ void orc_match_to_map(const uint8_t* desc, const orc_keypoint* kps, const uint8_
     }
   }
 }
+
+/* ---- matchToMapByThreadUnitialised (Frontend.cpp:1616-1719) -------------------------------------
+ * Landmarks that are not yet 3-D: every pooled descriptor d carries the observing ray e0_W[d]
+ * and camera centre r0_W[d].  Per keypoint k (use[k] != 0, Frontend.cpp:1621-1635):
+ * e1_W = C (e1_C / |e1_C|); dist < distances[k] -> epipolar-plane and divergence tests unless the
+ * rays are nearly parallel -> triangulateFast(sigma = 1/f) valid -> not closer than 0.2 m to
+ * either centre -> if the landmark is the one the keypoint already carries: count and leave this
+ * landmark's descriptor loop; else update distances[k], landmark, and hp (only when not parallel).
+ * previous[k] = index of the landmark keypoint k already carries, or -1. */
+void orc_match_to_map_uninit(const uint8_t* desc, const double* bp, const uint8_t* use,
+                             const int32_t* previous, int n_k, const int32_t* desc_begin, int n_lm,
+                             const uint8_t* pool, const double* e0_W, const double* r0_W,
+                             const orc_pose* T_WC1, double focal, double threshold,
+                             int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
+                             int32_t* ctr_out) {
+  const double sigma = 1.0 / focal;
+  const double cos6 = cos(6.0 * sigma);
+  int ctr = 0;
+  for (int k = 0; k < n_k; ++k) {
+    best_lm[k] = -1;
+    best_d[k] = (int32_t)threshold;
+    hp_set[k] = 0;
+    hps_W[4 * k] = hps_W[4 * k + 1] = hps_W[4 * k + 2] = hps_W[4 * k + 3] = 0.0;
+  }
+  for (int l = 0; l < n_lm; ++l) {
+    for (int k = 0; k < n_k; ++k) {
+      if (!use[k]) continue;
+      double en[3], e1_W[3];
+      normalize3(bp + 3 * (size_t)k, en);
+      rot(T_WC1->C, en, e1_W);
+      for (int d = desc_begin[l]; d < desc_begin[l + 1]; ++d) {
+        const double dist = (double)popc48(desc + 48 * (size_t)k, pool + 48 * (size_t)d);
+        if (dist < (double)best_d[k]) {
+          const double* e0 = e0_W + 3 * (size_t)d;
+          const double* r0 = r0_W + 3 * (size_t)d;
+          if (dot3(e0, e1_W) < cos6) {
+            double t[3], et[3], c0[3], c1[3], n0[3], n1[3], cx[3], nn[3], nnn[3];
+            for (int i = 0; i < 3; ++i) t[i] = T_WC1->r[i] - r0[i];
+            normalize3(t, et);
+            c0[0] = e0[1] * et[2] - e0[2] * et[1];
+            c0[1] = e0[2] * et[0] - e0[0] * et[2];
+            c0[2] = e0[0] * et[1] - e0[1] * et[0];
+            normalize3(c0, n0);
+            c1[0] = e1_W[1] * et[2] - e1_W[2] * et[1];
+            c1[1] = e1_W[2] * et[0] - e1_W[0] * et[2];
+            c1[2] = e1_W[0] * et[1] - e1_W[1] * et[0];
+            normalize3(c1, n1);
+            if (dot3(n0, n1) < cos6) continue; /* not in epipolar plane */
+            cx[0] = e0[1] * e1_W[2] - e0[2] * e1_W[1];
+            cx[1] = e0[2] * e1_W[0] - e0[0] * e1_W[2];
+            cx[2] = e0[0] * e1_W[1] - e0[1] * e1_W[0];
+            for (int i = 0; i < 3; ++i) nn[i] = n0[i] + n0[i];
+            normalize3(nn, nnn);
+            if (dot3(cx, nnn) > 0.0) continue; /* divergent rays */
+          }
+          double hp[4];
+          int is_valid = 0, is_parallel = 0;
+          orc_triangulate_fast(r0, e0, T_WC1->r, e1_W, sigma, hp, &is_valid, &is_parallel);
+          if (!is_valid) continue;
+          if (!is_parallel) {
+            double p[3], a[3], b[3];
+            for (int i = 0; i < 3; ++i) {
+              p[i] = hp[i] / hp[3];
+              a[i] = p[i] - r0[i];
+              b[i] = p[i] - T_WC1->r[i];
+            }
+            if (sqrt(dot3(a, a)) < 0.2) is_valid = 0;
+            if (sqrt(dot3(b, b)) < 0.2) is_valid = 0;
+          }
+          if (!is_valid) continue;
+          if (l == previous[k]) {
+            ++ctr;
+            break;
+          }
+          best_d[k] = (int32_t)dist;
+          best_lm[k] = l;
+          if (!is_parallel) {
+            memcpy(hps_W + 4 * (size_t)k, hp, 4 * sizeof(double));
+            hp_set[k] = 1;
+          }
+        }
+      }
+    }
+  }
+  *ctr_out = ctr;
+}

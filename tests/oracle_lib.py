@@ -283,3 +283,22 @@ def match_to_map(desc, kps, use, proj, desc_begin, pool, repr_thr, thr):
     lib().orc_match_to_map(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), n, _p(arrs[3]), _p(arrs[4]), nl,
                            _p(arrs[5]), C.c_double(repr_thr), C.c_double(thr), _p(bl), _p(bd))
     return bl[:n], bd[:n]
+
+
+def match_to_map_uninit(desc, bp, use, previous, desc_begin, pool, e0_W, r0_W, T1, focal, thr):
+    n, nl = len(desc), len(desc_begin) - 1
+    bl = np.zeros(max(n, 1), dtype=np.int32)
+    bd = np.zeros(max(n, 1), dtype=np.int32)
+    hp = np.zeros((max(n, 1), 4), dtype=np.float64)
+    hs = np.zeros(max(n, 1), dtype=np.uint8)
+    ctr = C.c_int32()
+    arrs = [np.ascontiguousarray(desc, dtype=np.uint8), np.ascontiguousarray(bp, dtype=np.float64),
+            np.ascontiguousarray(use, dtype=np.uint8), np.ascontiguousarray(previous, dtype=np.int32),
+            np.ascontiguousarray(desc_begin, dtype=np.int32), np.ascontiguousarray(pool, dtype=np.uint8),
+            np.ascontiguousarray(e0_W, dtype=np.float64), np.ascontiguousarray(r0_W, dtype=np.float64)]
+    P1 = make_pose(*T1)
+    lib().orc_match_to_map_uninit(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), n, _p(arrs[4]),
+                                  nl, _p(arrs[5]), _p(arrs[6]), _p(arrs[7]), C.byref(P1),
+                                  C.c_double(focal), C.c_double(thr), _p(bl), _p(bd), _p(hp), _p(hs),
+                                  C.byref(ctr))
+    return bl[:n], bd[:n], hp[:n], hs[:n], ctr.value

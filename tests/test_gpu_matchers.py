@@ -186,3 +186,58 @@ def test_hilti_five_cameras_overlap_driven_matching(oracle):
         got = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[i], f[j])
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
         assert (ref["k1"] >= 0).sum() > 10
+
+
+def test_match_to_map_uninitialised(oracle):
+    """Frontend.cpp:1616-1719: landmarks that are not 3-D yet, matched through the epipolar /
+    triangulation gates; includes the already-matched counting rule."""
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    fe = G.make_frontend(cfg)
+    rng = np.random.default_rng(12)
+    n_k, n_lm = 500, 900
+    focal = 0.5 * (cam.fu + cam.fv)
+    X = np.stack([rng.uniform(-2, 2, n_lm), rng.uniform(-1, 1, n_lm), rng.uniform(2.5, 10, n_lm)], 1)
+    th = 0.03
+    Ry = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    T1 = (Ry.reshape(-1), np.array([0.25, -0.03, 0.05]))
+    # current frame: keypoint k observes landmark k (k < n_k) with pixel noise
+    Xc = (X[:n_k] - T1[1]) @ Ry
+    kps = np.zeros(n_k, dtype=oracle.KEYPOINT_DTYPE)
+    for i in range(n_k):
+        st, pt, _ = oracle.cam_project(cam, Xc[i])
+        kps["x"][i], kps["y"][i] = pt if st == 0 else (9.0, 9.0)
+    kps["x"] += rng.normal(0, 0.4, n_k).astype(np.float32)
+    kps["y"] += rng.normal(0, 0.4, n_k).astype(np.float32)
+    bp, bv = oracle.backproject_keypoints(cam, kps)
+    desc = rng.integers(0, 256, (n_k, 48), dtype=np.uint8)
+    # pool: 1..3 earlier observations per landmark from other camera centres
+    counts = rng.integers(1, 4, n_lm)
+    desc_begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    m = desc_begin[-1]
+    pool = rng.integers(0, 256, (m, 48), dtype=np.uint8)
+    r0 = np.zeros((m, 3))
+    e0 = np.zeros((m, 3))
+    for l in range(n_lm):
+        for d in range(desc_begin[l], desc_begin[l + 1]):
+            r0[d] = rng.normal(0, 0.3, 3) + np.array([-0.2, 0, 0])
+            ray = X[l] - r0[d] + rng.normal(0, 0.002, 3)
+            e0[d] = ray / np.linalg.norm(ray)
+            if l < n_k and rng.random() < 0.8:
+                flips = (rng.random(48) < 0.04).astype(np.uint8) * rng.integers(0, 256, 48, dtype=np.uint8)
+                pool[d] = desc[l] ^ flips
+    use = (bv != 0) & (rng.random(n_k) > 0.1)
+    previous = np.full(n_k, -1, dtype=np.int32)
+    previous[::9] = np.arange(n_k)[::9]          # already carries the right landmark
+    previous[4::9] = (np.arange(n_k)[4::9] + 1) % n_lm  # carries another one
+    ref = oracle.match_to_map_uninit(desc, bp, use, previous, desc_begin, pool, e0, r0, T1, focal,
+                                     cfg.match_threshold)
+    got = fe.match_to_map_uninitialised(desc, bp, use, previous, desc_begin, pool, e0, r0, T1, focal)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[3], ref[3])
+    assert np.array_equal(got[2].view(np.uint64), ref[2].view(np.uint64))
+    assert got[4] == ref[4]
+    assert (ref[0] >= 0).sum() > 100 and ref[4] > 10 and ref[3].sum() > 50
+    e = fe.match_to_map_uninitialised(desc, bp, use, previous, np.zeros(1, np.int32), pool[:0], e0[:0],
+                                      r0[:0], T1, focal)
+    assert np.all(e[0] == -1) and e[4] == 0
