@@ -254,15 +254,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
   const bool store = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;  // clamped dword index for loads
   const size_t img_off = (size_t)blockIdx.z * (size_t)w * (size_t)h;
-  const uint32_t* img = reinterpret_cast<const uint32_t*>(images + img_off) + dcl;
-  int32_t* out = scores + img_off + (size_t)dcl * 4;
+  // buffer resources (SGPR base + 32-bit per-lane offset): no 64-bit VALU address arithmetic in
+  // the row loop; the row offset rides in the scalar offset operand
+  const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(images + img_off), 0, w * h, 0x00027000);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      scores + img_off, 0, w * h * 4, 0x00027000);
+  const int ld_off = dcl * 4;    // byte offset of this lane's dword within a pixel row
+  const int st_off = dcl * 16;   // byte offset of this lane's 4 scores within a score row
   const int m0 = d == 0 ? 0 : -1;        // column 0 is rim
   const int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
   const int k3 = 3 << 9, k10 = 10 << 9;  // gradients carry a factor 2^9: mulhi24 then yields >> 14
 
   auto load_row = [&](int row) -> uint32_t {
     row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
-    return img[(size_t)row * (size_t)nd];
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rsrc, ld_off, row * w, 0);
   };
   auto unpack4 = [](uint32_t c, int p[4]) {
     p[0] = c & 255;
@@ -371,7 +377,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       } else {
         sc[0] = sc[1] = sc[2] = sc[3] = 0;
       }
-      if (store) *reinterpret_cast<int4*>(out + (size_t)y * (size_t)w) = make_int4(sc[0], sc[1], sc[2], sc[3]);
+      if (store) {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i v = {sc[0], sc[1], sc[2], sc[3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, 0);
+      }
     }
   };
 
@@ -413,6 +423,10 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
       case 30: OKVFE_K1_LAUNCH(30); break;
       case 40: OKVFE_K1_LAUNCH(40); break;
       case 60: OKVFE_K1_LAUNCH(60); break;
+      case 80: OKVFE_K1_LAUNCH(80); break;
+      case 120: OKVFE_K1_LAUNCH(120); break;
+      case 160: OKVFE_K1_LAUNCH(160); break;
+      case 240: OKVFE_K1_LAUNCH(240); break;
       default: OKVFE_K1_LAUNCH(32); break;
     }
 #undef OKVFE_K1_LAUNCH
