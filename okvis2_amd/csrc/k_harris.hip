@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       int vs[4], vd[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        vs[i] = b[i] * k10 + (a[i] + c[i]) * k3;
+        vs[i] = __mul24(b[i], k10) + __mul24(a[i] + c[i], k3);
         vd[i] = c[i] - a[i];
       }
       // NOTE: the subtrahend of gx[0] is shifted in NEGATED form and added: hipcc folds
@@ -325,10 +325,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       gx[1] = vs[2] - vs[0];
       gx[2] = vs[3] - vs[1];
       gx[3] = (vs_r - vs[2]) & m3;
-      gy[0] = (vd[0] * k10 + (vd_l + vd[1]) * k3) & m0;
-      gy[1] = vd[1] * k10 + (vd[0] + vd[2]) * k3;
-      gy[2] = vd[2] * k10 + (vd[1] + vd[3]) * k3;
-      gy[3] = (vd[3] * k10 + (vd[2] + vd_r) * k3) & m3;
+      // __mul24: 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24, 4 cycles); a plain int
+      // expression here is lowered to v_mad_u64_u32, which is several times slower
+      gy[0] = (__mul24(vd[0], k10) + __mul24(vd_l + vd[1], k3)) & m0;
+      gy[1] = __mul24(vd[1], k10) + __mul24(vd[0] + vd[2], k3);
+      gy[2] = __mul24(vd[2], k10) + __mul24(vd[1] + vd[3], k3);
+      gy[3] = (__mul24(vd[3], k10) + __mul24(vd[2] + vd_r, k3)) & m3;
       int G[3][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
