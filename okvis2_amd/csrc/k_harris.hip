@@ -241,19 +241,23 @@ constexpr int kStripLanes = 62;
 
 template <int kTHF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
-    const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores) {
+    const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int strips,
+    int ytiles, int n_images) {
   const int lane = threadIdx.x;
-  const int strip = blockIdx.x;
+  int image, tile;
+  xcd_tile(strips * ytiles, n_images, &image, &tile);
+  const int ytile = tile / strips;
+  const int strip = tile - ytile * strips;
   const int nd = w >> 2;
   const int d = strip * kStripLanes + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int ys = (blockIdx.y * kWavesPerBlock + wave) * kTHF;
+  const int ys = (ytile * kWavesPerBlock + wave) * kTHF;
   if (ys >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
   const int ye = ys + kTHF < h ? ys + kTHF : h;
   const bool last_strip = strip * kStripLanes + 64 >= nd;
   const bool store = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;  // clamped dword index for loads
-  const size_t img_off = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+  const size_t img_off = (size_t)image * (size_t)w * (size_t)h;
   // buffer resources (SGPR base + 32-bit per-lane offset): no 64-bit VALU address arithmetic in
   // the row loop; the row offset rides in the scalar offset operand
   const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -416,9 +420,11 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
       return e ? atoi(e) : 0;
     }();
 #define OKVFE_K1_LAUNCH(TH)                                                                   \
-  hipLaunchKernelGGL(harris_kernel<TH>,                                                       \
-                     dim3(strips, (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock), n_images), \
-                     block, 0, stream, img, w, h, score)
+  {                                                                                           \
+    const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                 \
+    hipLaunchKernelGGL(harris_kernel<TH>, dim3(strips * ytiles * n_images), block, 0, stream, img, \
+                       w, h, score, strips, ytiles, n_images);                                \
+  }
     switch (th_env ? th_env : (h % 30 == 0 ? 30 : 32)) {
       case 16: OKVFE_K1_LAUNCH(16); break;
       case 24: OKVFE_K1_LAUNCH(24); break;

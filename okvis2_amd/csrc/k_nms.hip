@@ -115,17 +115,20 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
                                                           int h, int thr,
                                                           Candidate* __restrict__ cand,
                                                           int cand_cap,
-                                                          int32_t* __restrict__ cand_count) {
+                                                          int32_t* __restrict__ cand_count,
+                                                          int strips, int ytiles, int n_images) {
   __shared__ Candidate buf[kLdsCap];
   __shared__ int lds_cnt, lds_base;
-  const int img = blockIdx.z;
+  int img, tile;
+  xcd_tile(strips * ytiles, n_images, &img, &tile);
+  const int ytile = tile / strips;
+  const int strip = tile - ytile * strips;
   const int32_t* s = scores + (size_t)img * w * h;
   const int lane = threadIdx.x;
-  const int strip = blockIdx.x;
   const int nd = w >> 2;  // 16-byte groups per row
   const int d = strip * kStripLanes + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int ys = (blockIdx.y * kWaves + wave) * kRows;  // first centre row of this wave
+  const int ys = (ytile * kWaves + wave) * kRows;  // first centre row of this wave
   const bool last_strip = strip * kStripLanes + 64 >= nd;
   const bool own = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;
@@ -246,9 +249,10 @@ void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_thresh
     const int nd = w >> 2;
     int strips = 1;
     while ((strips - 1) * kStripLanes + 64 < nd) ++strips;
-    const dim3 grid(strips, (h + kRows * kWaves - 1) / (kRows * kWaves), n_images);
-    hipLaunchKernelGGL(nms_kernel, grid, dim3(64, kWaves, 1), 0, stream, score, w, h,
-                       abs_threshold, cand, cand_cap, cand_count);
+    const int ytiles = (h + kRows * kWaves - 1) / (kRows * kWaves);
+    hipLaunchKernelGGL(nms_kernel, dim3(strips * ytiles * n_images), dim3(64, kWaves, 1), 0, stream,
+                       score, w, h, abs_threshold, cand, cand_cap, cand_count, strips, ytiles,
+                       n_images);
   } else {
     const dim3 grid((w + 255) / 256, (h + 3) / 4, n_images);
     hipLaunchKernelGGL(nms_generic_kernel, grid, dim3(64, 4, 1), 0, stream, score, w, h,

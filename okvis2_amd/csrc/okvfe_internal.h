@@ -69,6 +69,29 @@ struct PairParams {  // one stereo pair on device
 
 }  // namespace okvfe
 
+// XCD-aware tile mapping (device): the dispatcher is observed to place linear workgroup id L on
+// XCD L % 8 (used for speed only, never for correctness).  All tiles of one image are handed to
+// ONE XCD, so row halos and the cache lines shared by neighbouring strips are served by that
+// XCD's L2 instead of being fetched from HBM once per XCD.  1-D grid of n_images * tiles blocks.
+#ifdef __HIPCC__
+__device__ __forceinline__ void xcd_tile(int tiles, int n_images, int* image, int* tile) {
+  const int L = blockIdx.x;
+  const int n8 = n_images & ~7;
+  const int full = n8 * tiles;
+  if (L < full) {
+    const int xcd = L & 7, slot = L >> 3;
+    const int g = slot / tiles;
+    *image = g * 8 + xcd;
+    *tile = slot - g * tiles;
+  } else {
+    const int r = L - full;
+    const int i = r / tiles;
+    *image = n8 + i;
+    *tile = r - i * tiles;
+  }
+}
+#endif
+
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 namespace okvfe {
 
