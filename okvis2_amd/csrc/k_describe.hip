@@ -95,26 +95,39 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     // fixed trip counts (fully unrolled, reads clamped into the box and masked) so that the LDS
     // reads of a sample are issued back to back instead of one dependent read per loop trip
     ret = 0;
+    // interior columns x_left+1 .. x_right-1 (<= 9 bytes) lie in at most 3 aligned dwords of the
+    // patch row: one byte mask per dword (hoisted out of the row loop), then
+    // v_sad_u8(dword & mask, 0, acc) sums 4 pixels per instruction
+    const int xi0 = x_left + 1 - px.x0;  // patch column of the first interior pixel
+    const int q0 = xi0 >> 2;
+    const int lo = xi0 & 3, ni = bw - 1;
+    uint32_t m[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      int sb = lo - 4 * j, eb = sb + ni;
+      sb = sb < 0 ? 0 : sb;
+      eb = eb > 4 ? 4 : eb;
+      const int nb = eb - sb;
+      m[j] = nb > 0 ? ((0xFFFFFFFFu >> (8 * (4 - nb))) << (8 * sb)) : 0u;
+    }
 #pragma unroll
     for (int dy = 0; dy <= kMaxBox; ++dy) {
       const int y = y_top + (dy < bh ? dy : bh);
       const int pl = px(y, x_left), pr = px(y, x_right);
-      int mid = 0;
-#pragma unroll
-      for (int dx = 1; dx < kMaxBox; ++dx) {
-        const int v = px(y, x_left + (dx < bw ? dx : bw));
-        mid += dx < bw ? v : 0;
-      }
+      const uint32_t* prow = px.row32(y) + q0;
+      uint32_t mid = __builtin_amdgcn_sad_u8(prow[0] & m[0], 0u, 0u);
+      mid = __builtin_amdgcn_sad_u8(prow[1] & m[1], 0u, mid);
+      mid = __builtin_amdgcn_sad_u8(prow[2] & m[2], 0u, mid);
       if (dy == 0) {
         ret = A * pl + B * pr;
-        upper = mid;
+        upper = (int)mid;
       } else {
         const bool is_bottom = dy == bh, is_mid = dy < bh;
         ret += is_bottom ? D * pl + C * pr : 0;
-        bottom += is_bottom ? mid : 0;
+        bottom += is_bottom ? (int)mid : 0;
         left += is_mid ? pl : 0;
         right += is_mid ? pr : 0;
-        middle += is_mid ? mid : 0;
+        middle += is_mid ? (int)mid : 0;
       }
     }
   } else {
@@ -203,7 +216,9 @@ struct GlobalPx {  // direct reads from the image (fallback when the patch does 
   static constexpr bool kFixedTrip = false;
   const uint8_t* img;
   int w;
+  int x0 = 0;  // unused: the fixed-trip path is compiled out for this reader
   __device__ __forceinline__ int operator()(int y, int x) const { return img[(size_t)y * w + x]; }
+  __device__ __forceinline__ const uint32_t* row32(int) const { return nullptr; }
 };
 struct PatchPx {   // reads from the keypoint's patch staged in LDS
   static constexpr bool kFixedTrip = true;
@@ -211,6 +226,9 @@ struct PatchPx {   // reads from the keypoint's patch staged in LDS
   int x0, y0;
   __device__ __forceinline__ int operator()(int y, int x) const {
     return patch[(y - y0) * kPatchPitch + (x - x0)];
+  }
+  __device__ __forceinline__ const uint32_t* row32(int y) const {
+    return reinterpret_cast<const uint32_t*>(patch + (y - y0) * kPatchPitch);
   }
 };
 
@@ -260,25 +278,24 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
   auto stage_patch = [&](int bx0, int bx1, int by0, int by1, PatchPx* ppx) -> bool {
     const int px0 = bx0 & ~3;
     const int pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
-    if (pw > kPatchPitch || ph > kPatchRows) return false;  // wave-uniform
+    if (pw > kPatchPitch - 8 || ph > kPatchRows) return false;  // wave-uniform; q0 + 2 < pitch / 4
     __builtin_amdgcn_wave_barrier();
     if (dword_ok) {
-      const int ndw = (pw + 3) >> 2;  // <= 24 dwords per row
-      const int total = ndw * ph;     // <= 1920 dwords = 30 per lane
-      uint32_t tmp[30];
-      int off[30];
+      const int ndw = (pw + 3) >> 2;  // <= 22 dwords per row: lanes 0..31 cover one row
+      const int lx = lane & 31, ly = lane >> 5;
+      uint32_t tmp[kPatchRows / 2];
 #pragma unroll
-      for (int it = 0; it < 30; ++it) {  // every global load is in flight before the first use
-        const int idx = it * 64 + lane;
-        const int r = idx / ndw, c = idx - r * ndw;
-        off[it] = idx < total ? r * kPatchPitch + c * 4 : -1;
+      for (int it = 0; it < kPatchRows / 2; ++it) {  // all global loads in flight before first use
+        const int r = it * 2 + ly;
         tmp[it] = 0;
-        if (idx < total)
-          tmp[it] = reinterpret_cast<const uint32_t*>(im + (size_t)(by0 + r) * w + px0)[c];
+        if (r < ph && lx < ndw)
+          tmp[it] = reinterpret_cast<const uint32_t*>(im + (size_t)(by0 + r) * w + px0)[lx];
       }
 #pragma unroll
-      for (int it = 0; it < 30; ++it)
-        if (off[it] >= 0) *reinterpret_cast<uint32_t*>(patch + off[it]) = tmp[it];
+      for (int it = 0; it < kPatchRows / 2; ++it) {
+        const int r = it * 2 + ly;
+        if (r < ph && lx < ndw) reinterpret_cast<uint32_t*>(patch + r * kPatchPitch)[lx] = tmp[it];
+      }
     } else {
       for (int r = 0; r < ph; ++r)
         for (int c = lane; c < pw; c += 64) patch[r * kPatchPitch + c] = im[(size_t)(by0 + r) * w + px0 + c];

@@ -39,5 +39,14 @@ for (w, h) in ((752, 480), (1024, 1024)):
     t1.record()
     torch.cuda.synchronize()
     copy_gbps = 8.0 * w * h * nn / (t0.elapsed_time(t1) / reps * 1e-3) / 1e9
+    torch.cuda.synchronize()
+    t0.record()
+    for _ in range(reps):
+        dst.zero_()
+    t1.record()
+    torch.cuda.synchronize()
+    fill_gbps = 4.0 * w * h * nn / (t0.elapsed_time(t1) / reps * 1e-3) / 1e9
+    print(f"   int32 fill kernel (write-only, same bytes as the score map): {fill_gbps:.0f} GB/s = "
+          f"{t0.elapsed_time(t1) / reps * 1e3:.1f} us")
     print(f"{w}x{h} x{nn}: harris {avg*1e3:.1f} us  {gbps:.0f} GB/s algorithmic "
           f"({gbps/8000:.1%} of 8 TB/s); int32 copy kernel {copy_gbps:.0f} GB/s")
