@@ -337,6 +337,17 @@ okvfe_status okvfe_fbrisk_mean(const uint8_t* descriptors, int32_t n, uint8_t* m
  * descriptors, back-projections, valid flags}; size depends only on
  * max_keypoints. */
 size_t okvfe_gather_block_bytes(const okvfe_ctx* ctx);
+/* Packs images first_index .. first_index+n-1 of the last batch into n contiguous blocks
+ * (stride okvfe_gather_block_bytes) with one kernel. */
+okvfe_status okvfe_pack_gather_blocks_device(okvfe_ctx* ctx, int32_t first_index, int32_t n,
+                                             void* blocks_dev, void* stream);
+/* Matches frame f of blocks0 with frame f of blocks1 for f < n_frames in one launch (both arrays
+ * contiguous with the block stride); matches_dev: [n_frames][max_keypoints]. */
+okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* blocks0_dev,
+                                                    const void* blocks1_dev, int32_t n_frames,
+                                                    const okvfe_pose* T_WC0,
+                                                    const okvfe_pose* T_WC1, double f0, double f1,
+                                                    okvfe_stereo_match* matches_dev, void* stream);
 /* Packs image `index` of the last batch into block_dev (device). */
 okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void* block_dev,
                                             void* stream);

@@ -71,7 +71,8 @@ EXPORTS = [
     "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap", "okvfe_compute",
     "okvfe_match_motion_stereo", "okvfe_match_to_map",
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
-    "okvfe_match_to_map_uninitialised",
+    "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
+    "okvfe_match_stereo_blocks_batch_device",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -419,6 +420,17 @@ class Frontend:
     def pack_gather_block_device(self, index, block_ptr, stream=None):
         self._check(lib().okvfe_pack_gather_block_device(self._h, int(index), _p(block_ptr),
                                                          _p(stream)))
+
+    def pack_gather_blocks_device(self, first, n, blocks_ptr, stream=None):
+        self._check(lib().okvfe_pack_gather_blocks_device(self._h, int(first), int(n),
+                                                          _p(blocks_ptr), _p(stream)))
+
+    def match_stereo_blocks_batch_device(self, blocks0_ptr, blocks1_ptr, n_frames, T0, T1, f0, f1,
+                                         matches_ptr, stream=None):
+        P0, P1 = make_pose(*T0), make_pose(*T1)
+        self._check(lib().okvfe_match_stereo_blocks_batch_device(
+            self._h, _p(blocks0_ptr), _p(blocks1_ptr), int(n_frames), C.byref(P0), C.byref(P1),
+            C.c_double(f0), C.c_double(f1), _p(matches_ptr), _p(stream)))
 
     def match_stereo_blocks_device(self, block0_ptr, block1_ptr, T0, T1, f0, f1, matches_ptr,
                                    stream=None):

@@ -564,7 +564,72 @@ __global__ __launch_bounds__(64) void match_to_map_uninit_kernel(
   if (threadIdx.x == 0 && ctr) atomicAdd(ctr_total, ctr);
 }
 
+// ---- gather blocks (cross-camera exchange) ---------------------------------------
+struct BlockOffsets {
+  int o_count, o_kps, o_desc, o_bp, o_bpv, total;
+};
+
+// packs images first .. first+n-1 of the context's result arrays into n contiguous blocks
+__global__ __launch_bounds__(256) void pack_blocks_kernel(BlockOffsets L, int first, int kp_cap,
+                                                          const int32_t* __restrict__ counts,
+                                                          const okvfe_keypoint* __restrict__ kps,
+                                                          const uint8_t* __restrict__ desc,
+                                                          const double* __restrict__ bp,
+                                                          const uint8_t* __restrict__ bpv,
+                                                          uint8_t* __restrict__ blocks) {
+  const int img = first + blockIdx.x;
+  uint8_t* b = blocks + (size_t)blockIdx.x * L.total;
+  const size_t off = (size_t)img * kp_cap;
+  const int tid = threadIdx.x;
+  if (tid == 0) *reinterpret_cast<int32_t*>(b + L.o_count) = counts[img];
+  const uint32_t* s32;
+  uint32_t* d32;
+  s32 = reinterpret_cast<const uint32_t*>(kps + off);
+  d32 = reinterpret_cast<uint32_t*>(b + L.o_kps);
+  for (int i = tid; i < kp_cap * 7; i += 256) d32[i] = s32[i];
+  s32 = reinterpret_cast<const uint32_t*>(desc + off * OKVFE_DESC_BYTES);
+  d32 = reinterpret_cast<uint32_t*>(b + L.o_desc);
+  for (int i = tid; i < kp_cap * 12; i += 256) d32[i] = s32[i];
+  s32 = reinterpret_cast<const uint32_t*>(bp + off * 3);
+  d32 = reinterpret_cast<uint32_t*>(b + L.o_bp);
+  for (int i = tid; i < kp_cap * 6; i += 256) d32[i] = s32[i];
+  for (int i = tid; i < kp_cap; i += 256) b[L.o_bpv + i] = bpv[off + i];
+}
+
+// matches frame f of two gathered block arrays: grid (rows, frames)
+__global__ __launch_bounds__(64) void match_stereo_blocks_kernel(
+    const PairParams* __restrict__ pair, BlockOffsets L, const uint8_t* __restrict__ blocks0,
+    const uint8_t* __restrict__ blocks1, int kp_cap, int threshold,
+    okvfe_stereo_match* __restrict__ out) {
+  const uint8_t* b0 = blocks0 + (size_t)blockIdx.y * L.total;
+  const uint8_t* b1 = blocks1 + (size_t)blockIdx.y * L.total;
+  BlockView I0, I1;
+  I0.desc = b0 + L.o_desc; I0.bp = reinterpret_cast<const double*>(b0 + L.o_bp); I0.bpv = b0 + L.o_bpv;
+  I0.n = *reinterpret_cast<const int32_t*>(b0 + L.o_count);
+  I1.desc = b1 + L.o_desc; I1.bp = reinterpret_cast<const double*>(b1 + L.o_bp); I1.bpv = b1 + L.o_bpv;
+  I1.n = *reinterpret_cast<const int32_t*>(b1 + L.o_count);
+  match_stereo_rows(*pair, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
+}
+
 }  // namespace
+
+void launch_pack_blocks(const int offs[6], int first, int n, int kp_cap, const int32_t* counts,
+                        const okvfe_keypoint* kps, const uint8_t* desc, const double* bp,
+                        const uint8_t* bpv, uint8_t* blocks, hipStream_t stream) {
+  if (n <= 0) return;
+  const BlockOffsets L{offs[0], offs[1], offs[2], offs[3], offs[4], offs[5]};
+  hipLaunchKernelGGL(pack_blocks_kernel, dim3(n), dim3(256), 0, stream, L, first, kp_cap, counts, kps,
+                     desc, bp, bpv, blocks);
+}
+
+void launch_match_stereo_blocks(const PairParams* pair, const int offs[6], const uint8_t* blocks0,
+                                const uint8_t* blocks1, int n_frames, int kp_cap, int threshold,
+                                okvfe_stereo_match* out, hipStream_t stream) {
+  if (n_frames <= 0) return;
+  const BlockOffsets L{offs[0], offs[1], offs[2], offs[3], offs[4], offs[5]};
+  hipLaunchKernelGGL(match_stereo_blocks_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64), 0,
+                     stream, pair, L, blocks0, blocks1, kp_cap, threshold, out);
+}
 
 void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, const double* bp,
                                 const uint8_t* use, const int32_t* previous, int n_k,

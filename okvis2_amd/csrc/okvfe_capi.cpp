@@ -53,6 +53,8 @@ struct okvfe_ctx {
   PairParams* d_pairs = nullptr;
   uint8_t* d_img_stage = nullptr;
   okvfe_stereo_match* d_match_stage = nullptr;
+  PairParams* d_block_pairs = nullptr;
+  unsigned block_pair_next = 0;
 
   std::vector<ImageParams> h_prm_last;  // what d_prm currently holds
   std::vector<PairParams> h_pairs_last;
@@ -1055,22 +1057,55 @@ BlockLayout block_layout(int kp_cap) {
 
 size_t okvfe_gather_block_bytes(const okvfe_ctx* ctx) { return ctx ? block_layout(ctx->kp_cap).total : 0; }
 
-okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void* block_dev, void* stream) {
+okvfe_status okvfe_pack_gather_blocks_device(okvfe_ctx* ctx, int32_t first_index, int32_t n, void* blocks_dev,
+                                             void* stream) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
-  if (index < 0 || index >= ctx->B || !block_dev)
-    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_pack_gather_block_device: bad argument");
+  if (first_index < 0 || n < 1 || first_index + n > ctx->B || !blocks_dev)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_pack_gather_blocks_device: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   hipStream_t s = pick_stream(ctx, stream);
   const BlockLayout L = block_layout(ctx->kp_cap);
-  uint8_t* b = static_cast<uint8_t*>(block_dev);
-  const size_t off = (size_t)index * ctx->kp_cap;
-  const size_t K = (size_t)ctx->kp_cap;
-  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_count, ctx->d_count + index, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_kps, ctx->d_kps + off, K * sizeof(okvfe_keypoint), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_desc, ctx->d_desc + off * OKVFE_DESC_BYTES, K * OKVFE_DESC_BYTES,
-                             hipMemcpyDeviceToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_bp, ctx->d_bp + off * 3, K * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(b + L.o_bpv, ctx->d_bpv + off, K, hipMemcpyDeviceToDevice, s));
+  const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  launch_pack_blocks(offs, first_index, n, ctx->kp_cap, ctx->d_count, ctx->d_kps, ctx->d_desc, ctx->d_bp,
+                     ctx->d_bpv, static_cast<uint8_t*>(blocks_dev), s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void* block_dev, void* stream) {
+  return okvfe_pack_gather_blocks_device(ctx, index, 1, block_dev, stream);
+}
+
+okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* blocks0_dev,
+                                                    const void* blocks1_dev, int32_t n_frames,
+                                                    const okvfe_pose* T_WC0, const okvfe_pose* T_WC1, double f0,
+                                                    double f1, okvfe_stereo_match* matches_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!blocks0_dev || !blocks1_dev || n_frames < 1 || !T_WC0 || !T_WC1 || !matches_dev || !(f0 > 0.0) || !(f1 > 0.0))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo_blocks_batch_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  okvfe_stereo_pair sp{};
+  sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
+  const PairParams pp = to_pair_params(sp);
+  // pair records live in a small ring inside the context so that consecutive calls for different
+  // camera pairs do not have to synchronise
+  if (!ctx->d_block_pairs) {
+    void* q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, 64 * sizeof(PairParams)));
+    ctx->allocs.push_back(q);
+    ctx->d_block_pairs = static_cast<PairParams*>(q);
+  }
+  PairParams* slot = ctx->d_block_pairs + (ctx->block_pair_next++ % 64);
+  if (ctx->block_pair_next % 64 == 0) HIP_TRY(ctx, hipStreamSynchronize(s));  // ring wrap: drain
+  HIP_TRY(ctx, hipMemcpyAsync(slot, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
+  launch_match_stereo_blocks(slot, offs, static_cast<const uint8_t*>(blocks0_dev),
+                             static_cast<const uint8_t*>(blocks1_dev), n_frames, ctx->kp_cap,
+                             ctx->cfg.match_threshold, matches_dev, s);
+  HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
   return OKVFE_OK;
 }
@@ -1078,31 +1113,8 @@ okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void*
 okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0_dev, const void* block1_dev,
                                               const okvfe_pose* T_WC0, const okvfe_pose* T_WC1, double f0,
                                               double f1, okvfe_stereo_match* matches_dev, void* stream) {
-  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
-  if (!block0_dev || !block1_dev || !T_WC0 || !T_WC1 || !matches_dev || !(f0 > 0.0) || !(f1 > 0.0))
-    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo_blocks_device: bad argument");
-  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  hipStream_t s = pick_stream(ctx, stream);
-  const BlockLayout L = block_layout(ctx->kp_cap);
-  okvfe_stereo_pair sp{};
-  sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
-  const PairParams pp = to_pair_params(sp);
-  // the pair record rides in the scratch buffer; block matching is a setup-light path (Hilti rig)
-  okvfe_status st = ensure_scratch(ctx, sizeof(PairParams));
-  if (st != OKVFE_OK) return st;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipStreamSynchronize(s));
-  const uint8_t* b0 = static_cast<const uint8_t*>(block0_dev);
-  const uint8_t* b1 = static_cast<const uint8_t*>(block1_dev);
-  launch_match_stereo_arrays(static_cast<PairParams*>(ctx->scratch), b0 + L.o_desc,
-                             reinterpret_cast<const double*>(b0 + L.o_bp), b0 + L.o_bpv,
-                             reinterpret_cast<const int32_t*>(b0 + L.o_count), 0, b1 + L.o_desc,
-                             reinterpret_cast<const double*>(b1 + L.o_bp), b1 + L.o_bpv,
-                             reinterpret_cast<const int32_t*>(b1 + L.o_count), 0, ctx->kp_cap,
-                             ctx->cfg.match_threshold, matches_dev, s);
-  HIP_TRY(ctx, hipGetLastError());
-  ctx->last_stream = s;
-  return OKVFE_OK;
+  return okvfe_match_stereo_blocks_batch_device(ctx, block0_dev, block1_dev, 1, T_WC0, T_WC1, f0, f1, matches_dev,
+                                                stream);
 }
 
 }  // extern "C"

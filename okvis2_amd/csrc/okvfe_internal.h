@@ -141,6 +141,12 @@ void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, c
                                 const double* e0_W, const double* r0_W, int threshold,
                                 int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
                                 int32_t* ctr_total, hipStream_t stream);
+void launch_pack_blocks(const int offs[6], int first, int n, int kp_cap, const int32_t* counts,
+                        const okvfe_keypoint* kps, const uint8_t* desc, const double* bp,
+                        const uint8_t* bpv, uint8_t* blocks, hipStream_t stream);
+void launch_match_stereo_blocks(const PairParams* pair, const int offs[6], const uint8_t* blocks0,
+                                const uint8_t* blocks1, int n_frames, int kp_cap, int threshold,
+                                okvfe_stereo_match* out, hipStream_t stream);
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
                            int32_t* best_j, uint32_t* best_d, hipStream_t stream);
 void launch_hamming_count(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,

@@ -106,12 +106,10 @@ class CrossCameraMatcher:
         fe, n = self.fe, self.n_frames
         cam_ids = np.full(n, 0, dtype=np.int32)  # this context holds its own camera in slot 0
         fe.detect_describe_batch_device(images_ptr, n, cam_ids, gravity, stream)
-        for f in range(n):
-            fe.pack_gather_block_device(f, self.local[f].data_ptr(), stream)
-        allb = all_gather_blocks(self.local, group)
-        for (i, j) in self.mine:
-            for f in range(n):
-                fe.match_stereo_blocks_device(allb[i, f].data_ptr(), allb[j, f].data_ptr(),
-                                              self.poses[i], self.poses[j], self.focal[i],
-                                              self.focal[j], self.out[(i, j)][f].data_ptr(), stream)
+        fe.pack_gather_blocks_device(0, n, self.local.data_ptr(), stream)   # one kernel
+        allb = all_gather_blocks(self.local, group)                          # one collective
+        for (i, j) in self.mine:                                             # one launch per pair
+            fe.match_stereo_blocks_batch_device(allb[i].data_ptr(), allb[j].data_ptr(), n,
+                                                self.poses[i], self.poses[j], self.focal[i],
+                                                self.focal[j], self.out[(i, j)].data_ptr(), stream)
         return allb, self.out

@@ -100,3 +100,45 @@ def test_gather_blocks_rccl_and_block_matching(oracle):
         assert np.array_equal(m.view(np.uint8), g["match_stereo"].view(np.uint8))
     finally:
         dist.destroy_process_group()
+
+
+def test_batched_block_pack_and_match(oracle):
+    """okvfe_pack_gather_blocks_device / okvfe_match_stereo_blocks_batch_device: the whole batch is
+    packed by one kernel and every frame of a camera pair is matched by one launch (the path
+    okvis2_amd.multigpu.CrossCameraMatcher drives on every rank)."""
+    cfg = synth.euroc_config()
+    nfr = 3
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                       match_threshold=cfg.match_threshold, num_cameras=2, max_batch=2 * nfr)
+    for ci in range(2):
+        fe.set_camera(ci, cfg.cams[ci])
+    pairs = [synth.stereo_pair(cfg.w, cfg.h, 300 + i) for i in range(nfr)]
+    # camera-major layout: images 0..nfr-1 = camera 0, nfr..2nfr-1 = camera 1
+    imgs = np.stack([p[0] for p in pairs] + [p[1] for p in pairs])
+    d_img = torch.from_numpy(imgs).cuda()
+    cam_ids = np.array([0] * nfr + [1] * nfr, dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (2 * nfr, 1))
+    stream = torch.cuda.current_stream().cuda_stream
+    fe.detect_describe_batch_device(d_img.data_ptr(), 2 * nfr, cam_ids, grav, stream)
+    nb = fe.gather_block_bytes()
+    blocks = torch.zeros((2, nfr, nb), dtype=torch.uint8, device="cuda")
+    fe.pack_gather_blocks_device(0, nfr, blocks[0].data_ptr(), stream)
+    fe.pack_gather_blocks_device(nfr, nfr, blocks[1].data_ptr(), stream)
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    d_m = torch.zeros((nfr, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8,
+                      device="cuda")
+    fe.match_stereo_blocks_batch_device(blocks[0].data_ptr(), blocks[1].data_ptr(), nfr, T0, T1, f0, f1,
+                                        d_m.data_ptr(), stream)
+    torch.cuda.synchronize()
+    host = blocks.cpu().numpy()
+    m = d_m.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(nfr, cfg.max_kpts)
+    for f in range(nfr):
+        k0, d0, b0, v0 = multigpu.unpack_block_host(host[0, f], cfg.max_kpts)
+        k1, d1, b1, v1 = multigpu.unpack_block_host(host[1, f], cfg.max_kpts)
+        g0 = fe.download(f)
+        assert np.array_equal(k0.view(np.uint8), g0[0].view(np.uint8)) and np.array_equal(d0, g0[1])
+        ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1, cfg.match_threshold)
+        assert np.array_equal(m[f, :len(k0)].view(np.uint8), ref.view(np.uint8))
+        assert (ref["k1"] >= 0).sum() > 10
