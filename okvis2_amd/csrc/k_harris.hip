@@ -230,6 +230,9 @@ __device__ __forceinline__ int mulhi24(int a, int b) {  // (a * b) >> 32 of the 
 __device__ __forceinline__ void dpp_fence(int& a, int& b, int& c, int& d, int& e, int& f) {
   asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
+__device__ __forceinline__ void dpp_fence2(int& a, int& b) {
+  asm volatile("s_nop 1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ int from_left(int v) {   // value of lane-1
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
 }
@@ -266,8 +269,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       scores + img_off, 0, w * h * 4, 0x00027000);
   const int ld_off = dcl * 4;    // byte offset of this lane's dword within a pixel row
   const int st_off = dcl * 16;   // byte offset of this lane's 4 scores within a score row
-  const int m0 = d == 0 ? 0 : -1;        // column 0 is rim
-  const int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
+  int m0 = d == 0 ? 0 : -1;        // column 0 is rim
+  int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
+  // keep the masks as opaque VGPR values: "x & m" then stays a 2-cycle v_and_b32 instead of being
+  // rewritten into a v_cndmask_b32_e64 on a re-materialised compare
+  asm volatile("" : "+v"(m0), "+v"(m3));
   const int k3 = 3 << 9, k10 = 10 << 9;  // gradients carry a factor 2^9: mulhi24 then yields >> 14
 
   auto load_row = [&](int row) -> uint32_t {
@@ -282,8 +288,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
   };
 
   int pr[3][4];      // rolling pixel rows (own 4 columns)
-  int hs[2][3][4];   // horizontally smoothed entries: current / previous row
-  int vp[2][3][4];   // vertical pair sums hs[g-1] + hs[g]
+  // stream 0 carries the xx and yy entries PACKED (xx | yy << 16: both are non-negative and every
+  // partial sum stays below 2^16, so one 32-bit add smooths two channels); stream 1 carries xy
+  int hs[2][2][4];   // horizontally smoothed entries: current / previous row
+  int vp[2][2][4];   // vertical pair sums hs[g-1] + hs[g]
   uint32_t raw[3];   // pixel rows in flight (loaded two steps ahead)
   {
     const uint32_t t0 = load_row(ys - 2), t1 = load_row(ys - 1);
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) hs[q][c][i] = vp[q][c][i] = 0;
 
@@ -335,16 +343,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       gy[1] = __mul24(vd[1], k10) + __mul24(vd[0] + vd[2], k3);
       gy[2] = __mul24(vd[2], k10) + __mul24(vd[1] + vd[3], k3);
       gy[3] = (__mul24(vd[3], k10) + __mul24(vd[2] + vd_r, k3)) & m3;
-      int G[3][4];
+      int G[2][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        G[0][i] = mulhi24(gx[i], gx[i]);
-        G[1][i] = mulhi24(gy[i], gy[i]);
-        G[2][i] = mulhi24(gx[i], gy[i]);
+        const int gxx = mulhi24(gx[i], gx[i]);
+        const int gyy = mulhi24(gy[i], gy[i]);
+        G[0][i] = gxx | (gyy << 16);
+        G[1][i] = mulhi24(gx[i], gy[i]);
       }
-      dpp_fence(G[0][0], G[0][3], G[1][0], G[1][3], G[2][0], G[2][3]);
+      dpp_fence2(G[1][0], G[1][3]);
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
+      for (int ch = 0; ch < 2; ++ch) {
         const int gl = from_left(G[ch][3]), gr = from_right(G[ch][0]);
         const int pm = gl + G[ch][0];
         const int p0 = G[ch][0] + G[ch][1];
@@ -358,12 +367,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       }
     } else {
 #pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
+      for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
         for (int i = 0; i < 4; ++i) H[ch][i] = 0;
     }
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
+    for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
       for (int i = 0; i < 4; ++i) V[ch][i] = Hp[ch][i] + H[ch][i];
     const int y = g - 1;
@@ -372,11 +381,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       if (y >= 1 && y <= h - 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int A = Vp[0][i] + V[0][i];
-          const int B = Vp[1][i] + V[1][i];
-          const int Cc = Vp[2][i] + V[2][i];
-          const int tq = ((A >> 1) + (B >> 1)) >> 1;
-          sc[i] = mul24(A, B) - mad24(tq, tq, mul24(Cc, Cc));
+          const unsigned AB = (unsigned)(Vp[0][i] + V[0][i]);  // A | B << 16
+          const int Cc = Vp[1][i] + V[1][i];
+          const int tq = (int)((((AB >> 1) & 0x7FFFu) + (AB >> 17)) >> 1);  // ((A>>1)+(B>>1))>>1
+          int ab;  // A * B straight from the packed halves (SDWA word selects): no unpacking
+          asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 "
+              "src1_sel:WORD_1"
+              : "=v"(ab)
+              : "v"(AB));
+          sc[i] = ab - mad24(tq, tq, mul24(Cc, Cc));
         }
         sc[0] &= m0;
         sc[3] &= m3;
