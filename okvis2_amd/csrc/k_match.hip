@@ -160,11 +160,26 @@ struct BlockView {  // per-image arrays as the matcher sees them
   int n;
 };
 
+// The k1 range is cut into kStereoSegs contiguous segments, one wave (threadIdx.y) each, so that
+// 4x as many waves hide the scalar-load and FP64 latency of the serial k1 loop.  The sequential
+// rule of the reference (first k1 reaching the smallest gated distance) is a pure function of the
+// candidate set, so merging the segments by (dist, segment) reproduces it exactly.
+constexpr int kStereoSegs = 4;
+struct SegBest {
+  double hp[4];
+  int best, k1, init, pad;
+};
+
 __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
                                   int threshold, okvfe_stereo_match* __restrict__ out) {
-  const int k0 = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ SegBest seg_best[kStereoSegs - 1][64];
+  const int seg = threadIdx.y;
+  const int per_seg = (I1.n + kStereoSegs - 1) / kStereoSegs;
+  const int k1_lo = min(seg * per_seg, I1.n), k1_hi = min(k1_lo + per_seg, I1.n);
+  if ((int)blockIdx.x * 64 >= I0.n) return;  // whole block past the last keypoint
+  const int k0 = blockIdx.x * 64 + threadIdx.x;
   const bool active = k0 < I0.n;
-  Desc12 d0;
+  Desc12 d0 = {};
   if (active) d0 = load_desc(I0.desc + (size_t)k0 * OKVFE_DESC_BYTES);
   double e0_W[3] = {0, 0, 0};
   const bool v0 = active && I0.bpv[k0] != 0;
@@ -177,33 +192,68 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   int k1_match = 0;
   bool initialisable = false;
   double hps[4] = {0, 0, 0, 0};
-  for (int k1 = 0; k1 < I1.n; ++k1) {
-    const uint32_t* d1 = reinterpret_cast<const uint32_t*>(I1.desc + (size_t)k1 * OKVFE_DESC_BYTES);
-    if (!active) continue;
-    const int dist = hamming(d0, d1);
-    if (dist < best) {
-      if (!v0) continue;
-      if (!I1.bpv[k1]) continue;
-      double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
-      rot(P.C1, I1.bp + 3 * (size_t)k1, v);
-      normalize3(v, e1_W);
-      bool is_valid, is_parallel;
-      triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
-      inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
-      inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
-      if (!is_parallel) {
-        const double w4 = hp_W[3];
-        hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
-        if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
-        if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
-        if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
-      }
-      if (is_valid) {
-        best = dist;
-        hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
-        k1_match = k1;
-        initialisable = !is_parallel;
-      }
+  // The reference walks k1 upwards and runs the geometric gate whenever dist < best; as the gate
+  // does not depend on `best`, its outcome is the gated candidate with the smallest (dist, k1).
+  // Each round therefore scans the segment branch-free for the smallest key above the last
+  // rejected one (wave-uniform descriptor loads, 24 VALU per k1) and runs the FP64 gate ONCE for
+  // all lanes together, instead of once per k1 for the one or two lanes that improved there.
+  constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+  uint32_t floor_key = 0;  // keys are ((dist << 22) | k1) + 1, so 0 admits everything
+  bool done = !v0;         // without a back-projection the gate rejects every candidate
+  while (__any(!done)) {
+    uint32_t cand = kNoKey;
+    for (int k1 = k1_lo; k1 < k1_hi; ++k1) {
+      const uint32_t* d1 =
+          reinterpret_cast<const uint32_t*>(I1.desc + (size_t)k1 * OKVFE_DESC_BYTES);
+      const uint32_t dist = (uint32_t)hamming(d0, d1);
+      const uint32_t key = ((dist << 22) | (uint32_t)k1) + 1u;
+      const bool ok = key > floor_key && dist < (uint32_t)threshold;
+      cand = ok ? min(cand, key) : cand;
+    }
+    if (done) continue;
+    if (cand == kNoKey) {
+      done = true;
+      continue;
+    }
+    floor_key = cand;
+    const int k1 = (int)((cand - 1u) & 0x3FFFFFu);
+    const int dist = (int)((cand - 1u) >> 22);
+    if (!I1.bpv[k1]) continue;
+    double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+    rot(P.C1, I1.bp + 3 * (size_t)k1, v);
+    normalize3(v, e1_W);
+    bool is_valid, is_parallel;
+    triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
+    inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+    inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+    if (!is_parallel) {
+      const double w4 = hp_W[3];
+      hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+      if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
+      if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
+      if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
+    }
+    if (is_valid) {
+      best = dist;
+      hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
+      k1_match = k1;
+      initialisable = !is_parallel;
+      done = true;
+    }
+  }
+  if (seg > 0) {
+    SegBest& sb = seg_best[seg - 1][threadIdx.x];
+    sb.best = best; sb.k1 = k1_match; sb.init = initialisable ? 1 : 0;
+    sb.hp[0] = hps[0]; sb.hp[1] = hps[1]; sb.hp[2] = hps[2]; sb.hp[3] = hps[3];
+  }
+  __syncthreads();
+  if (seg > 0) return;
+#pragma unroll
+  for (int s = 0; s < kStereoSegs - 1; ++s) {
+    const SegBest& sb = seg_best[s][threadIdx.x];
+    if (sb.best < best) {  // strict: ties stay with the lower segment = lower k1
+      best = sb.best; k1_match = sb.k1; initialisable = sb.init != 0;
+      hps[0] = sb.hp[0]; hps[1] = sb.hp[1]; hps[2] = sb.hp[2]; hps[3] = sb.hp[3];
     }
   }
   if (active) {
@@ -221,7 +271,7 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   }
 }
 
-__global__ __launch_bounds__(64) void match_stereo_kernel(
+__global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_kernel(
     const PairParams* __restrict__ pairs, const okvfe_keypoint* __restrict__ kps,
     const uint8_t* __restrict__ desc, const double* __restrict__ bp,
     const uint8_t* __restrict__ bpv, const int32_t* __restrict__ counts, int kp_cap,
@@ -238,7 +288,7 @@ __global__ __launch_bounds__(64) void match_stereo_kernel(
 }
 
 // explicit arrays (host-buffer API and gathered blocks)
-__global__ __launch_bounds__(64) void match_stereo_arrays_kernel(
+__global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_arrays_kernel(
     const PairParams* __restrict__ pair, const uint8_t* __restrict__ desc0,
     const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0, const int32_t* n0p, int n0,
     const uint8_t* __restrict__ desc1, const double* __restrict__ bp1,
@@ -597,7 +647,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(BlockOffsets L, int fi
 }
 
 // matches frame f of two gathered block arrays: grid (rows, frames)
-__global__ __launch_bounds__(64) void match_stereo_blocks_kernel(
+__global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_blocks_kernel(
     const PairParams* __restrict__ pair, BlockOffsets L, const uint8_t* __restrict__ blocks0,
     const uint8_t* __restrict__ blocks1, int kp_cap, int threshold,
     okvfe_stereo_match* __restrict__ out) {
@@ -627,7 +677,7 @@ void launch_match_stereo_blocks(const PairParams* pair, const int offs[6], const
                                 okvfe_stereo_match* out, hipStream_t stream) {
   if (n_frames <= 0) return;
   const BlockOffsets L{offs[0], offs[1], offs[2], offs[3], offs[4], offs[5]};
-  hipLaunchKernelGGL(match_stereo_blocks_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64), 0,
+  hipLaunchKernelGGL(match_stereo_blocks_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64, kStereoSegs), 0,
                      stream, pair, L, blocks0, blocks1, kp_cap, threshold, out);
 }
 
@@ -670,7 +720,7 @@ void launch_match_stereo(const PairParams* pairs, int n_pairs, const okvfe_keypo
                          const int32_t* counts, int kp_cap, int threshold,
                          okvfe_stereo_match* out, hipStream_t stream) {
   if (n_pairs <= 0) return;
-  hipLaunchKernelGGL(match_stereo_kernel, dim3((kp_cap + 63) / 64, n_pairs), dim3(64), 0, stream,
+  hipLaunchKernelGGL(match_stereo_kernel, dim3((kp_cap + 63) / 64, n_pairs), dim3(64, kStereoSegs), 0, stream,
                      pairs, kps, desc, bp, bpv, counts, kp_cap, threshold, out);
 }
 
@@ -680,7 +730,7 @@ void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, co
                                 const int32_t* n1p, int n1, int max_rows, int threshold,
                                 okvfe_stereo_match* out, hipStream_t stream) {
   if (max_rows <= 0) return;
-  hipLaunchKernelGGL(match_stereo_arrays_kernel, dim3((max_rows + 63) / 64), dim3(64), 0, stream,
+  hipLaunchKernelGGL(match_stereo_arrays_kernel, dim3((max_rows + 63) / 64), dim3(64, kStereoSegs), 0, stream,
                      pair, desc0, bp0, bpv0, n0p, n0, desc1, bp1, bpv1, n1p, n1, threshold, out);
 }
 
