@@ -73,13 +73,26 @@ void build_pattern(Pattern* p) {
   }
 }
 
-void build_uniformity_lut(float lut[31 * 31]) {
+void build_uniformity_lut(float lut[kLutFloats]) {
+  std::memset(lut, 0, sizeof(float) * kLutFloats);
   for (int y = 0; y < 31; ++y)
     for (int x = 0; x < 31; ++x) {
       const int d2 = (15 - x) * (15 - x) + (15 - y) * (15 - y);
       const double v = 1.0 - static_cast<double>(d2) / 225.0;
       lut[y * 31 + x] = static_cast<float>(v > 0.0 ? v : 0.0);
     }
+  // compacted stamp: only the cells with a non-zero weight, raster order, padded to kStampSlots
+  // with weight 0 (k_select.hip, select_wave_kernel: 11 cells per lane instead of 16)
+  int j = 0;
+  for (int t = 0; t < 31 * 31; ++t) {
+    if (!(lut[t] > 0.0f)) continue;
+    const uint32_t pos = (static_cast<uint32_t>(t / 31) << 8) | static_cast<uint32_t>(t % 31);
+    std::memcpy(&lut[kStampTableOffset + 2 * j], &pos, 4);
+    lut[kStampTableOffset + 2 * j + 1] = lut[t];
+    ++j;
+  }
+  const uint32_t centre = (15u << 8) | 15u;
+  for (; j < kStampSlots; ++j) std::memcpy(&lut[kStampTableOffset + 2 * j], &centre, 4);
 }
 
 namespace {

@@ -312,28 +312,31 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
 }
 
 // ---- single-wave greedy (the production path when the occupancy grid fits in LDS) ---------------
-// One WAVE per image: no workgroup barriers at all.  LDS holds the occupancy grid, a per-candidate
-// record {cell (cy << 16 | cx), level nsc1 (float)} for the first `pre_cap` candidates (the rest
-// lives in the dead Candidate array in HBM) and the indices of the accepted candidates.  Each
-// round tests 64 consecutive candidates, accepts the first that passes (all before it are dead
-// for good, occupancy only grows), and stamps its 31x31 patch: 16 cells per lane, all reads
-// issued before the writes.  Sub-pixel refinement of the accepted points runs at the end.
+// One WAVE per image: no workgroup barriers at all.  LDS holds the occupancy grid, the indices of
+// the accepted candidates (u16) and a sliding chunk of per-candidate records {cell (cy << 16 | cx),
+// level nsc1 (float)} that is refilled from the sorted keys whenever the 64-candidate window would
+// run past it -- the footprint stays under half a CU's LDS for EuRoC-sized grids, so two images
+// run per CU.  Each round tests 64 consecutive candidates and accepts, in order, every passing one
+// whose cell lies outside the stamps applied earlier in the same round; the stamp covers only the
+// 697 non-zero cells of the 31x31 weight table (11 per lane), all reads issued before the writes.
+// Sub-pixel refinement of the accepted points runs at the end.
+constexpr int kStampIts = kStampSlots / 64;
+
 __global__ __launch_bounds__(64) void select_wave_kernel(
-    const int32_t* __restrict__ scores, int w, int h, Candidate* __restrict__ cand, int cand_cap,
+    const int32_t* __restrict__ scores, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
-    float radius, int max_kpts, const float* __restrict__ lut, int occ_rows, int occ_cols,
-    int occ_bytes16, int pre_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
+    float radius, int max_kpts, const float* __restrict__ lut, int occ_cols, int occ_bytes16,
+    int acc_bytes16, int chunk_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
     int32_t* __restrict__ kp_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint8_t* occ = smem_raw;
-  int* acc_idx = reinterpret_cast<int*>(smem_raw + occ_bytes16);
-  uint2* pre_lds = reinterpret_cast<uint2*>(smem_raw + occ_bytes16 + ((kp_cap * 4 + 15) & ~15));
+  uint16_t* acc_idx = reinterpret_cast<uint16_t*>(smem_raw + occ_bytes16);
+  uint2* recs = reinterpret_cast<uint2*>(smem_raw + occ_bytes16 + acc_bytes16);
   const int img = blockIdx.x;
   const int lane = threadIdx.x;
   int n = cand_count[img];
   n = n > cand_cap ? cand_cap : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  uint2* pre_glb = reinterpret_cast<uint2*>(cand + (size_t)img * cand_cap);  // Candidate is dead after the sort
   const int32_t* sc = scores + (size_t)img * w * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
@@ -345,62 +348,91 @@ __global__ __launch_bounds__(64) void select_wave_kernel(
     }
     const float scaling = (float)(15.0 / (double)radius);
     const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-    for (int i = lane; i < n; i += 64) {
-      const uint64_t k = keys[i];
-      const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-      const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
-      const float fy = (float)y * scaling;
-      const float fx = (float)x * scaling;
-      const int cy = (int)(fy + 16.0f);
-      const int cx = (int)(fx + 16.0f);
-      const float q = (float)score / max_score;
-      const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
-      const uint2 rec = make_uint2(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1));
-      if (i < pre_cap) pre_lds[i] = rec; else pre_glb[i] = rec;
-    }
-    // per-lane stamp geometry: cells t = it*64 + lane of the 31x31 patch
-    float lutv[16];
-    int off[16];
+    // records of candidates [base, base + chunk_cap) -> recs[]
+    auto fill_chunk = [&](int base) {
+      const int cnt = min(chunk_cap, n - base);
+      for (int i = lane; i < cnt; i += 64) {
+        const uint64_t k = keys[base + i];
+        const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+        const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
+        const float fy = (float)y * scaling;
+        const float fx = (float)x * scaling;
+        const int cy = (int)(fy + 16.0f);
+        const int cx = (int)(fx + 16.0f);
+        const float q = (float)score / max_score;
+        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+        recs[i] = make_uint2(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1));
+      }
+    };
+    int chunk_base = 0;
+    fill_chunk(0);
+    // per-lane stamp geometry: slots j = it*64 + lane of the compacted table
+    float lutv[kStampIts];
+    int off[kStampIts];
+    const uint2* stamp = reinterpret_cast<const uint2*>(lut + kStampTableOffset);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int t = it * 64 + lane;
-      const int tt = t < 961 ? t : 0;
-      const int ry = tt / 31, rx = tt - ry * 31;
-      lutv[it] = t < 961 ? lut[tt] : 0.0f;   // add = ceil(0 * nsc) = 0 for the padding lanes
-      off[it] = (ry - 15) * occ_cols + (rx - 15);
+    for (int it = 0; it < kStampIts; ++it) {
+      const uint2 e = stamp[it * 64 + lane];
+      lutv[it] = __uint_as_float(e.y);
+      off[it] = ((int)(e.x >> 8) - 15) * occ_cols + ((int)(e.x & 0xFF) - 15);
+      asm volatile("" : "+v"(off[it]));  // keep the offsets resident, do not rematerialise them
     }
+    const bool last_writes = lane < kStampCells - (kStampIts - 1) * 64;  // padding slots stay idle
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
     int pos = 0;
     while (pos < n && kept < limit) {
+      if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
+        chunk_base = pos;
+        fill_chunk(pos);
+        __builtin_amdgcn_wave_barrier();
+      }
       const int idx = pos + lane;
       uint2 rec = make_uint2(0, 0);
-      if (idx < n) rec = idx < pre_cap ? pre_lds[idx] : pre_glb[idx];
-      const int cell = (int)(rec.x >> 16) * occ_cols + (int)(rec.x & 0xFFFF);
-      const float s0 = (float)occ[idx < n ? cell : 0];
+      if (idx < n) rec = recs[idx - chunk_base];
+      const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
+      const int cell = cy * occ_cols + cx;
+      const float s0 = (float)occ[cell];  // idx >= n reads cell 0: in range, result unused
       const bool pass = idx < n && !(__uint_as_float(rec.y) < s0);
-      const unsigned long long b = __ballot(pass);
-      if (b == 0) {
+      unsigned long long m = __ballot(pass);
+      if (m == 0) {
         pos += 64;
         continue;
       }
-      const int first = (int)__ffsll((long long)b) - 1;
-      const int wcell = __builtin_amdgcn_readlane(cell, first);
-      const float wnsc1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)rec.y, first));
-      const float nsc = (float)(0.99 * (double)wnsc1);
-      int v[16];
+      // A passing candidate outside every stamp of this round sees an unchanged occupancy value,
+      // so the sequential test of the reference would pass as well; the first one inside a fresh
+      // stamp ends the round and is re-tested.  The stamps go to the LDS queue back to back
+      // (in-order per wave): no read-after-write wait between two accepts.
+      unsigned long long blocked = 0;
+      int adv = 64;
+      while (m != 0 && kept < limit) {
+        const int first = (int)__ffsll((long long)m) - 1;
+        if ((blocked >> first) & 1) {
+          adv = first;
+          break;
+        }
+        const int wcell = __builtin_amdgcn_readlane(cell, first);
+        const int wcx = __builtin_amdgcn_readlane(cx, first);
+        const int wcy = __builtin_amdgcn_readlane(cy, first);
+        const float wnsc1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)rec.y, first));
+        const int ax = cx - wcx, ay = cy - wcy;
+        blocked |= __ballot((ax < 0 ? -ax : ax) <= 15 && (ay < 0 ? -ay : ay) <= 15);
+        const float nsc = (float)(0.99 * (double)wnsc1);
+        int v[kStampIts];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) v[it] = occ[wcell + off[it]];
+        for (int it = 0; it < kStampIts; ++it) v[it] = occ[wcell + off[it]];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const float m = lutv[it] * nsc;
-        const int nv = v[it] + (int)ceilf(m);
-        if (it < 15 || lane == 0) occ[wcell + off[it]] = (uint8_t)(nv > 255 ? 255 : nv);
+        for (int it = 0; it < kStampIts; ++it) {
+          const float mm = lutv[it] * nsc;
+          const int nv = v[it] + (int)ceilf(mm);
+          if (it < kStampIts - 1 || last_writes) occ[wcell + off[it]] = (uint8_t)(nv > 255 ? 255 : nv);
+        }
+        if (lane == 0) acc_idx[kept] = (uint16_t)(pos + first);
+        ++kept;
+        m &= m - 1;
       }
-      if (lane == 0) acc_idx[kept] = pos + first;
-      ++kept;
-      pos += first + 1;
+      pos += adv;
       __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_wave_barrier();
@@ -452,18 +484,23 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
   const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
-  // single-wave kernel: occupancy + accepted indices + as many candidate records as fit in LDS
-  const size_t acc_bytes = ((size_t)kp_cap * 4 + 15) & ~(size_t)15;
-  const size_t lds_budget = 152 * 1024;
-  if (occ_lds && occ_bytes + acc_bytes + 64 * 8 <= lds_budget && (cand_cap % 2) == 0) {
-    size_t pre_cap = (lds_budget - occ_bytes - acc_bytes) / 8;
-    if (pre_cap > (size_t)cand_cap) pre_cap = (size_t)cand_cap;
-    // keep two waves per CU resident when the candidate records allow it
-    const size_t lds = occ_bytes + acc_bytes + pre_cap * 8;
-    hipLaunchKernelGGL(select_wave_kernel, dim3(n_images), dim3(64), lds, stream, score, w, h, cand,
-                       cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, occ_rows,
-                       occ_cols, (int)occ_bytes, (int)pre_cap, kps, kp_cap, kp_count);
-    return;
+  // single-wave kernel: occupancy + accepted indices (u16) + a sliding chunk of candidate records.
+  // Half a CU's LDS (two images per CU) when at least 128 records fit, else the whole CU.
+  const size_t acc_bytes = ((size_t)kp_cap * 2 + 15) & ~(size_t)15;
+  if (occ_lds && cand_cap <= 65536) {
+    const size_t fixed = occ_bytes + acc_bytes;
+    const size_t half = 80 * 1024, full = 152 * 1024;
+    size_t budget = fixed + 128 * 8 <= half ? half : full;
+    if (fixed + 128 * 8 <= budget) {
+      size_t chunk = (budget - fixed) / 8 / 64 * 64;
+      const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
+      if (chunk > need) chunk = need;
+      const size_t lds = fixed + chunk * 8;
+      hipLaunchKernelGGL(select_wave_kernel, dim3(n_images), dim3(64), lds, stream, score, w, h,
+                         cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, occ_cols,
+                         (int)occ_bytes, (int)acc_bytes, (int)chunk, kps, kp_cap, kp_count);
+      return;
+    }
   }
   if (occ_lds) {
     hipLaunchKernelGGL(select_kernel<true>, dim3(n_images), dim3(kThreads), occ_bytes, stream,

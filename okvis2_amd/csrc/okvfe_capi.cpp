@@ -307,7 +307,7 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     A(d_cand_count, B);
     A(d_sort_ws, (size_t)c->ws_stride * B);
     A(d_occ, c->occ_image_bytes * B);
-    A(d_lut, 31 * 31);
+    A(d_lut, kLutFloats);
     A(d_pattern, 1);
     A(d_kps_det, K * B);
     A(d_det_count, B);
@@ -328,7 +328,7 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
 #undef A
     c->pair_cap = std::max(1, c->B);
     if ((s = dev_alloc(c, &c->d_pairs, (size_t)c->pair_cap)) != OKVFE_OK) return s;
-    float lut[31 * 31];
+    float lut[kLutFloats];
     build_uniformity_lut(lut);
     build_pattern(&c->host_pattern);
     HIP_TRY(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));

@@ -32,7 +32,13 @@ struct Pattern {
   float rot_cosf[kRot], rot_sinf[kRot];
 };
 void build_pattern(Pattern* p);
-void build_uniformity_lut(float lut[31 * 31]);
+// d_lut layout: [0, 961) the 31x31 weights; from kStampTableOffset the compacted stamp, one
+// {(ry << 8) | rx, weight} pair per non-zero cell (697 of them), padded to kStampSlots.
+constexpr int kStampSlots = 704;
+constexpr int kStampCells = 697;
+constexpr int kStampTableOffset = 1024;
+constexpr int kLutFloats = kStampTableOffset + 2 * kStampSlots;
+void build_uniformity_lut(float lut[kLutFloats]);
 void build_awareness_maps(const okvfe_camera& cam, float* rays_hw3, float* jac_hw6);
 bool camera_overlap(const okvfe_camera& cam, const okvfe_camera& other, const double R_other_cam[9],
                     uint8_t* mask_hw);
