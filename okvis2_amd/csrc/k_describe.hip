@@ -243,6 +243,32 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+// One THREAD per keypoint: border test and, in camera-aware mode, M = J [e_x e_y] / fu.  Done here
+// because in the wave-per-keypoint kernel all 64 lanes would repeat the same ~150 instructions.
+// M goes to the first 16 bytes of the keypoint's (not yet written) descriptor slot.
+__global__ __launch_bounds__(256) void describe_setup_kernel(
+    int w, int h, const Pattern* __restrict__ pat, const ImageParams* __restrict__ prm,
+    const float* const* __restrict__ rays, const float* const* __restrict__ jac,
+    const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
+    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
+  const int img = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= kp_count_in[img]) return;
+  const size_t slot = (size_t)img * kp_cap + k;
+  const okvfe_keypoint kp = kps_in[slot];
+  const ImageParams ip = prm[img];
+  const int border = pat->border;
+  bool valid = !(kp.x < (float)border || kp.x >= (float)(w - border) || kp.y < (float)border ||
+                 kp.y >= (float)(h - border));
+  float M[4] = {1.0f, 0.0f, 0.0f, 1.0f};
+  if (valid && ip.mode == kCameraAware) {
+    const float dir[3] = {ip.dir[0], ip.dir[1], ip.dir[2]};
+    valid = camera_aware_matrix(rays[ip.cam], jac[ip.cam], w, ip.fu, dir, kp.x, kp.y, M);
+  }
+  *reinterpret_cast<float4*>(desc_tmp + slot * OKVFE_DESC_BYTES) = make_float4(M[0], M[1], M[2], M[3]);
+  valid_tmp[slot] = valid ? 1 : 0;
+}
+
 // One wave per keypoint, lane i = pattern point i.  The pixels under the keypoint's pattern
 // (<= 80 x 96) are staged once in LDS with coalesced dword loads; all box sums then read LDS.
 __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
@@ -263,12 +289,13 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
   okvfe_keypoint kp = kps_in[slot];
   const ImageParams ip = prm[img];
   const int border = pat->border;
-  bool valid = !(kp.x < (float)border || kp.x >= (float)(w - border) || kp.y < (float)border ||
-                 kp.y >= (float)(h - border));
+  // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
+  bool valid = valid_tmp[slot] != 0;
   const bool active = lane < kPatternPoints;
   const int li = active ? lane : 0;
   const float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
-  float M[4] = {1.0f, 0.0f, 0.0f, 1.0f};
+  const float4 M4 = *reinterpret_cast<const float4*>(desc_tmp + slot * OKVFE_DESC_BYTES);
+  float M[4] = {M4.x, M4.y, M4.z, M4.w};
   float xf, yf;
   int* vals = values[wv];
   uint8_t* patch = patches[wv];
@@ -281,20 +308,38 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
     if (pw > kPatchPitch - 8 || ph > kPatchRows) return false;  // wave-uniform; q0 + 2 < pitch / 4
     __builtin_amdgcn_wave_barrier();
     if (dword_ok) {
-      const int ndw = (pw + 3) >> 2;  // <= 22 dwords per row: lanes 0..31 cover one row
-      const int lx = lane & 31, ly = lane >> 5;
-      uint32_t tmp[kPatchRows / 2];
+      // dword i = it*64 + lane of the patch, row-major over its ndw (<= 22) dwords per row, so the
+      // trip count follows the patch area (typically 60 x 16 dwords = 15 trips, at most 28);
+      // i / ndw by multiplication with ceil(2^16 / ndw) is exact for i < 2730.  All global loads
+      // of a group are in flight before the first LDS store.
+      const int ndw = (pw + 3) >> 2;
+      const int total = ph * ndw;
+      const uint32_t inv = (65536u + (uint32_t)ndw - 1u) / (uint32_t)ndw;
+      const uint8_t* src = im + (size_t)by0 * w + px0;
+      constexpr int kGroup = 7, kGroups = 4;  // 28 trips cover 80 rows x 22 dwords
+      uint32_t tmp[kGroup * kGroups];
 #pragma unroll
-      for (int it = 0; it < kPatchRows / 2; ++it) {  // all global loads in flight before first use
-        const int r = it * 2 + ly;
-        tmp[it] = 0;
-        if (r < ph && lx < ndw)
-          tmp[it] = reinterpret_cast<const uint32_t*>(im + (size_t)(by0 + r) * w + px0)[lx];
+      for (int g = 0; g < kGroups; ++g) {
+        if (g * kGroup * 64 >= total) break;  // wave-uniform
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+          const int it = g * kGroup + j;
+          const uint32_t i = (uint32_t)(it * 64 + lane);
+          const uint32_t r = (i * inv) >> 16, c = i - r * (uint32_t)ndw;
+          tmp[it] = 0;
+          if ((int)i < total) tmp[it] = reinterpret_cast<const uint32_t*>(src + r * (uint32_t)w)[c];
+        }
       }
 #pragma unroll
-      for (int it = 0; it < kPatchRows / 2; ++it) {
-        const int r = it * 2 + ly;
-        if (r < ph && lx < ndw) reinterpret_cast<uint32_t*>(patch + r * kPatchPitch)[lx] = tmp[it];
+      for (int g = 0; g < kGroups; ++g) {
+        if (g * kGroup * 64 >= total) break;
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+          const int it = g * kGroup + j;
+          const uint32_t i = (uint32_t)(it * 64 + lane);
+          const uint32_t r = (i * inv) >> 16, c = i - r * (uint32_t)ndw;
+          if ((int)i < total) reinterpret_cast<uint32_t*>(patch + r * kPatchPitch)[c] = tmp[it];
+        }
       }
     } else {
       for (int r = 0; r < ph; ++r)
@@ -317,11 +362,19 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
       bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
       bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
     } else {
-      const Box b = sample_box(xf, yf, sg);
-      bx0 = wave_min(active ? b.x_left : 0x7fffffff);
-      by0 = wave_min(active ? b.y_top : 0x7fffffff);
-      bx1 = wave_max(active ? b.x_right : -1);
-      by1 = wave_max(active ? b.y_bottom : -1);
+      // superset of all 60 boxes under M: |M p|_x <= |row_x(M)| * |p| and |p| + sigma_half stays
+      // below border - 1 for this pattern; the boxes themselves were checked to lie in the image
+      float nx = M[0] * M[0], t = M[1] * M[1];
+      nx = sqrtf(nx + t);
+      float ny = M[2] * M[2];
+      t = M[3] * M[3];
+      ny = sqrtf(ny + t);
+      const float ex = fmaxf(nx, 1.0f) * (float)(border - 1) + 1.5f;
+      const float ey = fmaxf(ny, 1.0f) * (float)(border - 1) + 1.5f;
+      bx0 = (int)floorf(kp.x - ex); bx1 = (int)ceilf(kp.x + ex) + 1;
+      by0 = (int)floorf(kp.y - ey); by1 = (int)ceilf(kp.y + ey) + 1;
+      bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+      bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
     }
     PatchPx ppx;
     int v = 0;
@@ -337,10 +390,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
     return true;
   };
 
-  if (valid && ip.mode == kCameraAware) {
-    const float dir[3] = {ip.dir[0], ip.dir[1], ip.dir[2]};
-    valid = camera_aware_matrix(rays[ip.cam], jac[ip.cam], w, ip.fu, dir, kp.x, kp.y, M);
-  } else if (valid && ip.mode == kGradient) {
+  if (valid && ip.mode == kGradient) {
     valid = sample_all(true);
     if (valid) {
       int d0 = 0, d1 = 0;
@@ -464,6 +514,9 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      hipStream_t stream) {
   if (n_images <= 0) return;
+  hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
+                     stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, desc_tmp,
+                     valid_tmp);
   const dim3 grid((kp_cap + kDescWaves - 1) / kDescWaves, n_images);
   hipLaunchKernelGGL(describe_kernel, grid, dim3(64 * kDescWaves), 0, stream, img, w, h, pat, prm,
                      rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp);
