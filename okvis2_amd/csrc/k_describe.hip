@@ -29,6 +29,8 @@ namespace {
 // float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
 constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
+constexpr int kPatchPitchBytes = 96;  // bytes per patch row in LDS (multiple of 4)
+constexpr int kPatchRowsTotal = 80;   // rows 0..78 hold pixels, row 79 stays zero
 struct Box {
   int x_left, x_right, y_top, y_bottom;
 };
@@ -92,13 +94,13 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
   int upper = 0, middle = 0, left = 0, right = 0, bottom = 0;
   const int bw = x_right - x_left, bh = y_bottom - y_top;  // >= 1 for sigma_half >= 0.5
   if (PX::kFixedTrip && __all(bw <= kMaxBox && bh <= kMaxBox)) {
-    // fixed trip counts (fully unrolled, reads clamped into the box and masked) so that the LDS
-    // reads of a sample are issued back to back instead of one dependent read per loop trip
-    ret = 0;
-    // interior columns x_left+1 .. x_right-1 (<= 9 bytes) lie in at most 3 aligned dwords of the
-    // patch row: one byte mask per dword (hoisted out of the row loop), then
-    // v_sad_u8(dword & mask, 0, acc) sums 4 pixels per instruction
-    const int xi0 = x_left + 1 - px.x0;  // patch column of the first interior pixel
+    // Fixed trip counts, no data-dependent selects: the top and the bottom row are read once each,
+    // then kMaxBox - 1 interior slots, where a slot past the box (dy >= bh) reads the all-zero
+    // row of the patch instead, so every accumulation is unconditional.  Interior columns
+    // x_left+1 .. x_right-1 (<= 9 bytes) lie in at most 3 aligned dwords of the patch row: one
+    // byte mask per dword, then v_sad_u8(dword & mask, 0, acc) sums 4 pixels per instruction.
+    const int cl = x_left - px.x0, cr = x_right - px.x0;  // patch columns of the rim pixels
+    const int xi0 = cl + 1;
     const int q0 = xi0 >> 2;
     const int lo = xi0 & 3, ni = bw - 1;
     uint32_t m[3];
@@ -110,26 +112,29 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
       const int nb = eb - sb;
       m[j] = nb > 0 ? ((0xFFFFFFFFu >> (8 * (4 - nb))) << (8 * sb)) : 0u;
     }
+    const uint8_t* top = px.row8(y_top);
+    const uint8_t* zero = px.zero_row8();
+    int pl, pr;
+    auto read_row = [&](const uint8_t* rp, uint32_t acc) -> uint32_t {
+      pl = rp[cl];
+      pr = rp[cr];
+      const uint32_t* d = reinterpret_cast<const uint32_t*>(rp) + q0;
+      acc = __builtin_amdgcn_sad_u8(d[0] & m[0], 0u, acc);
+      acc = __builtin_amdgcn_sad_u8(d[1] & m[1], 0u, acc);
+      return __builtin_amdgcn_sad_u8(d[2] & m[2], 0u, acc);
+    };
+    upper = (int)read_row(top, 0u);
+    ret = A * pl + B * pr;
+    bottom = (int)read_row(top + bh * kPatchPitchBytes, 0u);
+    ret += D * pl + C * pr;
+    uint32_t mid = 0u;
 #pragma unroll
-    for (int dy = 0; dy <= kMaxBox; ++dy) {
-      const int y = y_top + (dy < bh ? dy : bh);
-      const int pl = px(y, x_left), pr = px(y, x_right);
-      const uint32_t* prow = px.row32(y) + q0;
-      uint32_t mid = __builtin_amdgcn_sad_u8(prow[0] & m[0], 0u, 0u);
-      mid = __builtin_amdgcn_sad_u8(prow[1] & m[1], 0u, mid);
-      mid = __builtin_amdgcn_sad_u8(prow[2] & m[2], 0u, mid);
-      if (dy == 0) {
-        ret = A * pl + B * pr;
-        upper = (int)mid;
-      } else {
-        const bool is_bottom = dy == bh, is_mid = dy < bh;
-        ret += is_bottom ? D * pl + C * pr : 0;
-        bottom += is_bottom ? (int)mid : 0;
-        left += is_mid ? pl : 0;
-        right += is_mid ? pr : 0;
-        middle += is_mid ? (int)mid : 0;
-      }
+    for (int dy = 1; dy < kMaxBox; ++dy) {
+      mid = read_row(dy < bh ? top + dy * kPatchPitchBytes : zero, mid);
+      left += pl;
+      right += pr;
     }
+    middle = (int)mid;
   } else {
     for (int x = x_left + 1; x < x_right; ++x) {
       upper += px(y_top, x);
@@ -209,8 +214,8 @@ __device__ __forceinline__ bool camera_aware_matrix(const float* __restrict__ ra
 }
 
 constexpr int kDescWaves = 4;
-constexpr int kPatchPitch = 96;  // bytes per patch row in LDS (multiple of 4)
-constexpr int kPatchRows = 80;
+constexpr int kPatchPitch = kPatchPitchBytes;
+constexpr int kPatchRows = kPatchRowsTotal - 1;  // pixel rows; the last row of the buffer is zero
 
 struct GlobalPx {  // direct reads from the image (fallback when the patch does not fit in LDS)
   static constexpr bool kFixedTrip = false;
@@ -218,7 +223,8 @@ struct GlobalPx {  // direct reads from the image (fallback when the patch does 
   int w;
   int x0 = 0;  // unused: the fixed-trip path is compiled out for this reader
   __device__ __forceinline__ int operator()(int y, int x) const { return img[(size_t)y * w + x]; }
-  __device__ __forceinline__ const uint32_t* row32(int) const { return nullptr; }
+  __device__ __forceinline__ const uint8_t* row8(int) const { return nullptr; }
+  __device__ __forceinline__ const uint8_t* zero_row8() const { return nullptr; }
 };
 struct PatchPx {   // reads from the keypoint's patch staged in LDS
   static constexpr bool kFixedTrip = true;
@@ -227,8 +233,11 @@ struct PatchPx {   // reads from the keypoint's patch staged in LDS
   __device__ __forceinline__ int operator()(int y, int x) const {
     return patch[(y - y0) * kPatchPitch + (x - x0)];
   }
-  __device__ __forceinline__ const uint32_t* row32(int y) const {
-    return reinterpret_cast<const uint32_t*>(patch + (y - y0) * kPatchPitch);
+  __device__ __forceinline__ const uint8_t* row8(int y) const {
+    return patch + (y - y0) * kPatchPitch;
+  }
+  __device__ __forceinline__ const uint8_t* zero_row8() const {
+    return patch + kPatchRows * kPatchPitch;
   }
 };
 
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
     const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
     uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
-  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchRows * kPatchPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchRowsTotal * kPatchPitch];
   __shared__ int values[kDescWaves][64];
   const int img = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -299,6 +308,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
   float xf, yf;
   int* vals = values[wv];
   uint8_t* patch = patches[wv];
+  if (lane < kPatchPitch / 4) reinterpret_cast<uint32_t*>(patch + kPatchRows * kPatchPitch)[lane] = 0u;
   const bool dword_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0);
 
   // stages the pixels [bx0..bx1] x [by0..by1] (inside the image) into LDS; false if too large
