@@ -101,7 +101,6 @@ __global__ __launch_bounds__(256) void nms_generic_kernel(const int32_t* __restr
 constexpr int kStripLanes = 62;
 constexpr int kRows = 32;   // centre rows per wave
 constexpr int kWaves = 4;
-constexpr int kLdsCap = 1024;
 
 __device__ __forceinline__ int from_left(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
@@ -111,14 +110,18 @@ __device__ __forceinline__ int from_right(int v) {
 }
 __device__ __forceinline__ int max3(int a, int b, int c) { return max(max(a, b), c); }
 
+// One lane = 4 columns (one int4 per row), 62 owned lanes per strip + 2 halo lanes, kRows centre
+// rows per wave with the 3-row window rolled through registers (fully unrolled: no moves, row
+// numbers are immediates).  Inside the row loop a lane only records its hits as bits (one 32-bit
+// mask per column, bit = row): no ballots, no atomics, almost no scalar work.  After the loop the
+// wave counts its hits, takes ONE slot range from the image's counter and every lane writes its
+// own candidates (the scores are re-read, they are still in L2).
 __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restrict__ scores, int w,
                                                           int h, int thr,
                                                           Candidate* __restrict__ cand,
                                                           int cand_cap,
                                                           int32_t* __restrict__ cand_count,
                                                           int strips, int ytiles, int n_images) {
-  __shared__ Candidate buf[kLdsCap];
-  __shared__ int lds_cnt, lds_base;
   int img, tile;
   xcd_tile(strips * ytiles, n_images, &img, &tile);
   const int ytile = tile / strips;
@@ -129,112 +132,100 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
   const int d = strip * kStripLanes + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int ys = (ytile * kWaves + wave) * kRows;  // first centre row of this wave
+  if (ys >= h) return;                             // wave-uniform; no block barriers below
   const bool last_strip = strip * kStripLanes + 64 >= nd;
   const bool own = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;
   const int x0 = dcl * 4;
-  if (threadIdx.x == 0 && threadIdx.y == 0) lds_cnt = 0;
-  __syncthreads();
-
-  if (ys < h) {  // wave-uniform
-    const int ye = ys + kRows < h ? ys + kRows : h;
-    const int4* rows = reinterpret_cast<const int4*>(s) + dcl;
-    auto load_row = [&](int row) -> int4 {
-      row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
-      return rows[(size_t)row * (size_t)nd];
-    };
-    // horizontal 3-max of a row at this lane's 4 columns, plus the row's edge neighbours
-    auto hmax = [&](const int4& r, int hm[4], int& left, int& right) {
-      left = from_left(r.w);
-      right = from_right(r.x);
-      hm[0] = max3(left, r.x, r.y);
-      hm[1] = max3(r.x, r.y, r.z);
-      hm[2] = max3(r.y, r.z, r.w);
-      hm[3] = max3(r.z, r.w, right);
-    };
-    int4 rt = load_row(ys - 1), rc = load_row(ys), rb;
-    int4 nxt = load_row(ys + 1);
-    int hmt[4], hmc[4], hmb[4], cl, cr, tl, tr;
-    hmax(rt, hmt, tl, tr);
-    hmax(rc, hmc, cl, cr);
-    for (int y = ys; y < ye; ++y) {
-      rb = nxt;
-      nxt = load_row(y + 2);
-      int bl, br;
-      hmax(rb, hmb, bl, br);
-      const bool row_ok = y >= 2 && y < h - 2;
+  const int ye = ys + kRows < h ? ys + kRows : h;
+  const int4* rows = reinterpret_cast<const int4*>(s) + dcl;
+  auto load_row = [&](int row) -> int4 {
+    row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
+    return rows[(size_t)row * (size_t)nd];
+  };
+  // horizontal 3-max of a row at this lane's 4 columns
+  auto hmax = [&](const int4& r, int hm[4], int& left, int& right) {
+    left = from_left(r.w);
+    right = from_right(r.x);
+    hm[0] = max3(left, r.x, r.y);
+    hm[1] = max3(r.x, r.y, r.z);
+    hm[2] = max3(r.y, r.z, r.w);
+    hm[3] = max3(r.z, r.w, right);
+  };
+  constexpr int kAhead = 3;  // rows in flight beyond the window
+  int4 r[kRows + 2 + kAhead];  // fully unrolled below: every index is a compile-time constant
+  int hm[kRows + 2][4], lf[kRows + 2], rg[kRows + 2];
+#pragma unroll
+  for (int u = 0; u < 2 + kAhead; ++u) r[u] = load_row(ys - 1 + u);
+  hmax(r[0], hm[0], lf[0], rg[0]);
+  hmax(r[1], hm[1], lf[1], rg[1]);
+  uint32_t m[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < kRows; ++k) {  // centre row y = ys + k: window rows k, k+1, k+2 of r[]
+    const int y = ys + k;
+    if (y >= ye) break;  // wave-uniform
+    r[k + 2 + kAhead] = load_row(y + 1 + kAhead);
+    hmax(r[k + 2], hm[k + 2], lf[k + 2], rg[k + 2]);
+    if (y >= 2 && y < h - 2) {  // wave-uniform
+      const int4 rc = r[k + 1];
       const int c[4] = {rc.x, rc.y, rc.z, rc.w};
-      const int lft[4] = {cl, rc.x, rc.y, rc.z};
-      const int rgt[4] = {rc.y, rc.z, rc.w, cr};
-      bool p[4];
+      const int lft[4] = {lf[k + 1], rc.x, rc.y, rc.z};
+      const int rgt[4] = {rc.y, rc.z, rc.w, rg[k + 1]};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int x = x0 + i;
-        const int nb = max(max3(hmt[i], hmb[i], lft[i]), rgt[i]);
-        p[i] = row_ok && x >= 2 && x < w - 2 && c[i] >= thr && nb <= c[i];  // halo lanes too
+        // >= thr and no strictly greater neighbour  <=>  c >= max(all 8 neighbours, thr)
+        const int nb = max3(max3(hm[k][i], hm[k + 2][i], lft[i]), rgt[i], thr);
+        m[i] = c[i] >= nb ? (m[i] | (1u << k)) : m[i];
       }
-      // raster-scan parity only matters when two horizontally adjacent pixels both pass
-      const int p0_right = from_right(p[0] ? 1 : 0);
-      const bool adj = (p[0] && p[1]) || (p[1] && p[2]) || (p[2] && p[3]) || (p[3] && p0_right);
-      if (__builtin_expect(__any(adj), 0)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (p[i]) p[i] = accepted_slow(s, w, x0 + i, y, thr);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = p[i] && own;  // halo lanes only feed the adjacency test
-      unsigned long long b[4];
-      int total = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        b[i] = __ballot(p[i]);
-        total += __popcll(b[i]);
-      }
-      if (total) {  // wave-uniform
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&lds_cnt, total);
-        base = __shfl(base, 0);
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        int off = base;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (p[i]) {
-            const int pos = off + __popcll(b[i] & lt);
-            Candidate cd;
-            cd.x = x0 + i;
-            cd.y = y;
-            cd.score = c[i];
-            if (pos < kLdsCap) {
-              buf[pos] = cd;
-            } else {  // LDS staging full: append directly (rare)
-              const int gp = atomicAdd(&cand_count[img], 1);
-              if (gp < cand_cap) cand[(size_t)img * cand_cap + gp] = cd;
-            }
-          }
-          off += __popcll(b[i]);
-        }
-      }
-      // roll the window
-      rt = rc;
-      rc = rb;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        hmt[i] = hmc[i];
-        hmc[i] = hmb[i];
-      }
-      tl = cl; tr = cr;
-      cl = bl; cr = br;
     }
   }
-  __syncthreads();
-  const int n = lds_cnt < kLdsCap ? lds_cnt : kLdsCap;
-  if (n > 0) {
-    if (threadIdx.x == 0 && threadIdx.y == 0) lds_base = atomicAdd(&cand_count[img], n);
-    __syncthreads();
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < n; i += 64 * kWaves) {
-      const int gp = lds_base + i;
-      if (gp < cand_cap) cand[(size_t)img * cand_cap + gp] = buf[i];
+  // columns 0, 1, w-2, w-1 are never maxima
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (x0 + i < 2 || x0 + i >= w - 2) m[i] = 0u;
+  // The raster scan of the reference skips the pixel after a hit, which only matters where two
+  // horizontally adjacent pixels both pass (equal scores): re-derive those rows exactly.
+  const uint32_t adj = (m[0] & m[1]) | (m[1] & m[2]) | (m[2] & m[3]) |
+                       (m[3] & (uint32_t)from_right((int)m[0]));
+  if (__builtin_expect(__any(adj != 0u), 0)) {
+    uint32_t rows_adj = adj;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) rows_adj |= (uint32_t)__shfl_xor((int)rows_adj, dd);
+    while (rows_adj) {
+      const int k = __ffs((int)rows_adj) - 1;
+      rows_adj &= rows_adj - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((m[i] >> k) & 1u)
+          if (!accepted_slow(s, w, x0 + i, ys + k, thr)) m[i] &= ~(1u << k);
+    }
+  }
+  if (!own) m[0] = m[1] = m[2] = m[3] = 0u;  // halo lanes only fed the neighbours
+  const int cnt = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+  if (!__any(cnt != 0)) return;
+  int incl = cnt;
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const int t = __shfl_up(incl, dd);
+    if (lane >= dd) incl += t;
+  }
+  const int total = __shfl(incl, 63);
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&cand_count[img], total);
+  int pos = __shfl(base, 0) + incl - cnt;
+  Candidate* out = cand + (size_t)img * cand_cap;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t mm = m[i];
+    while (mm) {
+      const int k = __ffs((int)mm) - 1;
+      mm &= mm - 1;
+      Candidate cd;
+      cd.x = x0 + i;
+      cd.y = ys + k;
+      cd.score = s[(size_t)(ys + k) * w + x0 + i];
+      if (pos < cand_cap) out[pos] = cd;
+      ++pos;
     }
   }
 }
