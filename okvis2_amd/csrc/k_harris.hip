@@ -241,11 +241,40 @@ __device__ __forceinline__ int from_right(int v) {  // value of lane+1
 }
 
 constexpr int kStripLanes = 62;
+#ifndef OKVFE_K1_WAVES
+#define OKVFE_K1_WAVES __attribute__((amdgpu_waves_per_eu(6, 8)))
+#endif
 
-template <int kTHF>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
+// NMS = true fuses the detector's non-maximum suppression (K2) into the same pass: the wave also
+// computes the score rows ys-1 and ye (not stored), keeps the previous score row and the horizontal
+// 3-maxima of the last two rows in registers, and tests every centre row against
+// max(8 neighbours, thr) while it is still in registers -- the score map is then never read back
+// from HBM by the detector (a pure-read pass over it costs as much as this whole kernel).  Hits are
+// shifted into one 32-bit mask per column (v_cmp + v_addc_co), and written out after the row loop
+// through one slot reservation per wave.  Where two horizontally adjacent pixels both pass (equal
+// scores) the raster-scan rule of the reference needs the finished score row of the neighbouring
+// strips, so those candidates are flagged and settled by nms_fixup_kernel (k_nms.hip).
+struct NmsOut {
+  int thr;
+  Candidate* cand;
+  int cand_cap;
+  int32_t* cand_count;
+  int32_t* fix_count;
+};
+
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+// m = (m << 1) | (c >= nb)
+__device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb) {
+  asm volatile("v_cmp_ge_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+               : "+v"(m)
+               : "v"(c), "v"(nb)
+               : "vcc");
+}
+
+template <int kTHF, bool NMS>
+__global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int strips,
-    int ytiles, int n_images) {
+    int ytiles, int n_images, NmsOut nms) {
   const int lane = threadIdx.x;
   int image, tile;
   xcd_tile(strips * ytiles, n_images, &image, &tile);
@@ -254,9 +283,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
   const int nd = w >> 2;
   const int d = strip * kStripLanes + lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int ys = (ytile * kWavesPerBlock + wave) * kTHF;
-  if (ys >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
-  const int ye = ys + kTHF < h ? ys + kTHF : h;
+  const int ys_own = (ytile * kWavesPerBlock + wave) * kTHF;
+  if (ys_own >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
+  const int ye_own = ys_own + kTHF < h ? ys_own + kTHF : h;
+  // score rows computed by this wave: with NMS one more above and below the rows it owns
+  const int ys = NMS ? ys_own - 1 : ys_own;
+  const int ye = NMS ? ye_own + 1 : ye_own;
   const bool last_strip = strip * kStripLanes + 64 >= nd;
   const bool store = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;  // clamped dword index for loads
@@ -306,6 +338,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) hs[q][c][i] = vp[q][c][i] = 0;
+
+  // NMS state: scores + edge neighbours of the previous row, horizontal 3-max of the last two
+  int nc[4], nh[2][4], nl = 0, nr = 0;
+  uint32_t hits[4] = {0u, 0u, 0u, 0u};
+  const int yt0 = ys_own > 2 ? ys_own : 2;                  // tested centre rows [yt0, yt1)
+  const int yt1 = ye_own < h - 2 ? ye_own : h - 2;
+  if (NMS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nc[i] = nh[0][i] = nh[1][i] = 0;
+  }
 
   // step j: consume pixel row r = ys+j, covariance row g = r-1, score row y = g-1 (from j >= 2)
   auto step = [&](int j, int s_new, int s_a, int s_b, int q) {
@@ -396,10 +438,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
       } else {
         sc[0] = sc[1] = sc[2] = sc[3] = 0;
       }
-      if (store) {
+      if (store && (!NMS || (y >= ys_own && y < ye_own))) {
         typedef int v4i __attribute__((ext_vector_type(4)));
         const v4i v = {sc[0], sc[1], sc[2], sc[3]};
         __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, 0);
+      }
+      if (NMS) {
+        // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc) -> test centre row y-1
+        const int l = from_left(sc[3]), r2 = from_right(sc[0]);
+        const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
+                           max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
+        const int yc = y - 1;
+        if (yc >= yt0 && yc < yt1) {  // wave-uniform
+          const int* c = nc;
+          const int lft[4] = {nl, c[0], c[1], c[2]};
+          const int rgt[4] = {c[1], c[2], c[3], nr};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            push_hit(hits[i], c[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          nh[q][i] = hn[i];
+          nc[i] = sc[i];
+        }
+        nl = l;
+        nr = r2;
       }
     }
   };
@@ -414,13 +478,68 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void harris_kernel(
     if (j + 4 < jn) step(j + 4, 0, 1, 2, 0);
     if (j + 5 < jn) step(j + 5, 1, 2, 0, 1);
   }
+
+  if (NMS) {
+    const int tests = yt1 - yt0;  // bit b of hits[] <-> row yt0 + tests - 1 - b
+    if (tests <= 0) return;
+    const int x0 = dcl * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)  // columns 0, 1, w-2, w-1 are never maxima
+      if (x0 + i < 2 || x0 + i >= w - 2) hits[i] = 0u;
+    const uint32_t adj = (hits[0] & hits[1]) | (hits[1] & hits[2]) | (hits[2] & hits[3]) |
+                         (hits[3] & (uint32_t)from_right((int)hits[0]));
+    uint32_t rows_adj = 0u;
+    if (__builtin_expect(__any(adj != 0u), 0)) {
+      rows_adj = adj;
+#pragma unroll
+      for (int dd = 32; dd > 0; dd >>= 1) rows_adj |= (uint32_t)__shfl_xor((int)rows_adj, dd);
+    }
+    if (!store) hits[0] = hits[1] = hits[2] = hits[3] = 0u;  // halo lanes only fed the neighbours
+    const int cnt = __popc(hits[0]) + __popc(hits[1]) + __popc(hits[2]) + __popc(hits[3]);
+    if (!__any(cnt != 0)) return;
+    int incl = cnt;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int t = __shfl_up(incl, dd);
+      if (lane >= dd) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&nms.cand_count[image], total);
+    int pos = __shfl(base, 0) + incl - cnt;
+    Candidate* outc = nms.cand + (size_t)image * nms.cand_cap;
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
+    int flagged = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t mm = hits[i];
+      while (mm) {
+        const int b = __ffs((int)mm) - 1;
+        mm &= mm - 1;
+        const int y = yt0 + tests - 1 - b;
+        Candidate cd;
+        cd.x = x0 + i;
+        cd.y = y;
+        if ((rows_adj >> b) & 1u) {  // to be settled by nms_fixup_kernel
+          cd.y |= kCandidateFixupFlag;
+          ++flagged;
+        }
+        cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i + y * w * 4, 0, 1);
+        if (pos < nms.cand_cap) outc[pos] = cd;
+        ++pos;
+      }
+    }
+    if (rows_adj != 0u && __any(flagged != 0)) {
+      if (flagged) atomicAdd(&nms.fix_count[image], flagged);
+    }
+  }
 }
 
 }  // namespace
 
-void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
-                   hipStream_t stream) {
-  if (n_images <= 0) return;
+static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                               const NmsOut* nms, hipStream_t stream) {
+  if (n_images <= 0) return true;
   const dim3 block(64, kWavesPerBlock, 1);
   const bool aligned = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) &&
                        ((reinterpret_cast<uintptr_t>(score) & 15) == 0);
@@ -435,10 +554,16 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 #define OKVFE_K1_LAUNCH(TH)                                                                   \
   {                                                                                           \
     const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                 \
-    hipLaunchKernelGGL(harris_kernel<TH>, dim3(strips * ytiles * n_images), block, 0, stream, img, \
-                       w, h, score, strips, ytiles, n_images);                                \
+    if (nms)                                                                                  \
+      hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(strips * ytiles * n_images), block, 0, \
+                         stream, img, w, h, score, strips, ytiles, n_images, *nms);           \
+    else                                                                                      \
+      hipLaunchKernelGGL((harris_kernel<TH, false>), dim3(strips * ytiles * n_images), block, 0, \
+                         stream, img, w, h, score, strips, ytiles, n_images, NmsOut{});       \
   }
-    switch (th_env ? th_env : (h % 30 == 0 ? 30 : 32)) {
+    const int th = th_env ? th_env : (h % 30 == 0 ? 30 : 32);
+    if (nms && th > 32) return false;  // one hit bit per row in a 32-bit mask
+    switch (th) {
       case 16: OKVFE_K1_LAUNCH(16); break;
       case 24: OKVFE_K1_LAUNCH(24); break;
       case 30: OKVFE_K1_LAUNCH(30); break;
@@ -452,10 +577,26 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
     }
 #undef OKVFE_K1_LAUNCH
   } else {
+    if (nms) return false;
     const dim3 grid((w + 255) / 256, (h + kTH * kWavesPerBlock - 1) / (kTH * kWavesPerBlock),
                     n_images);
     hipLaunchKernelGGL(harris_generic_kernel<false>, grid, block, 0, stream, img, w, h, score);
   }
+  return true;
+}
+
+void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                   hipStream_t stream) {
+  (void)launch_harris_impl(img, w, h, n_images, score, nullptr, stream);
+}
+
+bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
+                       int32_t* fix_count, hipStream_t stream) {
+  static const bool off = getenv("OKVFE_NO_FUSED_NMS") != nullptr;  // A/B knob for profiling
+  if (off) return false;
+  const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count};
+  return launch_harris_impl(img, w, h, n_images, score, &nms, stream);
 }
 
 }  // namespace okvfe

@@ -230,7 +230,51 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
   }
 }
 
+// Settles the candidates the fused score+NMS kernel flagged (runs of horizontally adjacent equal
+// maxima): with the score map complete, accepted_slow applies the raster-scan rule exactly; the
+// rejected ones are removed from the (unordered) list.  One block per image, idle unless flagged.
+__global__ __launch_bounds__(256) void nms_fixup_kernel(const int32_t* __restrict__ scores, int w,
+                                                        int h, int thr, Candidate* __restrict__ cand,
+                                                        int cand_cap,
+                                                        int32_t* __restrict__ cand_count,
+                                                        const int32_t* __restrict__ fix_count) {
+  const int img = blockIdx.x;
+  if (fix_count[img] == 0) return;
+  const int32_t* s = scores + (size_t)img * w * h;
+  Candidate* c = cand + (size_t)img * cand_cap;
+  const int total = cand_count[img];
+  int n = total < cand_cap ? total : cand_cap;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int y = c[i].y;
+    if (y & kCandidateFixupFlag) {
+      const int yy = y & ~kCandidateFixupFlag;
+      c[i].y = accepted_slow(s, w, c[i].x, yy, thr) ? yy : -1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int i = 0;
+    while (i < n) {
+      if (c[i].y < 0) {
+        c[i] = c[n - 1];
+        --n;
+      } else {
+        ++i;
+      }
+    }
+    cand_count[img] = total > cand_cap ? total : n;  // an overflowing list stays marked as such
+  }
+}
+
 }  // namespace
+
+void launch_nms_fixup(const int32_t* score, int w, int h, int n_images, int abs_threshold,
+                      Candidate* cand, int cand_cap, int32_t* cand_count,
+                      const int32_t* fix_count, hipStream_t stream) {
+  if (n_images <= 0) return;
+  hipLaunchKernelGGL(nms_fixup_kernel, dim3(n_images), dim3(256), 0, stream, score, w, h,
+                     abs_threshold, cand, cand_cap, cand_count, fix_count);
+}
 
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream) {

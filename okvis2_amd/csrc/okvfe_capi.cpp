@@ -304,7 +304,7 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
 #define A(ptr, n) if ((s = dev_alloc(c, &c->ptr, (n))) != OKVFE_OK) return s
     A(d_scores, P * B);
     A(d_cand, (size_t)c->cand_cap * B);
-    A(d_cand_count, B);
+    A(d_cand_count, 2 * B);
     A(d_sort_ws, (size_t)c->ws_stride * B);
     A(d_occ, c->occ_image_bytes * B);
     A(d_lut, kLutFloats);
@@ -481,15 +481,24 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
   okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
   if (st != OKVFE_OK) return st;
   const int w = ctx->w, h = ctx->h;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, n_images * sizeof(int32_t), s));
+  // d_cand_count: [0, B) candidate counts, [B, 2B) per-image counts of flagged candidates
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+  int32_t* d_fix_count = ctx->d_cand_count + ctx->B;
+  bool fused;
   {
     StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
-    launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
+    fused = launch_harris_nms(images_dev, w, h, n_images, ctx->d_scores, ctx->cfg.absolute_threshold,
+                              ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, d_fix_count, s);
+    if (!fused) launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
   }
   {
     StageTimer t(ctx, OKVFE_STAGE_NMS, s);
-    launch_nms(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap,
-               ctx->d_cand_count, s);
+    if (fused)
+      launch_nms_fixup(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand,
+                       ctx->cand_cap, ctx->d_cand_count, d_fix_count, s);
+    else
+      launch_nms(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand,
+                 ctx->cand_cap, ctx->d_cand_count, s);
   }
   {
     StageTimer t(ctx, OKVFE_STAGE_SORT, s);
@@ -603,9 +612,16 @@ okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride, o
   if (st != OKVFE_OK) return st;
   hipStream_t s = ctx->stream;
   const int w = ctx->w, h = ctx->h;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, sizeof(int32_t), s));
-  launch_harris(ctx->d_img_stage, w, h, 1, ctx->d_scores, s);
-  launch_nms(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, s);
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+  int32_t* d_fix_count = ctx->d_cand_count + ctx->B;
+  if (launch_harris_nms(ctx->d_img_stage, w, h, 1, ctx->d_scores, ctx->cfg.absolute_threshold, ctx->d_cand,
+                        ctx->cand_cap, ctx->d_cand_count, d_fix_count, s)) {
+    launch_nms_fixup(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap,
+                     ctx->d_cand_count, d_fix_count, s);
+  } else {
+    launch_harris(ctx->d_img_stage, w, h, 1, ctx->d_scores, s);
+    launch_nms(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, s);
+  }
   launch_sort(ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, 1, ctx->cfg.uniformity_radius, ctx->d_sort_ws, s);
   launch_select(ctx->d_scores, w, h, 1, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, ctx->cfg.uniformity_radius,
                 ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ, ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols,

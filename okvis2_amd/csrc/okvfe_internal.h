@@ -47,6 +47,9 @@ bool host_backproject(const okvfe_camera& cam, double px, double py, double dir[
 struct Candidate {  // NMS maximum
   int32_t x, y, score;
 };
+// set in Candidate::y by the fused score+NMS kernel: acceptance still depends on the raster-scan
+// rule over a run of equal maxima, settled by nms_fixup_kernel
+constexpr int32_t kCandidateFixupFlag = 0x40000000;
 
 struct DeviceCamera {  // intrinsics for on-device back-projection
   double fu, fv, cu, cv;
@@ -103,6 +106,15 @@ namespace okvfe {
 
 void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                    hipStream_t stream);
+// Score map and NMS candidates in one pass (k_harris.hip); false = not applicable (unaligned
+// width, >32 rows per wave): the caller then runs launch_harris + launch_nms.  Must be followed by
+// launch_nms_fixup.
+bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
+                       int32_t* fix_count, hipStream_t stream);
+void launch_nms_fixup(const int32_t* score, int w, int h, int n_images, int abs_threshold,
+                      Candidate* cand, int cand_cap, int32_t* cand_count,
+                      const int32_t* fix_count, hipStream_t stream);
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
