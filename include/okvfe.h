@@ -208,6 +208,9 @@ typedef enum okvfe_stage {
   OKVFE_STAGE_MATCH = 7,    /* K7 gated stereo match */
   OKVFE_STAGE_COUNT = 8
 } okvfe_stage;
+/* enable: 0 = off, 1 = every stage, or an OR of OKVFE_PROFILE_STAGE(stage) to time only some
+ * stages (each timed launch costs two event records, i.e. two barrier packets on the stream). */
+#define OKVFE_PROFILE_STAGE(stage) (1 << (8 + (stage)))
 okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable);
 okvfe_status okvfe_profile_read(okvfe_ctx* ctx, double total_ms[OKVFE_STAGE_COUNT],
                                 int32_t launches[OKVFE_STAGE_COUNT]);

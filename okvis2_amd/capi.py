@@ -404,8 +404,14 @@ class Frontend:
         return bj[:len(A)], bd[:len(A)]
 
     # -- stage profiling (HIP events on the launch stream) --------------------------------
-    def profile_enable(self, on=True):
-        self._check(lib().okvfe_profile_enable(self._h, int(bool(on))))
+    def profile_enable(self, on=True, stages=None):
+        """on=True times every stage; stages=("harris", ...) only those (fewer event records)."""
+        flag = int(bool(on))
+        if on and stages:
+            flag = 0
+            for name in stages:
+                flag |= 1 << (8 + list(STAGES).index(name))
+        self._check(lib().okvfe_profile_enable(self._h, flag))
 
     def profile_read(self):
         ms = (C.c_double * len(STAGES))()

@@ -329,6 +329,9 @@ __global__ __launch_bounds__(64) void select_wave_kernel(
     int acc_bytes16, int chunk_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
     int32_t* __restrict__ kp_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // one serial dependency chain per wave: when other streams' kernels share the SIMD, this wave
+  // should win arbitration, the throughput kernels fill the gaps
+  __builtin_amdgcn_s_setprio(3);
   uint8_t* occ = smem_raw;
   uint16_t* acc_idx = reinterpret_cast<uint16_t*>(smem_raw + occ_bytes16);
   uint2* recs = reinterpret_cast<uint2*>(smem_raw + occ_bytes16 + acc_bytes16);

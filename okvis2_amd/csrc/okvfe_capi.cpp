@@ -73,7 +73,7 @@ struct okvfe_ctx {
   size_t h_pinned_bytes = 0;
 
   // stage profiling (okvfe_profile_*): event pairs per recorded stage launch
-  bool profiling = false;
+  uint32_t prof_mask = 0;  // bit s = stage s is timed
   struct StageEvents {
     int stage;
     hipEvent_t a, b;
@@ -176,7 +176,7 @@ struct StageTimer {
   hipStream_t s;
   int idx = -1;
   StageTimer(okvfe_ctx* c, int stage, hipStream_t st) : ctx(c), s(st) {
-    if (!c->profiling || c->prof_events.size() >= 65536) return;
+    if (!((c->prof_mask >> stage) & 1u) || c->prof_events.size() >= 65536) return;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
       if (!c->event_pool.empty()) {
@@ -1031,7 +1031,7 @@ okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable) {
     ctx->event_pool.push_back(e.b);
   }
   ctx->prof_events.clear();
-  ctx->profiling = enable != 0;
+  ctx->prof_mask = enable == 1 ? 0xFFu : (enable > 1 ? ((uint32_t)enable >> 8) & 0xFFu : 0u);
   return OKVFE_OK;
 }
 
