@@ -311,47 +311,60 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
   if (tid == 0) kp_count[img] = kept;
 }
 
-// ---- single-wave greedy (the production path when the occupancy grid fits in LDS) ---------------
-// One WAVE per image: no workgroup barriers at all.  LDS holds the occupancy grid, the indices of
-// the accepted candidates (u16) and a sliding chunk of per-candidate records {cell (cy << 16 | cx),
-// level nsc1 (float)} that is refilled from the sorted keys whenever the 64-candidate window would
-// run past it -- the footprint stays under half a CU's LDS for EuRoC-sized grids, so two images
-// run per CU.  Each round tests 64 consecutive candidates and accepts, in order, every passing one
-// whose cell lies outside the stamps applied earlier in the same round; the stamp covers only the
-// 697 non-zero cells of the 31x31 weight table (11 per lane), all reads issued before the writes.
-// Sub-pixel refinement of the accepted points runs at the end.
-constexpr int kStampIts = kStampSlots / 64;
+// ---- greedy selection, one workgroup of 4 waves per image (the production path when the
+// occupancy grid fits in LDS) ----------------------------------------------------------------
+// LDS holds the occupancy grid, the indices of the accepted candidates (u16), a sliding chunk of
+// per-candidate records {cell (cy << 16 | cx), level nsc1 (float)} refilled from the sorted keys,
+// and the accept list of the current round -- under half a CU's LDS for EuRoC-sized grids, so two
+// images run per CU.
+//   decide (wave 0): tests 64 consecutive candidates against the occupancy and accepts, in order,
+//     every passing one that is more than 30 cells (on either axis) away from all points accepted
+//     before it in the same round: its occupancy value is then unchanged, so the sequential test
+//     of the reference would pass as well, and its stamp is disjoint from theirs.  The first
+//     passing candidate closer than that ends the round and is re-tested in the next one.
+//     Windows without a passing candidate are skipped without leaving the wave.
+//   stamp (all 4 waves): every thread takes 3 of the 697 non-zero cells of the 31x31 weight table
+//     for each accepted point of the round; the stamps of a round touch disjoint cells, so no
+//     ordering between them is needed.
+// Two workgroup barriers per round; sub-pixel refinement of the accepted points runs at the end.
+constexpr int kSelThreads = 256;
+constexpr int kStampIts = (kStampCells + kSelThreads - 1) / kSelThreads;
+constexpr int kRoundCap = 64;
 
-__global__ __launch_bounds__(64) void select_wave_kernel(
+__global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     const int32_t* __restrict__ scores, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int occ_cols, int occ_bytes16,
     int acc_bytes16, int chunk_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
     int32_t* __restrict__ kp_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // one serial dependency chain per wave: when other streams' kernels share the SIMD, this wave
-  // should win arbitration, the throughput kernels fill the gaps
+  __shared__ int2 round_list[kRoundCap];  // {cell, 0.99 * level} of the points accepted this round
+  __shared__ int s_round, s_pos, s_kept;
+  // serial dependency chain: when other streams' kernels share the SIMD, these waves should win
+  // arbitration, the throughput kernels fill the gaps
   __builtin_amdgcn_s_setprio(3);
   uint8_t* occ = smem_raw;
   uint16_t* acc_idx = reinterpret_cast<uint16_t*>(smem_raw + occ_bytes16);
   uint2* recs = reinterpret_cast<uint2*>(smem_raw + occ_bytes16 + acc_bytes16);
   const int img = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const bool decider = tid < 64;  // wave 0
   int n = cand_count[img];
   n = n > cand_cap ? cand_cap : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
   const int32_t* sc = scores + (size_t)img * w * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
-  if (n > 0) {
+  if (n > 0) {  // block-uniform
     {
       uint4* z = reinterpret_cast<uint4*>(smem_raw);
       const uint4 zero = make_uint4(0, 0, 0, 0);
-      for (int i = lane; i < (occ_bytes16 >> 4); i += 64) z[i] = zero;
+      for (int i = tid; i < (occ_bytes16 >> 4); i += kSelThreads) z[i] = zero;
     }
     const float scaling = (float)(15.0 / (double)radius);
     const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-    // records of candidates [base, base + chunk_cap) -> recs[]
+    // records of candidates [base, base + chunk_cap) -> recs[] (wave 0 only)
     auto fill_chunk = [&](int base) {
       const int cnt = min(chunk_cap, n - base);
       for (int i = lane; i < cnt; i += 64) {
@@ -368,79 +381,115 @@ __global__ __launch_bounds__(64) void select_wave_kernel(
       }
     };
     int chunk_base = 0;
-    fill_chunk(0);
-    // per-lane stamp geometry: slots j = it*64 + lane of the compacted table
+    if (decider) fill_chunk(0);
+    // per-thread stamp geometry: slots j = it*256 + tid of the compacted table
     float lutv[kStampIts];
     int off[kStampIts];
     const uint2* stamp = reinterpret_cast<const uint2*>(lut + kStampTableOffset);
 #pragma unroll
     for (int it = 0; it < kStampIts; ++it) {
-      const uint2 e = stamp[it * 64 + lane];
+      const int j = it * kSelThreads + tid;
+      const uint2 e = stamp[j < kStampSlots ? j : kStampSlots - 1];  // padding slots: weight 0
       lutv[it] = __uint_as_float(e.y);
       off[it] = ((int)(e.x >> 8) - 15) * occ_cols + ((int)(e.x & 0xFF) - 15);
-      asm volatile("" : "+v"(off[it]));  // keep the offsets resident, do not rematerialise them
     }
-    const bool last_writes = lane < kStampCells - (kStampIts - 1) * 64;  // padding slots stay idle
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
+    const bool last_writes = (kStampIts - 1) * kSelThreads + tid < kStampCells;
     const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
     int pos = 0;
-    while (pos < n && kept < limit) {
-      if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
-        chunk_base = pos;
-        fill_chunk(pos);
-        __builtin_amdgcn_wave_barrier();
-      }
-      const int idx = pos + lane;
-      uint2 rec = make_uint2(0, 0);
-      if (idx < n) rec = recs[idx - chunk_base];
-      const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
-      const int cell = cy * occ_cols + cx;
-      const float s0 = (float)occ[cell];  // idx >= n reads cell 0: in range, result unused
-      const bool pass = idx < n && !(__uint_as_float(rec.y) < s0);
-      unsigned long long m = __ballot(pass);
-      if (m == 0) {
-        pos += 64;
-        continue;
-      }
-      // A passing candidate outside every stamp of this round sees an unchanged occupancy value,
-      // so the sequential test of the reference would pass as well; the first one inside a fresh
-      // stamp ends the round and is re-tested.  The stamps go to the LDS queue back to back
-      // (in-order per wave): no read-after-write wait between two accepts.
-      unsigned long long blocked = 0;
-      int adv = 64;
-      while (m != 0 && kept < limit) {
-        const int first = (int)__ffsll((long long)m) - 1;
-        if ((blocked >> first) & 1) {
-          adv = first;
+    __syncthreads();
+    while (true) {
+      if (decider) {
+        int nacc = 0;
+        while (pos < n && kept < limit) {
+          if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
+            chunk_base = pos;
+            fill_chunk(pos);
+            __builtin_amdgcn_wave_barrier();
+          }
+          const int idx = pos + lane;
+          uint2 rec = make_uint2(0, 0);
+          if (idx < n) rec = recs[idx - chunk_base];
+          const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
+          const int cell = cy * occ_cols + cx;
+          const float s0 = (float)occ[cell];  // idx >= n reads cell 0: in range, result unused
+          const bool pass = idx < n && !(__uint_as_float(rec.y) < s0);
+          unsigned long long m = __ballot(pass);
+          if (m == 0) {
+            pos += 64;
+            continue;
+          }
+          // One backward branch per accepted point.  `blocked` collects the candidates whose cell
+          // lies within 30 cells (both axes) of a point accepted in this round: the first such
+          // passing candidate ends the round and is re-tested in the next one.  Inside 15 cells
+          // its occupancy value changes; between 16 and 30 it would still pass, but its stamp
+          // would overlap the other one -- ending the round there keeps all stamps of a round
+          // disjoint, so the four waves can apply them without any ordering between them.
+          unsigned long long blocked = 0, accm = 0, rem = m, cand;
+          int first = (int)__ffsll((long long)rem) - 1;
+          bool go;
+          do {
+            const int wcx = __builtin_amdgcn_readlane(cx, first);
+            const int wcy = __builtin_amdgcn_readlane(cy, first);
+            const int ax = cx - wcx, ay = cy - wcy;
+            blocked |= __ballot((ax < 0 ? -ax : ax) <= 30 && (ay < 0 ? -ay : ay) <= 30);
+            accm |= 1ull << first;
+            ++nacc;
+            rem &= rem - 1;
+            cand = kept + nacc < limit ? rem : 0ull;
+            first = ((int)__ffsll((long long)cand) - 1) & 63;
+            go = cand != 0 && !((blocked >> first) & 1);
+          } while (go);
+          const int adv = cand != 0 ? first : 64;  // limit reached: the outer loop ends anyway
+          // accepted lanes publish themselves in order: rank = accepted lanes below this one
+          if ((accm >> lane) & 1) {
+            const int rank = __popcll(accm & ((1ull << lane) - 1ull));
+            const float nsc = (float)(0.99 * (double)__uint_as_float(rec.y));
+            round_list[rank] = make_int2(cell, __float_as_int(nsc));
+            acc_idx[kept + rank] = (uint16_t)idx;
+          }
+          kept += nacc;
+          pos += adv;
           break;
         }
-        const int wcell = __builtin_amdgcn_readlane(cell, first);
-        const int wcx = __builtin_amdgcn_readlane(cx, first);
-        const int wcy = __builtin_amdgcn_readlane(cy, first);
-        const float wnsc1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)rec.y, first));
-        const int ax = cx - wcx, ay = cy - wcy;
-        blocked |= __ballot((ax < 0 ? -ax : ax) <= 15 && (ay < 0 ? -ay : ay) <= 15);
-        const float nsc = (float)(0.99 * (double)wnsc1);
-        int v[kStampIts];
-#pragma unroll
-        for (int it = 0; it < kStampIts; ++it) v[it] = occ[wcell + off[it]];
-#pragma unroll
-        for (int it = 0; it < kStampIts; ++it) {
-          const float mm = lutv[it] * nsc;
-          const int nv = v[it] + (int)ceilf(mm);
-          if (it < kStampIts - 1 || last_writes) occ[wcell + off[it]] = (uint8_t)(nv > 255 ? 255 : nv);
+        if (lane == 0) {
+          s_round = nacc;
+          s_pos = pos;
+          s_kept = kept;
         }
-        if (lane == 0) acc_idx[kept] = (uint16_t)(pos + first);
-        ++kept;
-        m &= m - 1;
       }
-      pos += adv;
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
+      const int nacc = s_round;
+      pos = s_pos;
+      kept = s_kept;
+      if (nacc == 0) break;  // block-uniform: candidates exhausted or limit reached
+      // stamps of one round are disjoint: up to 4 are in flight together (all reads, then the
+      // arithmetic and the writes)
+      for (int a0 = 0; a0 < nacc; a0 += 4) {
+        int2 e[4];
+        int v[4][kStampIts];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = round_list[min(a0 + u, nacc - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int it = 0; it < kStampIts; ++it) v[u][it] = occ[e[u].x + off[it]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (a0 + u >= nacc) break;  // block-uniform
+          const float nsc = __int_as_float(e[u].y);
+#pragma unroll
+          for (int it = 0; it < kStampIts; ++it) {
+            const float mm = lutv[it] * nsc;
+            const int nv = v[u][it] + (int)ceilf(mm);
+            if (it < kStampIts - 1 || last_writes)
+              occ[e[u].x + off[it]] = (uint8_t)(nv > 255 ? 255 : nv);
+          }
+        }
+      }
+      __syncthreads();
     }
-    __builtin_amdgcn_wave_barrier();
   }
-  for (int i = lane; i < kept; i += 64) {
+  for (int i = tid; i < kept; i += kSelThreads) {
     const uint64_t k = keys[acc_idx[i]];
     const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
     const int v = (int)((k >> 16) & 0xFFFF), u = (int)(k & 0xFFFF);
@@ -462,7 +511,7 @@ __global__ __launch_bounds__(64) void select_wave_kernel(
     kp.class_id = -1;
     out[i] = kp;
   }
-  if (lane == 0) kp_count[img] = kept;
+  if (tid == 0) kp_count[img] = kept;
 }
 
 }  // namespace
@@ -487,19 +536,19 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
   const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
-  // single-wave kernel: occupancy + accepted indices (u16) + a sliding chunk of candidate records.
+  // greedy kernel: occupancy + accepted indices (u16) + a sliding chunk of candidate records.
   // Half a CU's LDS (two images per CU) when at least 128 records fit, else the whole CU.
   const size_t acc_bytes = ((size_t)kp_cap * 2 + 15) & ~(size_t)15;
   if (occ_lds && cand_cap <= 65536) {
     const size_t fixed = occ_bytes + acc_bytes;
-    const size_t half = 80 * 1024, full = 152 * 1024;
+    const size_t half = 79 * 1024, full = 152 * 1024;  // + ~0.5 KiB static: two blocks per CU
     size_t budget = fixed + 128 * 8 <= half ? half : full;
     if (fixed + 128 * 8 <= budget) {
       size_t chunk = (budget - fixed) / 8 / 64 * 64;
       const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
       if (chunk > need) chunk = need;
       const size_t lds = fixed + chunk * 8;
-      hipLaunchKernelGGL(select_wave_kernel, dim3(n_images), dim3(64), lds, stream, score, w, h,
+      hipLaunchKernelGGL(select_greedy_kernel, dim3(n_images), dim3(kSelThreads), lds, stream, score, w, h,
                          cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, occ_cols,
                          (int)occ_bytes, (int)acc_bytes, (int)chunk, kps, kp_cap, kp_count);
       return;
