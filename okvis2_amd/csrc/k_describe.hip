@@ -52,6 +52,25 @@ __device__ __forceinline__ Box sample_box(float xf, float yf, float sigma_half) 
   return b;
 }
 
+// floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
+// intensity): float reciprocal estimate (off by at most 1) + exact integer correction, instead of
+// the ~40-instruction generic 32-bit division
+__device__ __forceinline__ int div_nonneg(int num, int den) {
+  int q = (int)((float)num * __builtin_amdgcn_rcpf((float)den));
+  int r = num - q * den;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (r < 0) {
+      --q;
+      r += den;
+    } else if (r >= den) {
+      ++q;
+      r -= den;
+    }
+  }
+  return q;
+}
+
 template <typename PX>
 __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
                                                   float sigma_half) {
@@ -147,7 +166,7 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     }
   }
   ret += upper * r_y_1_i + middle * scaling + left * r_x_1_i + right * r_x1_i + bottom * r_y1_i;
-  return (ret + scaling2 / 2) / scaling2;
+  return div_nonneg(ret + scaling2 / 2, scaling2);
 }
 
 // sample position of this lane's pattern point under M; ok = box inside the image (NaN-safe)
@@ -310,45 +329,60 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
   uint8_t* patch = patches[wv];
   if (lane < kPatchPitch / 4) reinterpret_cast<uint32_t*>(patch + kPatchRows * kPatchPitch)[lane] = 0u;
   const bool dword_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0);
+  const __amdgpu_buffer_rsrc_t img_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
 
   // stages the pixels [bx0..bx1] x [by0..by1] (inside the image) into LDS; false if too large
   auto stage_patch = [&](int bx0, int bx1, int by0, int by1, PatchPx* ppx) -> bool {
+    // the bounds derive from the keypoint (same in every lane): tell the compiler they are scalar
+    bx0 = __builtin_amdgcn_readfirstlane(bx0);
+    bx1 = __builtin_amdgcn_readfirstlane(bx1);
+    by0 = __builtin_amdgcn_readfirstlane(by0);
+    by1 = __builtin_amdgcn_readfirstlane(by1);
     const int px0 = bx0 & ~3;
     const int pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
     if (pw > kPatchPitch - 8 || ph > kPatchRows) return false;  // wave-uniform; q0 + 2 < pitch / 4
     __builtin_amdgcn_wave_barrier();
     if (dword_ok) {
-      // dword i = it*64 + lane of the patch, row-major over its ndw (<= 22) dwords per row, so the
-      // trip count follows the patch area (typically 60 x 16 dwords = 15 trips, at most 28);
-      // i / ndw by multiplication with ceil(2^16 / ndw) is exact for i < 2730.  All global loads
-      // of a group are in flight before the first LDS store.
+      // Each trip moves R = 64 / ndw whole patch rows (ndw <= 22 dwords per row): lane -> (row rr
+      // within the trip, dword c) is fixed.  Loads go through a buffer resource over the image
+      // (scalar row offset, constant per-lane offset, out-of-range lanes read 0: no predication,
+      // no address arithmetic); a store costs one compare, one select (idle lanes are pointed at
+      // their own slot of `vals`, which is overwritten later anyway) and one add.  All loads are
+      // in flight before the first store.
       const int ndw = (pw + 3) >> 2;
-      const int total = ph * ndw;
-      const uint32_t inv = (65536u + (uint32_t)ndw - 1u) / (uint32_t)ndw;
-      const uint8_t* src = im + (size_t)by0 * w + px0;
-      constexpr int kGroup = 7, kGroups = 4;  // 28 trips cover 80 rows x 22 dwords
+      const uint32_t inv = (65536u + (uint32_t)ndw - 1u) / (uint32_t)ndw;  // i / ndw, i < 2730
+      const int R = (int)((64u * inv) >> 16);
+      constexpr int kGroup = 8, kGroups = 4;
+      if (ph > kGroup * kGroups * R) return false;  // wave-uniform; only for very wide AND tall patches
+      uint32_t rr = ((uint32_t)lane * inv) >> 16;
+      const uint32_t c = (uint32_t)lane - rr * (uint32_t)ndw;
+      const uint32_t src_lane = rr * (uint32_t)w + c * 4u;
+      const uint32_t dst_lane =
+          (uint32_t)(patch - &patches[0][0]) + rr * (uint32_t)kPatchPitch + c * 4u;
+      if ((int)rr >= R) rr = 1u << 20;  // lanes beyond the R rows of a trip never store
+      const uint32_t dummy = (uint32_t)(reinterpret_cast<uint8_t*>(&vals[lane]) - &patches[0][0]);
+      const int src0 = by0 * w + px0;
       uint32_t tmp[kGroup * kGroups];
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
-        if (g * kGroup * 64 >= total) break;  // wave-uniform
+        if (g * kGroup * R >= ph) break;  // wave-uniform
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
           const int it = g * kGroup + j;
-          const uint32_t i = (uint32_t)(it * 64 + lane);
-          const uint32_t r = (i * inv) >> 16, c = i - r * (uint32_t)ndw;
-          tmp[it] = 0;
-          if ((int)i < total) tmp[it] = reinterpret_cast<const uint32_t*>(src + r * (uint32_t)w)[c];
+          tmp[it] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rsrc, (int)src_lane,
+                                                                   src0 + it * R * w, 0);
         }
       }
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) {
-        if (g * kGroup * 64 >= total) break;
+        if (g * kGroup * R >= ph) break;
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
           const int it = g * kGroup + j;
-          const uint32_t i = (uint32_t)(it * 64 + lane);
-          const uint32_t r = (i * inv) >> 16, c = i - r * (uint32_t)ndw;
-          if ((int)i < total) reinterpret_cast<uint32_t*>(patch + r * kPatchPitch)[c] = tmp[it];
+          const int row0 = it * R;
+          const uint32_t at = (int)rr < ph - row0 ? dst_lane + (uint32_t)(row0 * kPatchPitch) : dummy;
+          *reinterpret_cast<uint32_t*>(&patches[0][0] + at) = tmp[it];
         }
       }
     } else {
@@ -374,11 +408,12 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
     } else {
       // superset of all 60 boxes under M: |M p|_x <= |row_x(M)| * |p| and |p| + sigma_half stays
       // below border - 1 for this pattern; the boxes themselves were checked to lie in the image
+      // (only a superset is needed: hardware sqrt estimate, rounded up by the 1.001 factor)
       float nx = M[0] * M[0], t = M[1] * M[1];
-      nx = sqrtf(nx + t);
+      nx = __builtin_amdgcn_sqrtf(nx + t) * 1.001f;
       float ny = M[2] * M[2];
       t = M[3] * M[3];
-      ny = sqrtf(ny + t);
+      ny = __builtin_amdgcn_sqrtf(ny + t) * 1.001f;
       const float ex = fmaxf(nx, 1.0f) * (float)(border - 1) + 1.5f;
       const float ey = fmaxf(ny, 1.0f) * (float)(border - 1) + 1.5f;
       bx0 = (int)floorf(kp.x - ex); bx1 = (int)ceilf(kp.x + ex) + 1;
