@@ -29,8 +29,10 @@ namespace {
 // float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
 constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
-constexpr int kPatchPitchBytes = 96;  // bytes per patch row in LDS (multiple of 4)
-constexpr int kPatchRowsTotal = 80;   // rows 0..78 hold pixels, row 79 stays zero
+// LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
+constexpr int kZeroRowBytes = 96;
+constexpr int kPatchBufBytes = 7680;
+constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
 struct Box {
   int x_left, x_right, y_top, y_bottom;
 };
@@ -144,12 +146,13 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     };
     upper = (int)read_row(top, 0u);
     ret = A * pl + B * pr;
-    bottom = (int)read_row(top + bh * kPatchPitchBytes, 0u);
+    const int pitch = px.pitch;
+    bottom = (int)read_row(top + bh * pitch, 0u);
     ret += D * pl + C * pr;
     uint32_t mid = 0u;
 #pragma unroll
     for (int dy = 1; dy < kMaxBox; ++dy) {
-      mid = read_row(dy < bh ? top + dy * kPatchPitchBytes : zero, mid);
+      mid = read_row(dy < bh ? top + dy * pitch : zero, mid);
       left += pl;
       right += pr;
     }
@@ -233,30 +236,28 @@ __device__ __forceinline__ bool camera_aware_matrix(const float* __restrict__ ra
 }
 
 constexpr int kDescWaves = 4;
-constexpr int kPatchPitch = kPatchPitchBytes;
-constexpr int kPatchRows = kPatchRowsTotal - 1;  // pixel rows; the last row of the buffer is zero
 
 struct GlobalPx {  // direct reads from the image (fallback when the patch does not fit in LDS)
   static constexpr bool kFixedTrip = false;
   const uint8_t* img;
   int w;
-  int x0 = 0;  // unused: the fixed-trip path is compiled out for this reader
+  int x0 = 0, pitch = 0;  // unused: the fixed-trip path is compiled out for this reader
   __device__ __forceinline__ int operator()(int y, int x) const { return img[(size_t)y * w + x]; }
   __device__ __forceinline__ const uint8_t* row8(int) const { return nullptr; }
   __device__ __forceinline__ const uint8_t* zero_row8() const { return nullptr; }
 };
 struct PatchPx {   // reads from the keypoint's patch staged in LDS
   static constexpr bool kFixedTrip = true;
-  const uint8_t* patch;
-  int x0, y0;
+  const uint8_t* patch;  // first pixel row; the zero row lies kZeroRowBytes before it
+  int x0, y0, pitch;
   __device__ __forceinline__ int operator()(int y, int x) const {
-    return patch[(y - y0) * kPatchPitch + (x - x0)];
+    return patch[(y - y0) * pitch + (x - x0)];
   }
   __device__ __forceinline__ const uint8_t* row8(int y) const {
-    return patch + (y - y0) * kPatchPitch;
+    return patch + (y - y0) * pitch;
   }
   __device__ __forceinline__ const uint8_t* zero_row8() const {
-    return patch + kPatchRows * kPatchPitch;
+    return patch - kZeroRowBytes;
   }
 };
 
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
     const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
     uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
-  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchRowsTotal * kPatchPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchBufBytes];
   __shared__ int values[kDescWaves][64];
   const int img = blockIdx.y;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
   float M[4] = {M4.x, M4.y, M4.z, M4.w};
   float xf, yf;
   int* vals = values[wv];
-  uint8_t* patch = patches[wv];
-  if (lane < kPatchPitch / 4) reinterpret_cast<uint32_t*>(patch + kPatchRows * kPatchPitch)[lane] = 0u;
+  uint8_t* patch = patches[wv] + kZeroRowBytes;
+  if (lane < kZeroRowBytes / 4) reinterpret_cast<uint32_t*>(patches[wv])[lane] = 0u;
   const bool dword_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0);
   const __amdgpu_buffer_rsrc_t img_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
@@ -341,58 +342,41 @@ __global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
     by1 = __builtin_amdgcn_readfirstlane(by1);
     const int px0 = bx0 & ~3;
     const int pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
-    if (pw > kPatchPitch - 8 || ph > kPatchRows) return false;  // wave-uniform; q0 + 2 < pitch / 4
+    const int ndw = (pw + 3) >> 2;  // dwords per patch row
+    const int pitch = ndw * 4;
+    if (pitch > kZeroRowBytes - 8 || ndw < 1) return false;  // wave-uniform
     __builtin_amdgcn_wave_barrier();
     if (dword_ok) {
-      // Each trip moves R = 64 / ndw whole patch rows (ndw <= 22 dwords per row): lane -> (row rr
-      // within the trip, dword c) is fixed.  Loads go through a buffer resource over the image
-      // (scalar row offset, constant per-lane offset, out-of-range lanes read 0: no predication,
-      // no address arithmetic); a store costs one compare, one select (idle lanes are pointed at
-      // their own slot of `vals`, which is overwritten later anyway) and one add.  All loads are
-      // in flight before the first store.
-      const int ndw = (pw + 3) >> 2;
+      // Each trip moves R = 64 / ndw whole patch rows straight from the image into LDS
+      // (buffer_load ... lds: lane l lands at the trip's LDS base + 4 l, which is exactly the
+      // dense row-major patch when lane = row * ndw + dword).  No VGPRs, no LDS stores, no index
+      // arithmetic per trip: scalar row offset, constant per-lane offset; lanes whose address falls
+      // outside the image read 0.
       const uint32_t inv = (65536u + (uint32_t)ndw - 1u) / (uint32_t)ndw;  // i / ndw, i < 2730
       const int R = (int)((64u * inv) >> 16);
-      constexpr int kGroup = 8, kGroups = 4;
-      if (ph > kGroup * kGroups * R) return false;  // wave-uniform; only for very wide AND tall patches
-      uint32_t rr = ((uint32_t)lane * inv) >> 16;
+      const int trips = (ph + R - 1) / R;
+      if (trips * R * pitch > kPatchDataBytes) return false;  // wave-uniform
+      const uint32_t rr = ((uint32_t)lane * inv) >> 16;
       const uint32_t c = (uint32_t)lane - rr * (uint32_t)ndw;
       const uint32_t src_lane = rr * (uint32_t)w + c * 4u;
-      const uint32_t dst_lane =
-          (uint32_t)(patch - &patches[0][0]) + rr * (uint32_t)kPatchPitch + c * 4u;
-      if ((int)rr >= R) rr = 1u << 20;  // lanes beyond the R rows of a trip never store
-      const uint32_t dummy = (uint32_t)(reinterpret_cast<uint8_t*>(&vals[lane]) - &patches[0][0]);
       const int src0 = by0 * w + px0;
-      uint32_t tmp[kGroup * kGroups];
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
-        if (g * kGroup * R >= ph) break;  // wave-uniform
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          const int it = g * kGroup + j;
-          tmp[it] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rsrc, (int)src_lane,
-                                                                   src0 + it * R * w, 0);
-        }
+      if ((int)rr < R) {
+        for (int it = 0; it < trips; ++it)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * R * pitch), 4,
+              (int)src_lane, src0 + it * R * w, 0, 0);
       }
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
-        if (g * kGroup * R >= ph) break;
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-          const int it = g * kGroup + j;
-          const int row0 = it * R;
-          const uint32_t at = (int)rr < ph - row0 ? dst_lane + (uint32_t)(row0 * kPatchPitch) : dummy;
-          *reinterpret_cast<uint32_t*>(&patches[0][0] + at) = tmp[it];
-        }
-      }
+      __builtin_amdgcn_s_waitcnt(0);
     } else {
+      if (ph * pitch > kPatchDataBytes) return false;
       for (int r = 0; r < ph; ++r)
-        for (int c = lane; c < pw; c += 64) patch[r * kPatchPitch + c] = im[(size_t)(by0 + r) * w + px0 + c];
+        for (int c = lane; c < pw; c += 64) patch[r * pitch + c] = im[(size_t)(by0 + r) * w + px0 + c];
     }
     __builtin_amdgcn_wave_barrier();
     ppx->patch = patch;
     ppx->x0 = px0;
     ppx->y0 = by0;
+    ppx->pitch = pitch;
     return true;
   };
   // values of all 60 samples under the current M; false when a box leaves the image
