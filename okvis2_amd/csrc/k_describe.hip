@@ -31,7 +31,7 @@ namespace {
 constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
 constexpr int kZeroRowBytes = 96;
-constexpr int kPatchBufBytes = 7680;
+constexpr int kPatchBufBytes = 6144;
 constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
 struct Box {
   int x_left, x_right, y_top, y_bottom;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
 
 // One wave per keypoint, lane i = pattern point i.  The pixels under the keypoint's pattern
 // (<= 80 x 96) are staged once in LDS with coalesced dword loads; all box sums then read LDS.
-__global__ __launch_bounds__(64 * kDescWaves) void describe_kernel(
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(6, 8))) void describe_kernel(
     const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
     const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
