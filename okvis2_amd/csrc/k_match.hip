@@ -165,6 +165,7 @@ struct BlockView {  // per-image arrays as the matcher sees them
 // rule of the reference (first k1 reaching the smallest gated distance) is a pure function of the
 // candidate set, so merging the segments by (dist, segment) reproduces it exactly.
 constexpr int kStereoSegs = 4;
+constexpr int kStereoChunk = 128;  // descriptors of one segment staged in LDS at a time (6 KiB)
 struct SegBest {
   double hp[4];
   int best, k1, init, pad;
@@ -173,6 +174,7 @@ struct SegBest {
 __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
                                   int threshold, okvfe_stereo_match* __restrict__ out) {
   __shared__ SegBest seg_best[kStereoSegs - 1][64];
+  __shared__ uint4 seg_desc[kStereoSegs][kStereoChunk * 3];
   const int seg = threadIdx.y;
   const int per_seg = (I1.n + kStereoSegs - 1) / kStereoSegs;
   const int k1_lo = min(seg * per_seg, I1.n), k1_hi = min(k1_lo + per_seg, I1.n);
@@ -200,15 +202,30 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   constexpr uint32_t kNoKey = 0xFFFFFFFFu;
   uint32_t floor_key = 0;  // keys are ((dist << 22) | k1) + 1, so 0 admits everything
   bool done = !v0;         // without a back-projection the gate rejects every candidate
+  // The segment's descriptors are staged in LDS by coalesced vector loads (all in flight at
+  // once) and read back as broadcasts: a serial chain of scalar loads from another XCD's L2 / HBM
+  // costs more than a microsecond per descriptor.  A segment of at most kStereoChunk descriptors
+  // (the usual case) stays resident across the rounds.
+  uint4* chunk = seg_desc[seg];
+  const bool resident = k1_hi - k1_lo <= kStereoChunk;
+  auto load_chunk = [&](int c0, int cnt) {
+    const uint4* src = reinterpret_cast<const uint4*>(I1.desc + (size_t)c0 * OKVFE_DESC_BYTES);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = threadIdx.x; i < cnt * 3; i += 64) chunk[i] = src[i];
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (resident) load_chunk(k1_lo, k1_hi - k1_lo);
   while (__any(!done)) {
     uint32_t cand = kNoKey;
-    for (int k1 = k1_lo; k1 < k1_hi; ++k1) {
-      const uint32_t* d1 =
-          reinterpret_cast<const uint32_t*>(I1.desc + (size_t)k1 * OKVFE_DESC_BYTES);
-      const uint32_t dist = (uint32_t)hamming(d0, d1);
-      const uint32_t key = ((dist << 22) | (uint32_t)k1) + 1u;
-      const bool ok = key > floor_key && dist < (uint32_t)threshold;
-      cand = ok ? min(cand, key) : cand;
+    for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
+      const int cnt = min(kStereoChunk, k1_hi - c0);
+      if (!resident) load_chunk(c0, cnt);
+      for (int j = 0; j < cnt; ++j) {
+        const uint32_t dist = (uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(chunk + 3 * j));
+        const uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
+        const bool ok = key > floor_key && dist < (uint32_t)threshold;
+        cand = ok ? min(cand, key) : cand;
+      }
     }
     if (done) continue;
     if (cand == kNoKey) {
