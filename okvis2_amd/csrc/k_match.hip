@@ -220,6 +220,7 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
     for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
       const int cnt = min(kStereoChunk, k1_hi - c0);
       if (!resident) load_chunk(c0, cnt);
+#pragma unroll 4
       for (int j = 0; j < cnt; ++j) {
         const uint32_t dist = (uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(chunk + 3 * j));
         const uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
