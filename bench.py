@@ -179,6 +179,14 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if os.environ.get("OKVFE_PMC_CALIB"):
+        # counter calibration for the --pmc passes (tools/collect_profiles.sh): a device-to-device
+        # copy of known size in the same process, so FETCH_SIZE / WRITE_SIZE units can be checked
+        cal_src = torch.zeros(256 << 20, dtype=torch.uint8, device=dev)
+        cal_dst = torch.empty_like(cal_src)
+        for _ in range(3):
+            torch.bitwise_not(cal_src, out=cal_dst)  # a kernel name of its own in the csv
+        torch.cuda.synchronize()
     # timed region: only the dominant kernel (score+NMS) carries HIP events, on its launch stream;
     # the full per-stage breakdown is taken in a short extra pass after the timed region
     for lane in lanes:
@@ -237,11 +245,14 @@ def main():
         # HBM traffic of the K1 launch from the PMC passes committed under profiles/ (rocprofv3
         # cannot run inside this process); only valid for the launch shape it was measured on
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "round1_k1_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "round1_v2_k1_pmc.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if pmc.get("algorithmic_bytes_per_launch") == 5 * P * n_img_launch:
-                traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/round1_k1_pmc.json"
+            # same kernel, same image shape: per-image HBM bytes x the images of one launch here
+            if pmc.get("algorithmic_bytes_per_launch") == 5 * P * pmc.get("images_per_launch", 0):
+                traffic = pmc["hbm_bytes_per_image"] * n_img_launch
+                traffic_src = ("profiles/round1_v2_k1_pmc.json (FETCH_SIZE/WRITE_SIZE passes at %d "
+                               "images per launch, scaled per image)" % pmc["images_per_launch"])
         m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
         fe._bench_matches = m
         result = {

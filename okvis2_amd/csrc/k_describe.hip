@@ -305,12 +305,15 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
     const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
-    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
+    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images) {
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchBufBytes];
   __shared__ int values[kDescWaves][64];
-  const int img = blockIdx.y;
+  // all keypoint blocks of an image run on the same XCD (block L -> XCD L % 8), so its pixels
+  // are fetched from HBM into ONE L2 instead of into all eight
+  int img, tile;
+  xcd_tile((kp_cap + kDescWaves - 1) / kDescWaves, n_images, &img, &tile);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x * kDescWaves + wv;
+  const int k = tile * kDescWaves + wv;
   const int n = kp_count_in[img];
   if (k >= n) return;  // whole wave exits; no block-wide barriers below
   const uint8_t* im = images + (size_t)img * w * h;
@@ -546,9 +549,9 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, desc_tmp,
                      valid_tmp);
-  const dim3 grid((kp_cap + kDescWaves - 1) / kDescWaves, n_images);
+  const dim3 grid(((kp_cap + kDescWaves - 1) / kDescWaves) * n_images);
   hipLaunchKernelGGL(describe_kernel, grid, dim3(64 * kDescWaves), 0, stream, img, w, h, pat, prm,
-                     rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp);
+                     rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images);
 }
 
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Builds profiles/<tag>_k1_pmc.json from the two PMC passes of tools/collect_profiles.sh.
+
+usage: make_k1_pmc_json.py <tag> [images_per_launch=512] [w=752] [h=480]
+FETCH_SIZE / WRITE_SIZE are reported in KiB; their scale is calibrated on the 256 MiB
+bitwise_not kernel bench.py runs under OKVFE_PMC_CALIB=1 in the same process (it reads and writes
+exactly 262144 KiB): on gfx950 FETCH_SIZE comes out at half the bytes read, WRITE_SIZE at 1.0."""
+import json
+import os
+import sys
+
+tag = sys.argv[1]
+n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+w = int(sys.argv[3]) if len(sys.argv) > 3 else 752
+h = int(sys.argv[4]) if len(sys.argv) > 4 else 480
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out")
+
+
+def rows(counter):
+    d = json.load(open(os.path.join(src, f"{tag}_pmc_{counter}.json")))
+    k1 = next(v for k, v in d.items() if k.startswith("harris_kernel"))
+    cal = next(v for k, v in d.items() if "bitwise_not" in k)
+    name = next(k for k in d if k.startswith("harris_kernel"))
+    return name, k1["mean_per_dispatch"][counter], cal["mean_per_dispatch"][counter]
+
+
+name, fetch, fetch_cal = rows("FETCH_SIZE")
+_, write, write_cal = rows("WRITE_SIZE")
+CAL_KIB = 262144.0
+f_scale, w_scale = CAL_KIB / fetch_cal, CAL_KIB / write_cal
+rd, wr = fetch * f_scale * 1024.0, write * w_scale * 1024.0
+out = {
+    "kernel": name,
+    "workload": f"{w}x{h} u8 x {n_img} images per launch (bench.py --lanes 1)",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- "
+               "python bench.py --steps 3 --warmup 3 --no-cpu-baseline --lanes 1 "
+               "(two separate passes, tools/collect_profiles.sh)",
+    "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+    "calibration": {"kernel": "at::native bitwise_not, 262144 KiB read + 262144 KiB written",
+                    "FETCH_SIZE_KiB": fetch_cal, "WRITE_SIZE_KiB": write_cal,
+                    "fetch_scale": f_scale, "write_scale": w_scale},
+    "hbm_read_bytes": rd, "hbm_write_bytes": wr,
+    "hbm_bytes_per_launch": rd + wr,
+    "images_per_launch": n_img,
+    "hbm_bytes_per_image": (rd + wr) / n_img,
+    "algorithmic_bytes_per_launch": 5 * w * h * n_img,
+    "ratio_to_algorithmic": (rd + wr) / (5.0 * w * h * n_img),
+}
+dst = os.path.join(root, "profiles", f"{tag}_k1_pmc.json")
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
