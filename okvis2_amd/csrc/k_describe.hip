@@ -305,13 +305,24 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
     const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
-    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images) {
+    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images, int tiles,
+    uint32_t inv_tiles) {
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchBufBytes];
   __shared__ int values[kDescWaves][64];
   // all keypoint blocks of an image run on the same XCD (block L -> XCD L % 8), so its pixels
   // are fetched from HBM into ONE L2 instead of into all eight
+  // (two thirds of the blocks find no keypoint in their slots and leave right here, so the
+  // block -> (image, tile) split uses a host-computed reciprocal instead of integer divisions)
   int img, tile;
-  xcd_tile((kp_cap + kDescWaves - 1) / kDescWaves, n_images, &img, &tile);
+  {
+    const uint32_t L = blockIdx.x, n8 = (uint32_t)n_images & ~7u, full = n8 * (uint32_t)tiles;
+    const uint32_t slot = L < full ? L >> 3 : L - full;
+    uint32_t g = (uint32_t)(((uint64_t)slot * inv_tiles) >> 32);  // slot / tiles, off by <= 1
+    if (g * (uint32_t)tiles > slot) --g;
+    if ((g + 1) * (uint32_t)tiles <= slot) ++g;
+    img = L < full ? (int)(g * 8u + (L & 7u)) : (int)(n8 + g);
+    tile = (int)(slot - g * (uint32_t)tiles);
+  }
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k = tile * kDescWaves + wv;
   const int n = kp_count_in[img];
@@ -549,9 +560,11 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, desc_tmp,
                      valid_tmp);
-  const dim3 grid(((kp_cap + kDescWaves - 1) / kDescWaves) * n_images);
-  hipLaunchKernelGGL(describe_kernel, grid, dim3(64 * kDescWaves), 0, stream, img, w, h, pat, prm,
-                     rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images);
+  const int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
+  const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
+  hipLaunchKernelGGL(describe_kernel, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
+                     w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
+                     valid_tmp, n_images, tiles, inv_tiles);
 }
 
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
