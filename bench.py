@@ -102,8 +102,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="stereo frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
     ap.add_argument("--max-candidates", type=int, default=16384)
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="independent contexts/streams the batch is split over on each GPU")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="independent contexts/streams the batch is split over on each GPU "
+                         "(2 overlaps the latency-bound kernels of one lane with the other's "
+                         "throughput-bound ones: about +5 %% frames/s, but the score kernel then "
+                         "shares the GPU while it is being timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
