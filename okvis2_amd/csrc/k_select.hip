@@ -52,9 +52,10 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
     for (int i = tid; i < np; i += kThreads) lds[i] = i < n ? make_key(c[i]) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= np; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int lj = 31 - __builtin_clz(k >> 1); lj >= 0; --lj) {  // j = 1 << lj
+        const int j = 1 << lj;
         for (int t = tid; t < (np >> 1); t += kThreads) {
-          const int lo = ((t / j) * (j << 1)) + (t % j);  // j is a power of two
+          const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));  // shifts, not t / j and t % j
           const int hi = lo + j;
           const bool up = ((lo & k) == 0);
           const uint64_t a = lds[lo], b = lds[hi];
@@ -71,9 +72,10 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
     for (int i = tid; i < np; i += kThreads) ws[i] = i < n ? make_key(c[i]) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= np; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int lj = 31 - __builtin_clz(k >> 1); lj >= 0; --lj) {
+        const int j = 1 << lj;
         for (int t = tid; t < (np >> 1); t += kThreads) {
-          const int lo = ((t / j) * (j << 1)) + (t % j);
+          const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
           const int hi = lo + j;
           const bool up = ((lo & k) == 0);
           const uint64_t a = ws[lo], b = ws[hi];
