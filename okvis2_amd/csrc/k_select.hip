@@ -51,18 +51,42 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
   if (np <= kLdsSortKeys) {
     for (int i = tid; i < np; i += kThreads) lds[i] = i < n ? make_key(c[i]) : ~0ull;
     __syncthreads();
+    // Two consecutive strides (2j, j) of a phase touch the same 4 elements {b, b+j, b+2j, b+3j}
+    // and all 4 lie in one k-block (same direction), so they are done in ONE pass with the keys in
+    // registers: half the LDS traffic and half the barriers of the plain network.
+    auto cswap = [](uint64_t& a, uint64_t& b, bool up) {
+      const bool sw = (a > b) == up;
+      const uint64_t x = sw ? b : a, y = sw ? a : b;
+      a = x;
+      b = y;
+    };
     for (int k = 2; k <= np; k <<= 1) {
-      for (int lj = 31 - __builtin_clz(k >> 1); lj >= 0; --lj) {  // j = 1 << lj
-        const int j = 1 << lj;
+      int lj = 31 - __builtin_clz(k >> 1);  // largest stride of the phase = 1 << lj
+      for (; lj >= 1; lj -= 2) {            // strides 1 << lj and 1 << (lj - 1)
+        const int j = 1 << (lj - 1);
+        for (int t = tid; t < (np >> 2); t += kThreads) {
+          const int b = ((t >> (lj - 1)) << (lj + 1)) | (t & (j - 1));
+          const bool up = ((b & k) == 0);
+          uint64_t e0 = lds[b], e1 = lds[b + j], e2 = lds[b + 2 * j], e3 = lds[b + 3 * j];
+          cswap(e0, e2, up);
+          cswap(e1, e3, up);
+          cswap(e0, e1, up);
+          cswap(e2, e3, up);
+          lds[b] = e0;
+          lds[b + j] = e1;
+          lds[b + 2 * j] = e2;
+          lds[b + 3 * j] = e3;
+        }
+        __syncthreads();
+      }
+      if (lj == 0) {  // odd number of strides in this phase: the last one (stride 1) alone
         for (int t = tid; t < (np >> 1); t += kThreads) {
-          const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));  // shifts, not t / j and t % j
-          const int hi = lo + j;
+          const int lo = t << 1;
           const bool up = ((lo & k) == 0);
-          const uint64_t a = lds[lo], b = lds[hi];
-          if ((a > b) == up) {
-            lds[lo] = b;
-            lds[hi] = a;
-          }
+          uint64_t a = lds[lo], b = lds[lo + 1];
+          cswap(a, b, up);
+          lds[lo] = a;
+          lds[lo + 1] = b;
         }
         __syncthreads();
       }
