@@ -390,10 +390,11 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     }
     const float scaling = (float)(15.0 / (double)radius);
     const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-    // records of candidates [base, base + chunk_cap) -> recs[] (wave 0 only)
+    // records of candidates [base, base + chunk_cap) -> recs[], by the whole workgroup (a handful
+    // of independent loads per thread, all in flight together)
     auto fill_chunk = [&](int base) {
       const int cnt = min(chunk_cap, n - base);
-      for (int i = lane; i < cnt; i += 64) {
+      for (int i = tid; i < cnt; i += kSelThreads) {
         const uint64_t k = keys[base + i];
         const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
         const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
       }
     };
     int chunk_base = 0;
-    if (decider) fill_chunk(0);
+    fill_chunk(0);
     // per-thread stamp geometry: slots j = it*256 + tid of the compacted table
     float lutv[kStampIts];
     int off[kStampIts];
@@ -424,13 +425,19 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     int pos = 0;
     __syncthreads();
     while (true) {
+      // the 64-candidate window would run past the resident chunk: slide it (block-uniform)
+      if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
+        chunk_base = pos;
+        fill_chunk(pos);
+        __syncthreads();
+      }
       if (decider) {
         int nacc = 0;
+        bool refill = false;
         while (pos < n && kept < limit) {
           if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
-            chunk_base = pos;
-            fill_chunk(pos);
-            __builtin_amdgcn_wave_barrier();
+            refill = true;  // skipped past the chunk through windows without a passing candidate
+            break;
           }
           const int idx = pos + lane;
           uint2 rec = make_uint2(0, 0);
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
           break;
         }
         if (lane == 0) {
-          s_round = nacc;
+          s_round = refill ? -1 : nacc;  // refill is only set with nacc == 0
           s_pos = pos;
           s_kept = kept;
         }
@@ -488,6 +495,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
       pos = s_pos;
       kept = s_kept;
       if (nacc == 0) break;  // block-uniform: candidates exhausted or limit reached
+      if (nacc < 0) continue;  // chunk refill requested: back to the top
       // stamps of one round are disjoint: up to 4 are in flight together (all reads, then the
       // arithmetic and the writes)
       for (int a0 = 0; a0 < nacc; a0 += 4) {
