@@ -1,0 +1,113 @@
+"""GPU: detector code paths that the default configuration does not take on every call.
+
+* the standalone score + NMS kernels (unaligned widths take them always; OKVFE_NO_FUSED_NMS forces
+  them for aligned widths) must give the same candidates as the fused score+NMS kernel -- both
+  against the oracle;
+* the fix-up of the fused kernel: plateaus that cross strip borders (x = 247|248, 495|496) and tile
+  borders (y = 29|30, ...), where the raster-scan rule of the reference needs the neighbour strip;
+* the greedy selection when the candidate list is longer than the LDS record chunk (several refills)
+  and when max_keypoints cuts the greedy short inside a round;
+* per-stage profiling mask of okvfe_profile_enable.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from okvis2_amd import capi, synth
+
+import gpu_common as G
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plateau_image(w, h, seed, bx, by):
+    """Random blocks of bx x by equal pixels: equal Harris scores on horizontally adjacent pixels,
+    with block edges placed on purpose at the strip and tile borders of the fused kernel."""
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, 256, size=((h + by - 1) // by, (w + bx - 1) // bx), dtype=np.uint8)
+    return np.ascontiguousarray(np.kron(small, np.ones((by, bx), dtype=np.uint8))[:h, :w])
+
+
+@pytest.mark.parametrize("w,h,bx,by", [(752, 480, 2, 1), (752, 480, 4, 3), (752, 480, 8, 5),
+                                       (1024, 120, 2, 2), (256, 64, 2, 1)])
+def test_fused_nms_plateaus_across_borders(oracle, w, h, bx, by):
+    img = _plateau_image(w, h, 5 + bx, bx, by)
+    # radius 12 does not fit the occupancy grid in LDS (legacy greedy kernel), radius 38 does
+    for thr, radius, maxk in ((1, 12.0, 4000), (150, 38.0, 700)):
+        fe = capi.Frontend(w, h, radius, 0, thr, maxk, max_candidates=1 << 16)
+        ref = oracle.detect(img, radius, 0, thr, maxk)
+        assert len(ref) > 20
+        G.assert_keypoints_equal(fe.detect(img), ref)
+
+
+def test_select_many_candidates_and_limit(oracle):
+    """> 4 record chunks of candidates (noise image, low threshold) and a keypoint limit that is
+    reached in the middle of a round."""
+    w, h = 752, 480
+    img = synth.noise_image(w, h, 77)
+    for maxk, radius in ((700, 38.0), (37, 38.0), (5, 20.0), (1, 38.0)):
+        fe = capi.Frontend(w, h, radius, 0, 40, maxk, max_candidates=1 << 16)
+        ref = oracle.detect(img, radius, 0, 40, maxk)
+        assert 0 < len(ref) <= maxk
+        G.assert_keypoints_equal(fe.detect(img), ref)
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from okvis2_amd import capi, synth
+import oracle_lib as O, gpu_common as G
+w, h = 752, 480
+for kind, thr in (("corners", 150), ("noise", 800), ("plateau", 1)):
+    if kind == "plateau":
+        rng = np.random.default_rng(3)
+        img = np.ascontiguousarray(np.kron(rng.integers(0, 256, (h, w // 2), dtype=np.uint8),
+                                           np.ones((1, 2), np.uint8)))
+    else:
+        img = synth.noise_image(w, h, 9) if kind == "noise" else synth.corners_image(w, h, 9)
+    fe = capi.Frontend(w, h, 38.0, 0, thr, 700, max_candidates=1 << 16)
+    ref = O.detect(img, 38.0, 0, thr, 700)
+    G.assert_keypoints_equal(fe.detect(img), ref)
+print("UNFUSED-OK")
+"""
+
+
+def test_standalone_score_and_nms_kernels(oracle):
+    env = dict(os.environ, OKVFE_NO_FUSED_NMS="1")
+    out = subprocess.run([sys.executable, "-c", _CHILD, ROOT], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "UNFUSED-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_profile_stage_mask():
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg, max_batch=2)
+    for ci, cam in enumerate(cfg.cams):
+        fe.set_camera(ci, cam)
+    L, R, _ = synth.stereo_pair(cfg.w, cfg.h, 4)
+    d_img = torch.from_numpy(np.stack([L, R])).cuda()
+    cam_ids = np.array([0, 1], dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (2, 1))
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(n):
+        for _ in range(n):
+            fe.detect_describe_batch_device(d_img.data_ptr(), 2, cam_ids, grav, s)
+
+    fe.profile_enable(True, stages=("harris", "describe"))
+    run(3)
+    p = fe.profile_read()
+    assert p["harris"][1] == 3 and p["describe"][1] == 3 and p["harris"][0] > 0.0
+    assert all(p[k][1] == 0 for k in ("nms", "sort", "select", "compact", "match"))
+    fe.profile_enable(True)
+    run(2)
+    p = fe.profile_read()
+    assert all(p[k][1] == 2 for k in ("harris", "nms", "sort", "select", "describe", "compact"))
+    fe.profile_enable(False)
+    run(1)
+    assert all(v[1] == 0 for v in fe.profile_read().values())
