@@ -46,6 +46,15 @@ void build_pattern(Pattern* p) {
   }
   p->n_points = n;
   p->border = static_cast<int>(std::ceil(reach)) + 1;
+  for (int i = 0; i < kPatternPoints; ++i) {
+    const float sg = i < n ? p->sigma_half[i] : 1.0f;
+    float area = 4.0f * sg;
+    area = area * sg;
+    const int scaling = static_cast<int>(4194304.0f / area);
+    const float s2 = static_cast<float>(scaling) * area;
+    p->box_scaling[i] = scaling;
+    p->box_scaling2[i] = static_cast<int>(s2 / 1024.0f);
+  }
   for (int i = 1; i < n; ++i) {
     for (int j = 0; j < i; ++j) {
       const double dx = ux[j] - ux[i], dy = uy[j] - uy[i];

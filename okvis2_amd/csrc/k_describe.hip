@@ -75,7 +75,7 @@ __device__ __forceinline__ int div_nonneg(int num, int den) {
 
 template <typename PX>
 __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
-                                                  float sigma_half) {
+                                                  float sigma_half, int scaling, int scaling2) {
   if (sigma_half < 0.5f) {
     const int x = (int)xf, y = (int)yf;
     const int r_x = (int)((xf - (float)x) * 1024.0f);
@@ -87,11 +87,8 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     ret += r_x_1 * r_y * px(y + 1, x);
     return (ret + 512) / 1024;
   }
-  float area = 4.0f * sigma_half;
-  area = area * sigma_half;
-  const int scaling = (int)(4194304.0f / area);
-  const float s2 = (float)scaling * area;
-  const int scaling2 = (int)(s2 / 1024.0f);
+  // scaling = (int)(4194304 / (4 sigma^2)) and scaling2 = (int)(scaling * 4 sigma^2 / 1024) come
+  // from the pattern table (Pattern::box_scaling*, host_tables.cpp)
   const float x_1 = xf - sigma_half, x1 = xf + sigma_half;
   const float y_1 = yf - sigma_half, y1 = yf + sigma_half;
   const int x_left = (int)(x_1 + 0.5f), y_top = (int)(y_1 + 0.5f);
@@ -337,6 +334,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   const bool active = lane < kPatternPoints;
   const int li = active ? lane : 0;
   const float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
+  const int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];
   const float4 M4 = *reinterpret_cast<const float4*>(desc_tmp + slot * OKVFE_DESC_BYTES);
   float M[4] = {M4.x, M4.y, M4.z, M4.w};
   float xf, yf;
@@ -422,10 +420,10 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     PatchPx ppx;
     int v = 0;
     if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
-      if (active) v = smoothed_intensity(ppx, xf, yf, sg);
+      if (active) v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
     } else {
       const GlobalPx gpx{im, w};
-      if (active) v = smoothed_intensity(gpx, xf, yf, sg);
+      if (active) v = smoothed_intensity(gpx, xf, yf, sg, bsc, bsc2);
     }
     __builtin_amdgcn_wave_barrier();
     vals[lane] = v;

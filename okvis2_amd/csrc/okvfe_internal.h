@@ -30,6 +30,10 @@ struct Pattern {
   int32_t border;
   int32_t rot_cos[kRot], rot_sin[kRot];
   float rot_cosf[kRot], rot_sinf[kRot];
+  // per sample, constants of the box mean that depend on sigma_half only: scaling =
+  // (int)(4194304 / (4 sigma^2)), scaling2 = (int)(scaling * 4 sigma^2 / 1024) (same float
+  // sequence as the device code used per keypoint before they were tabulated)
+  int32_t box_scaling[kPatternPoints], box_scaling2[kPatternPoints];
 };
 void build_pattern(Pattern* p);
 // d_lut layout: [0, 961) the 31x31 weights; from kStampTableOffset the compacted stamp, one
