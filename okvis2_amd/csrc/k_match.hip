@@ -216,47 +216,56 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   };
   if (resident) load_chunk(k1_lo, k1_hi - k1_lo);
   while (__any(!done)) {
-    uint32_t cand = kNoKey;
+    // the two smallest admissible keys of the segment in one scan: a rejected best candidate
+    // usually has its successor at hand, so the tail of the kernel is not set by re-scans
+    uint32_t c1 = kNoKey, c2 = kNoKey;
     for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
       const int cnt = min(kStereoChunk, k1_hi - c0);
       if (!resident) load_chunk(c0, cnt);
 #pragma unroll 4
       for (int j = 0; j < cnt; ++j) {
         const uint32_t dist = (uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(chunk + 3 * j));
-        const uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
-        const bool ok = key > floor_key && dist < (uint32_t)threshold;
-        cand = ok ? min(cand, key) : cand;
+        uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
+        key = (key > floor_key && dist < (uint32_t)threshold) ? key : kNoKey;
+        c2 = min(c2, max(c1, key));
+        c1 = min(c1, key);
       }
     }
-    if (done) continue;
-    if (cand == kNoKey) {
-      done = true;
-      continue;
-    }
-    floor_key = cand;
-    const int k1 = (int)((cand - 1u) & 0x3FFFFFu);
-    const int dist = (int)((cand - 1u) >> 22);
-    if (!I1.bpv[k1]) continue;
-    double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
-    rot(P.C1, I1.bp + 3 * (size_t)k1, v);
-    normalize3(v, e1_W);
-    bool is_valid, is_parallel;
-    triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
-    inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
-    inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
-    if (!is_parallel) {
-      const double w4 = hp_W[3];
-      hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
-      if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
-      if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
-      if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
-    }
-    if (is_valid) {
-      best = dist;
-      hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
-      k1_match = k1;
-      initialisable = !is_parallel;
-      done = true;
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t cand = t == 0 ? c1 : c2;
+      bool pending = !done;
+      if (pending && cand == kNoKey) {  // nothing (more) above the floor in this segment
+        done = true;
+        pending = false;
+      }
+      if (!__any(pending)) break;  // wave-uniform
+      if (!pending) continue;
+      floor_key = cand;
+      const int k1 = (int)((cand - 1u) & 0x3FFFFFu);
+      const int dist = (int)((cand - 1u) >> 22);
+      if (!I1.bpv[k1]) continue;
+      double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+      rot(P.C1, I1.bp + 3 * (size_t)k1, v);
+      normalize3(v, e1_W);
+      bool is_valid, is_parallel;
+      triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
+      inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+      inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+      if (!is_parallel) {
+        const double w4 = hp_W[3];
+        hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+        if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
+        if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
+        if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
+      }
+      if (is_valid) {
+        best = dist;
+        hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
+        k1_match = k1;
+        initialisable = !is_parallel;
+        done = true;
+      }
     }
   }
   if (seg > 0) {
