@@ -286,8 +286,10 @@ def main():
                          "isolated_launch_ms": iso[0] / iso[1],
                          "isolated_frac": 5.0 * P * n_img_launch / (iso[0] / iso[1] * 1e-3) / 1e9
                                           / HBM_PEAK_GBPS,
-                         "note": "avg_launch_ms is taken while the other lane's kernels share the "
-                                 "GPU; isolated_* is the same launch with the GPU to itself"},
+                         "note": ("one lane: the launch has the GPU to itself in the timed region "
+                                  "as well" if S == 1 else
+                                  "avg_launch_ms is taken while the other lanes' kernels share the "
+                                  "GPU; isolated_* is the same launch with the GPU to itself")},
             "stage_ms_per_launch": stage_ms,
             "stage_ms_note": "all-stage event pass of 3 steps after the timed region; avg_launch_ms of "
                              "the roofline comes from the timed region itself",
