@@ -171,6 +171,51 @@ struct SegBest {
   int best, k1, init, pad;
 };
 
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+// One scan of segment [k1_lo, k1_hi) of the other side's descriptors: the two smallest keys
+// ((dist << 22) | k1) + 1 that exceed floor_key, have dist < threshold and are not flagged in
+// skip1 (may be null).  The descriptors (and flags) are staged in LDS by coalesced vector loads
+// and read back as broadcasts; a segment of at most kStereoChunk descriptors stays resident
+// (`resident`: already loaded by load_scan_chunk before the first round).
+struct ScanChunk {
+  uint4* desc;     // kStereoChunk * 3
+  uint8_t* skip;   // kStereoChunk
+};
+__device__ __forceinline__ void load_scan_chunk(const ScanChunk& C, const uint8_t* __restrict__ desc1,
+                                                const uint8_t* __restrict__ skip1, int c0, int cnt) {
+  const uint4* src = reinterpret_cast<const uint4*>(desc1 + (size_t)c0 * OKVFE_DESC_BYTES);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = threadIdx.x; i < cnt * 3; i += 64) C.desc[i] = src[i];
+  if (skip1)
+    for (int i = threadIdx.x; i < cnt; i += 64) C.skip[i] = skip1[c0 + i];
+  __builtin_amdgcn_wave_barrier();
+}
+template <bool HAS_SKIP>
+__device__ __forceinline__ void scan_top2(const Desc12& d0, const ScanChunk& C,
+                                          const uint8_t* __restrict__ desc1,
+                                          const uint8_t* __restrict__ skip1, int k1_lo, int k1_hi,
+                                          bool resident, uint32_t floor_key, uint32_t threshold,
+                                          uint32_t* c1_out, uint32_t* c2_out) {
+  uint32_t c1 = kNoKey, c2 = kNoKey;
+  for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
+    const int cnt = min(kStereoChunk, k1_hi - c0);
+    if (!resident) load_scan_chunk(C, desc1, HAS_SKIP ? skip1 : nullptr, c0, cnt);
+#pragma unroll 4
+    for (int j = 0; j < cnt; ++j) {
+      const uint32_t dist = (uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(C.desc + 3 * j));
+      uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
+      bool ok = key > floor_key && dist < threshold;
+      if (HAS_SKIP) ok = ok && C.skip[j] == 0;
+      key = ok ? key : kNoKey;
+      c2 = min(c2, max(c1, key));
+      c1 = min(c1, key);
+    }
+  }
+  *c1_out = c1;
+  *c2_out = c2;
+}
+
 __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
                                   int threshold, okvfe_stereo_match* __restrict__ out) {
   __shared__ SegBest seg_best[kStereoSegs - 1][64];
@@ -199,38 +244,17 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   // Each round therefore scans the segment branch-free for the smallest key above the last
   // rejected one (wave-uniform descriptor loads, 24 VALU per k1) and runs the FP64 gate ONCE for
   // all lanes together, instead of once per k1 for the one or two lanes that improved there.
-  constexpr uint32_t kNoKey = 0xFFFFFFFFu;
   uint32_t floor_key = 0;  // keys are ((dist << 22) | k1) + 1, so 0 admits everything
   bool done = !v0;         // without a back-projection the gate rejects every candidate
-  // The segment's descriptors are staged in LDS by coalesced vector loads (all in flight at
-  // once) and read back as broadcasts: a serial chain of scalar loads from another XCD's L2 / HBM
-  // costs more than a microsecond per descriptor.  A segment of at most kStereoChunk descriptors
-  // (the usual case) stays resident across the rounds.
-  uint4* chunk = seg_desc[seg];
+  const ScanChunk chunk{seg_desc[seg], nullptr};
   const bool resident = k1_hi - k1_lo <= kStereoChunk;
-  auto load_chunk = [&](int c0, int cnt) {
-    const uint4* src = reinterpret_cast<const uint4*>(I1.desc + (size_t)c0 * OKVFE_DESC_BYTES);
-    __builtin_amdgcn_wave_barrier();
-    for (int i = threadIdx.x; i < cnt * 3; i += 64) chunk[i] = src[i];
-    __builtin_amdgcn_wave_barrier();
-  };
-  if (resident) load_chunk(k1_lo, k1_hi - k1_lo);
+  if (resident) load_scan_chunk(chunk, I1.desc, nullptr, k1_lo, k1_hi - k1_lo);
   while (__any(!done)) {
     // the two smallest admissible keys of the segment in one scan: a rejected best candidate
     // usually has its successor at hand, so the tail of the kernel is not set by re-scans
-    uint32_t c1 = kNoKey, c2 = kNoKey;
-    for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
-      const int cnt = min(kStereoChunk, k1_hi - c0);
-      if (!resident) load_chunk(c0, cnt);
-#pragma unroll 4
-      for (int j = 0; j < cnt; ++j) {
-        const uint32_t dist = (uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(chunk + 3 * j));
-        uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
-        key = (key > floor_key && dist < (uint32_t)threshold) ? key : kNoKey;
-        c2 = min(c2, max(c1, key));
-        c1 = min(c1, key);
-      }
-    }
+    uint32_t c1, c2;
+    scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
+                     (uint32_t)threshold, &c1, &c2);
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {
       const uint32_t cand = t == 0 ? c1 : c2;
@@ -394,40 +418,80 @@ __global__ __launch_bounds__(64) void hamming_emit_kernel(const uint8_t* __restr
 // depths >= 0.2 unless parallel.  The winner is re-projected into the current camera and must
 // land within 4 px (:1897-1905).  `cos_quality` is the cosine whose acos the reference stores
 // as match quality (:1887-1889); the host takes the acos.
-__global__ __launch_bounds__(64) void match_motion_kernel(
-    const PairParams* __restrict__ pair, const DeviceCamera* __restrict__ camera, int w, int h,
-    const uint8_t* __restrict__ desc0, const okvfe_keypoint* __restrict__ kp0,
-    const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0,
-    const uint8_t* __restrict__ skip0, int n0, const uint8_t* __restrict__ desc1,
-    const okvfe_keypoint* __restrict__ kp1, const double* __restrict__ bp1,
-    const uint8_t* __restrict__ bpv1, const uint8_t* __restrict__ matched1, int n1, int threshold,
-    okvfe_motion_match* __restrict__ out) {
-  const PairParams& P = *pair;
+// One side of the motion-stereo matcher (explicit arrays or a gather block)
+struct MotionView {
+  const uint8_t* desc;
+  const okvfe_keypoint* kps;
+  const double* bp;
+  const uint8_t* bpv;
+  const uint8_t* flag;  // side 0: skip0 (k0 is not matched), side 1: matched1 (k1 left out); may be null
+  int n;
+};
+struct SegBestMotion {
+  double hp[4];
+  double cosq;
+  int best, k1, init, pad;
+};
+
+// Same scheme as match_stereo_rows (segments, LDS scan of the two best keys, converged FP64 gate):
+// the gate of the reference loop (Frontend.cpp:1843-1895) does not depend on the running best, so
+// its result is the gated candidate with the smallest (dist, k1).
+__device__ void match_motion_rows(const PairParams& P, const DeviceCamera& camera, int w, int h,
+                                  const MotionView& I0, const MotionView& I1, int threshold,
+                                  okvfe_motion_match* __restrict__ out) {
+  __shared__ SegBestMotion seg_best[kStereoSegs - 1][64];
+  __shared__ uint4 seg_desc[kStereoSegs][kStereoChunk * 3];
+  __shared__ uint8_t seg_skip[kStereoSegs][kStereoChunk];
+  const int seg = threadIdx.y;
+  const int per_seg = (I1.n + kStereoSegs - 1) / kStereoSegs;
+  const int k1_lo = min(seg * per_seg, I1.n), k1_hi = min(k1_lo + per_seg, I1.n);
+  if ((int)blockIdx.x * 64 >= I0.n) return;  // whole block past the last keypoint
   const int k0 = blockIdx.x * 64 + threadIdx.x;
-  const bool in_range = k0 < n0;
-  bool active = in_range && !(skip0 && skip0[k0]) && bpv0[k0] != 0;
-  Desc12 d0;
+  const bool in_range = k0 < I0.n;
+  const bool active = in_range && !(I0.flag && I0.flag[k0]) && I0.bpv[k0] != 0;
+  Desc12 d0 = {};
   double e0_W[3] = {0, 0, 0};
   if (active) {
-    d0 = load_desc(desc0 + (size_t)k0 * OKVFE_DESC_BYTES);
+    d0 = load_desc(I0.desc + (size_t)k0 * OKVFE_DESC_BYTES);
     double v[3];
-    rot(P.C0, bp0 + 3 * (size_t)k0, v);
+    rot(P.C0, I0.bp + 3 * (size_t)k0, v);
     normalize3(v, e0_W);
   }
   int best = threshold;
-  int k1_max = 1000;
+  int k1_max = 0;
   bool initialisable = false;
   double cosq = 1.0;
   double hps[4] = {0, 0, 0, 0};
-  for (int k1 = 0; k1 < n1; ++k1) {
-    if (matched1 && matched1[k1]) continue;  // wave-uniform
-    const uint32_t* d1 = reinterpret_cast<const uint32_t*>(desc1 + (size_t)k1 * OKVFE_DESC_BYTES);
-    if (!active) continue;
-    const int dist = hamming(d0, d1);
-    if (dist < best) {
-      if (!bpv1[k1]) continue;
+  uint32_t floor_key = 0;
+  bool done = !active;
+  const ScanChunk chunk{seg_desc[seg], seg_skip[seg]};
+  const bool resident = k1_hi - k1_lo <= kStereoChunk;
+  const bool has_skip = I1.flag != nullptr;  // kernel-uniform
+  if (resident) load_scan_chunk(chunk, I1.desc, I1.flag, k1_lo, k1_hi - k1_lo);
+  while (__any(!done)) {
+    uint32_t c1, c2;
+    if (has_skip)
+      scan_top2<true>(d0, chunk, I1.desc, I1.flag, k1_lo, k1_hi, resident, floor_key,
+                      (uint32_t)threshold, &c1, &c2);
+    else
+      scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
+                       (uint32_t)threshold, &c1, &c2);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t cand = t == 0 ? c1 : c2;
+      bool pending = !done;
+      if (pending && cand == kNoKey) {
+        done = true;
+        pending = false;
+      }
+      if (!__any(pending)) break;  // wave-uniform
+      if (!pending) continue;
+      floor_key = cand;
+      const int k1 = (int)((cand - 1u) & 0x3FFFFFu);
+      const int dist = (int)((cand - 1u) >> 22);
+      if (!I1.bpv[k1]) continue;
       double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
-      rot(P.C1, bp1 + 3 * (size_t)k1, v);
+      rot(P.C1, I1.bp + 3 * (size_t)k1, v);
       normalize3(v, e1_W);
       const double ee = dot3(e0_W, e1_W);
       if (ee < 0.5) continue;
@@ -457,7 +521,23 @@ __global__ __launch_bounds__(64) void match_motion_kernel(
         cosq = dot3(an, bn);
         hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
         initialisable = !is_parallel;
+        done = true;
       }
+    }
+  }
+  if (seg > 0) {
+    SegBestMotion& sb = seg_best[seg - 1][threadIdx.x];
+    sb.best = best; sb.k1 = k1_max; sb.init = initialisable ? 1 : 0; sb.cosq = cosq;
+    sb.hp[0] = hps[0]; sb.hp[1] = hps[1]; sb.hp[2] = hps[2]; sb.hp[3] = hps[3];
+  }
+  __syncthreads();
+  if (seg > 0) return;
+#pragma unroll
+  for (int sg = 0; sg < kStereoSegs - 1; ++sg) {
+    const SegBestMotion& sb = seg_best[sg][threadIdx.x];
+    if (sb.best < best) {  // strict: ties stay with the lower segment = lower k1
+      best = sb.best; k1_max = sb.k1; initialisable = sb.init != 0; cosq = sb.cosq;
+      hps[0] = sb.hp[0]; hps[1] = sb.hp[1]; hps[2] = sb.hp[2]; hps[3] = sb.hp[3];
     }
   }
   if (in_range) {
@@ -475,18 +555,29 @@ __global__ __launch_bounds__(64) void match_motion_kernel(
     if (hit) {
       double hp_C1[4], head[3], pt1p[2];
       inv_transform_h(P.C1, P.r1, hps, hp_C1);
-      const double sgn = hp_C1[3] < 0 ? -1.0 : 1.0;  // projectHomogeneous: PinholeCamera.hpp:493-503
+      // projectHomogeneous: PinholeCamera.hpp:493-503
       head[0] = hp_C1[3] < 0 ? -hp_C1[0] : hp_C1[0];
       head[1] = hp_C1[3] < 0 ? -hp_C1[1] : hp_C1[1];
       head[2] = hp_C1[3] < 0 ? -hp_C1[2] : hp_C1[2];
-      (void)sgn;
-      const int status = cam::project(*camera, w, h, head, pt1p);
-      const double ex = (double)kp1[k1_max].x - pt1p[0], ey = (double)kp1[k1_max].y - pt1p[1];
+      const int status = cam::project(camera, w, h, head, pt1p);
+      const double ex = (double)I1.kps[k1_max].x - pt1p[0], ey = (double)I1.kps[k1_max].y - pt1p[1];
       m.accepted = (status == 0 && sqrt(ex * ex + ey * ey) < 4.0) ? 1 : 0;
     }
     out[k0] = m;
   }
-  (void)kp0;
+}
+
+__global__ __launch_bounds__(64 * kStereoSegs) void match_motion_kernel(
+    const PairParams* __restrict__ pair, const DeviceCamera* __restrict__ camera, int w, int h,
+    const uint8_t* __restrict__ desc0, const okvfe_keypoint* __restrict__ kp0,
+    const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0,
+    const uint8_t* __restrict__ skip0, int n0, const uint8_t* __restrict__ desc1,
+    const okvfe_keypoint* __restrict__ kp1, const double* __restrict__ bp1,
+    const uint8_t* __restrict__ bpv1, const uint8_t* __restrict__ matched1, int n1, int threshold,
+    okvfe_motion_match* __restrict__ out) {
+  const MotionView I0{desc0, kp0, bp0, bpv0, skip0, n0};
+  const MotionView I1{desc1, kp1, bp1, bpv1, matched1, n1};
+  match_motion_rows(*pair, *camera, w, h, I0, I1, threshold, out);
 }
 
 // ---- matchToMapByThread, 3-D landmarks (Frontend.cpp:1552-1589) ----------------------------------
@@ -727,7 +818,7 @@ void launch_match_motion(const PairParams* pair, const DeviceCamera* camera, int
                          const uint8_t* matched1, int n1, int threshold, okvfe_motion_match* out,
                          hipStream_t stream) {
   if (n0 <= 0) return;
-  hipLaunchKernelGGL(match_motion_kernel, dim3((n0 + 63) / 64), dim3(64), 0, stream, pair, camera, w,
+  hipLaunchKernelGGL(match_motion_kernel, dim3((n0 + 63) / 64), dim3(64, kStereoSegs), 0, stream, pair, camera, w,
                      h, desc0, kp0, bp0, bpv0, skip0, n0, desc1, kp1, bp1, bpv1, matched1, n1,
                      threshold, out);
 }
