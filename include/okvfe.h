@@ -354,6 +354,19 @@ okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* 
 /* Packs image `index` of the last batch into block_dev (device). */
 okvfe_status okvfe_pack_gather_block_device(okvfe_ctx* ctx, int32_t index, void* block_dev,
                                             void* stream);
+/* Device-resident variant of okvfe_match_motion_stereo: block0 = older frame, block1 = current
+ * frame, both gather blocks of camera slot `cam` (intrinsics from okvfe_set_camera; frame size =
+ * the context's).  skip0_dev / matched1_dev: device flag arrays [max_keypoints] or NULL.
+ * matches_dev: [max_keypoints] okvfe_motion_match, rows >= the block's keypoint count untouched.
+ * Nothing crosses PCIe but the two poses. */
+okvfe_status okvfe_match_motion_stereo_blocks_device(okvfe_ctx* ctx, int32_t cam,
+                                                     const void* block0_dev,
+                                                     const void* block1_dev,
+                                                     const uint8_t* skip0_dev,
+                                                     const uint8_t* matched1_dev,
+                                                     const okvfe_pose* T_WC0,
+                                                     const okvfe_pose* T_WC1,
+                                                     okvfe_motion_match* matches_dev, void* stream);
 /* Matches two gathered blocks (device), as okvfe_match_stereo_batch_device. */
 okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0_dev,
                                               const void* block1_dev, const okvfe_pose* T_WC0,

@@ -68,7 +68,7 @@ EXPORTS = [
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
-    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_camera_overlap", "okvfe_compute",
+    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_match_motion_stereo_blocks_device", "okvfe_camera_overlap", "okvfe_compute",
     "okvfe_match_motion_stereo", "okvfe_match_to_map",
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
@@ -93,6 +93,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch-ROCm ships its own libamdhip64; whichever HIP runtime is loaded second finds no
+        # GPU.  Importing torch first makes libokvfe.so bind to the runtime torch already loaded
+        # (same soname), so device pointers and streams are shared.  Without torch installed the
+        # system runtime under /opt/rocm is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.okvfe_last_error.restype = C.c_char_p
         L.okvfe_last_error.argtypes = [C.c_void_p]
@@ -437,6 +445,13 @@ class Frontend:
         self._check(lib().okvfe_match_stereo_blocks_batch_device(
             self._h, _p(blocks0_ptr), _p(blocks1_ptr), int(n_frames), C.byref(P0), C.byref(P1),
             C.c_double(f0), C.c_double(f1), _p(matches_ptr), _p(stream)))
+
+    def match_motion_stereo_blocks_device(self, cam, block0_ptr, block1_ptr, skip0_ptr,
+                                          matched1_ptr, T0, T1, matches_ptr, stream=None):
+        P0, P1 = make_pose(*T0), make_pose(*T1)
+        self._check(lib().okvfe_match_motion_stereo_blocks_device(
+            self._h, int(cam), _p(block0_ptr), _p(block1_ptr), _p(skip0_ptr), _p(matched1_ptr),
+            C.byref(P0), C.byref(P1), _p(matches_ptr), _p(stream)))
 
     def match_stereo_blocks_device(self, block0_ptr, block1_ptr, T0, T1, f0, f1, matches_ptr,
                                    stream=None):

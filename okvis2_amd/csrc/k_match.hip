@@ -779,7 +779,32 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_blocks_kernel(
   match_stereo_rows(*pair, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
 }
 
+// motion-stereo matcher on two gathered blocks (older frame, current frame) of one camera
+__global__ __launch_bounds__(64 * kStereoSegs) void match_motion_blocks_kernel(
+    const PairParams* __restrict__ pair, const DeviceCamera* __restrict__ camera, int w, int h,
+    BlockOffsets L, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
+    const uint8_t* __restrict__ skip0, const uint8_t* __restrict__ matched1, int threshold,
+    okvfe_motion_match* __restrict__ out) {
+  MotionView I0, I1;
+  I0.desc = b0 + L.o_desc; I0.kps = reinterpret_cast<const okvfe_keypoint*>(b0 + L.o_kps);
+  I0.bp = reinterpret_cast<const double*>(b0 + L.o_bp); I0.bpv = b0 + L.o_bpv; I0.flag = skip0;
+  I0.n = *reinterpret_cast<const int32_t*>(b0 + L.o_count);
+  I1.desc = b1 + L.o_desc; I1.kps = reinterpret_cast<const okvfe_keypoint*>(b1 + L.o_kps);
+  I1.bp = reinterpret_cast<const double*>(b1 + L.o_bp); I1.bpv = b1 + L.o_bpv; I1.flag = matched1;
+  I1.n = *reinterpret_cast<const int32_t*>(b1 + L.o_count);
+  match_motion_rows(*pair, *camera, w, h, I0, I1, threshold, out);
+}
+
 }  // namespace
+
+void launch_match_motion_blocks(const PairParams* pair, const DeviceCamera* camera, int w, int h,
+                                const int offs[6], const uint8_t* block0, const uint8_t* block1,
+                                const uint8_t* skip0, const uint8_t* matched1, int kp_cap,
+                                int threshold, okvfe_motion_match* out, hipStream_t stream) {
+  const BlockOffsets L{offs[0], offs[1], offs[2], offs[3], offs[4], offs[5]};
+  hipLaunchKernelGGL(match_motion_blocks_kernel, dim3((kp_cap + 63) / 64), dim3(64, kStereoSegs), 0,
+                     stream, pair, camera, w, h, L, block0, block1, skip0, matched1, threshold, out);
+}
 
 void launch_pack_blocks(const int offs[6], int first, int n, int kp_cap, const int32_t* counts,
                         const okvfe_keypoint* kps, const uint8_t* desc, const double* bp,

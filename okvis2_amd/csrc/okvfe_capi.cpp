@@ -1126,6 +1126,43 @@ okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* 
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_match_motion_stereo_blocks_device(okvfe_ctx* ctx, int32_t cam, const void* block0_dev,
+                                                     const void* block1_dev, const uint8_t* skip0_dev,
+                                                     const uint8_t* matched1_dev, const okvfe_pose* T_WC0,
+                                                     const okvfe_pose* T_WC1, okvfe_motion_match* matches_dev,
+                                                     void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!block0_dev || !block1_dev || !T_WC0 || !T_WC1 || !matches_dev || cam < 0 ||
+      cam >= (int)ctx->h_cams.size())
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_motion_stereo_blocks_device: bad argument");
+  const DeviceCamera& dc = ctx->h_cams[cam];
+  if (!(dc.fu > 0.0))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "camera slot %d has no intrinsics (okvfe_set_camera)", cam);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  okvfe_stereo_pair sp{};
+  sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1;
+  sp.f0 = sp.f1 = 0.5 * (dc.fu + dc.fv);  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834)
+  const PairParams pp = to_pair_params(sp);
+  if (!ctx->d_block_pairs) {
+    void* q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, 64 * sizeof(PairParams)));
+    ctx->allocs.push_back(q);
+    ctx->d_block_pairs = static_cast<PairParams*>(q);
+  }
+  PairParams* slot = ctx->d_block_pairs + (ctx->block_pair_next++ % 64);
+  if (ctx->block_pair_next % 64 == 0) HIP_TRY(ctx, hipStreamSynchronize(s));  // ring wrap: drain
+  HIP_TRY(ctx, hipMemcpyAsync(slot, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
+  launch_match_motion_blocks(slot, ctx->d_cams + cam, ctx->w, ctx->h, offs,
+                             static_cast<const uint8_t*>(block0_dev), static_cast<const uint8_t*>(block1_dev),
+                             skip0_dev, matched1_dev, ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0_dev, const void* block1_dev,
                                               const okvfe_pose* T_WC0, const okvfe_pose* T_WC1, double f0,
                                               double f1, okvfe_stereo_match* matches_dev, void* stream) {

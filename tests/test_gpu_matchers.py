@@ -79,6 +79,26 @@ def test_match_motion_stereo(oracle):
         q = np.array([math.acos(c) for c in got["cos_quality"][hit]])  # libm acos, as the C++ host does
         assert np.array_equal(q, ref["quality"][hit])
         assert hit.sum() > 100 and ref["accepted"].sum() > 50
+    # device-resident variant: the same frames as gather blocks in HBM, flags in device arrays
+    import torch
+    from okvis2_amd import multigpu
+    fe.set_camera(0, cam)
+    K = cfg.max_kpts
+    blk0 = torch.from_numpy(multigpu.pack_block_host(K, kp0, d0, bp0, bv0)).cuda()
+    blk1 = torch.from_numpy(multigpu.pack_block_host(K, kp1, d1, bp1, bv1)).cuda()
+    pad = lambda a: torch.from_numpy(np.concatenate([a, np.zeros(K - len(a), np.uint8)])).cuda()
+    d_s0, d_m1 = pad(skip0), pad(matched1)
+    d_out = torch.zeros((K, capi.MOTION_MATCH_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    for s0, m1, ps0, pm1 in ((skip0, matched1, d_s0.data_ptr(), d_m1.data_ptr()), (None, None, None, None)):
+        ref = oracle.match_motion_stereo(d0, kp0, bp0, bv0, s0, d1, kp1, bp1, bv1, m1, T0, T1, cam,
+                                         cfg.match_threshold)
+        fe.match_motion_stereo_blocks_device(0, blk0.data_ptr(), blk1.data_ptr(), ps0, pm1, T0, T1,
+                                             d_out.data_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(capi.MOTION_MATCH_DTYPE).reshape(-1)[:n]
+        for f in ("k1", "dist", "initialisable", "accepted"):
+            assert np.array_equal(got[f], ref[f]), f
+        assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
     # empty inputs
     assert len(fe.match_motion_stereo(cam, d0[:0], kp0[:0], bp0[:0], bv0[:0], None, d1, kp1, bp1, bv1,
                                       None, T0, T1)) == 0
