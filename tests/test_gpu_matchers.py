@@ -261,3 +261,59 @@ def test_match_to_map_uninitialised(oracle):
     e = fe.match_to_map_uninitialised(desc, bp, use, previous, np.zeros(1, np.int32), pool[:0], e0[:0],
                                       r0[:0], T1, focal)
     assert np.all(e[0] == -1) and e[4] == 0
+
+
+def test_gated_matchers_large_and_ambiguous(oracle):
+    """1500 keypoints per side (segments longer than the LDS chunk: the scan reloads chunks every
+    round) with clusters of near-identical descriptors, so that most rows have several candidates
+    under the threshold whose geometric gate fails -- many rounds, both keys of a scan used."""
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    n = 1500
+    fe = G.make_frontend(cfg, max_keypoints=2048)
+    rng = np.random.default_rng(21)
+    T0 = (np.eye(3).reshape(-1), np.zeros(3))
+    T1 = (np.eye(3).reshape(-1), np.array([0.11, 0.0, 0.0]))
+    X = np.stack([rng.uniform(-2.0, 2.0, n), rng.uniform(-1.0, 1.0, n), rng.uniform(2.0, 12.0, n)], 1)
+
+    def observe(T):
+        Xc = X - np.asarray(T[1])
+        kp = np.zeros(n, dtype=oracle.KEYPOINT_DTYPE)
+        kp["size"] = 12.0
+        for i in range(n):
+            st, pt, _ = oracle.cam_project(cam, Xc[i])
+            kp["x"][i], kp["y"][i] = pt if st == 0 else (5.0, 5.0)
+        kp["x"] += rng.normal(0, 0.2, n).astype(np.float32)
+        kp["y"] += rng.normal(0, 0.2, n).astype(np.float32)
+        bp, bv = oracle.backproject_keypoints(cam, kp)
+        return kp, bp, bv
+
+    kp0, bp0, bv0 = observe(T0)
+    kp1, bp1, bv1 = observe(T1)
+    # 60 descriptor clusters: every keypoint is a lightly perturbed copy of its cluster centre
+    centres = rng.integers(0, 256, (60, 48), dtype=np.uint8)
+    cl = rng.integers(0, 60, n)
+
+    def perturb(p):
+        return centres[cl] ^ ((rng.random((n, 48)) < p) * (1 << rng.integers(0, 8, (n, 48)))).astype(np.uint8)
+
+    d0, d1 = perturb(0.08), perturb(0.08)
+    perm = rng.permutation(n)
+    d1, kp1, bp1, bv1 = d1[perm], kp1[perm], bp1[perm], bv1[perm]
+    f = 0.5 * (cam.fu + cam.fv)
+    ref = oracle.match_stereo(d0, kp0, bp0, bv0, d1, kp1, bp1, bv1, T0, T1, f, f, cfg.match_threshold)
+    got = fe.match_stereo(d0, kp0, bp0, bv0, d1, kp1, bp1, bv1, T0, T1, f, f)
+    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    # how ambiguous the data is: candidates under the threshold per row
+    cnt = np.array([(np.unpackbits(d0[i] ^ d1, axis=1).sum(1) < cfg.match_threshold).sum()
+                    for i in range(0, n, 50)])
+    assert cnt.mean() > 5 and (ref["k1"] >= 0).sum() > 200
+    skip0 = (rng.random(n) < 0.1).astype(np.uint8)
+    matched1 = (rng.random(n) < 0.2).astype(np.uint8)
+    refm = oracle.match_motion_stereo(d0, kp0, bp0, bv0, skip0, d1, kp1, bp1, bv1, matched1, T0, T1,
+                                      cam, cfg.match_threshold)
+    gotm = fe.match_motion_stereo(cam, d0, kp0, bp0, bv0, skip0, d1, kp1, bp1, bv1, matched1, T0, T1)
+    for fld in ("k1", "dist", "initialisable", "accepted"):
+        assert np.array_equal(gotm[fld], refm[fld]), fld
+    assert np.array_equal(gotm["hp_W"].view(np.uint64), refm["hp_W"].view(np.uint64))
+    assert (refm["k1"] >= 0).sum() > 100
