@@ -237,7 +237,16 @@ def main():
         lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav, lanes[0][1])
         torch.cuda.synchronize()
     iso = lanes[0][0].profile_read()["harris"]
+    # the score kernel WITHOUT the fused NMS (okvfe_harris_score_device: the kernel behind the
+    # stand-alone K1 entry point), same images, for reference next to the fused launch
+    d_sc = torch.empty((n_lane_img, cfg.h, cfg.w), dtype=torch.int32, device=dev)
+    lanes[0][0].profile_enable(True, stages=("harris",))
+    for _ in range(5):
+        lanes[0][0].harris_score_device(lanes[0][2], n_lane_img, d_sc.data_ptr(), lanes[0][1])
+    torch.cuda.synchronize()
+    solo = lanes[0][0].profile_read()["harris"]
     lanes[0][0].profile_enable(False)
+    del d_sc
 
     if rank == 0:
         P = cfg.w * cfg.h
@@ -286,6 +295,13 @@ def main():
                          "isolated_launch_ms": iso[0] / iso[1],
                          "isolated_frac": 5.0 * P * n_img_launch / (iso[0] / iso[1] * 1e-3) / 1e9
                                           / HBM_PEAK_GBPS,
+                         "score_only_launch_ms": solo[0] / solo[1],
+                         "score_only_frac": 5.0 * P * n_img_launch / (solo[0] / solo[1] * 1e-3) / 1e9
+                                            / HBM_PEAK_GBPS,
+                         "score_only_note": "harris_kernel<30, false>: the score map alone (no NMS), "
+                                            "5 launches after the timed region; the pipeline uses "
+                                            "the fused kernel because a separate NMS pass re-reads "
+                                            "the whole score map (+0.2 ms per 512 images)",
                          "note": ("one lane: the launch has the GPU to itself in the timed region "
                                   "as well" if S == 1 else
                                   "avg_launch_ms is taken while the other lanes' kernels share the "
