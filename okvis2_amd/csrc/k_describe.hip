@@ -33,27 +33,6 @@ constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigm
 constexpr int kZeroRowBytes = 96;
 constexpr int kPatchBufBytes = 6144;
 constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
-struct Box {
-  int x_left, x_right, y_top, y_bottom;
-};
-__device__ __forceinline__ Box sample_box(float xf, float yf, float sigma_half) {
-  Box b;
-  if (sigma_half < 0.5f) {
-    b.x_left = (int)xf;
-    b.y_top = (int)yf;
-    b.x_right = b.x_left + 1;
-    b.y_bottom = b.y_top + 1;
-  } else {
-    const float x_1 = xf - sigma_half, x1 = xf + sigma_half;
-    const float y_1 = yf - sigma_half, y1 = yf + sigma_half;
-    b.x_left = (int)(x_1 + 0.5f);
-    b.y_top = (int)(y_1 + 0.5f);
-    b.x_right = (int)(x1 + 0.5f);
-    b.y_bottom = (int)(y1 + 0.5f);
-  }
-  return b;
-}
-
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
 // intensity): float reciprocal estimate (off by at most 1) + exact integer correction, instead of
 // the ~40-instruction generic 32-bit division
@@ -257,17 +236,6 @@ struct PatchPx {   // reads from the keypoint's patch staged in LDS
     return patch - kZeroRowBytes;
   }
 };
-
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
-  return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
-  return v;
-}
 
 // One THREAD per keypoint: border test and, in camera-aware mode, M = J [e_x e_y] / fu.  Done here
 // because in the wave-per-keypoint kernel all 64 lanes would repeat the same ~150 instructions.

@@ -7,17 +7,18 @@
 // okvis_frontend/src/Frontend.cpp:2406-2409 = uniformityRadius, octaves, absoluteThreshold,
 // maxNumKpt).
 //
-// Two kernels, one workgroup (1024 threads = 16 waves) per image:
-//   sort_kernel    bitonic sort of 64-bit keys (score descending, y, x ascending -- a total
-//                  order, so the result does not depend on the append order of K2) in LDS
-//                  (<= 8192 keys) or in the global workspace (larger candidate sets).
-//   select_kernel  the greedy is serial in its accepted points only: occupancy only grows, so a
-//                  candidate that fails its test once is dead for good.  Each round all 1024
-//                  threads test the next 1024 candidates against the current occupancy, the
-//                  first one that passes is accepted (everything before it is rejected for
-//                  good), its 31x31 stamp is added by 961 threads, and the window restarts
-//                  behind it.  Rounds = accepted points + empty windows.  The occupancy grid
-//                  lives in LDS when it fits (EuRoC: 222x330 B), else in the HBM workspace.
+// Kernels, one workgroup per image:
+//   sort_kernel           bitonic sort of 64-bit keys (score descending, y, x ascending -- a total
+//                         order, so the result does not depend on the append order of K2) in LDS
+//                         (<= 8192 keys; two strides per pass with 4 keys in registers) or in the
+//                         global workspace (larger candidate sets).
+//   select_greedy_kernel  production path (occupancy grid in LDS, two images per CU): the greedy
+//                         is serial in its accepted points only -- occupancy only grows, so a
+//                         candidate that fails its test once is dead for good.  See the comment
+//                         at the kernel: wave 0 decides 64-candidate windows, 4 waves stamp.
+//   select_kernel<>       fallback for grids that do not fit in LDS (small uniformity radius,
+//                         large images): 1024 threads test 1024 candidates per round, the first
+//                         that passes is accepted, 961 threads add its 31x31 stamp.
 // Bound: latency / LDS (no HBM roofline); batches keep all CUs busy with independent images.
 #include "okvfe_internal.h"
 
