@@ -111,3 +111,64 @@ def test_profile_stage_mask():
     fe.profile_enable(False)
     run(1)
     assert all(v[1] == 0 for v in fe.profile_read().values())
+
+
+@pytest.mark.parametrize("w,h", [(64, 64), (252, 65), (256, 90), (260, 121), (500, 64), (1000, 64),
+                                 (248, 91), (496, 119), (68, 200), (1280, 67)])
+def test_detect_ragged_sizes(oracle, w, h):
+    """Aligned widths around the 248-pixel strip width and heights around the 30-row tile of the
+    fused score+NMS kernel (partial last strip / tile, single tile, tile + 1 row ...)."""
+    rng = np.random.default_rng(w * 1000 + h)
+    for kind in ("noise", "blocks"):
+        if kind == "noise":
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        else:
+            img = _plateau_image(w, h, w + h, 3, 2)
+        for thr, radius, maxk in ((1, 6.0, 4000), (500, 10.0, 300)):
+            fe = capi.Frontend(w, h, radius, 0, thr, maxk, max_candidates=1 << 16)
+            ref = oracle.detect(img, radius, 0, thr, maxk)
+            G.assert_keypoints_equal(fe.detect(img), ref)
+
+
+@pytest.mark.parametrize("n_images,mode", [(11, "aware"), (19, "upright"), (8, "gradient")])
+def test_batch_of_odd_size_mixed_images(oracle, n_images, mode):
+    """Batch sizes that are not multiples of 8 (the XCD-aware block -> image maps of the score,
+    describe and NMS kernels have a tail path) with different image kinds in one batch, one of
+    them without a single corner."""
+    cfg = synth.mono640_config()
+    cam = cfg.cams[0]
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                       rotation_invariant=(mode == "gradient"), max_batch=n_images, num_cameras=1)
+    imgs = []
+    for i in range(n_images):
+        if i == 4:
+            imgs.append(np.full((cfg.h, cfg.w), 90, np.uint8))  # flat: no candidates at all
+        elif i % 3 == 0:
+            imgs.append(synth.noise_image(cfg.w, cfg.h, 50 + i))
+        else:
+            imgs.append(synth.corners_image(cfg.w, cfg.h, 50 + i))
+    imgs = np.stack(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    cam_ids, grav = None, None
+    omode = oracle.MODE_GRADIENT if mode == "gradient" else oracle.MODE_UPRIGHT
+    rays = jac = None
+    if mode == "aware":
+        fe.set_camera(0, cam)
+        cam_ids = np.zeros(n_images, dtype=np.int32)
+        grav = np.tile(np.array([0.05, 0.99, -0.1], dtype=np.float32), (n_images, 1))
+        rays, jac = oracle.awareness_maps(cam)
+        omode = oracle.MODE_CAMERA_AWARE
+    fe.detect_describe_batch_device(d_img.data_ptr(), n_images, cam_ids, grav,
+                                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    total = 0
+    for i in range(n_images):
+        k, d = oracle.detect_describe(imgs[i], cfg.uniformity_radius, 0, cfg.abs_threshold,
+                                      cfg.max_kpts, omode, rays, jac, np.float32(cam.fu),
+                                      (0.05, 0.99, -0.1))
+        g = fe.download(i)
+        G.assert_keypoints_equal(g[0], k)
+        assert np.array_equal(g[1], d)
+        total += len(k)
+    assert total > 100 * (n_images // 2)
+    assert len(fe.download(4)[0]) == 0
