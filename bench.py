@@ -130,6 +130,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     cfg = synth.euroc_config()
+    if os.environ.get("OKVFE_BENCH_MAXKP"):  # experiment knob: keypoint capacity of the context
+        cfg.max_kpts = int(os.environ["OKVFE_BENCH_MAXKP"])
     B = args.batch
     n_img = 2 * B
     distinct = min(args.distinct, B)
@@ -246,7 +248,19 @@ def main():
     torch.cuda.synchronize()
     solo = lanes[0][0].profile_read()["harris"]
     lanes[0][0].profile_enable(False)
-    del d_sc
+    # what a trivial device-to-device copy of the score map reaches on this box, same run
+    # (fraction of the nominal AND of the measured attainable bandwidth)
+    d_cp = torch.empty_like(d_sc)
+    d_cp.copy_(d_sc)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        d_cp.copy_(d_sc)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 2.0 * d_sc.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del d_sc, d_cp
 
     if rank == 0:
         P = cfg.w * cfg.h
@@ -295,6 +309,8 @@ def main():
                          "isolated_launch_ms": iso[0] / iso[1],
                          "isolated_frac": 5.0 * P * n_img_launch / (iso[0] / iso[1] * 1e-3) / 1e9
                                           / HBM_PEAK_GBPS,
+                         "copy_kernel_GBps": copy_gbps,
+                         "frac_of_copy_kernel": achieved / copy_gbps,
                          "score_only_launch_ms": solo[0] / solo[1],
                          "score_only_frac": 5.0 * P * n_img_launch / (solo[0] / solo[1] * 1e-3) / 1e9
                                             / HBM_PEAK_GBPS,
