@@ -585,35 +585,90 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_motion_kernel(
 // std::map); per landmark the image-distance gate |projection - keypoint|^2 <= thr^2, then its
 // <= 3 descriptors in order with the running minimum "dist < distances[k]" (strict, first-lowest
 // wins).  Returns per keypoint the distance and the landmark INDEX (or -1).
-__global__ __launch_bounds__(64) void match_to_map_kernel(
+// Lane = keypoint; the landmark list is cut into kMapSegs contiguous segments (one wave each) and
+// walked in chunks of 64: lane j of the wave fetches landmark j's projection and descriptor range
+// (coalesced), v_readlane broadcasts them, and the chunk's descriptors are staged in LDS.  The
+// Hamming part runs only for landmarks that have at least one keypoint of the wave inside the
+// reprojection radius.  Result = first landmark (ascending) reaching the smallest distance, as in
+// the reference loop, merged over the segments by (dist, segment).
+constexpr int kMapSegs = 4;
+constexpr int kMapChunk = 64;
+constexpr int kMapChunkDesc = 3 * kMapChunk;  // the reference keeps <= 3 descriptors per landmark
+
+__global__ __launch_bounds__(64 * kMapSegs) void match_to_map_kernel(
     const uint8_t* __restrict__ desc_k, const okvfe_keypoint* __restrict__ kps,
     const uint8_t* __restrict__ use, int n_k, const double* __restrict__ projections,
     const int32_t* __restrict__ desc_begin, int n_lm, const uint8_t* __restrict__ pool,
     double thr_sq, int threshold, int32_t* __restrict__ best_lm, int32_t* __restrict__ best_d) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+  __shared__ uint4 seg_desc[kMapSegs][kMapChunkDesc * 3];
+  __shared__ int2 seg_best[kMapSegs - 1][64];
+  const int lane = threadIdx.x, seg = threadIdx.y;
+  const int k = blockIdx.x * 64 + lane;
   const bool in_range = k < n_k;
   const bool active = in_range && use[k] != 0;
-  Desc12 dk;
+  Desc12 dk = {};
   double kx = 0.0, ky = 0.0;
   if (active) {
     dk = load_desc(desc_k + (size_t)k * OKVFE_DESC_BYTES);
     kx = (double)kps[k].x;
     ky = (double)kps[k].y;
   }
+  const int per_seg = (n_lm + kMapSegs - 1) / kMapSegs;
+  const int l_lo = min(seg * per_seg, n_lm), l_hi = min(l_lo + per_seg, n_lm);
+  uint4* chunk = seg_desc[seg];
   int best = threshold, lm = -1;
-  for (int l = 0; l < n_lm; ++l) {
-    const double px = projections[2 * l], py = projections[2 * l + 1];
-    const int b = desc_begin[l], e = desc_begin[l + 1];
-    if (!active) continue;
-    const double dx = px - kx, dy = py - ky;
-    const double dd = dx * dx + dy * dy;
-    if (dd > thr_sq) continue;
-    for (int d = b; d < e; ++d) {
-      const int dist = hamming(dk, reinterpret_cast<const uint32_t*>(pool + (size_t)d * OKVFE_DESC_BYTES));
-      if (dist < best) {
-        best = dist;
-        lm = l;
+  for (int l0 = l_lo; l0 < l_hi; l0 += kMapChunk) {
+    const int cnt = min(kMapChunk, l_hi - l0);
+    // lane j holds landmark l0 + j
+    double px = 0.0, py = 0.0;
+    int b = 0, e = 0;
+    if (lane < cnt) {
+      px = projections[2 * (size_t)(l0 + lane)];
+      py = projections[2 * (size_t)(l0 + lane) + 1];
+      b = desc_begin[l0 + lane];
+      e = desc_begin[l0 + lane + 1];
+    }
+    const int d_lo = __builtin_amdgcn_readfirstlane(b);
+    const int d_hi = __builtin_amdgcn_readlane(e, cnt - 1);
+    // descriptors of the chunk in LDS when they fit (always, with <= 3 per landmark)
+    const bool staged = d_hi - d_lo <= kMapChunkDesc;
+    __builtin_amdgcn_wave_barrier();
+    if (staged) {
+      const uint4* src = reinterpret_cast<const uint4*>(pool + (size_t)d_lo * OKVFE_DESC_BYTES);
+      for (int i = lane; i < (d_hi - d_lo) * 3; i += 64) chunk[i] = src[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < cnt; ++j) {
+      const double lpx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(px), j),
+                                          __builtin_amdgcn_readlane(__double2loint(px), j));
+      const double lpy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(py), j),
+                                          __builtin_amdgcn_readlane(__double2loint(py), j));
+      const int lb = __builtin_amdgcn_readlane(b, j), le = __builtin_amdgcn_readlane(e, j);
+      const double dx = lpx - kx, dy = lpy - ky;
+      const double dd = dx * dx + dy * dy;
+      const bool near = active && !(dd > thr_sq);
+      if (!__any(near)) continue;  // wave-uniform: no keypoint of this wave near the landmark
+      for (int d = lb; d < le; ++d) {
+        const uint32_t* dp = staged
+            ? reinterpret_cast<const uint32_t*>(chunk + 3 * (d - d_lo))
+            : reinterpret_cast<const uint32_t*>(pool + (size_t)d * OKVFE_DESC_BYTES);
+        const int dist = hamming(dk, dp);
+        if (near && dist < best) {
+          best = dist;
+          lm = l0 + j;
+        }
       }
+    }
+  }
+  if (seg > 0) seg_best[seg - 1][lane] = make_int2(best, lm);
+  __syncthreads();
+  if (seg > 0) return;
+#pragma unroll
+  for (int sgm = 0; sgm < kMapSegs - 1; ++sgm) {
+    const int2 o = seg_best[sgm][lane];
+    if (o.x < best) {  // strict: ties stay with the lower segment = lower landmark index
+      best = o.x;
+      lm = o.y;
     }
   }
   if (in_range) {
@@ -621,6 +676,7 @@ __global__ __launch_bounds__(64) void match_to_map_kernel(
     best_d[k] = best;
   }
 }
+
 
 // ---- matchToMapByThreadUnitialised (Frontend.cpp:1616-1719) --------------------------------------
 // Landmarks that are not 3-D yet: pooled descriptor d carries the observing ray e0_W[d] and camera
@@ -853,7 +909,7 @@ void launch_match_to_map(const uint8_t* desc_k, const okvfe_keypoint* kps, const
                          const uint8_t* pool, double thr_sq, int threshold, int32_t* best_lm,
                          int32_t* best_d, hipStream_t stream) {
   if (n_k <= 0) return;
-  hipLaunchKernelGGL(match_to_map_kernel, dim3((n_k + 63) / 64), dim3(64), 0, stream, desc_k, kps,
+  hipLaunchKernelGGL(match_to_map_kernel, dim3((n_k + 63) / 64), dim3(64, kMapSegs), 0, stream, desc_k, kps,
                      use, n_k, projections, desc_begin, n_lm, pool, thr_sq, threshold, best_lm,
                      best_d);
 }
