@@ -107,7 +107,10 @@ def test_match_motion_stereo(oracle):
     assert np.all(e["k1"] == -1)
 
 
-def test_match_to_map_3d(oracle):
+@pytest.mark.parametrize("max_desc", [4, 8])
+def test_match_to_map_3d(oracle, max_desc):
+    """max_desc = 8: landmarks with up to 7 descriptors (more than the reference keeps), so some
+    64-landmark chunks exceed the LDS staging area and take the direct-read path."""
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg)
     rng = np.random.default_rng(8)
@@ -117,7 +120,7 @@ def test_match_to_map_3d(oracle):
     kps["y"] = rng.uniform(30, 450, n_k)
     desc = rng.integers(0, 256, (n_k, 48), dtype=np.uint8)
     use = (rng.random(n_k) > 0.15).astype(np.uint8)
-    counts = rng.integers(1, 4, n_lm)
+    counts = rng.integers(1, max_desc, n_lm)
     counts[::17] = 0  # landmarks without descriptors
     desc_begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
     pool = rng.integers(0, 256, (desc_begin[-1], 48), dtype=np.uint8)
