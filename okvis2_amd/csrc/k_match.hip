@@ -10,13 +10,17 @@
 //                         other gated loops: Frontend.cpp:1566-1587, 1651-1716, 1844-1893).
 //   popcount primitive    = brisk::Hamming::PopcntofXORed(a, b, 3) (Frontend.cpp:2024).
 //
-// Mapping: lane = one k0 with its 48-byte descriptor in 12 VGPRs; the k1 loop is wave-uniform,
-// so descriptor k1 arrives through scalar loads (SGPR broadcast) and each lane keeps the
-// reference's running minimum ("dist < best", k1 ascending, first-lowest wins) -- literally
-// the reference loop per lane, no cross-lane reduction.  The FP64 gate runs only in lanes
-// whose distance beats their running best, exactly when the reference evaluates it.
-// Integer-ALU bound (v_xor + v_bcnt_u32_b32, 24 VALU per pair); inputs are 2 x 33.6 KB per
-// EuRoC stereo frame, so HBM is not the limit.
+//   match_motion_*        matchMotionStereo (Frontend.cpp:1789-1905), host arrays or gather blocks.
+//   match_to_map_*        matchToMapByThread[Unitialised] (Frontend.cpp:1552-1589, 1616-1719).
+//
+// Mapping of the gated matchers: lane = one k0 with its 48-byte descriptor in 12 VGPRs; the other
+// side is cut into 4 segments (one wave each) whose descriptors are staged in LDS by coalesced
+// loads and read back as broadcasts.  The geometric gate of the reference does not depend on the
+// running best, so "first k1 reaching the smallest gated distance" is found in rounds: a
+// branch-free scan yields the two smallest admissible (dist, k1) keys per lane, the FP64 gate runs
+// once per key for all lanes together, rejected lanes raise their floor and rescan; the segments
+// are merged by (dist, segment).  Integer-ALU bound (v_xor + v_bcnt_u32_b32, 24 VALU per pair);
+// inputs are 2 x 33.6 KB per EuRoC stereo frame, so HBM is not the limit.
 #include "camera_dev.h"
 #include "okvfe_internal.h"
 

@@ -6,14 +6,18 @@
 // neighbour is strictly greater; of a horizontal run of equal passing pixels every second one,
 // starting with the leftmost, is kept (the raster scan skips the pixel after a hit).
 //
-// Roofline: HBM, 4 B/px read + 12 B per maximum written.
-// Fast path (w % 4 == 0): same strip mapping as K1 -- lane = one 16-byte column group (4 px),
-// 62 valid lanes per wave, the wave walks down its strip with a rolling window of three rows:
-// every score is loaded exactly once (1 KiB per wave per row); horizontal neighbours come from
-// the adjacent lanes through DPP wave shifts; the per-row horizontal 3-max is computed once and
-// reused for the row above and below.  Maxima are collected in LDS and appended to the image's
-// candidate list with ONE global atomic per workgroup.  Equal-score horizontal runs (which need
-// the serial parity rule) are detected per wave and resolved on a slow path.
+// In the batch pipeline the NMS is FUSED into the score kernel (k_harris.hip,
+// harris_kernel<TH, true>): a stand-alone pass has to read the whole score map back (4 B/px at
+// the ~3.8 TB/s read-only kernels reach here), which costs as much as computing it.  This file
+// keeps
+//   nms_fixup_kernel    settles the candidates the fused kernel flagged (runs of equal maxima);
+//   nms_kernel          the stand-alone fast path (w % 4 == 0; OKVFE_NO_FUSED_NMS, tiles of more
+//                       than 32 rows): same strip mapping as K1 -- lane = one 16-byte column group
+//                       (4 px), 62 valid lanes per wave, rolling window of three rows (fully
+//                       unrolled), horizontal neighbours through DPP wave shifts, hits recorded
+//                       as one bit mask per column, ONE slot reservation per wave after the loop;
+//   nms_generic_kernel  any width.
+// Roofline of the stand-alone kernels: HBM, 4 B/px read + 12 B per maximum written.
 #include "okvfe_internal.h"
 
 namespace okvfe {
