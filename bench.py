@@ -5,8 +5,9 @@ Workload (BASELINE.json metric, configs[2]): synthetic EuRoC-shaped stereo, 752x
 front-end parameters of config/euroc.yaml:63-67 (uniformity radius 38, Harris threshold 150,
 <= 700 keypoints, Hamming threshold 60), camera-aware gravity-aligned BRISK2 extraction,
 matchStereo with the FP64 triangulation gate.  One "step" = one batch of `--batch` stereo frames
-through the whole hot path (K1 harris -> K2 nms -> K3 sort/select -> K5 integral -> K6 describe ->
-compaction + back-projection -> K7 gated stereo match), inputs resident in HBM.
+(default 768 = 1536 images) through the whole hot path (K1 score map with the K2 NMS fused in ->
+K3 sort + greedy selection, K4 sub-pixel -> K6 describe -> compaction + back-projection -> K7 gated
+stereo match), inputs resident in HBM.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N > 1 is launched by torch.distributed.run (one rank per GPU); stereo frames are independent
@@ -99,17 +100,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="stereo frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=768, help="stereo frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
     ap.add_argument("--max-candidates", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=1,
-                    help="independent contexts/streams the batch is split over on each GPU "
-                         "(2 overlaps the latency-bound kernels of one lane with the other's "
-                         "throughput-bound ones: about +5 %% frames/s, but the score kernel then "
-                         "shares the GPU while it is being timed)")
+                    help="independent contexts/streams the batch is split over on each GPU.  With "
+                         "3 lanes and the score kernels serialised across them (--stagger) the "
+                         "latency-bound kernels of one lane hide behind the score kernel of "
+                         "another: about +10 %% frames/s, but the score kernel then shares the GPU "
+                         "while it is being timed (roofline.frac 0.35 instead of 0.44)")
+    ap.add_argument("--stagger", type=int, default=1,
+                    help="with --lanes > 1: serialise the score kernels of the lanes (library env "
+                         "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.lanes > 1 and args.stagger:
+        os.environ["OKVFE_SCORE_TOKEN"] = "1"  # read by libokvfe.so at its first batch call
     import torch
     from okvis2_amd import capi, synth
 
@@ -297,6 +304,7 @@ def main():
             "config": {"workload": "EuRoC-shaped 752x480 stereo, euroc.yaml front-end params "
                                    "(radius 38, thr 150, <=700 kpts, match thr 60)",
                        "stereo_frames_per_step_per_gpu": B, "lanes_per_gpu": S,
+                       "score_kernels_serialised_across_lanes": bool(S > 1 and args.stagger),
                        "stereo_frames_per_launch": Bl, "distinct_frames": distinct,
                        "mean_keypoints_per_image": kp_total / max(1, min(n_img, 2 * distinct)),
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},

@@ -187,6 +187,17 @@ okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_ke
                                          uint8_t* descriptors, double* backproj,
                                          uint8_t* backproj_valid, int32_t cap, int32_t* n_out);
 
+/* The batch call in two halves, = Frame::detect / Frame::describe of the reference
+ * (okvis_cv/include/okvis/implementation/Frame.hpp:140-154, 160-175): okvfe_detect_batch_device
+ * leaves the detected keypoints in the context, okvfe_describe_batch_device (same images, same
+ * n_images) extracts descriptors, compacts and back-projects.  Splitting lets a caller with
+ * several contexts / streams enqueue detect for all of them before describe for all of them. */
+okvfe_status okvfe_detect_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                       int32_t n_images, void* stream);
+okvfe_status okvfe_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                         int32_t n_images, const int32_t* cam_ids,
+                                         const float* gravity_C, void* stream);
+
 /* ---- single stages on device buffers (parity tests, profiling) ----------- */
 /* K1: Harris score maps, n_images * H * W int32. */
 okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev,

@@ -68,7 +68,8 @@ EXPORTS = [
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
-    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_match_motion_stereo_blocks_device", "okvfe_camera_overlap", "okvfe_compute",
+    "okvfe_profile_enable", "okvfe_profile_read", "okvfe_match_motion_stereo_blocks_device",
+    "okvfe_detect_batch_device", "okvfe_describe_batch_device", "okvfe_camera_overlap", "okvfe_compute",
     "okvfe_match_motion_stereo", "okvfe_match_to_map",
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
@@ -299,6 +300,16 @@ class Frontend:
     def harris_score_device(self, images_ptr, n_images, scores_ptr, stream=None):
         self._check(lib().okvfe_harris_score_device(self._h, _p(images_ptr), int(n_images),
                                                     _p(scores_ptr), _p(stream)))
+
+    def detect_batch_device(self, images_ptr, n_images, stream=None):
+        self._check(lib().okvfe_detect_batch_device(self._h, _p(images_ptr), int(n_images),
+                                                    _p(stream)))
+
+    def describe_batch_device(self, images_ptr, n_images, cam_ids=None, gravity=None, stream=None):
+        ids = None if cam_ids is None else np.ascontiguousarray(cam_ids, dtype=np.int32)
+        g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float32)
+        self._check(lib().okvfe_describe_batch_device(self._h, _p(images_ptr), int(n_images),
+                                                      _p(ids), _p(g), _p(stream)))
 
     def detect_describe_batch_device(self, images_ptr, n_images, cam_ids=None, gravity=None,
                                      stream=None):

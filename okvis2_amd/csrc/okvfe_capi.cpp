@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 #include "okvfe_internal.h"
 
@@ -21,6 +22,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct okvfe_ctx {
   okvfe_config cfg{};
   hipStream_t stream = nullptr;
+  hipEvent_t heavy_done[2] = {nullptr, nullptr};  // OKVFE_SCORE_TOKEN: after the score / describe kernel
+  int detected_images = 0;  // images covered by the last okvfe_detect_batch_device
   std::string err;
   int w = 0, h = 0, B = 0, kp_cap = 0, cand_cap = 0, ws_stride = 0;
   int occ_rows = 0, occ_cols = 0;
@@ -83,6 +86,24 @@ struct okvfe_ctx {
 };
 
 namespace {
+
+// OKVFE_SCORE_TOKEN=1: the score (+NMS) kernels of ALL contexts of the process on a device run one
+// after the other, in the order they were enqueued (each waits for the previous one's completion
+// event), while everything downstream of them is free to overlap.  With several contexts fed in
+// turn from several streams this staggers the pipelines: the VALU-bound score kernel of one batch
+// runs next to the latency-bound sort / greedy selection / matching of another one instead of next
+// to another score kernel.  OKVFE_SCORE_TOKEN=2 also chains the describe kernels (for callers that
+// enqueue detect for all contexts, then describe for all contexts).
+constexpr int kMaxTokenDevices = 64;
+std::mutex g_token_mutex;
+hipEvent_t g_score_token[kMaxTokenDevices] = {};
+int score_token_mode() {  // 0 off, 1 score kernel only, 2 score and describe kernels
+  static const int mode = [] {
+    const char* e = getenv("OKVFE_SCORE_TOKEN");
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
+}
 
 okvfe_status fail(okvfe_ctx* ctx, okvfe_status st, const char* fmt, ...) {
   char buf[512];
@@ -372,6 +393,13 @@ void okvfe_destroy(okvfe_ctx* ctx) {
     (void)hipEventDestroy(e.b);
   }
   for (auto& e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t ev : ctx->heavy_done) {
+    if (!ev) continue;
+    std::lock_guard<std::mutex> lock(g_token_mutex);
+    for (auto& t : g_score_token)
+      if (t == ev) t = nullptr;
+    (void)hipEventDestroy(ev);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -469,21 +497,35 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
   return OKVFE_OK;
 }
 
-okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
-                                                int32_t n_images, const int32_t* cam_ids,
-                                                const float* gravity_C, void* stream) {
-  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
-  if (!images_dev || n_images < 1 || n_images > ctx->B)
-    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_device: n_images=%d (max_batch %d)",
-                n_images, ctx->B);
-  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  hipStream_t s = pick_stream(ctx, stream);
-  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
-  if (st != OKVFE_OK) return st;
+// ---- batch pipeline ----------------------------------------------------------------------------
+// OKVFE_SCORE_TOKEN: see g_score_token.
+namespace {
+okvfe_status heavy_begin(okvfe_ctx* ctx, hipStream_t s, int which, bool* token) {
+  *token = score_token_mode() > which && ctx->cfg.device >= 0 && ctx->cfg.device < kMaxTokenDevices;
+  if (!*token) return OKVFE_OK;
+  std::lock_guard<std::mutex> lock(g_token_mutex);
+  hipEvent_t prev = g_score_token[ctx->cfg.device];
+  if (prev) HIP_TRY(ctx, hipStreamWaitEvent(s, prev, 0));
+  return OKVFE_OK;
+}
+okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which) {
+  std::lock_guard<std::mutex> lock(g_token_mutex);
+  hipEvent_t& ev = ctx->heavy_done[which];
+  if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventRecord(ev, s));
+  g_score_token[ctx->cfg.device] = ev;
+  return OKVFE_OK;
+}
+
+// K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count
+okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
   const int w = ctx->w, h = ctx->h;
   // d_cand_count: [0, B) candidate counts, [B, 2B) per-image counts of flagged candidates
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
   int32_t* d_fix_count = ctx->d_cand_count + ctx->B;
+  bool token = false;
+  okvfe_status st = heavy_begin(ctx, s, 0, &token);
+  if (st != OKVFE_OK) return st;
   bool fused;
   {
     StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
@@ -491,6 +533,7 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
                               ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, d_fix_count, s);
     if (!fused) launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
   }
+  if (token && (st = heavy_end(ctx, s, 0)) != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_NMS, s);
     if (fused)
@@ -512,12 +555,25 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
                   ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols, ctx->d_kps_det, ctx->kp_cap,
                   ctx->d_det_count, ctx->d_sort_ws, s);
   }
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_n_images = n_images;
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+// K6 + compaction + back-projection of the keypoints detect_stage left in d_kps_det
+okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
+  const int w = ctx->w, h = ctx->h;
+  bool token = false;
+  okvfe_status st = heavy_begin(ctx, s, 1, &token);
+  if (st != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
   }
+  if (token && (st = heavy_end(ctx, s, 1)) != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_COMPACT, s);
     launch_compact(n_images, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp,
@@ -525,9 +581,52 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
                    ctx->d_count, s);
   }
   HIP_TRY(ctx, hipGetLastError());
-  ctx->last_n_images = n_images;
   ctx->last_stream = s;
   return OKVFE_OK;
+}
+}  // namespace
+
+okvfe_status okvfe_detect_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                       void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_batch_device: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  ctx->detected_images = 0;
+  okvfe_status st = detect_stage(ctx, images_dev, n_images, pick_stream(ctx, stream));
+  if (st == OKVFE_OK) ctx->detected_images = n_images;
+  return st;
+}
+
+okvfe_status okvfe_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                         const int32_t* cam_ids, const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images != ctx->detected_images)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT,
+                "okvfe_describe_batch_device: n_images=%d, but the last okvfe_detect_batch_device "
+                "covered %d", n_images, ctx->detected_images);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  if (st != OKVFE_OK) return st;
+  return describe_stage(ctx, images_dev, n_images, s);
+}
+
+okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                                int32_t n_images, const int32_t* cam_ids,
+                                                const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_device: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  if (st != OKVFE_OK) return st;
+  if ((st = detect_stage(ctx, images_dev, n_images, s)) != OKVFE_OK) return st;
+  ctx->detected_images = n_images;
+  return describe_stage(ctx, images_dev, n_images, s);
 }
 
 okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out) {
