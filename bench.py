@@ -278,13 +278,13 @@ def main():
         # HBM traffic of the K1 launch from the PMC passes committed under profiles/ (rocprofv3
         # cannot run inside this process); only valid for the launch shape it was measured on
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "round1_v2_k1_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "round1_v3_k1_pmc.json")
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
             # same kernel, same image shape: per-image HBM bytes x the images of one launch here
             if pmc.get("algorithmic_bytes_per_launch") == 5 * P * pmc.get("images_per_launch", 0):
                 traffic = pmc["hbm_bytes_per_image"] * n_img_launch
-                traffic_src = ("profiles/round1_v2_k1_pmc.json (FETCH_SIZE/WRITE_SIZE passes at %d "
+                traffic_src = ("profiles/round1_v3_k1_pmc.json (FETCH_SIZE/WRITE_SIZE passes at %d "
                                "images per launch, scaled per image)" % pmc["images_per_launch"])
         m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
         fe._bench_matches = m

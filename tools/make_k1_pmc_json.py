@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds profiles/<tag>_k1_pmc.json from the two PMC passes of tools/collect_profiles.sh.
 
-usage: make_k1_pmc_json.py <tag> [images_per_launch=512] [w=752] [h=480]
+usage: make_k1_pmc_json.py <tag> [images_per_launch (default: from gpurun_out/<tag>_bench.json)]
+       [w=752] [h=480]
 FETCH_SIZE / WRITE_SIZE are reported in KiB; their scale is calibrated on the 256 MiB
 bitwise_not kernel bench.py runs under OKVFE_PMC_CALIB=1 in the same process (it reads and writes
 exactly 262144 KiB): on gfx950 FETCH_SIZE comes out at half the bytes read, WRITE_SIZE at 1.0."""
@@ -10,7 +11,13 @@ import os
 import sys
 
 tag = sys.argv[1]
-n_img = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:  # images per launch of the profiled command = the bench line of the same collection
+    _b = json.load(open(os.path.join(_root, "gpurun_out", f"{tag}_bench.json")))
+    _default_n = 2 * int(_b["config"]["stereo_frames_per_launch"])
+except Exception:
+    _default_n = 512
+n_img = int(sys.argv[2]) if len(sys.argv) > 2 else _default_n
 w = int(sys.argv[3]) if len(sys.argv) > 3 else 752
 h = int(sys.argv[4]) if len(sys.argv) > 4 else 480
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
