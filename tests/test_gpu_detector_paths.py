@@ -172,3 +172,69 @@ def test_batch_of_odd_size_mixed_images(oracle, n_images, mode):
         total += len(k)
     assert total > 100 * (n_images // 2)
     assert len(fe.download(4)[0]) == 0
+
+
+def test_split_batch_api_equals_combined_call():
+    cfg = synth.euroc_config()
+    n = 6
+    fe = G.make_frontend(cfg, max_batch=n)
+    for ci, cam in enumerate(cfg.cams):
+        fe.set_camera(ci, cam)
+    imgs = np.stack([im for i in range(n // 2) for im in synth.stereo_pair(cfg.w, cfg.h, 60 + i)[:2]])
+    d_img = torch.from_numpy(imgs).cuda()
+    cam_ids = np.array([0, 1] * (n // 2), dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (n, 1))
+    s = torch.cuda.current_stream().cuda_stream
+    fe.detect_describe_batch_device(d_img.data_ptr(), n, cam_ids, grav, s)
+    ref = [fe.download(i) for i in range(n)]
+    fe.detect_batch_device(d_img.data_ptr(), n, s)
+    fe.describe_batch_device(d_img.data_ptr(), n, cam_ids, grav, s)
+    for i in range(n):
+        got = fe.download(i)
+        for a, b in zip(got, ref[i]):
+            assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+        assert len(got[0]) > 50
+    with pytest.raises(capi.OkvfeError):  # describe must follow a detect of the same size
+        fe.describe_batch_device(d_img.data_ptr(), n - 2, cam_ids[:n - 2], grav[:n - 2], s)
+
+
+_TOKEN_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import torch
+from okvis2_amd import capi, synth
+import oracle_lib as O, gpu_common as G
+cfg = synth.mono640_config()
+lanes = []
+for l in range(3):
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                       rotation_invariant=False, max_batch=4, num_cameras=1)
+    imgs = np.stack([synth.corners_image(cfg.w, cfg.h, 10 * l + i) for i in range(4)])
+    lanes.append((fe, imgs, torch.from_numpy(imgs).cuda(), torch.cuda.Stream()))
+torch.cuda.synchronize()
+for rep in range(5):
+    if int(sys.argv[2]) == 2:   # stage-major: all detects, then all describes
+        for fe, _, d, st in lanes: fe.detect_batch_device(d.data_ptr(), 4, st.cuda_stream)
+        for fe, _, d, st in lanes: fe.describe_batch_device(d.data_ptr(), 4, None, None, st.cuda_stream)
+    else:
+        for fe, _, d, st in lanes: fe.detect_describe_batch_device(d.data_ptr(), 4, None, None, st.cuda_stream)
+torch.cuda.synchronize()
+for fe, imgs, _, _ in lanes:
+    for i in range(4):
+        k, dsc = O.detect_describe(imgs[i], cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                   O.MODE_UPRIGHT)
+        g = fe.download(i)
+        G.assert_keypoints_equal(g[0], k)
+        assert np.array_equal(g[1], dsc)
+print("TOKEN-OK")
+"""
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_score_token_across_contexts(oracle, mode):
+    """OKVFE_SCORE_TOKEN chains the heavy kernels of three contexts on three streams through
+    events: same results, no deadlock, in both enqueue orders."""
+    env = dict(os.environ, OKVFE_SCORE_TOKEN=str(mode))
+    out = subprocess.run([sys.executable, "-c", _TOKEN_CHILD, ROOT, str(mode)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TOKEN-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
