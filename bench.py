@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--stagger", type=int, default=1,
                     help="with --lanes > 1: serialise the score kernels of the lanes (library env "
                          "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
+    ap.add_argument("--workload", choices=("euroc", "tumvi"), default="euroc",
+                    help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3], "
+                         "1024x1024 equidistant stereo with config/tumvi_slam_1024.yaml parameters "
+                         "(informational, batch 192 by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -136,7 +140,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = synth.euroc_config()
+    cfg = synth.euroc_config() if args.workload == "euroc" else synth.tumvi1024_config()
+    if args.workload == "tumvi" and args.batch == 768:
+        args.batch = 192  # same pixels per step as 768 EuRoC frames would be 264; keep it modest
     if os.environ.get("OKVFE_BENCH_MAXKP"):  # experiment knob: keypoint capacity of the context
         cfg.max_kpts = int(os.environ["OKVFE_BENCH_MAXKP"])
     B = args.batch
@@ -289,7 +295,9 @@ def main():
         m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
         fe._bench_matches = m
         result = {
-            "metric": "front-end stereo-frames/s (detect+describe+match), 752x480 stereo",
+            "metric": ("front-end stereo-frames/s (detect+describe+match), 752x480 stereo"
+                       if args.workload == "euroc" else
+                       "front-end stereo-frames/s (detect+describe+match), 1024x1024 stereo (TUM-VI)"),
             "value": world * B * args.steps / elapsed,
             "unit": "stereo-frames/s",
             "n_gpus": world,
@@ -301,8 +309,11 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32 (detect, describe, Hamming) + f64 (match gate)",
             "data": "synthetic",
-            "config": {"workload": "EuRoC-shaped 752x480 stereo, euroc.yaml front-end params "
-                                   "(radius 38, thr 150, <=700 kpts, match thr 60)",
+            "config": {"workload": ("EuRoC-shaped 752x480 stereo, euroc.yaml front-end params "
+                                    "(radius 38, thr 150, <=700 kpts, match thr 60)"
+                                    if args.workload == "euroc" else
+                                    "TUM-VI-shaped 1024x1024 equidistant stereo, tumvi_slam_1024.yaml "
+                                    "front-end params (radius 50, thr 5, <=1000 kpts, match thr 60)"),
                        "stereo_frames_per_step_per_gpu": B, "lanes_per_gpu": S,
                        "score_kernels_serialised_across_lanes": bool(S > 1 and args.stagger),
                        "stereo_frames_per_launch": Bl, "distinct_frames": distinct,

@@ -242,32 +242,43 @@ __global__ __launch_bounds__(256) void nms_fixup_kernel(const int32_t* __restric
                                                         int cand_cap,
                                                         int32_t* __restrict__ cand_count,
                                                         const int32_t* __restrict__ fix_count) {
+  __shared__ int wave_cnt[4];
+  __shared__ int s_base;
   const int img = blockIdx.x;
   if (fix_count[img] == 0) return;
   const int32_t* s = scores + (size_t)img * w * h;
   Candidate* c = cand + (size_t)img * cand_cap;
   const int total = cand_count[img];
-  int n = total < cand_cap ? total : cand_cap;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int y = c[i].y;
-    if (y & kCandidateFixupFlag) {
-      const int yy = y & ~kCandidateFixupFlag;
-      c[i].y = accepted_slow(s, w, c[i].x, yy, thr) ? yy : -1;
-    }
-  }
+  const int n = total < cand_cap ? total : cand_cap;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_base = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int i = 0;
-    while (i < n) {
-      if (c[i].y < 0) {
-        c[i] = c[n - 1];
-        --n;
-      } else {
-        ++i;
+  // in-place forward compaction in chunks of 256: a chunk is read completely before its survivors
+  // are written at or before their old positions
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + tid;
+    Candidate cd;
+    bool keep = false;
+    if (i < n) {
+      cd = c[i];
+      keep = true;
+      if (cd.y & kCandidateFixupFlag) {
+        cd.y &= ~kCandidateFixupFlag;
+        keep = accepted_slow(s, w, cd.x, cd.y, thr);
       }
     }
-    cand_count[img] = total > cand_cap ? total : n;  // an overflowing list stays marked as such
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) wave_cnt[wv] = __popcll(b);
+    __syncthreads();
+    int pos = s_base;
+    for (int k = 0; k < wv; ++k) pos += wave_cnt[k];
+    pos += __popcll(b & ((1ull << lane) - 1ull));
+    if (keep) c[pos] = cd;
+    __syncthreads();
+    if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
   }
+  if (tid == 0) cand_count[img] = total > cand_cap ? total : s_base;  // an overflowing list stays marked
 }
 
 }  // namespace
