@@ -29,15 +29,20 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~
 
 
 def make_inputs(cfg, n_frames, n_distinct, seed0):
+    """Multiframes of C = len(cfg.cams) images: cameras 0/1 are a synthetic stereo pair, further
+    cameras (Hilti-shaped rig) look elsewhere and get independent images."""
     from okvis2_amd import synth
+    C = len(cfg.cams)
     base = []
     for i in range(n_distinct):
         L, R, _ = synth.stereo_pair(cfg.w, cfg.h, seed0 + i)
         base.append(L)
         base.append(R)
-    base = np.stack(base)  # [2*n_distinct, H, W]
+        for c in range(2, C):
+            base.append(synth.corners_image(cfg.w, cfg.h, seed0 + 7919 * c + i))
+    base = np.stack(base)  # [C*n_distinct, H, W]
     reps = (n_frames + n_distinct - 1) // n_distinct
-    return np.concatenate([base] * reps)[: 2 * n_frames], base
+    return np.concatenate([base] * reps)[: C * n_frames], base
 
 
 def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
@@ -52,8 +57,9 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
     T0, T1 = synth.stereo_poses(cfg.baseline)
     f = [0.5 * (c.fu + c.fv) for c in cfg.cams]
     grav = (0.0, 1.0, 0.0)
-    n_distinct = len(base_imgs) // 2
-    out = [None, None]
+    C = len(cfg.cams)
+    n_distinct = len(base_imgs) // C
+    out = [None] * C
 
     def work(ci, img):
         cam = cfg.cams[ci]
@@ -67,29 +73,32 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
     t0 = time.perf_counter()
     while True:
         i = done % n_distinct
-        th = threading.Thread(target=work, args=(1, base_imgs[2 * i + 1]))
-        th.start()
-        work(0, base_imgs[2 * i])
-        th.join()
-        (k0, d0, b0, v0), (k1, d1, b1, v1) = out
+        ths = [threading.Thread(target=work, args=(c, base_imgs[C * i + c])) for c in range(1, C)]
+        for th in ths:
+            th.start()
+        work(0, base_imgs[C * i])
+        for th in ths:
+            th.join()
+        (k0, d0, b0, v0), (k1, d1, b1, v1) = out[0], out[1]
         m = O.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[0], f[1], cfg.match_threshold)
         done += 1
         elapsed = time.perf_counter() - t0
         if done <= n_distinct and fe is not None:  # checker leg, outside the measured work
             t_chk = time.perf_counter()
-            g0, g1 = fe.download(2 * i), fe.download(2 * i + 1)
-            ok = (np.array_equal(g0[0].view(np.uint8), k0.view(np.uint8)) and
-                  np.array_equal(g1[0].view(np.uint8), k1.view(np.uint8)) and
-                  np.array_equal(g0[1], d0) and np.array_equal(g1[1], d1) and
-                  np.array_equal(fe._bench_matches[i, :len(k0)]["k1"], m["k1"]))
+            ok = np.array_equal(fe._bench_matches[i, :len(k0)]["k1"], m["k1"])
+            for c in range(C):
+                g = fe.download(C * i + c)
+                ok = ok and np.array_equal(g[0].view(np.uint8), out[c][0].view(np.uint8)) \
+                    and np.array_equal(g[1], out[c][1])
             checked += 1
             mismatches += 0 if ok else 1
             t0 += time.perf_counter() - t_chk
         if elapsed >= budget_s and done >= 8:
             break
     elapsed = time.perf_counter() - t0
-    return {"value": done / elapsed, "unit": "stereo-frames/s", "cores": 2, "kind": "port",
-            "sample": f"{done} stereo frames of the bench workload ({n_distinct} distinct), "
+    return {"value": done / elapsed, "unit": "stereo-frames/s" if C == 2 else "multiframes/s",
+            "cores": C, "kind": "port",
+            "sample": f"{done} multiframes of the bench workload ({n_distinct} distinct), "
                       f"{elapsed:.1f} s; 1 thread per camera for detect+describe, match serial; "
                       f"host has {os.cpu_count()} logical cores",
             "parity_checked_frames": checked, "parity_mismatches": mismatches}
@@ -112,10 +121,12 @@ def main():
     ap.add_argument("--stagger", type=int, default=1,
                     help="with --lanes > 1: serialise the score kernels of the lanes (library env "
                          "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
-    ap.add_argument("--workload", choices=("euroc", "tumvi"), default="euroc",
+    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti"), default="euroc",
                     help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3], "
-                         "1024x1024 equidistant stereo with config/tumvi_slam_1024.yaml parameters "
-                         "(informational, batch 192 by default)")
+                         "1024x1024 equidistant stereo with config/tumvi_slam_1024.yaml parameters; "
+                         "hilti = configs[4] shape, 5 equidistant 720x540 cameras per multiframe "
+                         "(hilti_challenge_2022.yaml parameters), the forward pair matched "
+                         "(informational; batch 192 by default for both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,13 +151,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = synth.euroc_config() if args.workload == "euroc" else synth.tumvi1024_config()
-    if args.workload == "tumvi" and args.batch == 768:
-        args.batch = 192  # same pixels per step as 768 EuRoC frames would be 264; keep it modest
+    cfg = {"euroc": synth.euroc_config, "tumvi": synth.tumvi1024_config,
+           "hilti": synth.hilti_config}[args.workload]()
+    if args.workload == "hilti":
+        # synthetic rig: cameras 0/1 form the forward stereo pair (shared intrinsics so that the
+        # synthetic disparity is epipolar-consistent), 2..4 look elsewhere (no FoV overlap)
+        cfg.cams = [cfg.cams[0], cfg.cams[0]] + list(cfg.cams[2:])
+    if args.workload != "euroc" and args.batch == 768:
+        args.batch = 192
     if os.environ.get("OKVFE_BENCH_MAXKP"):  # experiment knob: keypoint capacity of the context
         cfg.max_kpts = int(os.environ["OKVFE_BENCH_MAXKP"])
     B = args.batch
-    n_img = 2 * B
+    C = len(cfg.cams)  # images per multiframe
+    n_img = C * B
     distinct = min(args.distinct, B)
     imgs, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank)
     d_img = torch.from_numpy(imgs).to(dev)
@@ -163,12 +180,12 @@ def main():
     f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
     d_match = torch.zeros((B, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8,
                           device=dev)
-    cam_ids = np.array([0, 1] * Bl, dtype=np.int32)
-    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (2 * Bl, 1))
+    cam_ids = np.array(list(range(C)) * Bl, dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (C * Bl, 1))
     pairs = []
     for i in range(Bl):
         sp = capi.StereoPair()
-        sp.image0, sp.image1 = 2 * i, 2 * i + 1
+        sp.image0, sp.image1 = C * i, C * i + 1
         sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
         sp.f0, sp.f1 = f0, f1
         pairs.append(sp)
@@ -176,14 +193,14 @@ def main():
     lanes = []
     for l in range(S):
         lfe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold,
-                            cfg.max_kpts, match_threshold=cfg.match_threshold, max_batch=2 * Bl,
-                            num_cameras=2, device=local_rank, max_candidates=args.max_candidates)
+                            cfg.max_kpts, match_threshold=cfg.match_threshold, max_batch=C * Bl,
+                            num_cameras=C, device=local_rank, max_candidates=args.max_candidates)
         for ci, cam in enumerate(cfg.cams):
             lfe.set_camera(ci, cam)
         st = torch.cuda.Stream(device=dev) if S > 1 else torch.cuda.current_stream()
-        lanes.append((lfe, st.cuda_stream, d_img[2 * l * Bl:].data_ptr(), d_match[l * Bl:].data_ptr(), st))
+        lanes.append((lfe, st.cuda_stream, d_img[C * l * Bl:].data_ptr(), d_match[l * Bl:].data_ptr(), st))
     fe = lanes[0][0]
-    n_lane_img = 2 * Bl
+    n_lane_img = C * Bl
 
     def step():
         for lfe, stream, img_ptr, match_ptr, _ in lanes:
@@ -225,7 +242,7 @@ def main():
     # capacity check (outside the timed region): download() raises OKVFE_ERR_CAPACITY if any NMS
     # candidate list of the checked images overflowed its buffer
     kp_total = 0
-    for i in range(min(n_img, 2 * distinct)):
+    for i in range(min(n_img, C * distinct)):
         k, _, _, _ = fe.download(i)
         kp_total += len(k)
 
@@ -295,11 +312,13 @@ def main():
         m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
         fe._bench_matches = m
         result = {
-            "metric": ("front-end stereo-frames/s (detect+describe+match), 752x480 stereo"
-                       if args.workload == "euroc" else
-                       "front-end stereo-frames/s (detect+describe+match), 1024x1024 stereo (TUM-VI)"),
+            "metric": {"euroc": "front-end stereo-frames/s (detect+describe+match), 752x480 stereo",
+                       "tumvi": "front-end stereo-frames/s (detect+describe+match), 1024x1024 stereo "
+                                "(TUM-VI)",
+                       "hilti": "front-end multiframes/s (5 x detect+describe + forward-pair match), "
+                                "720x540 x 5 cameras (Hilti 2022)"}[args.workload],
             "value": world * B * args.steps / elapsed,
-            "unit": "stereo-frames/s",
+            "unit": "stereo-frames/s" if C == 2 else "multiframes/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -313,11 +332,16 @@ def main():
                                     "(radius 38, thr 150, <=700 kpts, match thr 60)"
                                     if args.workload == "euroc" else
                                     "TUM-VI-shaped 1024x1024 equidistant stereo, tumvi_slam_1024.yaml "
-                                    "front-end params (radius 50, thr 5, <=1000 kpts, match thr 60)"),
+                                    "front-end params (radius 50, thr 5, <=1000 kpts, match thr 60)"
+                                    if args.workload == "tumvi" else
+                                    "Hilti-shaped rig, 5 equidistant 720x540 cameras, "
+                                    "hilti_challenge_2022.yaml front-end params (radius 50, thr 20, "
+                                    "<=700 kpts, match thr 60), forward pair matched"),
                        "stereo_frames_per_step_per_gpu": B, "lanes_per_gpu": S,
                        "score_kernels_serialised_across_lanes": bool(S > 1 and args.stagger),
                        "stereo_frames_per_launch": Bl, "distinct_frames": distinct,
-                       "mean_keypoints_per_image": kp_total / max(1, min(n_img, 2 * distinct)),
+                       "mean_keypoints_per_image": kp_total / max(1, min(n_img, C * distinct)),
+                       "cameras_per_multiframe": C,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"kernel": "harris_kernel<30, true> (K1 score map + fused K2 NMS)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -16,6 +16,10 @@ cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kerne
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats3 -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 3 > /tmp/prof_stats3.log 2>&1
 cp $(find /tmp/prof_stats3 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats_3lanes.csv
 grep '^{"metric"' /tmp/prof_stats3.log | tail -1 > $OUT/${TAG}_bench_3lanes.json
+# the other BASELINE shapes (informational bench lines, CPU baseline + parity leg included)
+for W in tumvi hilti; do
+  python $R/bench.py --workload $W 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_$W.json
+done
 export OKVFE_PMC_CALIB=1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o p -- $BENCH --steps 3 > /tmp/prof_$C.log 2>&1
