@@ -79,13 +79,16 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
         work(0, base_imgs[C * i])
         for th in ths:
             th.join()
-        (k0, d0, b0, v0), (k1, d1, b1, v1) = out[0], out[1]
-        m = O.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[0], f[1], cfg.match_threshold)
+        (k0, d0, b0, v0) = out[0]
+        m = None
+        if C > 1:
+            (k1, d1, b1, v1) = out[1]
+            m = O.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[0], f[1], cfg.match_threshold)
         done += 1
         elapsed = time.perf_counter() - t0
         if done <= n_distinct and fe is not None:  # checker leg, outside the measured work
             t_chk = time.perf_counter()
-            ok = np.array_equal(fe._bench_matches[i, :len(k0)]["k1"], m["k1"])
+            ok = m is None or np.array_equal(fe._bench_matches[i, :len(k0)]["k1"], m["k1"])
             for c in range(C):
                 g = fe.download(C * i + c)
                 ok = ok and np.array_equal(g[0].view(np.uint8), out[c][0].view(np.uint8)) \
@@ -96,7 +99,8 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
         if elapsed >= budget_s and done >= 8:
             break
     elapsed = time.perf_counter() - t0
-    return {"value": done / elapsed, "unit": "stereo-frames/s" if C == 2 else "multiframes/s",
+    return {"value": done / elapsed,
+            "unit": {1: "frames/s", 2: "stereo-frames/s"}.get(C, "multiframes/s"),
             "cores": C, "kind": "port",
             "sample": f"{done} multiframes of the bench workload ({n_distinct} distinct), "
                       f"{elapsed:.1f} s; 1 thread per camera for detect+describe, match serial; "
@@ -121,12 +125,13 @@ def main():
     ap.add_argument("--stagger", type=int, default=1,
                     help="with --lanes > 1: serialise the score kernels of the lanes (library env "
                          "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
-    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti"), default="euroc",
+    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640"), default="euroc",
                     help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3], "
                          "1024x1024 equidistant stereo with config/tumvi_slam_1024.yaml parameters; "
                          "hilti = configs[4] shape, 5 equidistant 720x540 cameras per multiframe "
                          "(hilti_challenge_2022.yaml parameters), the forward pair matched "
-                         "(informational; batch 192 by default for both)")
+                         "; mono640 = configs[1], 640x480 mono, ~1000 keypoints, detect+describe "
+                         "only (informational; batch 192 by default for these)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,7 +157,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     cfg = {"euroc": synth.euroc_config, "tumvi": synth.tumvi1024_config,
-           "hilti": synth.hilti_config}[args.workload]()
+           "hilti": synth.hilti_config, "mono640": synth.mono640_config}[args.workload]()
     if args.workload == "hilti":
         # synthetic rig: cameras 0/1 form the forward stereo pair (shared intrinsics so that the
         # synthetic disparity is epipolar-consistent), 2..4 look elsewhere (no FoV overlap)
@@ -177,7 +182,7 @@ def main():
     Bl = B // S
     T0, T1 = synth.stereo_poses(cfg.baseline)
     f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
-    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    f1 = 0.5 * (cfg.cams[min(1, C - 1)].fu + cfg.cams[min(1, C - 1)].fv)
     d_match = torch.zeros((B, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8,
                           device=dev)
     cam_ids = np.array(list(range(C)) * Bl, dtype=np.int32)
@@ -185,7 +190,7 @@ def main():
     pairs = []
     for i in range(Bl):
         sp = capi.StereoPair()
-        sp.image0, sp.image1 = C * i, C * i + 1
+        sp.image0, sp.image1 = C * i, C * i + (1 if C > 1 else 0)
         sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
         sp.f0, sp.f1 = f0, f1
         pairs.append(sp)
@@ -205,7 +210,8 @@ def main():
     def step():
         for lfe, stream, img_ptr, match_ptr, _ in lanes:
             lfe.detect_describe_batch_device(img_ptr, n_lane_img, cam_ids, grav, stream)
-            lfe.match_stereo_batch_device(pairs_arr, match_ptr, stream)
+            if C > 1:
+                lfe.match_stereo_batch_device(pairs_arr, match_ptr, stream)
 
     def barrier():
         if dist is not None:
@@ -316,9 +322,10 @@ def main():
                        "tumvi": "front-end stereo-frames/s (detect+describe+match), 1024x1024 stereo "
                                 "(TUM-VI)",
                        "hilti": "front-end multiframes/s (5 x detect+describe + forward-pair match), "
-                                "720x540 x 5 cameras (Hilti 2022)"}[args.workload],
+                                "720x540 x 5 cameras (Hilti 2022)",
+                       "mono640": "front-end frames/s (detect+describe), 640x480 mono"}[args.workload],
             "value": world * B * args.steps / elapsed,
-            "unit": "stereo-frames/s" if C == 2 else "multiframes/s",
+            "unit": {1: "frames/s", 2: "stereo-frames/s"}.get(C, "multiframes/s"),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -334,6 +341,8 @@ def main():
                                     "TUM-VI-shaped 1024x1024 equidistant stereo, tumvi_slam_1024.yaml "
                                     "front-end params (radius 50, thr 5, <=1000 kpts, match thr 60)"
                                     if args.workload == "tumvi" else
+                                    "640x480 mono (radius 10, thr 5, <=1000 kpts), detect+describe"
+                                    if args.workload == "mono640" else
                                     "Hilti-shaped rig, 5 equidistant 720x540 cameras, "
                                     "hilti_challenge_2022.yaml front-end params (radius 50, thr 20, "
                                     "<=700 kpts, match thr 60), forward pair matched"),
