@@ -358,22 +358,27 @@ constexpr int kSelThreads = 256;
 constexpr int kStampIts = (kStampCells + kSelThreads - 1) / kSelThreads;
 constexpr int kRoundCap = 64;
 
+// OCC_LDS = false: the occupancy grid does not fit in LDS (small uniformity radius or large images)
+// and lives in the context's HBM workspace (zeroed by the launcher); same algorithm, the byte
+// reads / read-modify-writes go to L2 and the workgroup barriers order them.
+template <bool OCC_LDS>
 __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     const int32_t* __restrict__ scores, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int occ_cols, int occ_bytes16,
     int acc_bytes16, int chunk_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
-    int32_t* __restrict__ kp_count) {
+    int32_t* __restrict__ kp_count, uint8_t* __restrict__ occ_hbm, size_t occ_hbm_pitch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int2 round_list[kRoundCap];  // {cell, 0.99 * level} of the points accepted this round
   __shared__ int s_round, s_pos, s_kept;
   // serial dependency chain: when other streams' kernels share the SIMD, these waves should win
   // arbitration, the throughput kernels fill the gaps
   __builtin_amdgcn_s_setprio(3);
-  uint8_t* occ = smem_raw;
-  uint16_t* acc_idx = reinterpret_cast<uint16_t*>(smem_raw + occ_bytes16);
-  uint2* recs = reinterpret_cast<uint2*>(smem_raw + occ_bytes16 + acc_bytes16);
   const int img = blockIdx.x;
+  const int lds_occ = OCC_LDS ? occ_bytes16 : 0;  // LDS bytes taken by the grid
+  uint8_t* occ = OCC_LDS ? smem_raw : occ_hbm + (size_t)img * occ_hbm_pitch;
+  uint16_t* acc_idx = reinterpret_cast<uint16_t*>(smem_raw + lds_occ);
+  uint2* recs = reinterpret_cast<uint2*>(smem_raw + lds_occ + acc_bytes16);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const bool decider = tid < 64;  // wave 0
@@ -384,7 +389,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
   if (n > 0) {  // block-uniform
-    {
+    if (OCC_LDS) {
       uint4* z = reinterpret_cast<uint4*>(smem_raw);
       const uint4 zero = make_uint4(0, 0, 0, 0);
       for (int i = tid; i < (occ_bytes16 >> 4); i += kSelThreads) z[i] = zero;
@@ -583,9 +588,25 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
       const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
       if (chunk > need) chunk = need;
       const size_t lds = fixed + chunk * 8;
-      hipLaunchKernelGGL(select_greedy_kernel, dim3(n_images), dim3(kSelThreads), lds, stream, score, w, h,
-                         cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, occ_cols,
-                         (int)occ_bytes, (int)acc_bytes, (int)chunk, kps, kp_cap, kp_count);
+      hipLaunchKernelGGL(select_greedy_kernel<true>, dim3(n_images), dim3(kSelThreads), lds, stream,
+                         score, w, h, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
+                         occ_cols, (int)occ_bytes, (int)acc_bytes, (int)chunk, kps, kp_cap, kp_count,
+                         (uint8_t*)nullptr, (size_t)0);
+      return;
+    }
+  }
+  if (radius > 0.0f && cand_cap <= 65536 && occupancy != nullptr) {
+    // grid in HBM: LDS only holds the accepted indices and the record chunk (24 KiB: 6 images / CU)
+    static const bool legacy = getenv("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
+    if (!legacy) {
+      size_t chunk = (24 * 1024 - acc_bytes) / 8 / 64 * 64;
+      const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
+      if (chunk > need) chunk = need;
+      (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
+      hipLaunchKernelGGL(select_greedy_kernel<false>, dim3(n_images), dim3(kSelThreads),
+                         acc_bytes + chunk * 8, stream, score, w, h, cand_cap, cand_count, sort_ws,
+                         ws_stride, radius, max_kpts, lut, occ_cols, (int)occ_bytes, (int)acc_bytes,
+                         (int)chunk, kps, kp_cap, kp_count, occupancy, occ_image_bytes);
       return;
     }
   }

@@ -84,6 +84,30 @@ def test_standalone_score_and_nms_kernels(oracle):
     assert out.returncode == 0 and "UNFUSED-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+_LEGACY_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from okvis2_amd import capi, synth
+import oracle_lib as O, gpu_common as G
+w, h = 640, 480
+for seed, radius, maxk in ((3, 10.0, 1000), (4, 6.0, 4000)):
+    img = synth.corners_image(w, h, seed)
+    fe = capi.Frontend(w, h, radius, 0, 5, maxk, max_candidates=1 << 16)
+    G.assert_keypoints_equal(fe.detect(img), O.detect(img, radius, 0, 5, maxk))
+print("LEGACY-OK")
+"""
+
+
+def test_legacy_select_kernel_for_grids_outside_lds(oracle):
+    """Occupancy grids that do not fit in LDS normally take select_greedy_kernel<false> (grid in
+    HBM; covered by the small-radius cases above); OKVFE_LEGACY_SELECT keeps the older
+    one-accept-per-round kernel reachable, which is also the path for > 65536 candidates."""
+    env = dict(os.environ, OKVFE_LEGACY_SELECT="1")
+    out = subprocess.run([sys.executable, "-c", _LEGACY_CHILD, ROOT], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "LEGACY-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_profile_stage_mask():
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg, max_batch=2)
