@@ -34,11 +34,17 @@ __device__ __forceinline__ uint64_t make_key(const Candidate& c) {
          (uint32_t)c.x;
 }
 
+// Launched twice when the candidate capacity exceeds kLdsSortKeys: first with 64 KiB of LDS for the
+// images whose (padded) candidate count fits 8192 keys -- two workgroups per CU --, then with
+// 128 KiB for the few that need up to 16384 keys; lds_lo_keys / lds_keys bound the range a launch
+// handles, every other image is left to the other launch.  Above 16384 keys the network runs in
+// the HBM workspace.
 __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restrict__ cand,
                                                         int cand_cap,
                                                         const int32_t* __restrict__ cand_count,
                                                         uint64_t* __restrict__ sort_ws,
-                                                        int ws_stride) {
+                                                        int ws_stride, int lds_lo_keys,
+                                                        int lds_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
   const int img = blockIdx.x;
@@ -49,7 +55,9 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
   int np = 1;
   while (np < n) np <<= 1;
   const int tid = threadIdx.x;
-  if (np <= kLdsSortKeys) {
+  if (np <= lds_lo_keys) return;  // handled by the launch with the smaller LDS allocation
+  if (np > lds_keys && lds_keys < 2 * kLdsSortKeys) return;  // left to the second launch
+  if (np <= lds_keys) {
     for (int i = tid; i < np; i += kThreads) lds[i] = i < n ? make_key(c[i]) : ~0ull;
     __syncthreads();
     // Two consecutive strides (2j, j) of a phase touch the same 4 elements {b, b+j, b+2j, b+3j}
@@ -562,8 +570,15 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
+  const bool two = ws_stride > kLdsSortKeys;
+  // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
   hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
-                     cand, cand_cap, cand_count, sort_ws, ws_stride);
+                     cand, cand_cap, cand_count, sort_ws, ws_stride, 0,
+                     two ? sort_keys : 2 * kLdsSortKeys);
+  if (two)  // second launch: 8193..16384 keys in 128 KiB, larger sets in the HBM workspace
+    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)2 * kLdsSortKeys * 8,
+                       stream, cand, cand_cap, cand_count, sort_ws, ws_stride, kLdsSortKeys,
+                       2 * kLdsSortKeys);
 }
 
 void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
