@@ -369,7 +369,8 @@ constexpr int kRoundCap = 64;
 // OCC_LDS = false: the occupancy grid does not fit in LDS (small uniformity radius or large images)
 // and lives in the context's HBM workspace (zeroed by the launcher); same algorithm, the byte
 // reads / read-modify-writes go to L2 and the workgroup barriers order them.
-template <bool OCC_LDS>
+// AccT: type of the accepted-candidate indices kept in LDS (u16 while the candidate capacity allows).
+template <bool OCC_LDS, typename AccT>
 __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     const int32_t* __restrict__ scores, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
   const int img = blockIdx.x;
   const int lds_occ = OCC_LDS ? occ_bytes16 : 0;  // LDS bytes taken by the grid
   uint8_t* occ = OCC_LDS ? smem_raw : occ_hbm + (size_t)img * occ_hbm_pitch;
-  uint16_t* acc_idx = reinterpret_cast<uint16_t*>(smem_raw + lds_occ);
+  AccT* acc_idx = reinterpret_cast<AccT*>(smem_raw + lds_occ);
   uint2* recs = reinterpret_cast<uint2*>(smem_raw + lds_occ + acc_bytes16);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
             const int rank = __popcll(accm & ((1ull << lane) - 1ull));
             const float nsc = (float)(0.99 * (double)__uint_as_float(rec.y));
             round_list[rank] = make_int2(cell, __float_as_int(nsc));
-            acc_idx[kept + rank] = (uint16_t)idx;
+            acc_idx[kept + rank] = (AccT)idx;
           }
           kept += nacc;
           pos += adv;
@@ -591,10 +592,13 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
   const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
-  // greedy kernel: occupancy + accepted indices (u16) + a sliding chunk of candidate records.
-  // Half a CU's LDS (two images per CU) when at least 128 records fit, else the whole CU.
-  const size_t acc_bytes = ((size_t)kp_cap * 2 + 15) & ~(size_t)15;
-  if (occ_lds && cand_cap <= 65536) {
+  // greedy kernel: occupancy + accepted indices (u16, u32 for capacities above 65536) + a sliding
+  // chunk of candidate records.  Half a CU's LDS (two images per CU) when at least 128 records
+  // fit, else the whole CU; grids that do not fit at all stay in the HBM workspace.
+  const bool wide = cand_cap > 65536;
+  const size_t acc_bytes = ((size_t)kp_cap * (wide ? 4 : 2) + 15) & ~(size_t)15;
+  static const bool legacy = getenv("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
+  if (occ_lds && !legacy) {
     const size_t fixed = occ_bytes + acc_bytes;
     const size_t half = 79 * 1024, full = 152 * 1024;  // + ~0.5 KiB static: two blocks per CU
     size_t budget = fixed + 128 * 8 <= half ? half : full;
@@ -603,28 +607,31 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
       const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
       if (chunk > need) chunk = need;
       const size_t lds = fixed + chunk * 8;
-      hipLaunchKernelGGL(select_greedy_kernel<true>, dim3(n_images), dim3(kSelThreads), lds, stream,
-                         score, w, h, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
-                         occ_cols, (int)occ_bytes, (int)acc_bytes, (int)chunk, kps, kp_cap, kp_count,
-                         (uint8_t*)nullptr, (size_t)0);
+#define OKVFE_SELECT_LAUNCH(LDS, T, BYTES, OCC, PITCH)                                           \
+  hipLaunchKernelGGL((select_greedy_kernel<LDS, T>), dim3(n_images), dim3(kSelThreads), BYTES,   \
+                     stream, score, w, h, cand_cap, cand_count, sort_ws, ws_stride, radius,      \
+                     max_kpts, lut, occ_cols, (int)occ_bytes, (int)acc_bytes, (int)chunk, kps,   \
+                     kp_cap, kp_count, OCC, PITCH)
+      if (wide)
+        OKVFE_SELECT_LAUNCH(true, uint32_t, lds, (uint8_t*)nullptr, (size_t)0);
+      else
+        OKVFE_SELECT_LAUNCH(true, uint16_t, lds, (uint8_t*)nullptr, (size_t)0);
       return;
     }
   }
-  if (radius > 0.0f && cand_cap <= 65536 && occupancy != nullptr) {
+  if (radius > 0.0f && occupancy != nullptr && !legacy && acc_bytes + 128 * 8 <= 24 * 1024) {
     // grid in HBM: LDS only holds the accepted indices and the record chunk (24 KiB: 6 images / CU)
-    static const bool legacy = getenv("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
-    if (!legacy) {
-      size_t chunk = (24 * 1024 - acc_bytes) / 8 / 64 * 64;
-      const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
-      if (chunk > need) chunk = need;
-      (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
-      hipLaunchKernelGGL(select_greedy_kernel<false>, dim3(n_images), dim3(kSelThreads),
-                         acc_bytes + chunk * 8, stream, score, w, h, cand_cap, cand_count, sort_ws,
-                         ws_stride, radius, max_kpts, lut, occ_cols, (int)occ_bytes, (int)acc_bytes,
-                         (int)chunk, kps, kp_cap, kp_count, occupancy, occ_image_bytes);
-      return;
-    }
+    size_t chunk = (24 * 1024 - acc_bytes) / 8 / 64 * 64;
+    const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
+    if (chunk > need) chunk = need;
+    (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
+    if (wide)
+      OKVFE_SELECT_LAUNCH(false, uint32_t, acc_bytes + chunk * 8, occupancy, occ_image_bytes);
+    else
+      OKVFE_SELECT_LAUNCH(false, uint16_t, acc_bytes + chunk * 8, occupancy, occ_image_bytes);
+    return;
   }
+#undef OKVFE_SELECT_LAUNCH
   if (occ_lds) {
     hipLaunchKernelGGL(select_kernel<true>, dim3(n_images), dim3(kThreads), occ_bytes, stream,
                        score, w, h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius,
