@@ -25,9 +25,16 @@
  * GPU and is single-threaded (the reference holds one detector/extractor per
  * camera under one mutex per camera, Frontend.cpp:226,2405-2413); different
  * contexts are independent.  "_device" entry points take HIP device pointers
- * and a hipStream_t (as void*; NULL = the context's own stream) and never
- * synchronise; the host-buffer entry points stage through pinned memory and
- * return only when the outputs are written.
+ * and a hipStream_t (as void*) and never synchronise the host: per-call host
+ * parameters (gravity, poses) ride through a ring of pinned slots with one
+ * asynchronous copy per call.  Stream argument: NULL = the context's own
+ * non-blocking stream; OKVFE_STREAM_LEGACY_DEFAULT = the HIP legacy default
+ * (null) stream -- the stream torch.cuda.default_stream() denotes, whose raw
+ * handle is 0 and therefore cannot be passed as itself; any other value = that
+ * hipStream_t.  Work enqueued on one stream is ordered with work on another
+ * only by the caller (events), exactly as for any HIP library.  The
+ * host-buffer entry points stage through pinned memory and return only when
+ * the outputs are written.
  *
  * There is NO CPU fallback: every compute entry point fails with
  * OKVFE_ERR_NO_DEVICE when no gfx950 device is usable.
@@ -43,6 +50,7 @@ extern "C" {
 #endif
 
 #define OKVFE_ABI_VERSION 1
+#define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
 typedef enum okvfe_status {
@@ -181,6 +189,14 @@ typedef struct okvfe_device_outputs {
   const int32_t* candidate_counts; /* [max_batch] NMS maxima found (may exceed capacity) */
 } okvfe_device_outputs;
 okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out);
+
+/* NMS candidate capacity check of the last batch (synchronises; one small copy): an image whose
+ * score map had more maxima than the context's candidate capacity (okvfe_config.max_candidates)
+ * keeps NO keypoints -- which maxima an overflowing list drops would depend on the order of the
+ * atomics -- and makes this call fail with OKVFE_ERR_CAPACITY (*first_overflowed = its index, -1
+ * if none; may be NULL).  Device-resident pipelines (batch detect -> match / gather) call this
+ * once per batch or once per sequence, as their budget allows. */
+okvfe_status okvfe_check_capacity(okvfe_ctx* ctx, int32_t n_images, int32_t* first_overflowed);
 
 /* Copies image `index` of the last batch to host buffers (synchronises). */
 okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_keypoint* keypoints,

@@ -73,7 +73,7 @@ EXPORTS = [
     "okvfe_match_motion_stereo", "okvfe_match_to_map",
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
-    "okvfe_match_stereo_blocks_batch_device",
+    "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -120,6 +120,21 @@ def _p(a):
     if isinstance(a, np.ndarray):
         return a.ctypes.data_as(C.c_void_p)
     return C.c_void_p(int(a))
+
+
+STREAM_LEGACY_DEFAULT = 1  # OKVFE_STREAM_LEGACY_DEFAULT (= hipStreamLegacy)
+
+
+def _s(stream):
+    """Stream argument of the "_device" entry points: None = the context's own stream; a
+    torch.cuda.Stream (anything with .cuda_stream) = that stream, torch's default stream (raw
+    handle 0) becoming OKVFE_STREAM_LEGACY_DEFAULT; an int = a raw hipStream_t (0 = None)."""
+    if stream is None:
+        return None
+    if hasattr(stream, "cuda_stream"):
+        h = int(stream.cuda_stream)
+        return C.c_void_p(h if h else STREAM_LEGACY_DEFAULT)
+    return C.c_void_p(int(stream)) if int(stream) else None
 
 
 def make_camera(cam) -> Camera:
@@ -299,17 +314,17 @@ class Frontend:
     # -- device-resident API --------------------------------------------------------------
     def harris_score_device(self, images_ptr, n_images, scores_ptr, stream=None):
         self._check(lib().okvfe_harris_score_device(self._h, _p(images_ptr), int(n_images),
-                                                    _p(scores_ptr), _p(stream)))
+                                                    _p(scores_ptr), _s(stream)))
 
     def detect_batch_device(self, images_ptr, n_images, stream=None):
         self._check(lib().okvfe_detect_batch_device(self._h, _p(images_ptr), int(n_images),
-                                                    _p(stream)))
+                                                    _s(stream)))
 
     def describe_batch_device(self, images_ptr, n_images, cam_ids=None, gravity=None, stream=None):
         ids = None if cam_ids is None else np.ascontiguousarray(cam_ids, dtype=np.int32)
         g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float32)
         self._check(lib().okvfe_describe_batch_device(self._h, _p(images_ptr), int(n_images),
-                                                      _p(ids), _p(g), _p(stream)))
+                                                      _p(ids), _p(g), _s(stream)))
 
     def detect_describe_batch_device(self, images_ptr, n_images, cam_ids=None, gravity=None,
                                      stream=None):
@@ -317,7 +332,7 @@ class Frontend:
         g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float32)
         self._check(lib().okvfe_detect_describe_batch_device(self._h, _p(images_ptr),
                                                              int(n_images), _p(ids), _p(g),
-                                                             _p(stream)))
+                                                             _s(stream)))
 
     def device_outputs(self) -> DeviceOutputs:
         out = DeviceOutputs()
@@ -336,10 +351,15 @@ class Frontend:
         k = n.value
         return kps[:k].copy(), desc[:k].copy(), bp[:k].copy(), bpv[:k].copy()
 
+    def check_capacity(self, n_images):
+        """Raises OkvfeError(ERR_CAPACITY) if an NMS candidate list of the last batch overflowed."""
+        first = C.c_int32(-1)
+        self._check(lib().okvfe_check_capacity(self._h, int(n_images), C.byref(first)))
+
     def match_stereo_batch_device(self, pairs, matches_ptr, stream=None):
         arr = pairs if isinstance(pairs, C.Array) else (StereoPair * len(pairs))(*pairs)
         self._check(lib().okvfe_match_stereo_batch_device(self._h, arr, len(pairs),
-                                                          _p(matches_ptr), _p(stream)))
+                                                          _p(matches_ptr), _s(stream)))
 
     # -- matching, host buffers -----------------------------------------------------------
     def match_stereo(self, desc0, kp0, bp0, bpv0, desc1, kp1, bp1, bpv1, T0, T1, f0, f1):
@@ -444,25 +464,25 @@ class Frontend:
 
     def pack_gather_block_device(self, index, block_ptr, stream=None):
         self._check(lib().okvfe_pack_gather_block_device(self._h, int(index), _p(block_ptr),
-                                                         _p(stream)))
+                                                         _s(stream)))
 
     def pack_gather_blocks_device(self, first, n, blocks_ptr, stream=None):
         self._check(lib().okvfe_pack_gather_blocks_device(self._h, int(first), int(n),
-                                                          _p(blocks_ptr), _p(stream)))
+                                                          _p(blocks_ptr), _s(stream)))
 
     def match_stereo_blocks_batch_device(self, blocks0_ptr, blocks1_ptr, n_frames, T0, T1, f0, f1,
                                          matches_ptr, stream=None):
         P0, P1 = make_pose(*T0), make_pose(*T1)
         self._check(lib().okvfe_match_stereo_blocks_batch_device(
             self._h, _p(blocks0_ptr), _p(blocks1_ptr), int(n_frames), C.byref(P0), C.byref(P1),
-            C.c_double(f0), C.c_double(f1), _p(matches_ptr), _p(stream)))
+            C.c_double(f0), C.c_double(f1), _p(matches_ptr), _s(stream)))
 
     def match_motion_stereo_blocks_device(self, cam, block0_ptr, block1_ptr, skip0_ptr,
                                           matched1_ptr, T0, T1, matches_ptr, stream=None):
         P0, P1 = make_pose(*T0), make_pose(*T1)
         self._check(lib().okvfe_match_motion_stereo_blocks_device(
             self._h, int(cam), _p(block0_ptr), _p(block1_ptr), _p(skip0_ptr), _p(matched1_ptr),
-            C.byref(P0), C.byref(P1), _p(matches_ptr), _p(stream)))
+            C.byref(P0), C.byref(P1), _p(matches_ptr), _s(stream)))
 
     def match_stereo_blocks_device(self, block0_ptr, block1_ptr, T0, T1, f0, f1, matches_ptr,
                                    stream=None):
@@ -470,4 +490,4 @@ class Frontend:
         self._check(lib().okvfe_match_stereo_blocks_device(self._h, _p(block0_ptr), _p(block1_ptr),
                                                            C.byref(P0), C.byref(P1),
                                                            C.c_double(f0), C.c_double(f1),
-                                                           _p(matches_ptr), _p(stream)))
+                                                           _p(matches_ptr), _s(stream)))

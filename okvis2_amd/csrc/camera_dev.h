@@ -3,8 +3,19 @@
 // (okvis_cv/include/okvis/cameras/implementation/PinholeCamera.hpp:241-283,574-593,
 //  RadialTangentialDistortion.hpp:90-135,214-252, EquidistantDistortion.hpp:87-171,319-351).
 // Component-wise, sums left to right, no FMA (-ffp-contract=off).
+//
+// Attribution: the distortion formulas in distort() below (radial-tangential value + Jacobian, and
+// the machine-generated equidistant Jacobian with its temporaries t2..t25) keep the reference's
+// operation order on purpose -- FP64 bit-exactness depends on it -- and are therefore a close
+// transcription of RadialTangentialDistortion.hpp:111-135 and EquidistantDistortion.hpp:128-171,
+// which are Copyright (c) 2015 Autonomous Systems Lab / ETH Zurich, (c) 2020 Smart Robotics Lab /
+// Imperial College London, (c) 2024 Smart Robotics Lab / Technical University of Munich,
+// distributed under the BSD 3-Clause licence (see the licence header of those files; the
+// conditions -- retain the copyright notice, the list of conditions and the disclaimer; no
+// endorsement with the holders' names -- apply to this fragment).
 #pragma once
 
+#include "atan_fixed.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -31,10 +42,10 @@ __device__ inline void distort(const DeviceCamera& c, double u0, double u1, doub
     J[3] = 1 + rad_dist_u + k1 * 2.0 * my_u + k2 * rho_u * 4 * my_u + 6 * p1 * u1 + 2.0 * p2 * u0;
     return;
   }
-  // equidistant (device atan; see DESIGN.md on its last-ulp caveat)
+  // equidistant; atan_fixed: the same operation sequence as on the host (atan_fixed.h)
   const double k1 = c.d[0], k2 = c.d[1], k3 = c.d[2], k4 = c.d[3];
   const double r = sqrt(u0 * u0 + u1 * u1);
-  const double theta = atan(r);
+  const double theta = atan_fixed(r);
   const double theta2 = theta * theta;
   const double theta4 = theta2 * theta2;
   const double theta6 = theta4 * theta2;
@@ -48,7 +59,7 @@ __device__ inline void distort(const DeviceCamera& c, double u0, double u1, doub
     t2 = u0 * u0;
     t3 = u1 * u1;
     t4 = t2 + t3;
-    t6 = atan(sqrt(t4));
+    t6 = atan_fixed(sqrt(t4));
     t7 = t6 * t6;
     t8 = 1.0 / sqrt(t4);
     t9 = t7 * t7;

@@ -9,9 +9,17 @@
 //                            Gauss-Newton undistortion of RadialTangentialDistortion.hpp:214-252 /
 //                            EquidistantDistortion.hpp:319-351.
 // FP64, explicit evaluation order, compiled with -ffp-contract=off.
+//
+// Attribution: distort() keeps the reference's operation order (bit-exact FP64 depends on it) and
+// is a close transcription of RadialTangentialDistortion.hpp:111-135 and
+// EquidistantDistortion.hpp:128-171 -- Copyright (c) 2015 Autonomous Systems Lab / ETH Zurich,
+// (c) 2020 Smart Robotics Lab / Imperial College London, (c) 2024 Smart Robotics Lab / Technical
+// University of Munich, BSD 3-Clause (licence text in the header of those files; its conditions
+// apply to that fragment).  atan comes from atan_fixed.h (same sequence as the device).
 #include <cmath>
 #include <cstring>
 
+#include "atan_fixed.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -139,7 +147,7 @@ void distort(const okvfe_camera& cam, Vec2 u, Vec2* out, Mat2* J) {
   }
   const double k1 = cam.d[0], k2 = cam.d[1], k3 = cam.d[2], k4 = cam.d[3];
   const double r = std::sqrt(u0 * u0 + u1 * u1);
-  const double theta = std::atan(r);
+  const double theta = atan_fixed(r);
   const double theta2 = theta * theta;
   const double theta4 = theta2 * theta2;
   const double theta6 = theta4 * theta2;
@@ -155,7 +163,7 @@ void distort(const okvfe_camera& cam, Vec2 u, Vec2* out, Mat2* J) {
     const double t2 = u0 * u0;
     const double t3 = u1 * u1;
     double t4 = t2 + t3;
-    const double t6 = std::atan(std::sqrt(t4));
+    const double t6 = atan_fixed(std::sqrt(t4));
     double t7 = t6 * t6;
     const double t8 = 1.0 / std::sqrt(t4);
     const double t9 = t7 * t7;

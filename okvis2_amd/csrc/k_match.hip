@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(BlockOffsets L, int fi
 
 // matches frame f of two gathered block arrays: grid (rows, frames)
 __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_blocks_kernel(
-    const PairParams* __restrict__ pair, BlockOffsets L, const uint8_t* __restrict__ blocks0,
+    const PairParams pair, BlockOffsets L, const uint8_t* __restrict__ blocks0,
     const uint8_t* __restrict__ blocks1, int kp_cap, int threshold,
     okvfe_stereo_match* __restrict__ out) {
   const uint8_t* b0 = blocks0 + (size_t)blockIdx.y * L.total;
@@ -836,12 +836,12 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_blocks_kernel(
   I0.n = *reinterpret_cast<const int32_t*>(b0 + L.o_count);
   I1.desc = b1 + L.o_desc; I1.bp = reinterpret_cast<const double*>(b1 + L.o_bp); I1.bpv = b1 + L.o_bpv;
   I1.n = *reinterpret_cast<const int32_t*>(b1 + L.o_count);
-  match_stereo_rows(*pair, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
+  match_stereo_rows(pair, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
 }
 
 // motion-stereo matcher on two gathered blocks (older frame, current frame) of one camera
 __global__ __launch_bounds__(64 * kStereoSegs) void match_motion_blocks_kernel(
-    const PairParams* __restrict__ pair, const DeviceCamera* __restrict__ camera, int w, int h,
+    const PairParams pair, const DeviceCamera* __restrict__ camera, int w, int h,
     BlockOffsets L, const uint8_t* __restrict__ b0, const uint8_t* __restrict__ b1,
     const uint8_t* __restrict__ skip0, const uint8_t* __restrict__ matched1, int threshold,
     okvfe_motion_match* __restrict__ out) {
@@ -852,12 +852,12 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_motion_blocks_kernel(
   I1.desc = b1 + L.o_desc; I1.kps = reinterpret_cast<const okvfe_keypoint*>(b1 + L.o_kps);
   I1.bp = reinterpret_cast<const double*>(b1 + L.o_bp); I1.bpv = b1 + L.o_bpv; I1.flag = matched1;
   I1.n = *reinterpret_cast<const int32_t*>(b1 + L.o_count);
-  match_motion_rows(*pair, *camera, w, h, I0, I1, threshold, out);
+  match_motion_rows(pair, *camera, w, h, I0, I1, threshold, out);
 }
 
 }  // namespace
 
-void launch_match_motion_blocks(const PairParams* pair, const DeviceCamera* camera, int w, int h,
+void launch_match_motion_blocks(const PairParams& pair, const DeviceCamera* camera, int w, int h,
                                 const int offs[6], const uint8_t* block0, const uint8_t* block1,
                                 const uint8_t* skip0, const uint8_t* matched1, int kp_cap,
                                 int threshold, okvfe_motion_match* out, hipStream_t stream) {
@@ -875,7 +875,7 @@ void launch_pack_blocks(const int offs[6], int first, int n, int kp_cap, const i
                      desc, bp, bpv, blocks);
 }
 
-void launch_match_stereo_blocks(const PairParams* pair, const int offs[6], const uint8_t* blocks0,
+void launch_match_stereo_blocks(const PairParams& pair, const int offs[6], const uint8_t* blocks0,
                                 const uint8_t* blocks1, int n_frames, int kp_cap, int threshold,
                                 okvfe_stereo_match* out, hipStream_t stream) {
   if (n_frames <= 0) return;

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
   uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
   const int img = blockIdx.x;
   int n = cand_count[img];
-  n = n > cand_cap ? cand_cap : n;
+  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
+  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
+  n = n > cand_cap ? 0 : n;
   const Candidate* c = cand + (size_t)img * cand_cap;
   uint64_t* ws = sort_ws + (size_t)img * ws_stride;
   int np = 1;
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
   int n = cand_count[img];
-  n = n > cand_cap ? cand_cap : n;
+  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
+  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
+  n = n > cand_cap ? 0 : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
   const int32_t* sc = scores + (size_t)img * w * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
@@ -392,7 +396,9 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
   const int lane = tid & 63;
   const bool decider = tid < 64;  // wave 0
   int n = cand_count[img];
-  n = n > cand_cap ? cand_cap : n;
+  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
+  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
+  n = n > cand_cap ? 0 : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
   const int32_t* sc = scores + (size_t)img * w * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;

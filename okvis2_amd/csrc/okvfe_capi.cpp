@@ -49,23 +49,32 @@ struct okvfe_ctx {
   double* d_bp = nullptr;
   uint8_t* d_bpv = nullptr;
   int32_t* d_count = nullptr;
-  ImageParams* d_prm = nullptr;
+  ImageParams* d_prm = nullptr;  // current slot of prm_ring
   DeviceCamera* d_cams = nullptr;
   const float** d_rays_ptrs = nullptr;
   const float** d_jac_ptrs = nullptr;
-  PairParams* d_pairs = nullptr;
   uint8_t* d_img_stage = nullptr;
   okvfe_stereo_match* d_match_stage = nullptr;
-  PairParams* d_block_pairs = nullptr;
-  unsigned block_pair_next = 0;
-
-  std::vector<ImageParams> h_prm_last;  // what d_prm currently holds
-  std::vector<PairParams> h_pairs_last;
+  // Per-call host parameters (ImageParams per image, PairParams per stereo pair) travel through
+  // rings of pinned host slots + device slots: the call fills a pinned slot, enqueues ONE async
+  // copy on its stream and the kernels read the device slot -- no host synchronisation.  A slot is
+  // reused only after the event recorded behind its last consumer has completed (normally long
+  // ago; the wait only bites when more than kRingSlots calls are in flight).
+  struct ParamRing {
+    static constexpr int kRingSlots = 8;
+    uint8_t* h = nullptr;  // pinned, kRingSlots * slot_bytes
+    uint8_t* d = nullptr;
+    size_t slot_bytes = 0;
+    hipEvent_t done[kRingSlots] = {};
+    bool pending[kRingSlots] = {};
+    unsigned next = 0;
+  };
+  ParamRing prm_ring, pair_ring;
+  int prm_slot = -1;  // slot d_prm points into
   std::vector<float*> cam_rays, cam_jac;  // device maps per camera slot (nullptr = not set)
   std::vector<float> cam_fu;
   std::vector<DeviceCamera> h_cams;
   std::vector<bool> cam_has_intrinsics;
-  int pair_cap = 0;
   int last_n_images = 0;
   hipStream_t last_stream = nullptr;
 
@@ -163,6 +172,66 @@ okvfe_status ensure_pinned(okvfe_ctx* ctx, size_t bytes) {
   return OKVFE_OK;
 }
 
+// (re)sizes a ring; only called while nothing of the ring is in flight (creation, or after a drain)
+okvfe_status ring_reserve(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, size_t slot_bytes) {
+  slot_bytes = align_up(std::max<size_t>(slot_bytes, 256), 256);
+  if (slot_bytes <= r->slot_bytes) return OKVFE_OK;
+  for (int i = 0; i < okvfe_ctx::ParamRing::kRingSlots; ++i)
+    if (r->pending[i]) {
+      HIP_TRY(ctx, hipEventSynchronize(r->done[i]));
+      r->pending[i] = false;
+    }
+  if (r->h) HIP_TRY(ctx, hipHostFree(r->h));
+  if (r->d) HIP_TRY(ctx, hipFree(r->d));
+  r->h = nullptr;
+  r->d = nullptr;
+  r->slot_bytes = 0;
+  void* q = nullptr;
+  HIP_TRY(ctx, hipHostMalloc(&q, slot_bytes * okvfe_ctx::ParamRing::kRingSlots, hipHostMallocDefault));
+  r->h = static_cast<uint8_t*>(q);
+  HIP_TRY(ctx, hipMalloc(&q, slot_bytes * okvfe_ctx::ParamRing::kRingSlots));
+  r->d = static_cast<uint8_t*>(q);
+  r->slot_bytes = slot_bytes;
+  for (auto& e : r->done)
+    if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return OKVFE_OK;
+}
+
+// takes the next slot, copies `bytes` from src through the pinned half to the device half on
+// stream s (asynchronous: returns at once) and hands back the device address
+okvfe_status ring_upload(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, const void* src, size_t bytes,
+                         hipStream_t s, void** d_out, int* slot_out) {
+  okvfe_status st = ring_reserve(ctx, r, bytes);
+  if (st != OKVFE_OK) return st;
+  const int slot = (int)(r->next++ % okvfe_ctx::ParamRing::kRingSlots);
+  if (r->pending[slot]) {
+    HIP_TRY(ctx, hipEventSynchronize(r->done[slot]));
+    r->pending[slot] = false;
+  }
+  uint8_t* h = r->h + (size_t)slot * r->slot_bytes;
+  uint8_t* d = r->d + (size_t)slot * r->slot_bytes;
+  std::memcpy(h, src, bytes);
+  HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+  *d_out = d;
+  *slot_out = slot;
+  return OKVFE_OK;
+}
+
+// marks the end of the slot's consumers on stream s
+okvfe_status ring_release(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, int slot, hipStream_t s) {
+  if (slot < 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipEventRecord(r->done[slot], s));
+  r->pending[slot] = true;
+  return OKVFE_OK;
+}
+
+void ring_destroy(okvfe_ctx::ParamRing* r) {
+  for (auto& e : r->done)
+    if (e) (void)hipEventDestroy(e);
+  if (r->h) (void)hipHostFree(r->h);
+  if (r->d) (void)hipFree(r->d);
+}
+
 DeviceCamera to_device_camera(const okvfe_camera& c) {
   DeviceCamera d{};
   d.fu = c.fu; d.fv = c.fv; d.cu = c.cu; d.cv = c.cv;
@@ -216,8 +285,13 @@ struct StageTimer {
   }
 };
 
+// NULL = the context's own non-blocking stream; OKVFE_STREAM_LEGACY_DEFAULT = the HIP legacy
+// default (null) stream, which is what torch.cuda.default_stream() is: its handle is 0 and could
+// not be told apart from "no stream given" otherwise.
 hipStream_t pick_stream(okvfe_ctx* ctx, void* stream) {
-  return stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  if (!stream) return ctx->stream;
+  if (stream == OKVFE_STREAM_LEGACY_DEFAULT) return static_cast<hipStream_t>(nullptr);
+  return static_cast<hipStream_t>(stream);
 }
 
 }  // namespace
@@ -340,15 +414,14 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     A(d_bp, K * B * 3);
     A(d_bpv, K * B);
     A(d_count, B);
-    A(d_prm, B);
     A(d_cams, (size_t)cfg->num_cameras);
     A(d_rays_ptrs, (size_t)cfg->num_cameras);
     A(d_jac_ptrs, (size_t)cfg->num_cameras);
     A(d_img_stage, P);
     A(d_match_stage, K);
 #undef A
-    c->pair_cap = std::max(1, c->B);
-    if ((s = dev_alloc(c, &c->d_pairs, (size_t)c->pair_cap)) != OKVFE_OK) return s;
+    if ((s = ring_reserve(c, &c->prm_ring, B * sizeof(ImageParams))) != OKVFE_OK) return s;
+    if ((s = ring_reserve(c, &c->pair_ring, std::max<size_t>(1, B / 2) * sizeof(PairParams))) != OKVFE_OK) return s;
     float lut[kLutFloats];
     build_uniformity_lut(lut);
     build_pattern(&c->host_pattern);
@@ -388,6 +461,8 @@ void okvfe_destroy(okvfe_ctx* ctx) {
     if (p) (void)hipFree(p);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  ring_destroy(&ctx->prm_ring);
+  ring_destroy(&ctx->pair_ring);
   for (auto& e : ctx->prof_events) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -486,34 +561,38 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
   }
   // intrinsics are needed for back-projection; a slot with maps only (set_camera_maps) keeps its
   // cam id for the maps and gets invalid back-projections (DeviceCamera zeroed -> fu = 0)
-  const bool same = ctx->h_prm_last.size() >= (size_t)n_images &&
-                    std::memcmp(ctx->h_prm_last.data(), prm.data(), n_images * sizeof(ImageParams)) == 0;
-  if (!same) {
-    if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_prm, prm.data(), n_images * sizeof(ImageParams), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    ctx->h_prm_last = prm;
-  }
+  void* d = nullptr;
+  okvfe_status st = ring_upload(ctx, &ctx->prm_ring, prm.data(), n_images * sizeof(ImageParams), s, &d,
+                                &ctx->prm_slot);
+  if (st != OKVFE_OK) return st;
+  ctx->d_prm = static_cast<ImageParams*>(d);
   return OKVFE_OK;
 }
 
 // ---- batch pipeline ----------------------------------------------------------------------------
 // OKVFE_SCORE_TOKEN: see g_score_token.
 namespace {
-okvfe_status heavy_begin(okvfe_ctx* ctx, hipStream_t s, int which, bool* token) {
-  *token = score_token_mode() > which && ctx->cfg.device >= 0 && ctx->cfg.device < kMaxTokenDevices;
-  if (!*token) return OKVFE_OK;
-  std::lock_guard<std::mutex> lock(g_token_mutex);
+// The token mutex is held from the wait on the previous holder's event to the record of this
+// launch's event, so two host threads can never chain on the same predecessor.
+struct TokenScope {
+  std::unique_lock<std::mutex> lock;
+  bool on = false;
+};
+okvfe_status heavy_begin(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) {
+  t->on = score_token_mode() > which && ctx->cfg.device >= 0 && ctx->cfg.device < kMaxTokenDevices;
+  if (!t->on) return OKVFE_OK;
+  t->lock = std::unique_lock<std::mutex>(g_token_mutex);
   hipEvent_t prev = g_score_token[ctx->cfg.device];
   if (prev) HIP_TRY(ctx, hipStreamWaitEvent(s, prev, 0));
   return OKVFE_OK;
 }
-okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which) {
-  std::lock_guard<std::mutex> lock(g_token_mutex);
+okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) {
+  if (!t->on) return OKVFE_OK;
   hipEvent_t& ev = ctx->heavy_done[which];
   if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventRecord(ev, s));
   g_score_token[ctx->cfg.device] = ev;
+  t->lock.unlock();
   return OKVFE_OK;
 }
 
@@ -523,7 +602,7 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
   // d_cand_count: [0, B) candidate counts, [B, 2B) per-image counts of flagged candidates
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
   int32_t* d_fix_count = ctx->d_cand_count + ctx->B;
-  bool token = false;
+  TokenScope token;
   okvfe_status st = heavy_begin(ctx, s, 0, &token);
   if (st != OKVFE_OK) return st;
   bool fused;
@@ -533,7 +612,7 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
                               ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, d_fix_count, s);
     if (!fused) launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
   }
-  if (token && (st = heavy_end(ctx, s, 0)) != OKVFE_OK) return st;
+  if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_NMS, s);
     if (fused)
@@ -564,7 +643,7 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
 // K6 + compaction + back-projection of the keypoints detect_stage left in d_kps_det
 okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
   const int w = ctx->w, h = ctx->h;
-  bool token = false;
+  TokenScope token;
   okvfe_status st = heavy_begin(ctx, s, 1, &token);
   if (st != OKVFE_OK) return st;
   {
@@ -573,7 +652,7 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
   }
-  if (token && (st = heavy_end(ctx, s, 1)) != OKVFE_OK) return st;
+  if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_COMPACT, s);
     launch_compact(n_images, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp,
@@ -582,7 +661,9 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
-  return OKVFE_OK;
+  const int slot = ctx->prm_slot;
+  ctx->prm_slot = -1;
+  return ring_release(ctx, &ctx->prm_ring, slot, s);  // the ImageParams slot has no reader after this
 }
 }  // namespace
 
@@ -640,6 +721,26 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
   out->scores = ctx->d_scores;
   out->detect_counts = ctx->d_det_count;
   out->candidate_counts = ctx->d_cand_count;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_check_capacity(okvfe_ctx* ctx, int32_t n_images, int32_t* first_overflowed) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n_images < 0 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_check_capacity: n_images=%d (max_batch %d)", n_images, ctx->B);
+  if (first_overflowed) *first_overflowed = -1;
+  if (n_images == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  std::vector<int32_t> counts(n_images);
+  HIP_TRY(ctx, hipMemcpy(counts.data(), ctx->d_cand_count, (size_t)n_images * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n_images; ++i)
+    if (counts[i] > ctx->cand_cap) {
+      if (first_overflowed) *first_overflowed = i;
+      return fail(ctx, OKVFE_ERR_CAPACITY,
+                  "image %d produced %d NMS maxima, candidate capacity is %d (its keypoint list was left empty)", i,
+                  counts[i], ctx->cand_cap);
+    }
   return OKVFE_OK;
 }
 
@@ -770,6 +871,11 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_n_images = 1;
   ctx->last_stream = s;
+  {
+    const int slot = ctx->prm_slot;
+    ctx->prm_slot = -1;
+    if ((st = ring_release(ctx, &ctx->prm_ring, slot, s)) != OKVFE_OK) return st;
+  }
   return okvfe_download_image_result(ctx, 0, keypoints, descriptors, backproj, backproj_valid, n_in, n_out);
 }
 
@@ -788,28 +894,17 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
       return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "pair %d: image index or focal length out of range", i);
     pp[i] = to_pair_params(pairs[i]);
   }
-  if (n_pairs > ctx->pair_cap) {
-    if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
-    void* q = nullptr;
-    HIP_TRY(ctx, hipMalloc(&q, (size_t)n_pairs * sizeof(PairParams)));
-    ctx->allocs.push_back(q);
-    ctx->d_pairs = static_cast<PairParams*>(q);
-    ctx->pair_cap = n_pairs;
-    ctx->h_pairs_last.clear();
-  }
-  const bool same = ctx->h_pairs_last.size() == (size_t)n_pairs &&
-                    std::memcmp(ctx->h_pairs_last.data(), pp.data(), n_pairs * sizeof(PairParams)) == 0;
-  if (!same) {
-    if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pairs, pp.data(), n_pairs * sizeof(PairParams), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    ctx->h_pairs_last = pp;
-  }
+  void* d_pairs = nullptr;
+  int slot = -1;
+  okvfe_status st = ring_upload(ctx, &ctx->pair_ring, pp.data(), (size_t)n_pairs * sizeof(PairParams), s,
+                                &d_pairs, &slot);
+  if (st != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_MATCH, s);
-    launch_match_stereo(ctx->d_pairs, n_pairs, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count,
-                        ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
+    launch_match_stereo(static_cast<const PairParams*>(d_pairs), n_pairs, ctx->d_kps, ctx->d_desc, ctx->d_bp,
+                        ctx->d_bpv, ctx->d_count, ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
   }
+  if ((st = ring_release(ctx, &ctx->pair_ring, slot, s)) != OKVFE_OK) return st;
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
   return OKVFE_OK;
@@ -1206,18 +1301,8 @@ okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* 
   okvfe_stereo_pair sp{};
   sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
   const PairParams pp = to_pair_params(sp);
-  // pair records live in a small ring inside the context so that consecutive calls for different
-  // camera pairs do not have to synchronise
-  if (!ctx->d_block_pairs) {
-    void* q = nullptr;
-    HIP_TRY(ctx, hipMalloc(&q, 64 * sizeof(PairParams)));
-    ctx->allocs.push_back(q);
-    ctx->d_block_pairs = static_cast<PairParams*>(q);
-  }
-  PairParams* slot = ctx->d_block_pairs + (ctx->block_pair_next++ % 64);
-  if (ctx->block_pair_next % 64 == 0) HIP_TRY(ctx, hipStreamSynchronize(s));  // ring wrap: drain
-  HIP_TRY(ctx, hipMemcpyAsync(slot, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
-  launch_match_stereo_blocks(slot, offs, static_cast<const uint8_t*>(blocks0_dev),
+  // the pair record travels by value as a kernel argument (232 bytes): nothing to keep alive
+  launch_match_stereo_blocks(pp, offs, static_cast<const uint8_t*>(blocks0_dev),
                              static_cast<const uint8_t*>(blocks1_dev), n_frames, ctx->kp_cap,
                              ctx->cfg.match_threshold, matches_dev, s);
   HIP_TRY(ctx, hipGetLastError());
@@ -1245,16 +1330,7 @@ okvfe_status okvfe_match_motion_stereo_blocks_device(okvfe_ctx* ctx, int32_t cam
   sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1;
   sp.f0 = sp.f1 = 0.5 * (dc.fu + dc.fv);  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834)
   const PairParams pp = to_pair_params(sp);
-  if (!ctx->d_block_pairs) {
-    void* q = nullptr;
-    HIP_TRY(ctx, hipMalloc(&q, 64 * sizeof(PairParams)));
-    ctx->allocs.push_back(q);
-    ctx->d_block_pairs = static_cast<PairParams*>(q);
-  }
-  PairParams* slot = ctx->d_block_pairs + (ctx->block_pair_next++ % 64);
-  if (ctx->block_pair_next % 64 == 0) HIP_TRY(ctx, hipStreamSynchronize(s));  // ring wrap: drain
-  HIP_TRY(ctx, hipMemcpyAsync(slot, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
-  launch_match_motion_blocks(slot, ctx->d_cams + cam, ctx->w, ctx->h, offs,
+  launch_match_motion_blocks(pp, ctx->d_cams + cam, ctx->w, ctx->h, offs,
                              static_cast<const uint8_t*>(block0_dev), static_cast<const uint8_t*>(block1_dev),
                              skip0_dev, matched1_dev, ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
   HIP_TRY(ctx, hipGetLastError());

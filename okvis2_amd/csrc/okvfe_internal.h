@@ -166,11 +166,11 @@ void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, c
 void launch_pack_blocks(const int offs[6], int first, int n, int kp_cap, const int32_t* counts,
                         const okvfe_keypoint* kps, const uint8_t* desc, const double* bp,
                         const uint8_t* bpv, uint8_t* blocks, hipStream_t stream);
-void launch_match_motion_blocks(const PairParams* pair, const DeviceCamera* camera, int w, int h,
+void launch_match_motion_blocks(const PairParams& pair, const DeviceCamera* camera, int w, int h,
                                 const int offs[6], const uint8_t* block0, const uint8_t* block1,
                                 const uint8_t* skip0, const uint8_t* matched1, int kp_cap,
                                 int threshold, okvfe_motion_match* out, hipStream_t stream);
-void launch_match_stereo_blocks(const PairParams* pair, const int offs[6], const uint8_t* blocks0,
+void launch_match_stereo_blocks(const PairParams& pair, const int offs[6], const uint8_t* blocks0,
                                 const uint8_t* blocks1, int n_frames, int kp_cap, int threshold,
                                 okvfe_stereo_match* out, hipStream_t stream);
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,

@@ -85,31 +85,111 @@ def all_gather_blocks(local_blocks, group=None):
     return out.view(world, frames, nbytes)
 
 
+def camera_owner(cam: int, world: int) -> int:
+    """Rank that detects + describes camera `cam` of the rig: round robin."""
+    return cam % world
+
+
 class CrossCameraMatcher:
-    """Rank r owns camera r of an n-camera rig (n == world).  `step` runs detect+describe for this
-    rank's camera on a batch of frames, gathers all cameras' blocks and matches the camera pairs
-    this rank owns.  Results: {(i, j): uint8 tensor [frames, kp_cap, 48]} of okvfe_stereo_match."""
+    """Cross-camera matchStereo of an n-camera rig whose cameras live on `world` ranks
+    (Frontend.cpp:1990-2026).
 
-    def __init__(self, fe: "capi.Frontend", cam_index: int, n_frames: int, poses_T_WC, focal,
-                 overlap, world: int, rank: int, device):
+    Camera c is owned by rank c % world, slot c // world of that rank; every rank holds
+    slots = ceil(n_cams / world) gather-block rows (unused ones stay empty: count 0).  `step`
+      1. runs detect + describe of every LOCAL camera on that camera's own engine (one context
+         per camera, like one detector/extractor per camera in the reference,
+         Frontend.cpp:2405-2413) and stream, and packs the results into gather blocks (one kernel
+         per camera),
+      2. moves all blocks with ONE all-gather ([slots, frames, block] bytes per rank; RCCL over
+         xGMI with backend nccl),
+      3. matches, with one launch per pair over all frames, the camera pairs this rank owns:
+         pair (i, j), i < j, FoV-overlapping only (MultiFrame::hasOverlap, Frontend.cpp:1998),
+         belongs to rank (i + j) % world.
+    Stream discipline: every library call carries an explicit stream; the pack kernels' streams
+    are joined into `main` before the collective, which is issued with `main` current, and the
+    matchers run on `main` after it -- the exchange is ordered by streams, never by timing.
+
+    engines: {cam: engine} for the local cameras.  An engine is a capi.Frontend or anything with
+    its five methods used here (the CPU gloo tests pass an oracle-backed host engine):
+    detect_describe_batch_device, pack_gather_blocks_device, match_stereo_blocks_batch_device,
+    gather_block_bytes, max_keypoints.
+    Results: {(i, j): uint8 tensor [frames, max_keypoints, sizeof(okvfe_stereo_match)]}."""
+
+    def __init__(self, engines: dict, n_cams: int, n_frames: int, poses_T_WC, focal, overlap,
+                 world: int, rank: int, device, group=None):
         import torch
-        self.fe, self.cam, self.n_frames = fe, cam_index, n_frames
-        self.poses, self.focal = poses_T_WC, focal
-        self.world, self.rank = world, rank
-        self.block_bytes = fe.gather_block_bytes()
-        self.local = torch.zeros((n_frames, self.block_bytes), dtype=torch.uint8, device=device)
-        self.mine = [(i, j) for (i, j, o) in pair_schedule(world, overlap, world) if o == rank]
-        self.out = {p: torch.zeros((n_frames, fe.max_keypoints, capi.STEREO_MATCH_DTYPE.itemsize),
-                                   dtype=torch.uint8, device=device) for p in self.mine}
+        self.torch = torch
+        self.n_cams, self.n_frames, self.world, self.rank = n_cams, n_frames, world, rank
+        self.local_cams = [c for c in range(n_cams) if camera_owner(c, world) == rank]
+        if sorted(engines) != self.local_cams:
+            raise ValueError(f"rank {rank} of {world} owns cameras {self.local_cams}, "
+                             f"engines were given for {sorted(engines)}")
+        self.engines = engines
+        self.poses, self.focal, self.group = poses_T_WC, focal, group
+        self.slots = (n_cams + world - 1) // world
+        any_engine = engines[self.local_cams[0]] if self.local_cams else None
+        if any_engine is None:
+            raise ValueError("a rank without a camera cannot take part (world > n_cams)")
+        self.matcher = any_engine
+        self.block_bytes = any_engine.gather_block_bytes()
+        self.kp_cap = any_engine.max_keypoints
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.local = torch.zeros((self.slots, n_frames, self.block_bytes), dtype=torch.uint8,
+                                 device=self.device)
+        self.gathered = torch.zeros((world * self.slots, n_frames, self.block_bytes),
+                                    dtype=torch.uint8, device=self.device)
+        self.schedule = pair_schedule(n_cams, overlap, world)
+        self.mine = [(i, j) for (i, j, o) in self.schedule if o == rank]
+        self.out = {p: torch.zeros((n_frames, self.kp_cap, capi.STEREO_MATCH_DTYPE.itemsize),
+                                   dtype=torch.uint8, device=self.device) for p in self.mine}
+        if self.cuda:
+            self.main = torch.cuda.Stream(device=self.device)
+            self.cam_streams = {c: torch.cuda.Stream(device=self.device) for c in self.local_cams}
+            torch.cuda.current_stream(self.device).synchronize()  # the zero fills above
+        else:
+            self.main, self.cam_streams = None, {c: None for c in self.local_cams}
 
-    def step(self, images_ptr, gravity, stream=None, group=None):
-        fe, n = self.fe, self.n_frames
-        cam_ids = np.full(n, 0, dtype=np.int32)  # this context holds its own camera in slot 0
-        fe.detect_describe_batch_device(images_ptr, n, cam_ids, gravity, stream)
-        fe.pack_gather_blocks_device(0, n, self.local.data_ptr(), stream)   # one kernel
-        allb = all_gather_blocks(self.local, group)                          # one collective
-        for (i, j) in self.mine:                                             # one launch per pair
-            fe.match_stereo_blocks_batch_device(allb[i].data_ptr(), allb[j].data_ptr(), n,
-                                                self.poses[i], self.poses[j], self.focal[i],
-                                                self.focal[j], self.out[(i, j)].data_ptr(), stream)
-        return allb, self.out
+    def block_of(self, gathered, cam: int):
+        """[frames, block_bytes] view of camera `cam` in the all-gathered tensor."""
+        return gathered[camera_owner(cam, self.world) * self.slots + cam // self.world]
+
+    def step(self, images_ptrs: dict, gravities: dict):
+        """images_ptrs[c]: device pointer of camera c's [frames, H, W] u8 images; gravities[c]:
+        float32 [frames, 3] extraction directions (gravity in camera c's frame).  Returns
+        (gathered blocks [world*slots, frames, block], {pair: matches}); the caller synchronises
+        (`finish`) before reading."""
+        torch, n = self.torch, self.n_frames
+        cam_ids = np.zeros(n, dtype=np.int32)  # every engine holds its camera in slot 0
+        for c in self.local_cams:
+            st = self.cam_streams[c]
+            if self.cuda:
+                st.wait_stream(self.main)  # the previous step's collective has read self.local
+            eng = self.engines[c]
+            eng.detect_describe_batch_device(images_ptrs[c], n, cam_ids, gravities[c], st)
+            eng.pack_gather_blocks_device(0, n, self.local[c // self.world].data_ptr(), st)
+        if self.cuda:
+            for c in self.local_cams:
+                self.main.wait_stream(self.cam_streams[c])
+            with torch.cuda.stream(self.main):
+                self._gather()
+        else:
+            self._gather()
+        for (i, j) in self.mine:  # one launch per pair
+            self.matcher.match_stereo_blocks_batch_device(
+                self.block_of(self.gathered, i).data_ptr(), self.block_of(self.gathered, j).data_ptr(),
+                n, self.poses[i], self.poses[j], self.focal[i], self.focal[j],
+                self.out[(i, j)].data_ptr(), self.main)
+        return self.gathered, self.out
+
+    def _gather(self):
+        import torch.distributed as dist
+        if self.world == 1 and not dist.is_initialized():
+            self.gathered.copy_(self.local)
+            return
+        dist.all_gather_into_tensor(self.gathered.view(self.world, -1),
+                                    self.local.view(1, -1), group=self.group)
+
+    def finish(self):
+        if self.cuda:
+            self.main.synchronize()

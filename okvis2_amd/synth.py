@@ -86,6 +86,7 @@ class Config:
     match_threshold: int
     octaves: int
     max_kpts: int
+    T_SC: list = None  # per camera (C_SC 3x3, r_SC 3): sensor-from-camera extrinsics, if the rig has them
 
 
 def euroc_config() -> Config:
@@ -134,10 +135,112 @@ def hilti_config() -> Config:
          (-0.03842764034005408, -0.005841411460411122, 0.003451041303088915,
           -0.0011463543672005018)]
     cams = [Camera(720, 540, f[i][0], f[i][1], c[i][0], c[i][1], 2, d[i]) for i in range(5)]
-    return Config("hilti", 720, 540, cams, 0.1, 50.0, 20, 60, 0, 700)
+    # T_SC rows 0..2 of hilti_challenge_2022.yaml:4-7,18-21,32-35,46-49,60-63 (row-major 3x4)
+    T = [
+        [0.0067080214518005230, 0.0024256436418034670, 0.9999745590269414341, 0.0512635496824681014,
+         0.9999264200621181820, 0.0100911970216882967, -0.0067321767970210744, 0.0453901220122367860,
+         -0.0101072701536598954, 0.9999461405473762943, -0.0023577731969992165, -0.0132149126987094190],
+        [0.0016556126470598073, 0.0009350089535378861, 0.9999981923508760584, 0.0503920182199237218,
+         0.9999840642813063729, 0.0053956906150397291, -0.0016606342845620788, -0.0627831669975007084,
+         -0.0053972335694489823, 0.9999850060281121333, -0.0009260608798763888, -0.0131432680426852699],
+        [0.9999897552434932058, 0.0042384707008869303, -0.0015889537990238949, 0.0068411376086779559,
+         0.0042340516721276989, -0.9999871881804247575, -0.0027742172670246496, -0.0079967741380297819,
+         -0.0016006918802386875, 0.0027674611333545632, -0.9999948894591306203, -0.0341138037431789470],
+        [-0.9998916894135628786, 0.0127071404640830849, 0.0074254981595154035, -0.0027416993947013656,
+         0.0073960416730231545, -0.0023635309353156166, 0.9999698556902045787, 0.0572301653448225520,
+         0.0127243078107144667, 0.9999164676625461601, 0.0022692923994765855, -0.0110114836506446101],
+        [0.9999880402484466746, 0.0047970088651064294, -0.0009529249803788963, -0.0065676390423793146,
+         -0.0009424276629318935, -0.0021900897852223104, -0.9999971576643765792, -0.0748375416968655310,
+         -0.0047990822216628587, 0.9999860960096795814, -0.0021855427584385988, -0.0168332753720958905],
+    ]
+    T_SC = []
+    for row in T:
+        m = np.array(row, dtype=np.float64).reshape(3, 4)
+        T_SC.append((m[:, :3].copy(), m[:, 3].copy()))
+    return Config("hilti", 720, 540, cams, 0.1, 50.0, 20, 60, 0, 700, T_SC)
 
 
 def stereo_poses(baseline: float):
     """T_WC0 = identity, T_WC1 = pure x translation by the baseline (row-major C, r)."""
     eye = np.eye(3, dtype=np.float64).reshape(-1)
     return (eye.copy(), np.zeros(3)), (eye.copy(), np.array([baseline, 0.0, 0.0]))
+
+
+def rig_poses(cfg: Config, C_WS=None, r_WS=None):
+    """T_WC = T_WS * T_SC per camera (Frontend.cpp:2004-2005) as (C row-major flat, r)."""
+    C_WS = np.eye(3) if C_WS is None else np.asarray(C_WS, dtype=np.float64)
+    r_WS = np.zeros(3) if r_WS is None else np.asarray(r_WS, dtype=np.float64)
+    return [((C_WS @ C).reshape(-1).copy(), C_WS @ r + r_WS) for C, r in cfg.T_SC]
+
+
+def gravity_in_camera(C_WC) -> np.ndarray:
+    """Extraction direction of Frontend::detectAndDescribe: T_WC.inverse().C() * (0,0,-1) as
+    float32 (Frontend.cpp:247-251)."""
+    C_WC = np.asarray(C_WC, dtype=np.float64).reshape(3, 3)
+    return (C_WC.T @ np.array([0.0, 0.0, -1.0])).astype(np.float32)
+
+
+def rig_overlap_pairs(cfg: Config, overlap_fn, subsample: int = 4):
+    """Camera pairs im0 < im1 Frontend::matchStereo visits (Frontend.cpp:1990-2000): those with
+    MultiFrame::hasOverlap(im0, im1) -- NCameraSystem::computeOverlaps
+    (okvis_cv/src/NCameraSystem.cpp:48-119) -- evaluated on `subsample`-times smaller cameras
+    (every subsample-th pixel ray; the test is an "any pixel" test).  overlap_fn(camera, other,
+    R_other_cam) -> bool is okvfe_camera_overlap (capi.camera_overlap) or the oracle's."""
+    q = float(subsample)
+    small = [Camera(c.w // subsample, c.h // subsample, c.fu / q, c.fv / q, c.cu / q, c.cv / q,
+                    c.dist_type, c.d) for c in cfg.cams]
+    n = len(cfg.cams)
+    return [(i, j) for i in range(n) for j in range(i + 1, n)
+            if overlap_fn(small[j], small[i], cfg.T_SC[i][0].T @ cfg.T_SC[j][0])]
+
+
+_CUBE_CACHE = {}
+
+
+def _cube_faces(seed: int, size: int, cell: int):
+    key = (seed, size, cell)
+    if key not in _CUBE_CACHE:
+        _CUBE_CACHE[key] = np.stack([corners_image(size, size, seed + 31 * f, cell=cell)
+                                     for f in range(6)]).astype(np.float32)
+    return _CUBE_CACHE[key]
+
+
+def render_rig(cfg: Config, rays_per_cam, seed: int, radius: float = 4.0, face: int = 1536,
+               cell: int = 32, r_S=None):
+    """One multiframe of a rig with extrinsics: the sensor sits at r_S (default origin) inside a
+    textured sphere of `radius` metres centred at the origin; every camera pixel's unit ray
+    (rays_per_cam[c]: H x W x 3, e.g. the awareness-map rays of okvfe_build_awareness_maps) is
+    intersected with the sphere and the hit point looks up a cube-mapped corner texture.  All
+    cameras therefore see ONE consistent 3-D scene with real parallax (baseline / radius), so
+    cross-camera matches triangulate."""
+    r_S = np.zeros(3) if r_S is None else np.asarray(r_S, dtype=np.float64)
+    tex = _cube_faces(seed, face, cell)
+    out = []
+    for ci, cam in enumerate(cfg.cams):
+        C, r = cfg.T_SC[ci]
+        rays = np.asarray(rays_per_cam[ci], dtype=np.float64).reshape(-1, 3)
+        valid = np.abs(rays).sum(axis=1) > 0
+        d = rays @ C.T                       # ray directions in the sensor (= world) frame
+        o = r + r_S                          # camera centre
+        od = d @ o
+        s = -od + np.sqrt(np.maximum(od * od - (o @ o - radius * radius), 0.0))
+        p = o[None, :] + s[:, None] * d
+        a = np.abs(p)
+        ax = np.argmax(a, axis=1)
+        m = np.take_along_axis(a, ax[:, None], axis=1)[:, 0] + 1e-30
+        sign = np.take_along_axis(p, ax[:, None], axis=1)[:, 0] < 0
+        fidx = 2 * ax + sign
+        u_ax, v_ax = (ax + 1) % 3, (ax + 2) % 3
+        u = np.take_along_axis(p, u_ax[:, None], axis=1)[:, 0] / m
+        v = np.take_along_axis(p, v_ax[:, None], axis=1)[:, 0] / m
+        fu_ = (u * 0.5 + 0.5) * (face - 1)
+        fv_ = (v * 0.5 + 0.5) * (face - 1)
+        x0 = np.clip(np.floor(fu_).astype(np.int64), 0, face - 2)
+        y0 = np.clip(np.floor(fv_).astype(np.int64), 0, face - 2)
+        ax_, ay_ = (fu_ - x0).astype(np.float32), (fv_ - y0).astype(np.float32)
+        t = tex[fidx, y0, x0] * (1 - ax_) * (1 - ay_) + tex[fidx, y0, x0 + 1] * ax_ * (1 - ay_) + \
+            tex[fidx, y0 + 1, x0] * (1 - ax_) * ay_ + tex[fidx, y0 + 1, x0 + 1] * ax_ * ay_
+        rng = np.random.default_rng(seed * 131 + ci)
+        img = np.where(valid, t + rng.integers(-2, 3, size=t.shape), 0.0)
+        out.append(np.clip(np.rint(img), 0, 255).astype(np.uint8).reshape(cam.h, cam.w))
+    return out

@@ -119,6 +119,8 @@ typedef struct orc_camera {
   double d[4]; /* k1 k2 p1 p2 | k1 k2 k3 k4 */
 } orc_camera;
 
+/* fixed-sequence FP64 atan used by the equidistant model (see orc_camera.c header) */
+double orc_atan_fixed(double x);
 int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], double J[4]);
 int orc_cam_undistort(const orc_camera* c, const double pd[2], double out[2]);
 int orc_cam_backproject(const orc_camera* c, const double pt[2], double dir[3]);

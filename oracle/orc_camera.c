@@ -13,12 +13,76 @@
  * left to right with explicit temporaries (build with -ffp-contract=off).
  * Pinned against the tolerances of okvis_cv/test/TestPinholeCamera.cpp:52-140
  * (back-project/project round trip < 0.01 px, analytic vs numeric Jacobian
- * < 1e-4) in tests/test_oracle_camera.py.
+ * < 1e-4) in tests/test_oracle_pins.py.
+ *
+ * atan: the reference calls libm's atan (EquidistantDistortion.hpp:98,138).  A libm atan is
+ * not reproducible across libm versions or on the GPU, so this oracle evaluates orc_atan_fixed
+ * -- its own copy of the published fdlibm reduction + degree-23 odd polynomial, a fixed
+ * sequence of IEEE operations -- which stays within 1 ulp of glibc's atan
+ * (tests/test_oracle_pins.py::test_fixed_atan_within_one_ulp_of_libm).  The product carries the
+ * same sequence (okvis2_amd/csrc/atan_fixed.h), which is what makes equidistant back-projections
+ * comparable as bit patterns.
+ *
+ * Attribution: orc_cam_distort keeps the reference's operation order and is a close
+ * transcription of RadialTangentialDistortion.hpp:111-135 / EquidistantDistortion.hpp:128-171,
+ * Copyright (c) 2015 Autonomous Systems Lab / ETH Zurich, (c) 2020 Smart Robotics Lab / Imperial
+ * College London, (c) 2024 Smart Robotics Lab / Technical University of Munich, BSD 3-Clause
+ * (licence text in the header of those files; its conditions apply to that fragment).
  */
 #include "okvfe_oracle.h"
 
 #include <math.h>
 #include <string.h>
+
+/* fdlibm-style atan (K.C. Ng's published scheme): break points 7/16, 11/16, 19/16, 39/16 */
+double orc_atan_fixed(double x) {
+  static const double hi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                               9.82793723247329054082e-01, 1.57079632679489655800e+00};
+  static const double lo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                               1.39033110312309984516e-17, 6.12323399573676603587e-17};
+  static const double aT[11] = {
+      3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+      -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
+      6.66107313738753120669e-02, -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+      -3.65315727442169155270e-02, 1.62858201153657823623e-02};
+  double ax, t, z, w, s1, s2, r;
+  int id, neg;
+  if (x != x) return x;
+  neg = x < 0.0;
+  ax = neg ? -x : x;
+  if (ax >= 7.378697629483821e19) { /* 2^66 */
+    r = hi[3] + lo[3];
+    return neg ? -r : r;
+  }
+  if (ax < 0.4375) {
+    if (ax < 1.862645149230957e-09) return x; /* 2^-29 */
+    id = -1;
+    t = ax;
+  } else if (ax < 1.1875) {
+    if (ax < 0.6875) {
+      id = 0;
+      t = (2.0 * ax - 1.0) / (2.0 + ax);
+    } else {
+      id = 1;
+      t = (ax - 1.0) / (ax + 1.0);
+    }
+  } else if (ax < 2.4375) {
+    id = 2;
+    t = (ax - 1.5) / (1.0 + 1.5 * ax);
+  } else {
+    id = 3;
+    t = -1.0 / ax;
+  }
+  z = t * t;
+  w = z * z;
+  s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+  s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+  if (id < 0)
+    r = t - t * (s1 + s2);
+  else
+    r = hi[id] - ((t * (s1 + s2) - lo[id]) - t);
+  return neg ? -r : r;
+}
 
 /* distort u -> out, with the 2x2 Jacobian J (row-major) when J != NULL */
 int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], double J[4]) {
@@ -54,7 +118,7 @@ int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], doubl
   {
     const double k1 = c->d[0], k2 = c->d[1], k3 = c->d[2], k4 = c->d[3];
     const double r = sqrt(u0 * u0 + u1 * u1);
-    const double theta = atan(r);
+    const double theta = orc_atan_fixed(r);
     const double theta2 = theta * theta;
     const double theta4 = theta2 * theta2;
     const double theta6 = theta4 * theta2;
@@ -69,7 +133,7 @@ int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], doubl
         t2 = u0 * u0;
         t3 = u1 * u1;
         t4 = t2 + t3;
-        t6 = atan(sqrt(t4));
+        t6 = orc_atan_fixed(sqrt(t4));
         t7 = t6 * t6;
         t8 = 1.0 / sqrt(t4);
         t9 = t7 * t7;

@@ -177,6 +177,14 @@ def popcnt_xor(a, b, n128=3) -> int:
     return int(lib().orc_popcnt_xor(_p(a), _p(b), int(n128)))
 
 
+def atan_fixed(x) -> np.ndarray:
+    """orc_atan_fixed element-wise (the oracle's fixed-sequence FP64 atan)."""
+    f = lib().orc_atan_fixed
+    f.restype, f.argtypes = C.c_double, [C.c_double]
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    return np.array([f(float(v)) for v in x], dtype=np.float64)
+
+
 def awareness_maps(cam):
     c = make_camera(cam)
     rays = np.zeros((cam.h, cam.w, 3), dtype=np.float32)

@@ -46,7 +46,9 @@ def test_hip_path_reproduces_golden_vectors():
     (k0, d0, b0, v0), (k1, d1, b1, v1) = res
     m = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1)
     assert np.array_equal(m.view(np.uint8), g["match_stereo"].view(np.uint8))
-    # noise frame with the reference's smoke-test detector parameters (TestFrame.cpp:75-77)
+    # noise frame (the reference's smoke-test INPUT kind, TestFrame.cpp:83-85) with its radius /
+    # threshold / count (34, 800, 450) but octaves = 0; the reference's own call passes octaves = 2
+    # (TestFrame.cpp:75-77) -- that case is tests/test_gpu_octaves.py
     fe2 = capi.Frontend(W, H, 34.0, 0, 800, 450)
     assert np.array_equal(fe2.detect(g["noise"]).view(np.uint8), g["kp_noise"].view(np.uint8))
     # score map
@@ -73,7 +75,7 @@ def test_gather_blocks_rccl_and_block_matching(oracle):
             fe.set_camera(ci, cams[ci])
         imgs = torch.from_numpy(np.stack([g["left"], g["right"]])).cuda()
         grav = np.tile(np.array([0.1, 0.98, -0.05], dtype=np.float32), (2, 1))
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream()  # torch default stream -> OKVFE_STREAM_LEGACY_DEFAULT
         fe.detect_describe_batch_device(imgs.data_ptr(), 2, np.array([0, 1], dtype=np.int32), grav, stream)
         nb = fe.gather_block_bytes()
         assert nb == multigpu.block_layout(maxk)["total"]
@@ -118,7 +120,7 @@ def test_batched_block_pack_and_match(oracle):
     d_img = torch.from_numpy(imgs).cuda()
     cam_ids = np.array([0] * nfr + [1] * nfr, dtype=np.int32)
     grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (2 * nfr, 1))
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream()  # torch default stream -> OKVFE_STREAM_LEGACY_DEFAULT
     fe.detect_describe_batch_device(d_img.data_ptr(), 2 * nfr, cam_ids, grav, stream)
     nb = fe.gather_block_bytes()
     blocks = torch.zeros((2, nfr, nb), dtype=torch.uint8, device="cuda")

@@ -147,8 +147,7 @@ def test_match_to_map_3d(oracle, max_desc):
 
 def test_tumvi_1024_equidistant(oracle):
     """config/tumvi_slam_1024.yaml: 1024x1024, radius 50, threshold 5, <= 1000 keypoints.
-    Detect + describe are bit-exact; back-projection of an equidistant camera uses atan() and is
-    compared to 1e-12."""
+    Detect + describe and the equidistant back-projections (fixed-sequence atan) are bit-exact."""
     cfg = synth.tumvi1024_config()
     fe = G.make_frontend(cfg)
     cam = cfg.cams[0]
@@ -162,8 +161,7 @@ def test_tumvi_1024_equidistant(oracle):
     G.assert_keypoints_equal(kps, rk)
     assert np.array_equal(desc, rd) and len(kps) > 200
     rbp, rv = oracle.backproject_keypoints(cam, rk)
-    # fisheye rim: tangent values up to ~65, so the tolerance is relative (measured: 2e-14 rel.)
-    assert np.array_equal(bpv, rv) and np.allclose(bp, rbp, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(bpv, rv) and np.array_equal(bp.view(np.uint64), rbp.view(np.uint64))
     # the noise frame has ~50k NMS maxima: exercises the global-memory sort path
     noise = synth.noise_image(cfg.w, cfg.h, 78)
     G.assert_keypoints_equal(fe.detect(noise),
@@ -203,8 +201,11 @@ def test_hilti_five_cameras_overlap_driven_matching(oracle):
     f = [0.5 * (c.fu + c.fv) for c in cams]
     for (i, j) in visit:
         (k0, d0, b0, v0), (k1, d1, b1, v1) = res[i], res[j]
-        # both sides consume the GPU's back-projections (equidistant: atan last-ulp caveat)
-        ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[i], f[j],
+        # the oracle consumes ITS OWN back-projections (bit-equal to the GPU's since round 2)
+        ob0, ov0 = oracle.backproject_keypoints(cams[i], k0)
+        ob1, ov1 = oracle.backproject_keypoints(cams[j], k1)
+        assert np.array_equal(ob0.view(np.uint64), b0.view(np.uint64)) and np.array_equal(ov0, v0)
+        ref = oracle.match_stereo(d0, k0, ob0, ov0, d1, k1, ob1, ov1, T0, T1, f[i], f[j],
                                   cfg.match_threshold)
         got = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f[i], f[j])
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))

@@ -174,3 +174,20 @@ def test_triangulate_fast_cases(oracle):
     s2 /= np.linalg.norm(s2)
     hp, valid, par = oracle.triangulate_fast(p1, e1, p2, s2, sigma)
     assert not valid
+
+
+def test_fixed_atan_within_one_ulp_of_libm(oracle):
+    """The reference's equidistant model calls libm atan (EquidistantDistortion.hpp:98,138); the
+    oracle (and, with the same sequence, the product: okvis2_amd/csrc/atan_fixed.h) evaluates a
+    fixed IEEE operation sequence instead.  Pin: never more than 1 ulp from this host's libm."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-10), np.log(1e6), 20000)),
+                        np.array([0.0, 0.4375, 0.6875, 1.1875, 2.4375, 1.0, 1e300]),
+                        np.nextafter(np.array([0.4375, 0.6875, 1.1875, 2.4375]), 0.0)])
+    x = np.concatenate([x, -x])
+    got = oracle.atan_fixed(x)
+    want = np.arctan(x)
+    ulps = np.abs(got.view(np.int64) - want.view(np.int64))
+    assert ulps.max() <= 1
+    assert (ulps != 0).mean() < 0.03
+    assert np.isnan(oracle.atan_fixed(np.nan)[0])
