@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libokvfe.so")
+LIB_PATH = os.environ.get("OKVFE_LIB") or os.path.join(_HERE, "libokvfe.so")  # OKVFE_LIB: A/B builds
 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \

@@ -17,6 +17,7 @@
 // v_mul_i32_i24 / v_mad_i32_i24 (emitted explicitly: the compiler otherwise falls back to the
 // quarter-rate v_mul_lo_u32 for loop-carried values whose range it cannot prove).
 #include <cstdlib>
+#include <type_traits>
 
 #include "okvfe_internal.h"
 
@@ -25,7 +26,10 @@ namespace okvfe {
 namespace {
 
 constexpr int kTH = 32;  // output rows per wave
-constexpr int kWavesPerBlock = 4;
+#ifndef OKVFE_K1_WPB
+#define OKVFE_K1_WPB 4
+#endif
+constexpr int kWavesPerBlock = OKVFE_K1_WPB;
 
 __device__ __forceinline__ int mul24(int a, int b) {
   int d;
@@ -230,6 +234,9 @@ __device__ __forceinline__ int mulhi24(int a, int b) {  // (a * b) >> 32 of the 
 __device__ __forceinline__ void dpp_fence(int& a, int& b, int& c, int& d, int& e, int& f) {
   asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
+__device__ __forceinline__ void dpp_fence4(int& a, int& b, int& c, int& d) {
+  asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 __device__ __forceinline__ void dpp_fence2(int& a, int& b) {
   asm volatile("s_nop 1" : "+v"(a), "+v"(b));
 }
@@ -242,7 +249,7 @@ __device__ __forceinline__ int from_right(int v) {  // value of lane+1
 
 constexpr int kStripLanes = 62;
 #ifndef OKVFE_K1_WAVES
-#define OKVFE_K1_WAVES __attribute__((amdgpu_waves_per_eu(6, 8)))
+#define OKVFE_K1_WAVES __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
 
 // NMS = true fuses the detector's non-maximum suppression (K2) into the same pass: the wave also
@@ -250,10 +257,11 @@ constexpr int kStripLanes = 62;
 // 3-maxima of the last two rows in registers, and tests every centre row against
 // max(8 neighbours, thr) while it is still in registers -- the score map is then never read back
 // from HBM by the detector (a pure-read pass over it costs as much as this whole kernel).  Hits are
-// shifted into one 32-bit mask per column (v_cmp + v_addc_co), and written out after the row loop
-// through one slot reservation per wave.  Where two horizontally adjacent pixels both pass (equal
-// scores) the raster-scan rule of the reference needs the finished score row of the neighbouring
-// strips, so those candidates are flagged and settled by nms_fixup_kernel (k_nms.hip).
+// shifted into 32-bit masks, one per column (v_cmp + v_addc_co); a tile of more than 32 rows uses
+// two mask sets (the first 30 tested rows, then the rest).  The masks are written out after the row
+// loop through one slot reservation per wave.  Where two horizontally adjacent pixels both pass
+// (equal scores) the raster-scan rule of the reference needs the finished score row of the
+// neighbouring strips, so those candidates are flagged and settled by nms_fixup_kernel (k_nms.hip).
 struct NmsOut {
   int thr;
   Candidate* cand;
@@ -263,18 +271,59 @@ struct NmsOut {
 };
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-// m = (m << 1) | (c >= nb)
-__device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb) {
-  asm volatile("v_cmp_ge_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-               : "+v"(m)
+// Candidate scores ride from the test to the epilogue in LDS: re-reading them from the score map
+// after the row loop missed the L2 (the tile's own stores had pushed them out) and cost one 64-128 B
+// HBM fetch per candidate -- 0.44 GB per 1536 images, as much as 80 % of the image bytes themselves.
+// Layout: entry e of lane l of wave v at byte e * (256 * waves per block) + v * 256 + l * 4 (bank-conflict-free); a
+// lane pushes in test order.  Entries >= kScoreSlots fall outside the workgroup's LDS allocation:
+// the hardware range check discards those writes and the epilogue reads such scores from the map.
+constexpr int kScoreSlots = 16;
+// m = (m << 1) | (c >= nb); lanes that hit push c
+__device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& sp) {
+  uint64_t mask, sav;
+#ifndef OKVFE_K1_NOLDSPUSH
+  // about half of the (row, column) tests of a wave have no hit at all: the push is branched over
+  asm volatile(
+      "v_cmp_ge_i32_e64 %[mask], %[c], %[nb]\n\t"
+      "v_addc_co_u32_e64 %[m], vcc, %[m], %[m], %[mask]\n\t"
+      "s_and_saveexec_b64 %[sav], %[mask]\n\t"
+      "s_cbranch_execz .Lokvfe_nopush%=\n\t"
+      "ds_write_b32 %[sp], %[c]\n\t"
+      "v_add_u32 %[sp], %[stride], %[sp]\n"
+      ".Lokvfe_nopush%=:\n\t"
+      "s_mov_b64 exec, %[sav]"
+      : [m] "+v"(m), [sp] "+v"(sp), [mask] "=&s"(mask), [sav] "=&s"(sav)
+      : [c] "v"(c), [nb] "v"(nb), [stride] "i"(kWavesPerBlock * 256)
+      : "vcc", "scc", "memory");
+#else
+  (void)sav;
+  (void)sp;
+  asm volatile("v_cmp_ge_i32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, vcc, %0, %0, %1"
+               : "+v"(m), "=&s"(mask)
                : "v"(c), "v"(nb)
                : "vcc");
+#endif
 }
 
+constexpr int kSplitTests = 30;  // tiles of more than 32 rows: hit bits of the first 30 tested rows
+
+// One wave = one strip x kTHF rows, ONE branch-free code path for every tile: a prologue,
+// kMain / 6 groups of six identical steps (the rolling buffers have periods 2 and 3, so after six
+// steps every value is back in the register it started in and the loop carries no copies) and, with
+// the NMS fused, one final step.  The image rim costs no vector work:
+//   * pixel rows outside the image: the scalar row offset is clamped;
+//   * covariance rows 0 and h-1 (zero by definition): the filter constants k3 / k10 of that step are
+//     selected to 0 on the scalar unit, which zeroes both gradients;
+//   * score rows 0 and h-1: computed like any other row (they are never an NMS centre and never the
+//     neighbour of a tested row) and overwritten with zeros after the loop by the two waves that
+//     own them; rows past the image (partial last tile) are not stored;
+//   * hit bits of rows that may not be maxima (y < 2, y >= h-2) are masked in the epilogue.
 template <int kTHF, bool NMS>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int strips,
     int ytiles, int n_images, NmsOut nms) {
+  constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
+  static_assert(kMain % 6 == 0 && kTHF <= 61, "rows per wave: 6k (+1 with the fused NMS), <= 61");
   const int lane = threadIdx.x;
   int image, tile;
   xcd_tile(strips * ytiles, n_images, &image, &tile);
@@ -286,9 +335,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   const int ys_own = (ytile * kWavesPerBlock + wave) * kTHF;
   if (ys_own >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
   const int ye_own = ys_own + kTHF < h ? ys_own + kTHF : h;
-  // score rows computed by this wave: with NMS one more above and below the rows it owns
-  const int ys = NMS ? ys_own - 1 : ys_own;
-  const int ye = NMS ? ye_own + 1 : ye_own;
+  const int ys = NMS ? ys_own - 1 : ys_own;  // first score row computed (with NMS one above the tile)
   const bool last_strip = strip * kStripLanes + 64 >= nd;
   const bool store = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;  // clamped dword index for loads
@@ -300,18 +347,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       scores + img_off, 0, w * h * 4, 0x00027000);
   const int ld_off = dcl * 4;    // byte offset of this lane's dword within a pixel row
-  const int st_off = dcl * 16;   // byte offset of this lane's 4 scores within a score row
+  // halo lanes (and lanes past the image) store nowhere: their per-lane offset lies outside the
+  // resource, so the hardware range check drops the store (the scalar offset is not range-checked)
+  const int st_off = store ? dcl * 16 : 0x7FFFFFF0;
   int m0 = d == 0 ? 0 : -1;        // column 0 is rim
   int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
   // keep the masks as opaque VGPR values: "x & m" then stays a 2-cycle v_and_b32 instead of being
   // rewritten into a v_cndmask_b32_e64 on a re-materialised compare
   asm volatile("" : "+v"(m0), "+v"(m3));
-  const int k3 = 3 << 9, k10 = 10 << 9;  // gradients carry a factor 2^9: mulhi24 then yields >> 14
 
-  auto load_row = [&](int row) -> uint32_t {
-    row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rsrc, ld_off, row * w, 0);
-  };
   auto unpack4 = [](uint32_t c, int p[4]) {
     p[0] = c & 255;
     p[1] = (c >> 8) & 255;
@@ -324,14 +368,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // partial sum stays below 2^16, so one 32-bit add smooths two channels); stream 1 carries xy
   int hs[2][2][4];   // horizontally smoothed entries: current / previous row
   int vp[2][2][4];   // vertical pair sums hs[g-1] + hs[g]
-  uint32_t raw[3];   // pixel rows in flight (loaded two steps ahead)
-  {
-    const uint32_t t0 = load_row(ys - 2), t1 = load_row(ys - 1);
-    raw[0] = load_row(ys);
-    raw[1] = load_row(ys + 1);
-    unpack4(t0, pr[0]);
-    unpack4(t1, pr[1]);
-  }
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -340,162 +376,260 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       for (int i = 0; i < 4; ++i) hs[q][c][i] = vp[q][c][i] = 0;
 
   // NMS state: scores + edge neighbours of the previous row, horizontal 3-max of the last two
-  int nc[4], nh[2][4], nl = 0, nr = 0;
-  uint32_t hits[4] = {0u, 0u, 0u, 0u};
-  const int yt0 = ys_own > 2 ? ys_own : 2;                  // tested centre rows [yt0, yt1)
-  const int yt1 = ye_own < h - 2 ? ye_own : h - 2;
-  if (NMS) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) nc[i] = nh[0][i] = nh[1][i] = 0;
-  }
+  int nc[4] = {0, 0, 0, 0}, nh[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, nl = 0, nr = 0;
+  uint32_t hits[4] = {0u, 0u, 0u, 0u}, hitsA[4] = {0u, 0u, 0u, 0u};
+  constexpr int n_a = (NMS && kTHF > 32) ? kSplitTests : 0;  // tests recorded in hitsA
+  __shared__ int32_t score_stack[NMS ? kScoreSlots * kWavesPerBlock * 64 : 1];
+  const uint32_t sp0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
+                       (uint32_t)(wave * 256 + lane * 4);
+  uint32_t sp = sp0;  // LDS byte address of this lane's next score slot
 
-  // step j: consume pixel row r = ys+j, covariance row g = r-1, score row y = g-1 (from j >= 2)
-  auto step = [&](int j, int s_new, int s_a, int s_b, int q) {
-    const int r = ys + j;
-    raw[s_new] = load_row(r + 2);   // raw slot (j+2)%3 is free
-    unpack4(raw[s_a], pr[s_new]);   // raw slot j%3 holds row r
-    const int g = r - 1;
-    const int* a = pr[s_a];
-    const int* b = pr[s_b];
-    const int* c = pr[s_new];
-    int (*H)[4] = hs[q];
-    int (*Hp)[4] = hs[q ^ 1];
-    int (*V)[4] = vp[q];
-    int (*Vp)[4] = vp[q ^ 1];
-    if (g >= 1 && g <= h - 2) {  // wave-uniform
-      int vs[4], vd[4];
+  // covariance row g from pixel rows a (g-1), b (g), c (g+1) -> H (horizontally smoothed); k3, k10 =
+  // the (3, 10, 3) filter taps times 2^9 (mulhi24 of two such gradients then yields g*g >> 14), or
+  // 0, 0 for a rim row
+  auto cov_row = [&](const int* a, const int* b, const int* c, int (*H)[4], int k3, int k10) {
+    int vs[4], vd[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        vs[i] = __mul24(b[i], k10) + __mul24(a[i] + c[i], k3);
-        vd[i] = c[i] - a[i];
-      }
-      // NOTE: the subtrahend of gx[0] is shifted in NEGATED form and added: hipcc folds
-      // "x - dpp(y)" into v_subrev_u32_dpp wave_shr:1, which does not shift on gfx950
-      // (tools/ubench/dpp_test.hip); v_add_u32_dpp / v_sub_u32_dpp(dpp - x) are fine.
-      const int vs_l_neg = from_left(-vs[3]), vs_r = from_right(vs[0]);
-      const int vd_l = from_left(vd[3]), vd_r = from_right(vd[0]);
-      int gx[4], gy[4];
-      gx[0] = (vs[1] + vs_l_neg) & m0;
-      gx[1] = vs[2] - vs[0];
-      gx[2] = vs[3] - vs[1];
-      gx[3] = (vs_r - vs[2]) & m3;
-      // __mul24: 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24, 4 cycles); a plain int
-      // expression here is lowered to v_mad_u64_u32, which is several times slower
-      gy[0] = (__mul24(vd[0], k10) + __mul24(vd_l + vd[1], k3)) & m0;
-      gy[1] = __mul24(vd[1], k10) + __mul24(vd[0] + vd[2], k3);
-      gy[2] = __mul24(vd[2], k10) + __mul24(vd[1] + vd[3], k3);
-      gy[3] = (__mul24(vd[3], k10) + __mul24(vd[2] + vd_r, k3)) & m3;
-      int G[2][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gxx = mulhi24(gx[i], gx[i]);
-        const int gyy = mulhi24(gy[i], gy[i]);
-        G[0][i] = gxx | (gyy << 16);
-        G[1][i] = mulhi24(gx[i], gy[i]);
-      }
-      dpp_fence2(G[1][0], G[1][3]);
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {
-        const int gl = from_left(G[ch][3]), gr = from_right(G[ch][0]);
-        const int pm = gl + G[ch][0];
-        const int p0 = G[ch][0] + G[ch][1];
-        const int p1 = G[ch][1] + G[ch][2];
-        const int p2 = G[ch][2] + G[ch][3];
-        const int p3 = G[ch][3] + gr;
-        H[ch][0] = pm + p0;
-        H[ch][1] = p0 + p1;
-        H[ch][2] = p1 + p2;
-        H[ch][3] = p2 + p3;
-      }
-    } else {
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) H[ch][i] = 0;
+    for (int i = 0; i < 4; ++i) {
+      vs[i] = __mul24(b[i], k10) + __mul24(a[i] + c[i], k3);
+      vd[i] = c[i] - a[i];
     }
+    // NOTE: the subtrahend of gx[0] is shifted in NEGATED form and added: hipcc folds
+    // "x - dpp(y)" into v_subrev_u32_dpp wave_shr:1, which does not shift on gfx950
+    // (tools/ubench/dpp_test.hip); v_add_u32_dpp / v_sub_u32_dpp(dpp - x) are fine.
+    const int vs_l_neg = from_left(-vs[3]), vs_r = from_right(vs[0]);
+    const int vd_l = from_left(vd[3]), vd_r = from_right(vd[0]);
+    int gx[4], gy[4];
+    gx[0] = (vs[1] + vs_l_neg) & m0;
+    gx[1] = vs[2] - vs[0];
+    gx[2] = vs[3] - vs[1];
+    gx[3] = (vs_r - vs[2]) & m3;
+    // __mul24: 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24); a plain int expression here is
+    // lowered to v_mad_u64_u32, which is several times slower
+    gy[0] = (__mul24(vd[0], k10) + __mul24(vd_l + vd[1], k3)) & m0;
+    gy[1] = __mul24(vd[1], k10) + __mul24(vd[0] + vd[2], k3);
+    gy[2] = __mul24(vd[2], k10) + __mul24(vd[1] + vd[3], k3);
+    gy[3] = (__mul24(vd[3], k10) + __mul24(vd[2] + vd_r, k3)) & m3;
+    int G[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // xx | yy << 16 without a separate pack: the second product is written into the upper half
+      // of the register that already holds the first one (SDWA destination select; both products
+      // are < 2^10)
+#ifndef OKVFE_K1_NOPACKMERGE
+      int g0 = mulhi24(gx[i], gx[i]);
+      asm("v_mul_hi_i32_i24_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE "
+          "src0_sel:DWORD src1_sel:DWORD"
+          : "+v"(g0)
+          : "v"(gy[i]));
+      G[0][i] = g0;
+#else
+      G[0][i] = mulhi24(gx[i], gx[i]) | (mulhi24(gy[i], gy[i]) << 16);
+#endif
+      G[1][i] = mulhi24(gx[i], gy[i]);
+    }
+    dpp_fence4(G[0][0], G[0][3], G[1][0], G[1][3]);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const int gl = from_left(G[ch][3]), gr = from_right(G[ch][0]);
+      const int pm = gl + G[ch][0];
+      const int p0 = G[ch][0] + G[ch][1];
+      const int p1 = G[ch][1] + G[ch][2];
+      const int p2 = G[ch][2] + G[ch][3];
+      const int p3 = G[ch][3] + gr;
+      H[ch][0] = pm + p0;
+      H[ch][1] = p0 + p1;
+      H[ch][2] = p1 + p2;
+      H[ch][3] = p2 + p3;
+    }
+  };
+  // score row from the vertical pair sums of the last two steps
+  auto score_row = [&](int (*Vp)[4], int (*V)[4], int sc[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned AB = (unsigned)(Vp[0][i] + V[0][i]);  // A | B << 16
+      const int Cc = Vp[1][i] + V[1][i];
+      const int tq = (int)((((AB >> 1) & 0x7FFFu) + (AB >> 17)) >> 1);  // ((A>>1)+(B>>1))>>1
+      int ab;  // A * B straight from the packed halves (SDWA word selects): no unpacking
+      asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 "
+          "src1_sel:WORD_1"
+          : "=v"(ab)
+          : "v"(AB));
+      sc[i] = ab - mad24(tq, tq, mul24(Cc, Cc));
+    }
+    sc[0] &= m0;
+    sc[3] &= m3;
+  };
+#ifndef OKVFE_K1_STORE_AUX
+#define OKVFE_K1_STORE_AUX 0
+#endif
+  auto store_row = [&](const int sc[4], int y) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = {sc[0], sc[1], sc[2], sc[3]};
+#ifndef OKVFE_K1_NOSTORE
+    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, OKVFE_K1_STORE_AUX);
+#else
+    if (v.x == 0x12345678 && v.y == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, 0);
+#endif
+  };
+  // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc): optionally test centre row y-1, then
+  // roll the state
+  auto nms_row = [&](const int sc[4], int q, bool test) {
+    const int l = from_left(sc[3]), r2 = from_right(sc[0]);
+    const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
+                       max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
+#ifdef OKVFE_K1_NONMS
+    test = false;
+#endif
+    if (test) {
+      const int lft[4] = {nl, nc[0], nc[1], nc[2]};
+      const int rgt[4] = {nc[1], nc[2], nc[3], nr};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        push_hit(hits[i], nc[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr), sp);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      nh[q][i] = hn[i];
+      nc[i] = sc[i];
+    }
+    nl = l;
+    nr = r2;
+  };
+
+  // pixel rows are loaded kAhead steps before they are consumed (ring of 6 slots)
+#ifndef OKVFE_K1_AHEAD
+#define OKVFE_K1_AHEAD 3
+#endif
+  constexpr int kAhead = OKVFE_K1_AHEAD;
+  static_assert(kAhead >= 1 && kAhead <= 5, "prefetch distance");
+  int row_next = ys - 2;  // next pixel row to load (scalar)
+  auto load_next = [&]() -> uint32_t {
+    const int r = row_next < 0 ? 0 : (row_next > h - 1 ? h - 1 : row_next);
+    ++row_next;
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(img_rsrc, ld_off, r * w, 0);
+  };
+  uint32_t ring[6];
+  {
+    const uint32_t t0 = load_next(), t1 = load_next();
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) ring[i] = load_next();
+    unpack4(t0, pr[0]);
+    unpack4(t1, pr[1]);
+  }
+  int y = ys - 2;  // score row completed by the current step (meaningful from step 2 on)
+  // step j (compile-time phase PH = j % 6): pixel row ys+j, covariance row g = ys+j-1, score row
+  // y = ys+j-2
+  auto step = [&](auto ph, auto want_score, auto want_store, auto want_test) {
+    constexpr int PH = decltype(ph)::value;
+    constexpr int s_new = (PH + 2) % 3, s_a = PH % 3, s_b = (PH + 1) % 3, q = PH % 2;
+    ring[(PH + kAhead) % 6] = load_next();
+    unpack4(ring[PH], pr[s_new]);
+    const int g = y + 1;
+    const bool inner = g >= 1 && g <= h - 2;  // scalar
+    cov_row(pr[s_a], pr[s_b], pr[s_new], hs[q], inner ? 3 << 9 : 0, inner ? 10 << 9 : 0);
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) V[ch][i] = Hp[ch][i] + H[ch][i];
-    const int y = g - 1;
-    if (j >= 2 && y < ye) {  // wave-uniform
+      for (int i = 0; i < 4; ++i) vp[q][ch][i] = hs[q ^ 1][ch][i] + hs[q][ch][i];
+    if (decltype(want_score)::value) {
       int sc[4];
-      if (y >= 1 && y <= h - 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned AB = (unsigned)(Vp[0][i] + V[0][i]);  // A | B << 16
-          const int Cc = Vp[1][i] + V[1][i];
-          const int tq = (int)((((AB >> 1) & 0x7FFFu) + (AB >> 17)) >> 1);  // ((A>>1)+(B>>1))>>1
-          int ab;  // A * B straight from the packed halves (SDWA word selects): no unpacking
-          asm("v_mul_u32_u24_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 "
-              "src1_sel:WORD_1"
-              : "=v"(ab)
-              : "v"(AB));
-          sc[i] = ab - mad24(tq, tq, mul24(Cc, Cc));
-        }
-        sc[0] &= m0;
-        sc[3] &= m3;
-      } else {
-        sc[0] = sc[1] = sc[2] = sc[3] = 0;
+      score_row(vp[q ^ 1], vp[q], sc);
+      if (decltype(want_store)::value) {
+        if (y < h) store_row(sc, y);  // scalar branch around one instruction (partial last tile)
       }
-      if (store && (!NMS || (y >= ys_own && y < ye_own))) {
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        const v4i v = {sc[0], sc[1], sc[2], sc[3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, 0);
-      }
-      if (NMS) {
-        // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc) -> test centre row y-1
-        const int l = from_left(sc[3]), r2 = from_right(sc[0]);
-        const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
-                           max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
-        const int yc = y - 1;
-        if (yc >= yt0 && yc < yt1) {  // wave-uniform
-          const int* c = nc;
-          const int lft[4] = {nl, c[0], c[1], c[2]};
-          const int rgt[4] = {c[1], c[2], c[3], nr};
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            push_hit(hits[i], c[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          nh[q][i] = hn[i];
-          nc[i] = sc[i];
-        }
-        nl = l;
-        nr = r2;
-      }
+      if (NMS) nms_row(sc, q, decltype(want_test)::value);
     }
+    ++y;
   };
-
-  // pixel slots have period 3, the hs/vp ping-pong period 2 -> unroll by 6
-  const int jn = (ye - ys) + 2;
-  for (int j = 0; j < jn; j += 6) {
-    step(j, 2, 0, 1, 0);
-    if (j + 1 < jn) step(j + 1, 0, 1, 2, 1);
-    if (j + 2 < jn) step(j + 2, 1, 2, 0, 0);
-    if (j + 3 < jn) step(j + 3, 2, 0, 1, 1);
-    if (j + 4 < jn) step(j + 4, 0, 1, 2, 0);
-    if (j + 5 < jn) step(j + 5, 1, 2, 0, 1);
+  using T = std::true_type;
+  using F = std::false_type;
+#define OKVFE_PH(n) std::integral_constant<int, (n) % 6>()
+  step(OKVFE_PH(0), F(), F(), F());
+  step(OKVFE_PH(1), F(), F(), F());
+  if (NMS) {
+    step(OKVFE_PH(2), T(), F(), F());  // score row ys_own - 1: NMS state only
+    step(OKVFE_PH(3), T(), T(), F());  // score row ys_own: stored, nothing to test yet
+    for (int g = 0; g < kMain / 6; ++g) {
+      if (n_a != 0 && g == kSplitTests / 6) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          hitsA[i] = hits[i];
+          hits[i] = 0u;
+        }
+      }
+      step(OKVFE_PH(4), T(), T(), T());
+      step(OKVFE_PH(5), T(), T(), T());
+      step(OKVFE_PH(6), T(), T(), T());
+      step(OKVFE_PH(7), T(), T(), T());
+      step(OKVFE_PH(8), T(), T(), T());
+      step(OKVFE_PH(9), T(), T(), T());
+    }
+    step(OKVFE_PH(kTHF + 3), T(), F(), T());  // score row ys_own + kTHF: last test, not stored
+  } else {
+    for (int g = 0; g < kMain / 6; ++g) {
+      step(OKVFE_PH(2), T(), T(), F());
+      step(OKVFE_PH(3), T(), T(), F());
+      step(OKVFE_PH(4), T(), T(), F());
+      step(OKVFE_PH(5), T(), T(), F());
+      step(OKVFE_PH(6), T(), T(), F());
+      step(OKVFE_PH(7), T(), T(), F());
+    }
+  }
+#undef OKVFE_PH
+  // rim score rows are zero by definition (same lanes, same addresses as the stores above, which a
+  // wave's memory operations reach in order)
+  if (ys_own == 0 || ye_own == h) {
+    const int zero[4] = {0, 0, 0, 0};
+    if (ys_own == 0) store_row(zero, 0);
+    if (ye_own == h) store_row(zero, h - 1);
   }
 
   if (NMS) {
-    const int tests = yt1 - yt0;  // bit b of hits[] <-> row yt0 + tests - 1 - b
-    if (tests <= 0) return;
+    // hit bits -> candidate records.  Test t = centre row ys_own + t, t in [0, kTHF).  Set A: tests
+    // [0, n_a), bit b <-> t = n_a - 1 - b; set B: tests [n_a, kTHF), bit b <-> t = kTHF - 1 - b.
+    // Rows that may carry maxima: 2 <= y < h - 2 (and inside the tile).
+    const int t_lo = 2 - ys_own > 0 ? 2 - ys_own : 0;
+    const int t_hi = (ye_own < h - 2 ? ye_own : h - 2) - ys_own;  // valid tests [t_lo, t_hi)
+    if (t_hi <= t_lo) return;
+    auto bits_of = [](int t0, int t1, int base, int n) -> uint32_t {
+      // mask of the bits whose test index base + (n - 1 - b) lies in [t0, t1)
+      uint32_t m = 0u;
+      const int lo = t0 - base > 0 ? t0 - base : 0, hi = t1 - base < n ? t1 - base : n;  // local tests
+      if (hi > lo) {
+        const int b_lo = n - hi, cnt = hi - lo;
+        m = (cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << b_lo;
+      }
+      return m;
+    };
+    const uint32_t valid[2] = {n_a ? bits_of(t_lo, t_hi, 0, n_a) : 0u,
+                               bits_of(t_lo, t_hi, n_a, kTHF - n_a)};
     const int x0 = dcl * 4;
+    uint32_t rows_adj[2] = {0u, 0u};
+    int cnt = 0;
+    // every hit was pushed, the ones masked below included: slot indices count the unmasked bits
+    const uint32_t rawA[4] = {hitsA[0], hitsA[1], hitsA[2], hitsA[3]};
+    const uint32_t rawB[4] = {hits[0], hits[1], hits[2], hits[3]};
+    const int pushed_a = __popc(rawA[0]) + __popc(rawA[1]) + __popc(rawA[2]) + __popc(rawA[3]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)  // columns 0, 1, w-2, w-1 are never maxima
-      if (x0 + i < 2 || x0 + i >= w - 2) hits[i] = 0u;
-    const uint32_t adj = (hits[0] & hits[1]) | (hits[1] & hits[2]) | (hits[2] & hits[3]) |
-                         (hits[3] & (uint32_t)from_right((int)hits[0]));
-    uint32_t rows_adj = 0u;
-    if (__builtin_expect(__any(adj != 0u), 0)) {
-      rows_adj = adj;
+    for (int set = 0; set < 2; ++set) {
+      uint32_t* m = set == 0 ? hitsA : hits;
 #pragma unroll
-      for (int dd = 32; dd > 0; dd >>= 1) rows_adj |= (uint32_t)__shfl_xor((int)rows_adj, dd);
+      for (int i = 0; i < 4; ++i) {  // columns 0, 1, w-2, w-1 are never maxima
+        m[i] &= valid[set];
+        if (x0 + i < 2 || x0 + i >= w - 2) m[i] = 0u;
+      }
+      const uint32_t adj = (m[0] & m[1]) | (m[1] & m[2]) | (m[2] & m[3]) |
+                           (m[3] & (uint32_t)from_right((int)m[0]));
+      if (__builtin_expect(__any(adj != 0u), 0)) {
+        uint32_t ra = adj;
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) ra |= (uint32_t)__shfl_xor((int)ra, dd);
+        rows_adj[set] = ra;
+      }
+      if (!store) m[0] = m[1] = m[2] = m[3] = 0u;  // halo lanes only fed the neighbours
+      cnt += __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
     }
-    if (!store) hits[0] = hits[1] = hits[2] = hits[3] = 0u;  // halo lanes only fed the neighbours
-    const int cnt = __popc(hits[0]) + __popc(hits[1]) + __popc(hits[2]) + __popc(hits[3]);
     if (!__any(cnt != 0)) return;
     int incl = cnt;
 #pragma unroll
@@ -511,25 +645,45 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
     int flagged = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t mm = hits[i];
-      while (mm) {
-        const int b = __ffs((int)mm) - 1;
-        mm &= mm - 1;
-        const int y = yt0 + tests - 1 - b;
-        Candidate cd;
-        cd.x = x0 + i;
-        cd.y = y;
-        if ((rows_adj >> b) & 1u) {  // to be settled by nms_fixup_kernel
-          cd.y |= kCandidateFixupFlag;
-          ++flagged;
+    for (int set = 0; set < 2; ++set) {
+      const uint32_t* m = set == 0 ? hitsA : hits;
+      const int row_hi = ys_own + (set == 0 ? n_a : kTHF) - 1;  // row of bit 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t mm = m[i];
+        while (mm) {
+          const int b = __ffs((int)mm) - 1;
+          mm &= mm - 1;
+          const int yy = row_hi - b;
+          Candidate cd;
+          cd.x = x0 + i;
+          cd.y = yy;
+          if ((rows_adj[set] >> b) & 1u) {  // to be settled by nms_fixup_kernel
+            cd.y |= kCandidateFixupFlag;
+            ++flagged;
+          }
+          // slot = pushes of earlier tests (higher bits; all of set A for set B) + pushes of the
+          // same test in the columns before i
+          const uint32_t* raw = set == 0 ? rawA : rawB;
+          int e = set == 0 ? 0 : pushed_a;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            e += __popc((raw[c] >> b) >> 1);
+            if (c < i) e += (int)((raw[c] >> b) & 1u);
+          }
+#ifdef OKVFE_K1_NOLDSPUSH
+          e = kScoreSlots;
+#endif
+          if (e < kScoreSlots)
+            cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
+          else
+            cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, dcl * 16 + 4 * i + yy * w * 4, 0, 1);
+          if (pos < nms.cand_cap) outc[pos] = cd;
+          ++pos;
         }
-        cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i + y * w * 4, 0, 1);
-        if (pos < nms.cand_cap) outc[pos] = cd;
-        ++pos;
       }
     }
-    if (rows_adj != 0u && __any(flagged != 0)) {
+    if ((rows_adj[0] | rows_adj[1]) != 0u && __any(flagged != 0)) {
       if (flagged) atomicAdd(&nms.fix_count[image], flagged);
     }
   }
@@ -548,34 +702,33 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     int strips = 1;
     while ((strips - 1) * kStripLanes + 64 < nd) ++strips;  // last strip must reach dword nd-1
     static const int th_env = [] {
-      const char* e = getenv("OKVFE_K1_TH");  // tuning knob: output rows per wave
+      const char* e = getenv("OKVFE_K1_TH");  // A/B knob: rows per wave of the fused kernel (25..61)
       return e ? atoi(e) : 0;
     }();
-#define OKVFE_K1_LAUNCH(TH)                                                                   \
-  {                                                                                           \
-    const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                 \
-    if (nms)                                                                                  \
-      hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(strips * ytiles * n_images), block, 0, \
-                         stream, img, w, h, score, strips, ytiles, n_images, *nms);           \
-    else                                                                                      \
-      hipLaunchKernelGGL((harris_kernel<TH, false>), dim3(strips * ytiles * n_images), block, 0, \
-                         stream, img, w, h, score, strips, ytiles, n_images, NmsOut{});       \
+#define OKVFE_K1_NMS_LAUNCH(TH)                                                                 \
+  {                                                                                              \
+    const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                    \
+    hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(strips * ytiles * n_images), block, 0,    \
+                       stream, img, w, h, score, strips, ytiles, n_images, *nms);                \
   }
-    const int th = th_env ? th_env : (h % 30 == 0 ? 30 : 32);
-    if (nms && th > 32) return false;  // one hit bit per row in a 32-bit mask
-    switch (th) {
-      case 16: OKVFE_K1_LAUNCH(16); break;
-      case 24: OKVFE_K1_LAUNCH(24); break;
-      case 30: OKVFE_K1_LAUNCH(30); break;
-      case 40: OKVFE_K1_LAUNCH(40); break;
-      case 60: OKVFE_K1_LAUNCH(60); break;
-      case 80: OKVFE_K1_LAUNCH(80); break;
-      case 120: OKVFE_K1_LAUNCH(120); break;
-      case 160: OKVFE_K1_LAUNCH(160); break;
-      case 240: OKVFE_K1_LAUNCH(240); break;
-      default: OKVFE_K1_LAUNCH(32); break;
+    if (nms) {
+      // rows per wave (6k + 1): more rows = fewer halo rows per tile (6 per tile), but longer waves
+      // (tail) and a later epilogue
+      switch (th_env) {
+        case 25: OKVFE_K1_NMS_LAUNCH(25); break;
+        case 31: OKVFE_K1_NMS_LAUNCH(31); break;
+        case 37: OKVFE_K1_NMS_LAUNCH(37); break;
+        case 43: OKVFE_K1_NMS_LAUNCH(43); break;
+        case 49: OKVFE_K1_NMS_LAUNCH(49); break;
+        case 55: OKVFE_K1_NMS_LAUNCH(55); break;
+        default: OKVFE_K1_NMS_LAUNCH(61); break;
+      }
+    } else {
+      const int ytiles = (h + 30 * kWavesPerBlock - 1) / (30 * kWavesPerBlock);
+      hipLaunchKernelGGL((harris_kernel<30, false>), dim3(strips * ytiles * n_images), block, 0, stream,
+                         img, w, h, score, strips, ytiles, n_images, NmsOut{});
     }
-#undef OKVFE_K1_LAUNCH
+#undef OKVFE_K1_NMS_LAUNCH
   } else {
     if (nms) return false;
     const dim3 grid((w + 255) / 256, (h + kTH * kWavesPerBlock - 1) / (kTH * kWavesPerBlock),

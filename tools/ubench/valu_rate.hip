@@ -40,6 +40,55 @@
 #define DPPMOV(x) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
 #define SUBSDWA(x) asm volatile("v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_0" : "+v"(x) : "v"(b));
 
+#define MAX3(x) asm volatile("v_max3_i32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define MAXI(x) asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define BFE(x) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(x));
+#define LSHLOR(x) asm volatile("v_lshl_or_b32 %0, %0, 16, %1" : "+v"(x) : "v"(b));
+#define ANDLIT(x) asm volatile("v_and_b32 %0, 0x7fff, %0" : "+v"(x));
+#define CMPADDC(x) asm volatile("v_cmp_ge_i32_e32 vcc, %0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(b) : "vcc");
+#define MULHISDWA(x) asm volatile("v_mul_hi_i32_i24_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(x) : "v"(b));
+#define MULU24SDWA(x) asm volatile("v_mul_u32_u24_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(x));
+#define PKLSHR(x) asm volatile("v_pk_lshrrev_b16 %0, 1, %0" : "+v"(x));
+#define ADDSDWA(x) asm volatile("v_add_u32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(x));
+#define DPPADD(x) asm volatile("v_add_u32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b));
+#define DPPROW(x) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+#define SADU8(x) asm volatile("v_sad_u8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(b));
+#define SUB(x) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define LSHR(x) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(x));
+#define MADU24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define ADDMIX(x) asm volatile("v_add_u32 %0, %0, %1\n\tv_mul_i32_i24 %0, %0, %1" : "+v"(x) : "v"(b));
+#define LSHRB16(x) asm volatile("v_lshrrev_b16 %0, 1, %0" : "+v"(x));
+#define ADDU16(x) asm volatile("v_add_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MULHI32(x) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define DOT4I8(x) asm volatile("v_dot4_i32_i8 %0, %0, %1, %0" : "+v"(x) : "v"(b));
+#define XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define ADDSGPR(x) asm volatile("v_add_u32 %0, s4, %0" : "+v"(x));
+#define CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b));
+KERNEL(k_lshrb16, DECL_I, OP8(LSHRB16))
+KERNEL(k_addu16, DECL_I, OP8(ADDU16))
+KERNEL(k_mulhi32, DECL_I, OP8(MULHI32))
+KERNEL(k_dot4i8, DECL_I, OP8(DOT4I8))
+KERNEL(k_xor, DECL_I, OP8(XOR))
+KERNEL(k_cndmask, DECL_I, OP8(CNDMASK))
+KERNEL(k_max3, DECL_I, OP8(MAX3))
+KERNEL(k_maxi, DECL_I, OP8(MAXI))
+KERNEL(k_bfe, DECL_I, OP8(BFE))
+KERNEL(k_lshlor, DECL_I, OP8(LSHLOR))
+KERNEL(k_andlit, DECL_I, OP8(ANDLIT))
+KERNEL(k_cmpaddc2, DECL_I, OP8(CMPADDC))
+KERNEL(k_mulhisdwa, DECL_I, OP8(MULHISDWA))
+KERNEL(k_mulu24sdwa, DECL_I, OP8(MULU24SDWA))
+KERNEL(k_pklshr, DECL_I, OP8(PKLSHR))
+KERNEL(k_addsdwa, DECL_I, OP8(ADDSDWA))
+KERNEL(k_dppadd, DECL_I, OP8(DPPADD))
+KERNEL(k_dpprow, DECL_I, OP8(DPPROW))
+KERNEL(k_sadu8, DECL_I, OP8(SADU8))
+KERNEL(k_mov, DECL_I, OP8(MOV))
+KERNEL(k_sub, DECL_I, OP8(SUB))
+KERNEL(k_lshr, DECL_I, OP8(LSHR))
+KERNEL(k_madu24, DECL_I, OP8(MADU24))
+KERNEL(k_addmul2, DECL_I, OP8(ADDMIX))
 KERNEL(k_add, DECL_I, OP8(ADD))
 KERNEL(k_mul24, DECL_I, OP8(MUL24))
 KERNEL(k_mad24, DECL_I, OP8(MAD24))
@@ -88,5 +137,10 @@ int main() {
   RUN(k_add) RUN(k_mul24) RUN(k_mad24) RUN(k_mullo) RUN(k_mulhi24) RUN(k_ashr) RUN(k_add3) RUN(k_lshladd)
   RUN(k_pkadd) RUN(k_pkmad) RUN(k_pkmul) RUN(k_madi16) RUN(k_dot2) RUN(k_dot4) RUN(k_perm) RUN(k_alignbit)
   RUN(k_fma) RUN(k_and) RUN(k_dppmov) RUN(k_subsdwa)
+  printf("-- round 2 additions (k_cmpaddc2 and k_addmul2 are TWO instructions per count)\n");
+  RUN(k_max3) RUN(k_maxi) RUN(k_bfe) RUN(k_lshlor) RUN(k_andlit) RUN(k_cmpaddc2) RUN(k_mulhisdwa)
+  RUN(k_mulu24sdwa) RUN(k_pklshr) RUN(k_addsdwa) RUN(k_dppadd) RUN(k_dpprow) RUN(k_sadu8) RUN(k_mov)
+  RUN(k_sub) RUN(k_lshr) RUN(k_madu24) RUN(k_addmul2)
+  RUN(k_lshrb16) RUN(k_addu16) RUN(k_mulhi32) RUN(k_dot4i8) RUN(k_xor) RUN(k_cndmask)
   return 0;
 }
