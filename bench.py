@@ -28,44 +28,68 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def make_inputs(cfg, n_frames, n_distinct, seed0):
+def make_inputs(cfg, n_frames, n_distinct, seed0, content="corners"):
     """Multiframes of C = len(cfg.cams) images: cameras 0/1 are a synthetic stereo pair, further
-    cameras (Hilti-shaped rig) look elsewhere and get independent images."""
+    cameras (Hilti-shaped rig without extrinsics) look elsewhere and get independent images.
+    content: "corners" = jittered random-gray cells of 12 px + noise (about 320 keypoints per 752x480
+    image under the EuRoC parameters: the uniformity stage, not the corner supply, sets that number);
+    "checker" = exact two-level 12 px checker cells without noise, whose tied scores all pass the
+    uniformity stage (about 660 keypoints: the matcher's 700 x 700 regime)."""
     from okvis2_amd import synth
     C = len(cfg.cams)
+    kw = dict(cell=12) if content == "corners" else dict(cell=12, levels=(0, 255), noise=0, jitter=0)
     base = []
     for i in range(n_distinct):
-        L, R, _ = synth.stereo_pair(cfg.w, cfg.h, seed0 + i)
+        L, R, _ = synth.stereo_pair(cfg.w, cfg.h, seed0 + i, **kw)
         base.append(L)
         base.append(R)
         for c in range(2, C):
-            base.append(synth.corners_image(cfg.w, cfg.h, seed0 + 7919 * c + i))
+            base.append(synth.corners_image(cfg.w, cfg.h, seed0 + 7919 * c + i, **kw))
     base = np.stack(base)  # [C*n_distinct, H, W]
     reps = (n_frames + n_distinct - 1) // n_distinct
     return np.concatenate([base] * reps)[: C * n_frames], base
 
 
-def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
+N_VARIANTS = 4  # distinct per-step host parameter sets (gravity directions, poses)
+
+
+def gravity_variant(v, n_images):
+    """Extraction directions of step variant v: a few degrees around (0, 1, 0), different per image
+    and per variant, so every step uploads fresh parameters like every real frame does (new T_WC =>
+    new gravity direction, Frontend.cpp:247-251)."""
+    i = np.arange(n_images)
+    g = np.stack([0.02 * (((i + v) % 5) - 2), np.ones(n_images), 0.01 * ((i // 3 + v) % 3 - 1)], axis=1)
+    return (g / np.linalg.norm(g, axis=1, keepdims=True)).astype(np.float32)
+
+
+def pose_variant(cfg, v):
+    """T_WC0 / T_WC1 of step variant v: the rig translated by a variant-dependent offset."""
+    from okvis2_amd import synth
+    (C0, r0), (C1, r1) = synth.stereo_poses(cfg.baseline)
+    off = np.array([0.01 * v, -0.02 * v, 0.005 * v])
+    return (C0, r0 + off), (C1, r1 + off)
+
+
+def cpu_baseline(cfg, base_imgs, fe, grav, poses, budget_s=12.0):
     """Times the CPU oracle (a port of the algorithm, NOT the reference binary, which cannot be
     built here) with the reference's threading shape: one thread per camera for detect+describe
     (ThreadedSlam.cpp:434-448), matchStereo single-threaded (Frontend.cpp:2016).  Also compares
-    the oracle's outputs with the GPU's for the same frames (the oracle acting as checker)."""
+    the oracle's outputs with the GPU's for the same frames (the oracle acting as checker).
+    grav / poses: what the GPU's last step used for these frames."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from okvis2_amd import synth
     maps = [O.awareness_maps(c) for c in cfg.cams]
-    T0, T1 = synth.stereo_poses(cfg.baseline)
+    T0, T1 = poses
     f = [0.5 * (c.fu + c.fv) for c in cfg.cams]
-    grav = (0.0, 1.0, 0.0)
     C = len(cfg.cams)
     n_distinct = len(base_imgs) // C
     out = [None] * C
 
-    def work(ci, img):
+    def work(ci, img, g):
         cam = cfg.cams[ci]
         k, d = O.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
                                  O.MODE_CAMERA_AWARE, maps[ci][0], maps[ci][1], np.float32(cam.fu),
-                                 grav)
+                                 tuple(float(x) for x in g))
         bp, bv = O.backproject_keypoints(cam, k)
         out[ci] = (k, d, bp, bv)
 
@@ -73,10 +97,11 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
     t0 = time.perf_counter()
     while True:
         i = done % n_distinct
-        ths = [threading.Thread(target=work, args=(c, base_imgs[C * i + c])) for c in range(1, C)]
+        ths = [threading.Thread(target=work, args=(c, base_imgs[C * i + c], grav[C * i + c]))
+               for c in range(1, C)]
         for th in ths:
             th.start()
-        work(0, base_imgs[C * i])
+        work(0, base_imgs[C * i], grav[C * i])
         for th in ths:
             th.join()
         (k0, d0, b0, v0) = out[0]
@@ -88,11 +113,13 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
         elapsed = time.perf_counter() - t0
         if done <= n_distinct and fe is not None:  # checker leg, outside the measured work
             t_chk = time.perf_counter()
-            ok = m is None or np.array_equal(fe._bench_matches[i, :len(k0)]["k1"], m["k1"])
+            ok = m is None or np.array_equal(fe._bench_matches[i, :len(k0)].view(np.uint8),
+                                             m.view(np.uint8))
             for c in range(C):
                 g = fe.download(C * i + c)
                 ok = ok and np.array_equal(g[0].view(np.uint8), out[c][0].view(np.uint8)) \
-                    and np.array_equal(g[1], out[c][1])
+                    and np.array_equal(g[1], out[c][1]) \
+                    and np.array_equal(g[2].view(np.uint64), out[c][2].view(np.uint64))
             checked += 1
             mismatches += 0 if ok else 1
             t0 += time.perf_counter() - t_chk
@@ -105,7 +132,153 @@ def cpu_baseline(cfg, base_imgs, fe, budget_s=12.0):
             "sample": f"{done} multiframes of the bench workload ({n_distinct} distinct), "
                       f"{elapsed:.1f} s; 1 thread per camera for detect+describe, match serial; "
                       f"host has {os.cpu_count()} logical cores",
-            "parity_checked_frames": checked, "parity_mismatches": mismatches}
+            "parity_checked_frames": checked, "parity_mismatches": mismatches,
+            "parity_scope": "keypoints, descriptors, back-projections (u64), match rows incl. hp_W"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run with one
+    rank per GPU on this node and pass its output through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+WORKLOAD_TEXT = {
+    "euroc": ("front-end stereo-frames/s (detect+describe+match), 752x480 stereo",
+              "EuRoC-shaped 752x480 stereo, euroc.yaml front-end params (radius 38, thr 150, "
+              "<=700 kpts, match thr 60)"),
+    "tumvi": ("front-end stereo-frames/s (detect+describe+match), 1024x1024 stereo (TUM-VI)",
+              "TUM-VI-shaped 1024x1024 equidistant stereo, tumvi_slam_1024.yaml front-end params "
+              "(radius 50, thr 5, <=1000 kpts, match thr 60)"),
+    "hilti": ("front-end multiframes/s (5 x detect+describe + cross-camera match), 720x540 x 5 "
+              "cameras (Hilti 2022)",
+              "Hilti 2022 rig, 5 equidistant 720x540 cameras, hilti_challenge_2022.yaml front-end "
+              "params (radius 50, thr 20, <=700 kpts, match thr 60)"),
+    "mono640": ("front-end frames/s (detect+describe), 640x480 mono",
+                "640x480 mono (radius 10, thr 5, <=1000 kpts), detect+describe"),
+}
+
+
+def k1_name(h):
+    return "harris_kernel<61, true> (K1 score map + fused K2 NMS)"
+
+
+def roofline_block(P, n_img_launch, harris_ms, extra):
+    achieved = 5.0 * P * n_img_launch / (harris_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "round2_k1_pmc.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        # same kernel, same image shape: per-image HBM bytes x the images of one launch here
+        if pmc.get("algorithmic_bytes_per_launch") == 5 * P * pmc.get("images_per_launch", 0):
+            traffic = pmc["hbm_bytes_per_image"] * n_img_launch
+            traffic_src = ("profiles/round2_k1_pmc.json (FETCH_SIZE/WRITE_SIZE passes at %d images "
+                           "per launch, scaled per image; rocprofv3 cannot run inside this process)"
+                           % pmc["images_per_launch"])
+    r = {"kernel": k1_name(0), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+         "algorithmic_bytes_per_launch": 5 * P * n_img_launch, "avg_launch_ms": harris_ms}
+    r.update(extra)
+    return r
+
+
+def run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev):
+    """BASELINE configs[4]: the Hilti rig with its real extrinsics, cameras spread over the ranks
+    (camera c on rank c % world), ONE RCCL all-gather of the gather blocks per step and the 9
+    FoV-overlapping pairs matched by their owner ranks -- okvis2_amd.multigpu.CrossCameraMatcher."""
+    from okvis2_amd import multigpu
+    cfg = synth.hilti_config()
+    B = args.batch
+    pairs = synth.rig_overlap_pairs(cfg, capi.camera_overlap)
+    poses = synth.rig_poses(cfg)
+    focal = [0.5 * (c.fu + c.fv) for c in cfg.cams]
+    local = [c for c in range(5) if multigpu.camera_owner(c, world) == rank]
+    if not local:
+        raise SystemExit("--split cameras needs at most 5 ranks")
+    distinct = min(args.distinct, B, 8)
+    rays = {c: capi.build_awareness_maps(cfg.cams[c])[0] for c in range(5)}
+    frames = [synth.render_rig(cfg, [rays[c] for c in range(5)], 500 + i) for i in range(distinct)]
+    engines, d_img, grav = {}, {}, {}
+    for c in local:
+        engines[c] = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold,
+                                   cfg.max_kpts, match_threshold=cfg.match_threshold, max_batch=B,
+                                   num_cameras=1, device=dev.index, max_candidates=args.max_candidates)
+        engines[c].set_camera(0, cfg.cams[c])
+        imgs = np.stack([frames[i % distinct][c] for i in range(B)])
+        d_img[c] = torch.from_numpy(imgs).to(dev)
+        grav[c] = np.tile(synth.gravity_in_camera(poses[c][0]), (B, 1))
+    ccm = multigpu.CrossCameraMatcher(engines, 5, B, poses, focal, lambda i, j: (i, j) in pairs,
+                                      world, rank, dev)
+    ptrs = {c: d_img[c].data_ptr() for c in local}
+    for c in local:
+        engines[c].profile_enable(True, stages=("harris",))
+
+    def step():
+        ccm.step(ptrs, grav)
+
+    for _ in range(args.warmup):
+        step()
+    ccm.finish()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ccm.finish()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for c in local:
+        engines[c].check_capacity(B)
+    prof = [engines[c].profile_read()["harris"] for c in local]
+    harris_ms = sum(p[0] for p in prof) / max(1, sum(p[1] for p in prof))
+    host_blocks = ccm.gathered.cpu().numpy()
+    n_matches = {}
+    for p in ccm.mine:  # rows beyond a frame's keypoint count are not written by the matcher
+        rows = ccm.out[p].cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, -1)
+        blk = host_blocks[multigpu.camera_owner(p[0], world) * ccm.slots + p[0] // world]
+        n0 = blk[:, :4].copy().view(np.int32)[:, 0]
+        n_matches[p] = int(sum((rows[f, :n0[f]]["k1"] >= 0).sum() for f in range(B)))
+    if rank != 0:
+        return None
+    metric, text = WORKLOAD_TEXT["hilti"]
+    res = {
+        "metric": metric, "value": B * args.steps / elapsed, "unit": "multiframes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8/int32 (detect, describe, Hamming) + f64 (match gate)", "data": "synthetic",
+        "config": {"workload": text + ", real T_SC (hilti_challenge_2022.yaml:3-71), rendered "
+                               "textured-sphere scene, 9 FoV-overlapping pairs matched",
+                   "multiframes_per_step": B, "distinct_frames": distinct,
+                   "cameras_per_multiframe": 5, "pairs": [list(p) for p in pairs],
+                   "parallelism": f"cameras split over {world} rank(s) (camera c on rank c % world), "
+                                  f"one RCCL all-gather of {ccm.slots} x {B} gather blocks "
+                                  f"({ccm.block_bytes} B each) per rank per step, pair (i, j) matched "
+                                  f"on rank (i + j) % world",
+                   "rank0_pairs": [list(p) for p in ccm.mine],
+                   "rank0_matches_per_step": sum(n_matches.values())},
+        "roofline": roofline_block(cfg.w * cfg.h, B, harris_ms,
+                                   {"note": "one launch per local camera; the cameras of a rank run on "
+                                            "their own streams and may overlap"}),
+    }
+    return res
 
 
 def main():
@@ -120,81 +293,103 @@ def main():
                     help="independent contexts/streams the batch is split over on each GPU.  With "
                          "3 lanes and the score kernels serialised across them (--stagger) the "
                          "latency-bound kernels of one lane hide behind the score kernel of "
-                         "another: about +10 %% frames/s, but the score kernel then shares the GPU "
-                         "while it is being timed (roofline.frac 0.35 instead of 0.44)")
+                         "another, but the score kernel then shares the GPU while it is being timed")
     ap.add_argument("--stagger", type=int, default=1,
                     help="with --lanes > 1: serialise the score kernels of the lanes (library env "
                          "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
     ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640"), default="euroc",
-                    help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3], "
-                         "1024x1024 equidistant stereo with config/tumvi_slam_1024.yaml parameters; "
-                         "hilti = configs[4] shape, 5 equidistant 720x540 cameras per multiframe "
-                         "(hilti_challenge_2022.yaml parameters), the forward pair matched "
-                         "; mono640 = configs[1], 640x480 mono, ~1000 keypoints, detect+describe "
-                         "only (informational; batch 192 by default for these)")
+                    help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3]; "
+                         "hilti = configs[4] (5 cameras); mono640 = configs[1] (informational; batch "
+                         "192 by default for these)")
+    ap.add_argument("--split", choices=("frames", "cameras"), default="frames",
+                    help="hilti only: frames = every rank runs whole multiframes (forward pair "
+                         "matched, no collective); cameras = the rig's cameras are spread over the "
+                         "ranks, gathered with one RCCL all-gather per step, 9 pairs matched")
+    ap.add_argument("--feed", choices=("device", "host"), default="device",
+                    help="device = images resident in HBM (the metric); host = every step copies its "
+                         "images from pinned host memory (okvfe_detect_describe_batch_host, copy "
+                         "overlapped with the previous step's kernels).  The device-fed run also "
+                         "reports a short host-fed measurement as `host_fed`")
+    ap.add_argument("--content", choices=("corners", "checker"), default="corners")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-fed / dense-content legs")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        self_launch(args)
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...)")
     if args.lanes > 1 and args.stagger:
         os.environ["OKVFE_SCORE_TOKEN"] = "1"  # read by libokvfe.so at its first batch call
     import torch
     from okvis2_amd import capi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if world > 1 or (args.workload == "hilti" and args.split == "cameras"):
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.workload != "euroc" and args.batch == 768:
+        args.batch = 192
+    if args.workload == "hilti" and args.split == "cameras":
+        res = run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev)
+        if res is not None:
+            print(json.dumps(res), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     cfg = {"euroc": synth.euroc_config, "tumvi": synth.tumvi1024_config,
            "hilti": synth.hilti_config, "mono640": synth.mono640_config}[args.workload]()
     if args.workload == "hilti":
-        # synthetic rig: cameras 0/1 form the forward stereo pair (shared intrinsics so that the
-        # synthetic disparity is epipolar-consistent), 2..4 look elsewhere (no FoV overlap)
+        # frame-sharded variant: cameras 0/1 form the forward stereo pair (shared intrinsics so that
+        # the synthetic disparity is epipolar-consistent), 2..4 get independent images
         cfg.cams = [cfg.cams[0], cfg.cams[0]] + list(cfg.cams[2:])
-    if args.workload != "euroc" and args.batch == 768:
-        args.batch = 192
     if os.environ.get("OKVFE_BENCH_MAXKP"):  # experiment knob: keypoint capacity of the context
         cfg.max_kpts = int(os.environ["OKVFE_BENCH_MAXKP"])
     B = args.batch
     C = len(cfg.cams)  # images per multiframe
     n_img = C * B
     distinct = min(args.distinct, B)
-    imgs, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank)
+    imgs, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank, args.content)
     d_img = torch.from_numpy(imgs).to(dev)
     # `--lanes` independent contexts, each with its own HIP stream and B / lanes stereo frames of
-    # the batch: the latency-bound kernels of one lane (greedy select, sort, gated match) overlap
-    # with the throughput-bound ones (score+NMS, describe) of the others.  Frames are independent
-    # units, so this is the same sharding as across GPUs, applied within one.
+    # the batch.  Frames are independent units, so this is the same sharding as across GPUs.
     S = max(1, min(args.lanes, B))
     while B % S or B // S < distinct:  # the parity leg checks the first `distinct` frames of lane 0
         S -= 1
     Bl = B // S
-    T0, T1 = synth.stereo_poses(cfg.baseline)
     f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
     f1 = 0.5 * (cfg.cams[min(1, C - 1)].fu + cfg.cams[min(1, C - 1)].fv)
     d_match = torch.zeros((B, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8,
                           device=dev)
     cam_ids = np.array(list(range(C)) * Bl, dtype=np.int32)
-    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (C * Bl, 1))
-    pairs = []
-    for i in range(Bl):
-        sp = capi.StereoPair()
-        sp.image0, sp.image1 = C * i, C * i + (1 if C > 1 else 0)
-        sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
-        sp.f0, sp.f1 = f0, f1
-        pairs.append(sp)
-    pairs_arr = (capi.StereoPair * Bl)(*pairs)
+    # host parameters differ from step to step (N_VARIANTS sets, cycled): every call goes through
+    # the library's parameter upload, as every real frame would
+    grav_v = [gravity_variant(v, C * Bl) for v in range(N_VARIANTS)]
+    pairs_v = []
+    for v in range(N_VARIANTS):
+        T0, T1 = pose_variant(cfg, v)
+        pairs = []
+        for i in range(Bl):
+            sp = capi.StereoPair()
+            sp.image0, sp.image1 = C * i, C * i + (1 if C > 1 else 0)
+            sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
+            sp.f0, sp.f1 = f0, f1
+            pairs.append(sp)
+        pairs_v.append((capi.StereoPair * Bl)(*pairs))
     lanes = []
     for l in range(S):
         lfe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold,
@@ -202,23 +397,57 @@ def main():
                             num_cameras=C, device=local_rank, max_candidates=args.max_candidates)
         for ci, cam in enumerate(cfg.cams):
             lfe.set_camera(ci, cam)
-        st = torch.cuda.Stream(device=dev) if S > 1 else torch.cuda.current_stream()
-        lanes.append((lfe, st.cuda_stream, d_img[C * l * Bl:].data_ptr(), d_match[l * Bl:].data_ptr(), st))
+        st = torch.cuda.Stream(device=dev)
+        lanes.append((lfe, st, d_img[C * l * Bl:].data_ptr(), d_match[l * Bl:].data_ptr()))
     fe = lanes[0][0]
     n_lane_img = C * Bl
+    h_img = None  # pinned host copy of the images for the host-fed legs
+    state = {"step": 0}
 
-    def step():
-        for lfe, stream, img_ptr, match_ptr, _ in lanes:
-            lfe.detect_describe_batch_device(img_ptr, n_lane_img, cam_ids, grav, stream)
+    def ensure_pinned():
+        nonlocal h_img
+        if h_img is None:
+            h_img = torch.from_numpy(imgs).pin_memory()
+        return h_img
+
+    def step(feed="device"):
+        v = state["step"] % N_VARIANTS
+        state["step"] += 1
+        for l, (lfe, st, img_ptr, match_ptr) in enumerate(lanes):
+            if feed == "host":
+                lfe.detect_describe_batch_host(h_img[C * l * Bl:].data_ptr(), n_lane_img, cam_ids,
+                                               grav_v[v], st)
+            else:
+                lfe.detect_describe_batch_device(img_ptr, n_lane_img, cam_ids, grav_v[v], st)
             if C > 1:
-                lfe.match_stereo_batch_device(pairs_arr, match_ptr, stream)
+                lfe.match_stereo_batch_device(pairs_v[v], match_ptr, st)
+        return v
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    def timed(n_steps, feed):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v = 0
+        for _ in range(n_steps):
+            v = step(feed)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, v
+
+    if args.feed == "host":
+        ensure_pinned()
+    torch.cuda.synchronize()  # allocations / fills above ran on torch's default stream
     for _ in range(args.warmup):
-        step()
+        step(args.feed)
     torch.cuda.synchronize()
     if os.environ.get("OKVFE_PMC_CALIB"):
         # counter calibration for the --pmc passes (tools/collect_profiles.sh): a device-to-device
@@ -232,25 +461,16 @@ def main():
     # the full per-stage breakdown is taken in a short extra pass after the timed region
     for lane in lanes:
         lane[0].profile_enable(True, stages=("harris",))
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # capacity check (outside the timed region): download() raises OKVFE_ERR_CAPACITY if any NMS
-    # candidate list of the checked images overflowed its buffer
+    elapsed, last_v = timed(args.steps, args.feed)
+    # capacity check of EVERY image of every lane (outside the timed region): an overflowed NMS
+    # candidate list would have left that image without keypoints
+    for lane in lanes:
+        lane[0].check_capacity(n_lane_img)
     kp_total = 0
     for i in range(min(n_img, C * distinct)):
         k, _, _, _ = fe.download(i)
         kp_total += len(k)
+    m_host = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts).copy()
 
     def read_profiles():
         acc = {}
@@ -263,20 +483,25 @@ def main():
         return acc
 
     prof = read_profiles()
+    # the CPU leg must see exactly what the GPU computed in its LAST step -> run it before any
+    # further step overwrites the context's outputs
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        fe._bench_matches = m_host
+        cpu = cpu_baseline(cfg, base, fe, grav_v[last_v], pose_variant(cfg, last_v))
     for lane in lanes:
         lane[0].profile_enable(True)
     for _ in range(3):
-        step()
+        step("device")
     torch.cuda.synchronize()
     prof_all = read_profiles()
     # the same kernel with nothing else on the GPU: one lane alone, harris events only
     lanes[0][0].profile_enable(True, stages=("harris",))
     for _ in range(3):
-        lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav, lanes[0][1])
+        lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav_v[0], lanes[0][1])
         torch.cuda.synchronize()
     iso = lanes[0][0].profile_read()["harris"]
-    # the score kernel WITHOUT the fused NMS (okvfe_harris_score_device: the kernel behind the
-    # stand-alone K1 entry point), same images, for reference next to the fused launch
+    # the score kernel WITHOUT the fused NMS (okvfe_harris_score_device), same images, for reference
     d_sc = torch.empty((n_lane_img, cfg.h, cfg.w), dtype=torch.int32, device=dev)
     lanes[0][0].profile_enable(True, stages=("harris",))
     for _ in range(5):
@@ -284,8 +509,7 @@ def main():
     torch.cuda.synchronize()
     solo = lanes[0][0].profile_read()["harris"]
     lanes[0][0].profile_enable(False)
-    # what a trivial device-to-device copy of the score map reaches on this box, same run
-    # (fraction of the nominal AND of the measured attainable bandwidth)
+    # what plain streaming kernels reach on this box, same run
     d_cp = torch.empty_like(d_sc)
     d_cp.copy_(d_sc)
     torch.cuda.synchronize()
@@ -296,36 +520,61 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     copy_gbps = 2.0 * d_sc.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    e0.record()
+    for _ in range(5):
+        d_cp.zero_()
+    e1.record()
+    torch.cuda.synchronize()
+    fill_gbps = d_sc.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del d_sc, d_cp
+
+    extras = {}
+    if not args.no_extras and args.feed == "device":
+        # (1) host-fed: the same step with every image crossing PCIe from pinned memory, the copy of
+        # step k+1 overlapped with the kernels of step k inside the library
+        ensure_pinned()
+        for _ in range(2):
+            step("host")
+        n_h = max(3, min(args.steps, 8))
+        el_h, _ = timed(n_h, "host")
+        extras["host_fed"] = {
+            "value": world * B * n_h / el_h, "unit": "multiframes/s" if C > 2 else
+            ("stereo-frames/s" if C == 2 else "frames/s"), "steps": n_h,
+            "ms_per_step": 1e3 * el_h / n_h,
+            "pcie_GBps_per_gpu": C * B * cfg.w * cfg.h * n_h / el_h / 1e9,
+            "note": "okvfe_detect_describe_batch_host: pinned host images, H2D copy on the "
+                    "library's copy stream into a double buffer, kernels wait through events; "
+                    "PCIe-inclusive, never `value`"}
+        # (2) dense content: tied checker corners that all pass the uniformity stage (~700
+        # keypoints per image): the matcher's 700 x 700 regime
+        if args.content == "corners" and C > 1:
+            imgs_d, _ = make_inputs(cfg, B, distinct, 5000 + 977 * rank, "checker")
+            d_img.copy_(torch.from_numpy(imgs_d).to(dev))
+            for _ in range(2):
+                step("device")
+            n_d = max(3, min(args.steps, 8))
+            el_d, _ = timed(n_d, "device")
+            for lane in lanes:
+                lane[0].check_capacity(n_lane_img)
+            kp_d = sum(len(fe.download(i)[0]) for i in range(min(n_img, C * distinct)))
+            extras["dense_content"] = {
+                "value": world * B * n_d / el_d, "steps": n_d, "ms_per_step": 1e3 * el_d / n_d,
+                "mean_keypoints_per_image": kp_d / max(1, min(n_img, C * distinct)),
+                "note": "exact two-level checker cells: tied maxima all pass the uniformity stage, "
+                        "the stereo matcher works on ~700 x 700 descriptors per frame"}
 
     if rank == 0:
         P = cfg.w * cfg.h
-        n_img_launch = n_lane_img
         stage_ms = {k: (v[0] / v[1] if v[1] else None) for k, v in prof_all.items()}
         harris_ms = prof["harris"][0] / prof["harris"][1]
-        achieved = 5.0 * P * n_img_launch / (harris_ms * 1e-3) / 1e9
-        # HBM traffic of the K1 launch from the PMC passes committed under profiles/ (rocprofv3
-        # cannot run inside this process); only valid for the launch shape it was measured on
-        traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "round1_v3_k1_pmc.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            # same kernel, same image shape: per-image HBM bytes x the images of one launch here
-            if pmc.get("algorithmic_bytes_per_launch") == 5 * P * pmc.get("images_per_launch", 0):
-                traffic = pmc["hbm_bytes_per_image"] * n_img_launch
-                traffic_src = ("profiles/round1_v3_k1_pmc.json (FETCH_SIZE/WRITE_SIZE passes at %d "
-                               "images per launch, scaled per image)" % pmc["images_per_launch"])
-        m = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
-        fe._bench_matches = m
+        metric, text = WORKLOAD_TEXT[args.workload]
+        if args.workload == "hilti":
+            text += ", forward pair matched (frame-sharded variant; --split cameras runs the 9-pair rig)"
+        unit = {1: "frames/s", 2: "stereo-frames/s"}.get(C, "multiframes/s")
         result = {
-            "metric": {"euroc": "front-end stereo-frames/s (detect+describe+match), 752x480 stereo",
-                       "tumvi": "front-end stereo-frames/s (detect+describe+match), 1024x1024 stereo "
-                                "(TUM-VI)",
-                       "hilti": "front-end multiframes/s (5 x detect+describe + forward-pair match), "
-                                "720x540 x 5 cameras (Hilti 2022)",
-                       "mono640": "front-end frames/s (detect+describe), 640x480 mono"}[args.workload],
+            "metric": metric,
             "value": world * B * args.steps / elapsed,
-            "unit": {1: "frames/s", 2: "stereo-frames/s"}.get(C, "multiframes/s"),
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -335,51 +584,36 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32 (detect, describe, Hamming) + f64 (match gate)",
             "data": "synthetic",
-            "config": {"workload": ("EuRoC-shaped 752x480 stereo, euroc.yaml front-end params "
-                                    "(radius 38, thr 150, <=700 kpts, match thr 60)"
-                                    if args.workload == "euroc" else
-                                    "TUM-VI-shaped 1024x1024 equidistant stereo, tumvi_slam_1024.yaml "
-                                    "front-end params (radius 50, thr 5, <=1000 kpts, match thr 60)"
-                                    if args.workload == "tumvi" else
-                                    "640x480 mono (radius 10, thr 5, <=1000 kpts), detect+describe"
-                                    if args.workload == "mono640" else
-                                    "Hilti-shaped rig, 5 equidistant 720x540 cameras, "
-                                    "hilti_challenge_2022.yaml front-end params (radius 50, thr 20, "
-                                    "<=700 kpts, match thr 60), forward pair matched"),
+            "config": {"workload": text,
                        "stereo_frames_per_step_per_gpu": B, "lanes_per_gpu": S,
                        "score_kernels_serialised_across_lanes": bool(S > 1 and args.stagger),
                        "stereo_frames_per_launch": Bl, "distinct_frames": distinct,
+                       "content": args.content, "feed": args.feed,
+                       "host_parameter_variants": N_VARIANTS,
                        "mean_keypoints_per_image": kp_total / max(1, min(n_img, C * distinct)),
                        "cameras_per_multiframe": C,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
-            "roofline": {"kernel": "harris_kernel<30, true> (K1 score map + fused K2 NMS)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": 5 * P * n_img_launch,
-                         "avg_launch_ms": harris_ms,
-                         "isolated_launch_ms": iso[0] / iso[1],
-                         "isolated_frac": 5.0 * P * n_img_launch / (iso[0] / iso[1] * 1e-3) / 1e9
-                                          / HBM_PEAK_GBPS,
-                         "copy_kernel_GBps": copy_gbps,
-                         "frac_of_copy_kernel": achieved / copy_gbps,
-                         "score_only_launch_ms": solo[0] / solo[1],
-                         "score_only_frac": 5.0 * P * n_img_launch / (solo[0] / solo[1] * 1e-3) / 1e9
-                                            / HBM_PEAK_GBPS,
-                         "score_only_note": "harris_kernel<30, false>: the score map alone (no NMS), "
-                                            "5 launches after the timed region; the pipeline uses "
-                                            "the fused kernel because a separate NMS pass re-reads "
-                                            "the whole score map (+0.2 ms per 512 images)",
-                         "note": ("one lane: the launch has the GPU to itself in the timed region "
-                                  "as well" if S == 1 else
-                                  "avg_launch_ms is taken while the other lanes' kernels share the "
-                                  "GPU; isolated_* is the same launch with the GPU to itself")},
+            "roofline": roofline_block(P, n_lane_img, harris_ms, {
+                "isolated_launch_ms": iso[0] / iso[1],
+                "isolated_frac": 5.0 * P * n_lane_img / (iso[0] / iso[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "copy_kernel_GBps": copy_gbps, "fill_kernel_GBps": fill_gbps,
+                "frac_of_copy_kernel": 5.0 * P * n_lane_img / (harris_ms * 1e-3) / 1e9 / copy_gbps,
+                "score_only_launch_ms": solo[0] / solo[1],
+                "score_only_frac": 5.0 * P * n_lane_img / (solo[0] / solo[1] * 1e-3) / 1e9
+                                   / HBM_PEAK_GBPS,
+                "score_only_note": "harris_kernel<30, false>: the score map alone (no NMS), 5 launches "
+                                   "after the timed region",
+                "note": ("one lane: the launch has the GPU to itself in the timed region as well"
+                         if S == 1 else
+                         "avg_launch_ms is taken while the other lanes' kernels share the GPU; "
+                         "isolated_* is the same launch with the GPU to itself")}),
             "stage_ms_per_launch": stage_ms,
             "stage_ms_note": "all-stage event pass of 3 steps after the timed region; avg_launch_ms of "
                              "the roofline comes from the timed region itself",
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, base, fe)
+        result.update(extras)
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

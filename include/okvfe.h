@@ -177,6 +177,18 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
                                                 int32_t n_images, const int32_t* cam_ids,
                                                 const float* gravity_C, void* stream);
 
+/* Host-fed form of the batch call: images_host = n_images contiguous H*W u8 images in HOST
+ * memory, as frames arrive in the reference (cv::Mat handed to the multiframe,
+ * okvis_multisensor_processing/src/ThreadedSlam.cpp:247-265).  The context owns two device image
+ * buffers and a copy stream: the PCIe copy of this batch is enqueued at once and the kernels wait
+ * for it through an event, so with pinned host memory (hipHostMalloc / cudaHostRegister; a pageable
+ * source makes the runtime stage the copy synchronously) the call returns immediately and the copy
+ * of batch k+1 runs under the kernels of batch k.  images_host must stay valid until the work
+ * enqueued on `stream` by this call has completed.  Results as okvfe_detect_describe_batch_device. */
+okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* images_host,
+                                              int32_t n_images, const int32_t* cam_ids,
+                                              const float* gravity_C, void* stream);
+
 typedef struct okvfe_device_outputs {
   int32_t max_keypoints;         /* row capacity per image */
   const int32_t* counts;         /* [max_batch] kept keypoints per image */

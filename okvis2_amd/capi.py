@@ -74,6 +74,7 @@ EXPORTS = [
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
+    "okvfe_detect_describe_batch_host",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -333,6 +334,16 @@ class Frontend:
         self._check(lib().okvfe_detect_describe_batch_device(self._h, _p(images_ptr),
                                                              int(n_images), _p(ids), _p(g),
                                                              _s(stream)))
+
+    def detect_describe_batch_host(self, images_host_ptr, n_images, cam_ids=None, gravity=None,
+                                   stream=None):
+        """images_host_ptr: address of n_images contiguous images in (preferably pinned) HOST
+        memory; the copy overlaps the previous batch's kernels (okvfe_detect_describe_batch_host)."""
+        ids = None if cam_ids is None else np.ascontiguousarray(cam_ids, dtype=np.int32)
+        g = None if gravity is None else np.ascontiguousarray(gravity, dtype=np.float32)
+        self._check(lib().okvfe_detect_describe_batch_host(self._h, _p(images_host_ptr),
+                                                           int(n_images), _p(ids), _p(g),
+                                                           _s(stream)))
 
     def device_outputs(self) -> DeviceOutputs:
         out = DeviceOutputs()

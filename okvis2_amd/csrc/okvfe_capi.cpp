@@ -71,6 +71,14 @@ struct okvfe_ctx {
   };
   ParamRing prm_ring, pair_ring;
   int prm_slot = -1;  // slot d_prm points into
+
+  // host-fed batches (okvfe_detect_describe_batch_host): two device image buffers filled by an
+  // internal copy stream, so the PCIe copy of batch k+1 runs under the kernels of batch k
+  uint8_t* d_feed[2] = {nullptr, nullptr};
+  hipStream_t feed_stream = nullptr;
+  hipEvent_t feed_copied[2] = {nullptr, nullptr}, feed_consumed[2] = {nullptr, nullptr};
+  bool feed_busy[2] = {false, false};
+  unsigned feed_next = 0;
   std::vector<float*> cam_rays, cam_jac;  // device maps per camera slot (nullptr = not set)
   std::vector<float> cam_fu;
   std::vector<DeviceCamera> h_cams;
@@ -463,6 +471,13 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   ring_destroy(&ctx->prm_ring);
   ring_destroy(&ctx->pair_ring);
+  if (ctx->feed_stream) (void)hipStreamSynchronize(ctx->feed_stream);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->d_feed[i]) (void)hipFree(ctx->d_feed[i]);
+    if (ctx->feed_copied[i]) (void)hipEventDestroy(ctx->feed_copied[i]);
+    if (ctx->feed_consumed[i]) (void)hipEventDestroy(ctx->feed_consumed[i]);
+  }
+  if (ctx->feed_stream) (void)hipStreamDestroy(ctx->feed_stream);
   for (auto& e : ctx->prof_events) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
@@ -708,6 +723,42 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
   if ((st = detect_stage(ctx, images_dev, n_images, s)) != OKVFE_OK) return st;
   ctx->detected_images = n_images;
   return describe_stage(ctx, images_dev, n_images, s);
+}
+
+okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* images_host, int32_t n_images,
+                                              const int32_t* cam_ids, const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_host || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_host: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const size_t P = (size_t)ctx->w * ctx->h;
+  if (!ctx->feed_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->feed_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      void* q = nullptr;
+      HIP_TRY(ctx, hipMalloc(&q, P * (size_t)ctx->B));
+      ctx->d_feed[i] = static_cast<uint8_t*>(q);
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->feed_copied[i], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->feed_consumed[i], hipEventDisableTiming));
+    }
+  }
+  const int slot = (int)(ctx->feed_next++ & 1u);
+  // the buffer is rewritten only after the kernels of the batch that used it two calls ago
+  if (ctx->feed_busy[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->feed_stream, ctx->feed_consumed[slot], 0));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_feed[slot], images_host, P * (size_t)n_images, hipMemcpyHostToDevice,
+                              ctx->feed_stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->feed_copied[slot], ctx->feed_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->feed_copied[slot], 0));
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  if (st != OKVFE_OK) return st;
+  if ((st = detect_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
+  ctx->detected_images = n_images;
+  if ((st = describe_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
+  HIP_TRY(ctx, hipEventRecord(ctx->feed_consumed[slot], s));
+  ctx->feed_busy[slot] = true;
+  return OKVFE_OK;
 }
 
 okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out) {

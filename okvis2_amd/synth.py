@@ -22,13 +22,19 @@ def noise_image(w: int, h: int, seed: int) -> np.ndarray:
     return rng.integers(0, 256, size=(h, w), dtype=np.uint8)
 
 
-def corners_image(w: int, h: int, seed: int, cell: int = 16) -> np.ndarray:
+def corners_image(w: int, h: int, seed: int, cell: int = 16, levels=None, noise: int = 4,
+                  jitter: int = 3) -> np.ndarray:
+    """levels: None = cell grays U[16, 240], else the grays to draw from; noise: +-noise iid;
+    jitter: +-jitter px on every cell border (0 = exact grid)."""
     rng = np.random.default_rng(seed)
     ncx, ncy = w // cell + 3, h // cell + 3
-    level = rng.integers(16, 241, size=(ncy + 1, ncx + 1)).astype(np.int32)
+    if levels is None:
+        level = rng.integers(16, 241, size=(ncy + 1, ncx + 1)).astype(np.int32)
+    else:
+        level = rng.choice(np.asarray(levels, dtype=np.int32), size=(ncy + 1, ncx + 1))
     # jittered borders: bx[row band][i] is the x position of vertical border i in that band
-    bx = cell * np.arange(1, ncx + 1)[None, :] + rng.integers(-3, 4, size=(ncy, ncx))
-    by = cell * np.arange(1, ncy + 1)[None, :] + rng.integers(-3, 4, size=(ncx, ncy))
+    bx = cell * np.arange(1, ncx + 1)[None, :] + rng.integers(-jitter, jitter + 1, size=(ncy, ncx))
+    by = cell * np.arange(1, ncy + 1)[None, :] + rng.integers(-jitter, jitter + 1, size=(ncx, ncy))
     xs = np.arange(w)
     ys = np.arange(h)
     col = np.empty((h, w), dtype=np.int32)
@@ -43,22 +49,24 @@ def corners_image(w: int, h: int, seed: int, cell: int = 16) -> np.ndarray:
         if x0 >= w:
             break
         row[:, x0:x1] = np.searchsorted(by[i], ys, side="right")[:, None]
-    img = level[row, col] + rng.integers(-4, 5, size=(h, w))
+    img = level[row, col] + rng.integers(-noise, noise + 1, size=(h, w))
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def stereo_pair(w: int, h: int, seed: int, kind: str = "corners"):
+def stereo_pair(w: int, h: int, seed: int, kind: str = "corners", **corner_kw):
     """Left/right images; right = left content shifted left by `disparity` px (fresh content
-    enters on the right edge), plus independent sensor noise."""
+    enters on the right edge), plus independent sensor noise (none when corner_kw asks for
+    noise = 0).  corner_kw: passed to corners_image."""
     rng = np.random.default_rng(seed ^ 0x5EED)
     disparity = int(rng.integers(4, 41))
     if kind == "noise":
         wide = noise_image(w + 64, h, seed)
     else:
-        wide = corners_image(w + 64, h, seed)
+        wide = corners_image(w + 64, h, seed, **corner_kw)
     left = wide[:, :w].copy()
     right = wide[:, disparity:disparity + w].astype(np.int32)
-    right = np.clip(right + rng.integers(-2, 3, size=right.shape), 0, 255).astype(np.uint8)
+    sn = 0 if corner_kw.get("noise", 4) == 0 else 2
+    right = np.clip(right + rng.integers(-sn, sn + 1, size=right.shape), 0, 255).astype(np.uint8)
     return left, right, disparity
 
 
