@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Writes the seeded inputs of the reference bit-compare (tools/ref_compare/CMakeLists.txt):
+8-bit PGM images, awareness maps as raw float32 and manifest.txt, one case per line.
+
+Cases: the reference's own smoke-test call (752x480 iid-uniform image, detector (34, 2, 800, 450),
+extractor (true, false): okvis_cv/test/TestFrame.cpp:75-85), the dbow2_test call ((36, 0, 100,
+700), (false, false): okvis_apps/src/dbow2_test.cpp:100-101), and the shipped configurations
+(euroc.yaml, tumvi_slam_1024.yaml, hilti_challenge_2022.yaml front-end blocks) in the production
+camera-aware mode, on this repo's seeded corner / noise images.
+
+usage: make_inputs.py <out_dir>      (needs only numpy + this repo; host code, no GPU)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from okvis2_amd import capi, synth  # noqa: E402
+
+
+def write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, dtype=np.uint8).tobytes())
+
+
+def cases():
+    """(name, image, radius, octaves, thr, max_kpts, rot_inv, scale_inv, mode, camera, gravity)"""
+    out = []
+    noise = synth.noise_image(752, 480, 0x0C0FFEE0)
+    out.append(("testframe_noise_oct2", noise, 34.0, 2, 800, 450, 1, 0, 0, None, None))
+    out.append(("testframe_noise_oct0", noise, 34.0, 0, 800, 450, 1, 0, 0, None, None))
+    out.append(("dbow2_corners", synth.corners_image(752, 480, 11), 36.0, 0, 100, 700, 0, 0, 0, None,
+                None))
+    for cfg, seed in ((synth.euroc_config(), 21), (synth.tumvi1024_config(), 22),
+                      (synth.hilti_config(), 23), (synth.mono640_config(), 24)):
+        L, R, _ = synth.stereo_pair(cfg.w, cfg.h, seed)
+        for ci, img in enumerate((L, R)[: min(2, len(cfg.cams))]):
+            out.append((f"{cfg.name}_cam{ci}_aware", img, cfg.uniformity_radius, cfg.octaves,
+                        cfg.abs_threshold, cfg.max_kpts, 1, 0, 2, cfg.cams[ci], (0.1, 0.98, -0.05)))
+        out.append((f"{cfg.name}_cam0_gradient", L, cfg.uniformity_radius, cfg.octaves,
+                    cfg.abs_threshold, cfg.max_kpts, 1, 0, 0, None, None))
+        out.append((f"{cfg.name}_cam0_upright", L, cfg.uniformity_radius, cfg.octaves,
+                    cfg.abs_threshold, cfg.max_kpts, 0, 0, 0, None, None))
+    return out
+
+
+def main():
+    out_dir = sys.argv[1]
+    os.makedirs(out_dir, exist_ok=True)
+    lines = ["# name image W H radius octaves abs_threshold max_kpts rot_inv scale_inv mode fu gx gy gz "
+             "rays jac"]
+    maps_done = {}
+    for (name, img, radius, octaves, thr, maxk, rot, sc, mode, cam, grav) in cases():
+        write_pgm(os.path.join(out_dir, name + ".pgm"), img)
+        rays_f = jac_f = "-"
+        fu, g = 1.0, (0.0, 1.0, 0.0)
+        if mode == 2:
+            key = (cam.w, cam.h, cam.fu, cam.cu, cam.dist_type, cam.d)
+            if key not in maps_done:
+                rays, jac = capi.build_awareness_maps(cam)
+                stem = f"maps{len(maps_done)}"
+                rays.tofile(os.path.join(out_dir, stem + ".rays.f32"))
+                jac.tofile(os.path.join(out_dir, stem + ".jac.f32"))
+                maps_done[key] = stem
+            rays_f, jac_f = maps_done[key] + ".rays.f32", maps_done[key] + ".jac.f32"
+            fu, g = float(np.float32(cam.fu)), grav
+        h, w = img.shape
+        lines.append(f"{name} {name}.pgm {w} {h} {radius:.9g} {octaves} {thr} {maxk} {rot} {sc} {mode} "
+                     f"{fu:.9g} {g[0]:.9g} {g[1]:.9g} {g[2]:.9g} {rays_f} {jac_f}")
+    with open(os.path.join(out_dir, "manifest.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(f"{len(lines) - 1} cases written to {out_dir}")
+
+
+if __name__ == "__main__":
+    main()
