@@ -86,3 +86,16 @@ def test_detect_then_compute_equals_detect_describe(oracle):
     rim = kd[:5].copy()
     rim["x"] = 3.0
     assert len(fe.compute(img, rim)[0]) == 0
+
+
+def test_cv_adapters_and_vi_frontend_interface_run():
+    """tests/cpp/adapters_check: okvfe::cv_adapters::HipDetector / HipExtractor through their
+    cv::Feature2D base pointers and okvfe::HipViFrontend through okvis::ViFrontendInterface (both
+    against the compile-check declarations of tests/mock/), on the GPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "adapters_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "okvis2_amd") + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "adapters ok" in out.stdout
