@@ -65,5 +65,7 @@ int main() {
   fe->dataAssociationAndInitialization(est, okvis::ViParameters(), mf, &key);
   std::printf("adapters ok: %zu keypoints via HipViFrontend, %zu via cv::Feature2D adapters, desc %dx%d, key=%d\n",
               mf->kps_[0].size(), kps.size(), desc.rows, desc.cols, int(key));
-  return (mf->kps_[0].size() > 10 && kps.size() == mf->kps_[0].size() && desc.cols == 48 && key) ? 0 : 1;
+  // the camera-aware extractor of HipViFrontend removes a few more rim keypoints than the plain one
+  return (mf->kps_[0].size() > 10 && kps.size() >= mf->kps_[0].size() && size_t(desc.rows) == kps.size() &&
+          desc.cols == 48 && key) ? 0 : 1;
 }
