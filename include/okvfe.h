@@ -58,7 +58,7 @@ typedef enum okvfe_status {
   OKVFE_ERR_INVALID_ARGUMENT = 1,
   OKVFE_ERR_NO_DEVICE = 2,
   OKVFE_ERR_OUT_OF_MEMORY = 3,
-  OKVFE_ERR_UNSUPPORTED = 4, /* e.g. octaves > 0 */
+  OKVFE_ERR_UNSUPPORTED = 4, /* e.g. scale_invariant extraction, octaves > 4 */
   OKVFE_ERR_CAPACITY = 5,    /* a caller- or context-sized buffer was too small */
   OKVFE_ERR_DEVICE = 6,      /* HIP runtime error; see okvfe_last_error */
   OKVFE_ERR_NOT_READY = 7    /* e.g. camera-aware extraction without okvfe_set_camera */
@@ -105,7 +105,10 @@ typedef struct okvfe_config {
   int32_t max_batch;          /* images per batch call (>= 1) */
   int32_t num_cameras;        /* camera slots for camera-aware extraction (>= 1) */
   float uniformity_radius;    /* detection_threshold: uniformity radius in px */
-  int32_t octaves;            /* 0 = single scale (every shipped config) */
+  int32_t octaves;            /* 0 = single scale (every shipped config); 1..4 = scale space of
+                               * 2*octaves layers (the reference's own smoke test uses 2,
+                               * okvis_cv/test/TestFrame.cpp:75-77): every layer may deliver
+                               * max_keypoints, so rows per image = 2*octaves*max_keypoints */
   int32_t absolute_threshold; /* Harris noise floor, >= 1 */
   int32_t max_keypoints;      /* max_num_keypoints */
   int32_t rotation_invariant; /* Frontend.cpp:142 default true */
@@ -190,7 +193,7 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
                                               const float* gravity_C, void* stream);
 
 typedef struct okvfe_device_outputs {
-  int32_t max_keypoints;         /* row capacity per image */
+  int32_t max_keypoints;         /* row capacity per image (= max_keypoints * layers) */
   const int32_t* counts;         /* [max_batch] kept keypoints per image */
   const okvfe_keypoint* keypoints; /* [max_batch][max_keypoints] */
   const uint8_t* descriptors;    /* [max_batch][max_keypoints][48] */

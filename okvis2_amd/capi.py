@@ -239,7 +239,10 @@ class Frontend:
                      int(max_keypoints), int(bool(rotation_invariant)), int(bool(scale_invariant)),
                      int(match_threshold), int(max_candidates))
         self._h = C.c_void_p()
-        self.w, self.h, self.max_batch, self.max_keypoints = width, height, max_batch, max_keypoints
+        # row capacity per image: a scale space (octaves > 0) has 2 * octaves layers and every layer
+        # may deliver max_keypoints (okvfe_device_outputs.max_keypoints reports the same number)
+        self.w, self.h, self.max_batch = width, height, max_batch
+        self.max_keypoints = int(max_keypoints) * max(1, 2 * int(octaves))
         st = lib().okvfe_create(C.byref(cfg), C.byref(self._h))
         if st != OK:
             raise OkvfeError(st, lib().okvfe_last_error(None).decode())

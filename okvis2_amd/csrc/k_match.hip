@@ -162,7 +162,19 @@ struct BlockView {  // per-image arrays as the matcher sees them
   const double* bp;
   const uint8_t* bpv;
   int n;
+  const okvfe_keypoint* kps = nullptr;  // size classes (octave field); only read when P.cls != null
 };
+// cos(2.6 sigma), cos(6 sigma) for the size classes of the two keypoints
+__device__ __forceinline__ void gate_cos(const PairParams& P, const okvfe_keypoint* kps0, int k0,
+                                         const okvfe_keypoint* kps1, int k1, double* c26, double* c6) {
+  *c26 = P.cos26;
+  *c6 = P.cos6;
+  if (P.cls != nullptr && kps0 != nullptr && kps1 != nullptr) {
+    const int i = (kps0[k0].octave & (kSizeClasses - 1)) * kSizeClasses + (kps1[k1].octave & (kSizeClasses - 1));
+    *c26 = P.cls[i];
+    *c6 = P.cls[kSizeClasses * kSizeClasses + i];
+  }
+}
 
 // The k1 range is cut into kStereoSegs contiguous segments, one wave (threadIdx.y) each, so that
 // 4x as many waves hide the scalar-load and FP64 latency of the serial k1 loop.  The sequential
@@ -277,7 +289,9 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
       rot(P.C1, I1.bp + 3 * (size_t)k1, v);
       normalize3(v, e1_W);
       bool is_valid, is_parallel;
-      triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
+      double c26, c6;
+      gate_cos(P, I0.kps, k0, I1.kps, k1, &c26, &c6);
+      triangulate_fast(P.r0, e0_W, P.r1, e1_W, c26, c6, hp_W, &is_valid, &is_parallel);
       inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
       inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
       if (!is_parallel) {
@@ -331,14 +345,13 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_kernel(
     const uint8_t* __restrict__ desc, const double* __restrict__ bp,
     const uint8_t* __restrict__ bpv, const int32_t* __restrict__ counts, int kp_cap,
     int threshold, okvfe_stereo_match* __restrict__ out) {
-  (void)kps;
   const PairParams& P = pairs[blockIdx.y];
   BlockView I0, I1;
   const size_t o0 = (size_t)P.image0 * kp_cap, o1 = (size_t)P.image1 * kp_cap;
   I0.desc = desc + o0 * OKVFE_DESC_BYTES; I0.bp = bp + o0 * 3; I0.bpv = bpv + o0;
-  I0.n = counts[P.image0];
+  I0.n = counts[P.image0]; I0.kps = kps + o0;
   I1.desc = desc + o1 * OKVFE_DESC_BYTES; I1.bp = bp + o1 * 3; I1.bpv = bpv + o1;
-  I1.n = counts[P.image1];
+  I1.n = counts[P.image1]; I1.kps = kps + o1;
   match_stereo_rows(P, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
 }
 
@@ -348,10 +361,11 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_arrays_kernel(
     const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0, const int32_t* n0p, int n0,
     const uint8_t* __restrict__ desc1, const double* __restrict__ bp1,
     const uint8_t* __restrict__ bpv1, const int32_t* n1p, int n1, int threshold,
-    okvfe_stereo_match* __restrict__ out) {
+    okvfe_stereo_match* __restrict__ out, const okvfe_keypoint* __restrict__ kp0,
+    const okvfe_keypoint* __restrict__ kp1) {
   BlockView I0, I1;
-  I0.desc = desc0; I0.bp = bp0; I0.bpv = bpv0; I0.n = n0p ? *n0p : n0;
-  I1.desc = desc1; I1.bp = bp1; I1.bpv = bpv1; I1.n = n1p ? *n1p : n1;
+  I0.desc = desc0; I0.bp = bp0; I0.bpv = bpv0; I0.n = n0p ? *n0p : n0; I0.kps = kp0;
+  I1.desc = desc1; I1.bp = bp1; I1.bpv = bpv1; I1.n = n1p ? *n1p : n1; I1.kps = kp1;
   match_stereo_rows(*pair, I0, I1, threshold, out);
 }
 
@@ -500,7 +514,9 @@ __device__ void match_motion_rows(const PairParams& P, const DeviceCamera& camer
       const double ee = dot3(e0_W, e1_W);
       if (ee < 0.5) continue;
       bool is_valid, is_parallel;
-      triangulate_fast(P.r0, e0_W, P.r1, e1_W, P.cos26, P.cos6, hp_W, &is_valid, &is_parallel);
+      double c26, c6;  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834): the table is constant in k1
+      gate_cos(P, I0.kps, k0, I1.kps, k1, &c26, &c6);
+      triangulate_fast(P.r0, e0_W, P.r1, e1_W, c26, c6, hp_W, &is_valid, &is_parallel);
       if (!is_valid) continue;
       inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
       inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
@@ -834,8 +850,10 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_blocks_kernel(
   BlockView I0, I1;
   I0.desc = b0 + L.o_desc; I0.bp = reinterpret_cast<const double*>(b0 + L.o_bp); I0.bpv = b0 + L.o_bpv;
   I0.n = *reinterpret_cast<const int32_t*>(b0 + L.o_count);
+  I0.kps = reinterpret_cast<const okvfe_keypoint*>(b0 + L.o_kps);
   I1.desc = b1 + L.o_desc; I1.bp = reinterpret_cast<const double*>(b1 + L.o_bp); I1.bpv = b1 + L.o_bpv;
   I1.n = *reinterpret_cast<const int32_t*>(b1 + L.o_count);
+  I1.kps = reinterpret_cast<const okvfe_keypoint*>(b1 + L.o_kps);
   match_stereo_rows(pair, I0, I1, threshold, out + (size_t)blockIdx.y * kp_cap);
 }
 
@@ -931,10 +949,11 @@ void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, co
                                 const uint8_t* bpv0, const int32_t* n0p, int n0,
                                 const uint8_t* desc1, const double* bp1, const uint8_t* bpv1,
                                 const int32_t* n1p, int n1, int max_rows, int threshold,
-                                okvfe_stereo_match* out, hipStream_t stream) {
+                                okvfe_stereo_match* out, hipStream_t stream, const okvfe_keypoint* kp0,
+                                const okvfe_keypoint* kp1) {
   if (max_rows <= 0) return;
   hipLaunchKernelGGL(match_stereo_arrays_kernel, dim3((max_rows + 63) / 64), dim3(64, kStereoSegs), 0, stream,
-                     pair, desc0, bp0, bpv0, n0p, n0, desc1, bp1, bpv1, n1p, n1, threshold, out);
+                     pair, desc0, bp0, bpv0, n0p, n0, desc1, bp1, bpv1, n1p, n1, threshold, out, kp0, kp1);
 }
 
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,

@@ -69,8 +69,17 @@ struct okvfe_ctx {
     bool pending[kRingSlots] = {};
     unsigned next = 0;
   };
-  ParamRing prm_ring, pair_ring;
+  ParamRing prm_ring, pair_ring, cls_ring;
   int prm_slot = -1;  // slot d_prm points into
+
+  // scale space (octaves > 0): one detect-only child context per layer (K1..K4 at the layer's
+  // size), layer images for l >= 1 owned here; this (parent) context keeps the merged keypoints
+  // and everything from the descriptor stage on
+  bool child = false;
+  int n_layers = 1;
+  std::vector<okvfe_ctx*> layers;
+  std::vector<uint8_t*> d_layer_img;
+  std::vector<int> layer_w, layer_h;
 
   // host-fed batches (okvfe_detect_describe_batch_host): two device image buffers filled by an
   // internal copy stream, so the PCIe copy of batch k+1 runs under the kernels of batch k
@@ -265,7 +274,38 @@ PairParams to_pair_params(const okvfe_stereo_pair& p) {
   const double sigma = std::max(s0, s1) * 0.125;
   q.cos26 = std::cos(2.6 * sigma);  // stereo_triangulation.cpp:86,121
   q.cos6 = std::cos(6.0 * sigma);   // stereo_triangulation.cpp:127
+  q.cls = nullptr;
   return q;
+}
+
+// keypoint size of scale-space layer l: 12 * scale(l) (exact in float)
+double layer_keypoint_size(int l) {
+  const int num = (l & 1) ? 3 << ((l - 1) / 2) : 1 << (l / 2);
+  return 12.0 * (double)num / ((l & 1) ? 2.0 : 1.0);
+}
+// size-class table [2][kSizeClasses][kSizeClasses]: cos(2.6 sigma) then cos(6 sigma).
+// stereo: sigma = max(size0/f0, size1/f1) * 0.125 (Frontend.cpp:2035);
+// motion: sigma = size0/f0 * 0.125 (Frontend.cpp:1834)
+void fill_class_table(double* t, double f0, double f1, bool motion) {
+  for (int c0 = 0; c0 < kSizeClasses; ++c0)
+    for (int c1 = 0; c1 < kSizeClasses; ++c1) {
+      const double s0 = layer_keypoint_size(c0) / f0, s1 = layer_keypoint_size(c1) / f1;
+      const double sigma = (motion ? s0 : std::max(s0, s1)) * 0.125;
+      t[c0 * kSizeClasses + c1] = std::cos(2.6 * sigma);
+      t[kSizeClasses * kSizeClasses + c0 * kSizeClasses + c1] = std::cos(6.0 * sigma);
+    }
+}
+constexpr size_t kClassTableDoubles = 2 * kSizeClasses * kSizeClasses;
+
+// host keypoints -> size classes present?  Fails unless every size is 12 * scale(octave).
+okvfe_status check_size_classes(okvfe_ctx* ctx, const okvfe_keypoint* kp, int n, bool* multi) {
+  for (int i = 0; kp && i < n; ++i) {
+    const int l = kp[i].octave;
+    if (l < 0 || l >= kSizeClasses || (double)kp[i].size != layer_keypoint_size(l))
+      return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint %d: size %f is not 12 * scale(octave %d)", i, kp[i].size, l);
+    if (l != 0) *multi = true;
+  }
+  return OKVFE_OK;
 }
 
 // RAII-free stage timer: records an event pair around a launch when profiling is on
@@ -339,14 +379,37 @@ okvfe_status okvfe_camera_overlap(const okvfe_camera* camera, const okvfe_camera
   return OKVFE_OK;
 }
 
-okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
+}  // extern "C"
+
+namespace {
+void layer_size(int w, int h, int l, int* lw, int* lh) {  // oracle: orc_layer_size
+  if (l == 0) {
+    *lw = w; *lh = h;
+  } else if (l == 1) {
+    *lw = (w / 3) * 2; *lh = (h / 3) * 2;
+  } else {
+    int pw, ph;
+    layer_size(w, h, l - 2, &pw, &ph);
+    *lw = pw / 2; *lh = ph / 2;
+  }
+}
+void layer_scale(int l, int* num, int* den) {  // oracle: orc_layer_scale
+  if ((l & 1) == 0) {
+    *num = 1 << (l / 2); *den = 1;
+  } else {
+    *num = 3 << ((l - 1) / 2); *den = 2;
+  }
+}
+
+// child = a detect-only layer context of a scale space (K1..K4 buffers only, any size >= 16)
+okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
   if (!cfg || !out) return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: null argument");
   *out = nullptr;
   if (cfg->abi_version != OKVFE_ABI_VERSION)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: abi_version %d != %d",
                 cfg->abi_version, OKVFE_ABI_VERSION);
-  if (cfg->width < 64 || cfg->height < 64 || cfg->width > 4096 || cfg->height > 4096 ||
-      (int64_t)cfg->width * cfg->height * 255 >= (int64_t)INT32_MAX)
+  if (cfg->width < (child ? 16 : 64) || cfg->height < (child ? 16 : 64) || cfg->width > 4096 ||
+      cfg->height > 4096 || (int64_t)cfg->width * cfg->height * 255 >= (int64_t)INT32_MAX)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT,
                 "okvfe_create: image size %dx%d out of range (64..4096, w*h*255 < 2^31)", cfg->width,
                 cfg->height);
@@ -358,9 +421,16 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: absolute_threshold must be >= 1");
   if (cfg->match_threshold < 0 || cfg->match_threshold > 385)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: match_threshold out of range");
-  if (cfg->octaves != 0)
-    return fail(nullptr, OKVFE_ERR_UNSUPPORTED,
-                "okvfe_create: octaves=%d unsupported (every shipped OKVIS2 config uses 0)", cfg->octaves);
+  if (cfg->octaves < 0 || cfg->octaves > 4)
+    return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: octaves=%d out of range (0..4)", cfg->octaves);
+  const int n_layers = cfg->octaves > 0 ? 2 * cfg->octaves : 1;
+  if (cfg->octaves > 0) {
+    int lw, lh;
+    layer_size(cfg->width, cfg->height, n_layers - 1, &lw, &lh);
+    if (lw < 16 || lh < 16)
+      return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: %dx%d is too small for %d octaves (top layer %dx%d)",
+                  cfg->width, cfg->height, cfg->octaves, lw, lh);
+  }
   if (cfg->scale_invariant)
     return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: scale_invariant extraction unsupported");
 
@@ -381,7 +451,10 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
   ctx->w = cfg->width;
   ctx->h = cfg->height;
   ctx->B = cfg->max_batch;
-  ctx->kp_cap = cfg->max_keypoints;
+  ctx->child = child;
+  ctx->n_layers = n_layers;
+  // row capacity per image: every layer of a scale space may deliver max_keypoints
+  ctx->kp_cap = cfg->max_keypoints * n_layers;
   const int worst = (cfg->width / 2 + 1) * (cfg->height - 4);
   ctx->cand_cap = cfg->max_candidates > 0 ? std::min(cfg->max_candidates, worst) : worst;
   ctx->cand_cap = (std::max(ctx->cand_cap, 64) + 1) & ~1;  // even: the array doubles as 8-byte records
@@ -405,28 +478,33 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     const size_t P = (size_t)c->w * c->h, B = (size_t)c->B, K = (size_t)c->kp_cap;
     okvfe_status s;
 #define A(ptr, n) if ((s = dev_alloc(c, &c->ptr, (n))) != OKVFE_OK) return s
-    A(d_scores, P * B);
-    A(d_cand, (size_t)c->cand_cap * B);
-    A(d_cand_count, 2 * B);
-    A(d_sort_ws, (size_t)c->ws_stride * B);
-    A(d_occ, c->occ_image_bytes * B);
+    const bool detects = n_layers == 1;  // a scale-space parent detects in its children
+    const bool describes = !child;
+    if (detects) {
+      A(d_scores, P * B);
+      A(d_cand, (size_t)c->cand_cap * B);
+      A(d_cand_count, 2 * B);
+      A(d_sort_ws, (size_t)c->ws_stride * B);
+      A(d_occ, c->occ_image_bytes * B);
+    }
     A(d_lut, kLutFloats);
     A(d_pattern, 1);
     A(d_kps_det, K * B);
     A(d_det_count, B);
-    A(d_kps_tmp, K * B);
-    A(d_desc_tmp, K * B * OKVFE_DESC_BYTES);
-    A(d_valid_tmp, K * B);
-    A(d_kps, K * B);
-    A(d_desc, K * B * OKVFE_DESC_BYTES);
-    A(d_bp, K * B * 3);
-    A(d_bpv, K * B);
-    A(d_count, B);
+    const size_t Kd = describes ? K : 1, Bd = describes ? B : 1;
+    A(d_kps_tmp, Kd * Bd);
+    A(d_desc_tmp, Kd * Bd * OKVFE_DESC_BYTES);
+    A(d_valid_tmp, Kd * Bd);
+    A(d_kps, Kd * Bd);
+    A(d_desc, Kd * Bd * OKVFE_DESC_BYTES);
+    A(d_bp, Kd * Bd * 3);
+    A(d_bpv, Kd * Bd);
+    A(d_count, Bd);
     A(d_cams, (size_t)cfg->num_cameras);
     A(d_rays_ptrs, (size_t)cfg->num_cameras);
     A(d_jac_ptrs, (size_t)cfg->num_cameras);
-    A(d_img_stage, P);
-    A(d_match_stage, K);
+    A(d_img_stage, describes ? P : 1);
+    A(d_match_stage, Kd);
 #undef A
     if ((s = ring_reserve(c, &c->prm_ring, B * sizeof(ImageParams))) != OKVFE_OK) return s;
     if ((s = ring_reserve(c, &c->pair_ring, std::max<size_t>(1, B / 2) * sizeof(PairParams))) != OKVFE_OK) return s;
@@ -435,9 +513,9 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     build_pattern(&c->host_pattern);
     HIP_TRY(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_pattern, &c->host_pattern, sizeof(Pattern), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_count, 0, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->d_count, 0, Bd * sizeof(int32_t)));
     HIP_TRY(c, hipMemset(c->d_det_count, 0, B * sizeof(int32_t)));
-    HIP_TRY(c, hipMemset(c->d_cand_count, 0, B * sizeof(int32_t)));
+    if (detects) HIP_TRY(c, hipMemset(c->d_cand_count, 0, 2 * B * sizeof(int32_t)));
     HIP_TRY(c, hipMemset(c->d_cams, 0, cfg->num_cameras * sizeof(DeviceCamera)));
     HIP_TRY(c, hipMemset(c->d_rays_ptrs, 0, cfg->num_cameras * sizeof(float*)));
     HIP_TRY(c, hipMemset(c->d_jac_ptrs, 0, cfg->num_cameras * sizeof(float*)));
@@ -446,6 +524,32 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
     c->cam_fu.assign(cfg->num_cameras, 0.0f);
     c->h_cams.assign(cfg->num_cameras, DeviceCamera{});
     c->cam_has_intrinsics.assign(cfg->num_cameras, false);
+    if (n_layers > 1) {
+      // children: layer l at its own size, same detector parameters, single scale
+      for (int l = 0; l < n_layers; ++l) {
+        okvfe_config lc = *cfg;
+        layer_size(cfg->width, cfg->height, l, &lc.width, &lc.height);
+        lc.octaves = 0;
+        lc.num_cameras = 1;
+        okvfe_ctx* ch = nullptr;
+        const okvfe_status cs = create_impl(&lc, true, &ch);
+        if (cs != OKVFE_OK) return fail(c, cs, "layer %d (%dx%d): %s", l, lc.width, lc.height, g_create_error.c_str());
+        c->layers.push_back(ch);
+        c->layer_w.push_back(lc.width);
+        c->layer_h.push_back(lc.height);
+        uint8_t* img = nullptr;
+        if (l > 0) {
+          void* q = nullptr;
+          HIP_TRY(c, hipMalloc(&q, (size_t)lc.width * lc.height * B));
+          img = static_cast<uint8_t*>(q);
+        }
+        c->d_layer_img.push_back(img);
+      }
+      // single-scale views of the parent (score map of the full-resolution layer etc.)
+      c->d_scores = c->layers[0]->d_scores;
+      c->d_cand_count = c->layers[0]->d_cand_count;
+      c->cand_cap = c->layers[0]->cand_cap;
+    }
     return OKVFE_OK;
   };
   st = run();
@@ -457,11 +561,20 @@ okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) {
   *out = ctx.release();
   return OKVFE_OK;
 }
+}  // namespace
+
+extern "C" {
+
+okvfe_status okvfe_create(const okvfe_config* cfg, okvfe_ctx** out) { return create_impl(cfg, false, out); }
 
 void okvfe_destroy(okvfe_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->cfg.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
+  for (okvfe_ctx* ch : ctx->layers) okvfe_destroy(ch);
+  for (uint8_t* p : ctx->d_layer_img)
+    if (p) (void)hipFree(p);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (float* p : ctx->cam_rays)
     if (p) (void)hipFree(p);
@@ -471,6 +584,7 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   ring_destroy(&ctx->prm_ring);
   ring_destroy(&ctx->pair_ring);
+  ring_destroy(&ctx->cls_ring);
   if (ctx->feed_stream) (void)hipStreamSynchronize(ctx->feed_stream);
   for (int i = 0; i < 2; ++i) {
     if (ctx->d_feed[i]) (void)hipFree(ctx->d_feed[i]);
@@ -611,47 +725,153 @@ okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) 
   return OKVFE_OK;
 }
 
-// K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count
+// K1 + K2 of one layer context `L` (score map + NMS candidates), launched for `owner`
+void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipStream_t s, bool* fused) {
+  int32_t* d_fix_count = L->d_cand_count + L->B;  // [0, B) candidate counts, [B, 2B) flagged counts
+  *fused = launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->cfg.absolute_threshold,
+                             L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count, s);
+  if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
+}
+void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
+  int32_t* d_fix_count = L->d_cand_count + L->B;
+  if (fused)
+    launch_nms_fixup(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
+                     L->d_cand_count, d_fix_count, s);
+  else
+    launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
+               L->d_cand_count, s);
+}
+void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
+  launch_sort(L->d_cand, L->cand_cap, L->d_cand_count, n_images, L->cfg.uniformity_radius, L->d_sort_ws, s);
+}
+void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
+  launch_select(L->d_scores, L->w, L->h, n_images, L->d_cand, L->cand_cap, L->d_cand_count,
+                L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ, L->occ_image_bytes,
+                L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count, L->d_sort_ws, s);
+}
+
+// K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count.
+// octaves > 0: the same per layer of the scale space (k_pyramid.hip), with the cross-layer maximum
+// test between NMS and selection and the merge into image coordinates at the end.
 okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
-  const int w = ctx->w, h = ctx->h;
-  // d_cand_count: [0, B) candidate counts, [B, 2B) per-image counts of flagged candidates
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
-  int32_t* d_fix_count = ctx->d_cand_count + ctx->B;
   TokenScope token;
-  okvfe_status st = heavy_begin(ctx, s, 0, &token);
-  if (st != OKVFE_OK) return st;
-  bool fused;
-  {
-    StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
-    fused = launch_harris_nms(images_dev, w, h, n_images, ctx->d_scores, ctx->cfg.absolute_threshold,
-                              ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, d_fix_count, s);
-    if (!fused) launch_harris(images_dev, w, h, n_images, ctx->d_scores, s);
-  }
-  if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
-  {
-    StageTimer t(ctx, OKVFE_STAGE_NMS, s);
-    if (fused)
-      launch_nms_fixup(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand,
-                       ctx->cand_cap, ctx->d_cand_count, d_fix_count, s);
-    else
-      launch_nms(ctx->d_scores, w, h, n_images, ctx->cfg.absolute_threshold, ctx->d_cand,
-                 ctx->cand_cap, ctx->d_cand_count, s);
-  }
-  {
-    StageTimer t(ctx, OKVFE_STAGE_SORT, s);
-    launch_sort(ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, n_images, ctx->cfg.uniformity_radius,
-                ctx->d_sort_ws, s);
-  }
-  {
-    StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
-    launch_select(ctx->d_scores, w, h, n_images, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count,
-                  ctx->cfg.uniformity_radius, ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ,
-                  ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols, ctx->d_kps_det, ctx->kp_cap,
-                  ctx->d_det_count, ctx->d_sort_ws, s);
+  okvfe_status st;
+  if (ctx->n_layers == 1) {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+    if ((st = heavy_begin(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    bool fused;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+      layer_score_nms(ctx, images_dev, n_images, s, &fused);
+    }
+    if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_NMS, s);
+      layer_nms_finish(ctx, n_images, s, fused);
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SORT, s);
+      layer_sort(ctx, n_images, s);
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
+      layer_select(ctx, n_images, s);
+    }
+  } else {
+    const int L = ctx->n_layers;
+    std::vector<const uint8_t*> img(L);
+    std::vector<bool> fused(L);
+    img[0] = images_dev;
+    if ((st = heavy_begin(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+      for (int l = 1; l < L; ++l) {
+        if (l == 1)
+          launch_twothird(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_layer_img[1], s);
+        else
+          launch_halfsample(img[l - 2], ctx->layer_w[l - 2], ctx->layer_h[l - 2], n_images, ctx->d_layer_img[l], s);
+        img[l] = ctx->d_layer_img[l];
+      }
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        HIP_TRY(ctx, hipMemsetAsync(ch->d_cand_count, 0, 2 * (size_t)ch->B * sizeof(int32_t), s));
+        bool f;
+        layer_score_nms(ch, img[l], n_images, s, &f);
+        fused[l] = f;
+      }
+    }
+    if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_NMS, s);
+      for (int l = 0; l < L; ++l) layer_nms_finish(ctx->layers[l], n_images, s, fused[l]);
+      // scale-space maxima: every layer against the finished score maps below and above
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        int sn, sd;
+        layer_scale(l, &sn, &sd);
+        const int32_t *below = nullptr, *above = nullptr;
+        int rb[2] = {1, 1}, ra[2] = {1, 1};
+        auto ratio = [&](int m, int out[2]) {  // scale_l / scale_m, reduced
+          int mn, md;
+          layer_scale(m, &mn, &md);
+          int rn = sn * md, rd = sd * mn;
+          for (int g = 2; g <= 3; ++g)
+            while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+          out[0] = rn; out[1] = rd;
+        };
+        if (l > 0) { below = ctx->layers[l - 1]->d_scores; ratio(l - 1, rb); }
+        if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; ratio(l + 1, ra); }
+        launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below,
+                            l > 0 ? ctx->layer_w[l - 1] : 0, l > 0 ? ctx->layer_h[l - 1] : 0, rb[0], rb[1], above,
+                            l + 1 < L ? ctx->layer_w[l + 1] : 0, l + 1 < L ? ctx->layer_h[l + 1] : 0, ra[0], ra[1], s);
+      }
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SORT, s);
+      for (int l = 0; l < L; ++l) layer_sort(ctx->layers[l], n_images, s);
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
+      for (int l = 0; l < L; ++l) layer_select(ctx->layers[l], n_images, s);
+      const okvfe_keypoint* kps[8];
+      const int32_t* counts[8];
+      float scale[8];
+      for (int l = 0; l < L; ++l) {
+        kps[l] = ctx->layers[l]->d_kps_det;
+        counts[l] = ctx->layers[l]->d_det_count;
+        int sn, sd;
+        layer_scale(l, &sn, &sd);
+        scale[l] = (float)sn / (float)sd;
+      }
+      launch_merge_layers(kps, counts, scale, L, ctx->cfg.max_keypoints, n_images, ctx->d_kps_det, ctx->kp_cap,
+                          ctx->d_det_count, s);
+    }
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_n_images = n_images;
   ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+// first image of the last batch whose NMS candidate list overflowed in any layer (-1 = none);
+// synchronises the last stream
+okvfe_status find_overflow(okvfe_ctx* ctx, int first, int n_images, int* bad, int* count, int* cap) {
+  *bad = -1;
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  std::vector<int32_t> counts(n_images);
+  const int L = ctx->n_layers;
+  for (int l = 0; l < L && *bad < 0; ++l) {
+    okvfe_ctx* lc = L == 1 ? ctx : ctx->layers[l];
+    HIP_TRY(ctx, hipMemcpy(counts.data(), lc->d_cand_count + first, (size_t)n_images * sizeof(int32_t),
+                           hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_images; ++i)
+      if (counts[i] > lc->cand_cap) {
+        *bad = first + i;
+        *count = counts[i];
+        *cap = lc->cand_cap;
+        break;
+      }
+  }
   return OKVFE_OK;
 }
 
@@ -782,16 +1002,15 @@ okvfe_status okvfe_check_capacity(okvfe_ctx* ctx, int32_t n_images, int32_t* fir
   if (first_overflowed) *first_overflowed = -1;
   if (n_images == 0) return OKVFE_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
-  std::vector<int32_t> counts(n_images);
-  HIP_TRY(ctx, hipMemcpy(counts.data(), ctx->d_cand_count, (size_t)n_images * sizeof(int32_t), hipMemcpyDeviceToHost));
-  for (int i = 0; i < n_images; ++i)
-    if (counts[i] > ctx->cand_cap) {
-      if (first_overflowed) *first_overflowed = i;
-      return fail(ctx, OKVFE_ERR_CAPACITY,
-                  "image %d produced %d NMS maxima, candidate capacity is %d (its keypoint list was left empty)", i,
-                  counts[i], ctx->cand_cap);
-    }
+  int bad = -1, count = 0, cap = 0;
+  okvfe_status st = find_overflow(ctx, 0, n_images, &bad, &count, &cap);
+  if (st != OKVFE_OK) return st;
+  if (bad >= 0) {
+    if (first_overflowed) *first_overflowed = bad;
+    return fail(ctx, OKVFE_ERR_CAPACITY,
+                "image %d produced %d NMS maxima, candidate capacity is %d (its keypoint list was left empty)", bad,
+                count, cap);
+  }
   return OKVFE_OK;
 }
 
@@ -806,10 +1025,14 @@ okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_ke
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   int32_t counts[2] = {0, 0};
   HIP_TRY(ctx, hipMemcpy(&counts[0], ctx->d_count + index, sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(&counts[1], ctx->d_cand_count + index, sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (counts[1] > ctx->cand_cap)
-    return fail(ctx, OKVFE_ERR_CAPACITY, "image %d produced %d NMS maxima, candidate capacity is %d", index,
-                counts[1], ctx->cand_cap);
+  {
+    int bad = -1, cnt = 0, cap_c = 0;
+    okvfe_status st = find_overflow(ctx, index, 1, &bad, &cnt, &cap_c);
+    if (st != OKVFE_OK) return st;
+    if (bad >= 0)
+      return fail(ctx, OKVFE_ERR_CAPACITY, "image %d produced %d NMS maxima, candidate capacity is %d", index, cnt,
+                  cap_c);
+  }
   const int n = counts[0];
   *n_out = n;
   if (n > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
@@ -862,29 +1085,15 @@ okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride, o
   okvfe_status st = stage_image(ctx, image, stride);
   if (st != OKVFE_OK) return st;
   hipStream_t s = ctx->stream;
-  const int w = ctx->w, h = ctx->h;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
-  int32_t* d_fix_count = ctx->d_cand_count + ctx->B;
-  if (launch_harris_nms(ctx->d_img_stage, w, h, 1, ctx->d_scores, ctx->cfg.absolute_threshold, ctx->d_cand,
-                        ctx->cand_cap, ctx->d_cand_count, d_fix_count, s)) {
-    launch_nms_fixup(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap,
-                     ctx->d_cand_count, d_fix_count, s);
-  } else {
-    launch_harris(ctx->d_img_stage, w, h, 1, ctx->d_scores, s);
-    launch_nms(ctx->d_scores, w, h, 1, ctx->cfg.absolute_threshold, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, s);
-  }
-  launch_sort(ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, 1, ctx->cfg.uniformity_radius, ctx->d_sort_ws, s);
-  launch_select(ctx->d_scores, w, h, 1, ctx->d_cand, ctx->cand_cap, ctx->d_cand_count, ctx->cfg.uniformity_radius,
-                ctx->cfg.max_keypoints, ctx->d_lut, ctx->d_occ, ctx->occ_image_bytes, ctx->occ_rows, ctx->occ_cols,
-                ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_sort_ws, s);
-  HIP_TRY(ctx, hipGetLastError());
+  if ((st = detect_stage(ctx, ctx->d_img_stage, 1, s)) != OKVFE_OK) return st;
   HIP_TRY(ctx, hipStreamSynchronize(s));
-  ctx->last_stream = s;
-  int32_t n = 0, nc = 0;
+  int32_t n = 0;
   HIP_TRY(ctx, hipMemcpy(&n, ctx->d_det_count, sizeof(int32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(&nc, ctx->d_cand_count, sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (nc > ctx->cand_cap)
-    return fail(ctx, OKVFE_ERR_CAPACITY, "%d NMS maxima, candidate capacity is %d", nc, ctx->cand_cap);
+  {
+    int bad = -1, cnt = 0, cap_c = 0;
+    if ((st = find_overflow(ctx, 0, 1, &bad, &cnt, &cap_c)) != OKVFE_OK) return st;
+    if (bad >= 0) return fail(ctx, OKVFE_ERR_CAPACITY, "%d NMS maxima, candidate capacity is %d", cnt, cap_c);
+  }
   *n_out = n;
   if (n > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
   if (n > 0 && keypoints)
@@ -945,10 +1154,34 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
       return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "pair %d: image index or focal length out of range", i);
     pp[i] = to_pair_params(pairs[i]);
   }
+  okvfe_status st;
+  int cls_slot = -1;
+  if (ctx->n_layers > 1) {
+    // one table per distinct (f0, f1); usually one for the whole call
+    std::vector<double> tables;
+    std::vector<std::pair<double, double>> seen;
+    std::vector<int> which(n_pairs);
+    for (int i = 0; i < n_pairs; ++i) {
+      int j = 0;
+      for (; j < (int)seen.size(); ++j)
+        if (seen[j].first == pairs[i].f0 && seen[j].second == pairs[i].f1) break;
+      if (j == (int)seen.size()) {
+        seen.emplace_back(pairs[i].f0, pairs[i].f1);
+        tables.resize(tables.size() + kClassTableDoubles);
+        fill_class_table(tables.data() + (size_t)j * kClassTableDoubles, pairs[i].f0, pairs[i].f1, false);
+      }
+      which[i] = j;
+    }
+    void* d_tab = nullptr;
+    if ((st = ring_upload(ctx, &ctx->cls_ring, tables.data(), tables.size() * sizeof(double), s, &d_tab,
+                          &cls_slot)) != OKVFE_OK)
+      return st;
+    for (int i = 0; i < n_pairs; ++i)
+      pp[i].cls = static_cast<const double*>(d_tab) + (size_t)which[i] * kClassTableDoubles;
+  }
   void* d_pairs = nullptr;
   int slot = -1;
-  okvfe_status st = ring_upload(ctx, &ctx->pair_ring, pp.data(), (size_t)n_pairs * sizeof(PairParams), s,
-                                &d_pairs, &slot);
+  st = ring_upload(ctx, &ctx->pair_ring, pp.data(), (size_t)n_pairs * sizeof(PairParams), s, &d_pairs, &slot);
   if (st != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_MATCH, s);
@@ -956,6 +1189,7 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
                         ctx->d_bpv, ctx->d_count, ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
   }
   if ((st = ring_release(ctx, &ctx->pair_ring, slot, s)) != OKVFE_OK) return st;
+  if ((st = ring_release(ctx, &ctx->cls_ring, cls_slot, s)) != OKVFE_OK) return st;
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
   return OKVFE_OK;
@@ -970,44 +1204,56 @@ okvfe_status okvfe_match_stereo(okvfe_ctx* ctx, const uint8_t* desc0, const okvf
   if (n0 < 0 || n1 < 0 || !T_WC0 || !T_WC1 || !(f0 > 0.0) || !(f1 > 0.0) ||
       (n0 > 0 && (!desc0 || !backproj0 || !valid0 || !matches)) || (n1 > 0 && (!desc1 || !backproj1 || !valid1)))
     return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo: bad argument");
-  // single-scale contract: every keypoint carries size 12 (cos tables are per size class)
-  for (int i = 0; kp0 && i < n0; ++i)
-    if (kp0[i].size != 12.0f) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint size %f != 12 (multi-scale unsupported)", kp0[i].size);
-  for (int i = 0; kp1 && i < n1; ++i)
-    if (kp1[i].size != 12.0f) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint size %f != 12 (multi-scale unsupported)", kp1[i].size);
+  // keypoint sizes select the triangulation sigma (Frontend.cpp:2031-2035): sizes must be
+  // 12 * scale(octave); only a scale-space detector produces anything but 12
+  bool multi = false;
+  okvfe_status st = check_size_classes(ctx, kp0, n0, &multi);
+  if (st == OKVFE_OK) st = check_size_classes(ctx, kp1, n1, &multi);
+  if (st != OKVFE_OK) return st;
+  if (multi && (!kp0 || !kp1)) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo: keypoints needed");
   if (n0 == 0) return OKVFE_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   hipStream_t s = ctx->stream;
-  const size_t a = 256;
-  const size_t o_pair = 0;
-  const size_t o_d0 = align_up(o_pair + sizeof(PairParams), a);
-  const size_t o_b0 = align_up(o_d0 + (size_t)n0 * 48, a);
-  const size_t o_v0 = align_up(o_b0 + (size_t)n0 * 24, a);
-  const size_t o_d1 = align_up(o_v0 + (size_t)n0, a);
-  const size_t o_b1 = align_up(o_d1 + (size_t)n1 * 48, a);
-  const size_t o_v1 = align_up(o_b1 + (size_t)n1 * 24, a);
-  const size_t o_out = align_up(o_v1 + (size_t)n1, a);
-  const size_t total = o_out + (size_t)n0 * sizeof(okvfe_stereo_match);
-  okvfe_status st = ensure_scratch(ctx, total);
-  if (st != OKVFE_OK) return st;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  const size_t o_pair = take(sizeof(PairParams)), o_cls = take(kClassTableDoubles * sizeof(double));
+  const size_t o_d0 = take((size_t)n0 * 48), o_b0 = take((size_t)n0 * 24), o_v0 = take(n0),
+               o_k0 = take((size_t)n0 * sizeof(okvfe_keypoint));
+  const size_t o_d1 = take((size_t)n1 * 48), o_b1 = take((size_t)n1 * 24), o_v1 = take(n1),
+               o_k1 = take((size_t)n1 * sizeof(okvfe_keypoint));
+  const size_t o_out = take((size_t)n0 * sizeof(okvfe_stereo_match));
+  if ((st = ensure_scratch(ctx, off)) != OKVFE_OK) return st;
   uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
   okvfe_stereo_pair sp{};
   sp.image0 = 0; sp.image1 = 0; sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
-  const PairParams pp = to_pair_params(sp);
-  HIP_TRY(ctx, hipMemcpyAsync(base + o_pair, &pp, sizeof(pp), hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(base + o_d0, desc0, (size_t)n0 * 48, hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(base + o_b0, backproj0, (size_t)n0 * 24, hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemcpyAsync(base + o_v0, valid0, (size_t)n0, hipMemcpyHostToDevice, s));
-  if (n1 > 0) {
-    HIP_TRY(ctx, hipMemcpyAsync(base + o_d1, desc1, (size_t)n1 * 48, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(base + o_b1, backproj1, (size_t)n1 * 24, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(base + o_v1, valid1, (size_t)n1, hipMemcpyHostToDevice, s));
+  PairParams pp = to_pair_params(sp);
+  double table[kClassTableDoubles];
+  if (multi) {
+    fill_class_table(table, f0, f1, false);
+    pp.cls = reinterpret_cast<const double*>(base + o_cls);
   }
+  auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRY(ctx, up(o_pair, &pp, sizeof(pp)));
+  if (multi) {
+    HIP_TRY(ctx, up(o_cls, table, sizeof(table)));
+    HIP_TRY(ctx, up(o_k0, kp0, (size_t)n0 * sizeof(okvfe_keypoint)));
+    HIP_TRY(ctx, up(o_k1, kp1, (size_t)n1 * sizeof(okvfe_keypoint)));
+  }
+  HIP_TRY(ctx, up(o_d0, desc0, (size_t)n0 * 48));
+  HIP_TRY(ctx, up(o_b0, backproj0, (size_t)n0 * 24));
+  HIP_TRY(ctx, up(o_v0, valid0, (size_t)n0));
+  HIP_TRY(ctx, up(o_d1, desc1, (size_t)n1 * 48));
+  HIP_TRY(ctx, up(o_b1, backproj1, (size_t)n1 * 24));
+  HIP_TRY(ctx, up(o_v1, valid1, (size_t)n1));
   HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources must stay valid until copied
   launch_match_stereo_arrays(reinterpret_cast<PairParams*>(base + o_pair), base + o_d0,
                              reinterpret_cast<double*>(base + o_b0), base + o_v0, nullptr, n0, base + o_d1,
                              reinterpret_cast<double*>(base + o_b1), base + o_v1, nullptr, n1, n0,
-                             ctx->cfg.match_threshold, reinterpret_cast<okvfe_stereo_match*>(base + o_out), s);
+                             ctx->cfg.match_threshold, reinterpret_cast<okvfe_stereo_match*>(base + o_out), s,
+                             multi ? reinterpret_cast<const okvfe_keypoint*>(base + o_k0) : nullptr,
+                             multi ? reinterpret_cast<const okvfe_keypoint*>(base + o_k1) : nullptr);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(matches, base + o_out, (size_t)n0 * sizeof(okvfe_stereo_match), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1025,15 +1271,20 @@ okvfe_status okvfe_match_motion_stereo(okvfe_ctx* ctx, const okvfe_camera* camer
       (n0 > 0 && (!desc0 || !kp0 || !backproj0 || !valid0 || !matches)) ||
       (n1 > 0 && (!desc1 || !kp1 || !backproj1 || !valid1)))
     return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_motion_stereo: bad argument");
-  for (int i = 0; i < n0; ++i)
-    if (kp0[i].size != 12.0f) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "keypoint size %f != 12 (multi-scale unsupported)", kp0[i].size);
+  bool multi = false;
+  {
+    okvfe_status cst = check_size_classes(ctx, kp0, n0, &multi);
+    if (cst == OKVFE_OK) cst = check_size_classes(ctx, kp1, n1, &multi);
+    if (cst != OKVFE_OK) return cst;
+  }
   if (n0 == 0) return OKVFE_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   hipStream_t s = ctx->stream;
   const size_t a = 256;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), a); return o; };
-  const size_t o_pair = take(sizeof(PairParams)), o_cam = take(sizeof(DeviceCamera));
+  const size_t o_pair = take(sizeof(PairParams)), o_cam = take(sizeof(DeviceCamera)),
+               o_cls = take(kClassTableDoubles * sizeof(double));
   const size_t o_d0 = take((size_t)n0 * 48), o_k0 = take((size_t)n0 * sizeof(okvfe_keypoint)), o_b0 = take((size_t)n0 * 24),
                o_v0 = take(n0), o_s0 = take(n0);
   const size_t o_d1 = take((size_t)n1 * 48), o_k1 = take((size_t)n1 * sizeof(okvfe_keypoint)), o_b1 = take((size_t)n1 * 24),
@@ -1045,11 +1296,17 @@ okvfe_status okvfe_match_motion_stereo(okvfe_ctx* ctx, const okvfe_camera* camer
   okvfe_stereo_pair sp{};
   sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1;
   sp.f0 = sp.f1 = 0.5 * (camera->fu + camera->fv);  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834)
-  const PairParams pp = to_pair_params(sp);
+  PairParams pp = to_pair_params(sp);
   const DeviceCamera dc = to_device_camera(*camera);
   auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
   };
+  double table[kClassTableDoubles];
+  if (multi) {
+    fill_class_table(table, sp.f0, sp.f1, true);
+    pp.cls = reinterpret_cast<const double*>(base + o_cls);
+    HIP_TRY(ctx, up(o_cls, table, sizeof(table)));
+  }
   HIP_TRY(ctx, up(o_pair, &pp, sizeof(pp)));
   HIP_TRY(ctx, up(o_cam, &dc, sizeof(dc)));
   HIP_TRY(ctx, up(o_d0, desc0, (size_t)n0 * 48));
@@ -1351,14 +1608,23 @@ okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* 
   const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
   okvfe_stereo_pair sp{};
   sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1; sp.f0 = f0; sp.f1 = f1;
-  const PairParams pp = to_pair_params(sp);
-  // the pair record travels by value as a kernel argument (232 bytes): nothing to keep alive
+  PairParams pp = to_pair_params(sp);
+  int cls_slot = -1;
+  if (ctx->n_layers > 1) {
+    double table[kClassTableDoubles];
+    fill_class_table(table, f0, f1, false);
+    void* d_tab = nullptr;
+    okvfe_status st = ring_upload(ctx, &ctx->cls_ring, table, sizeof(table), s, &d_tab, &cls_slot);
+    if (st != OKVFE_OK) return st;
+    pp.cls = static_cast<const double*>(d_tab);
+  }
+  // the pair record travels by value as a kernel argument: nothing to keep alive
   launch_match_stereo_blocks(pp, offs, static_cast<const uint8_t*>(blocks0_dev),
                              static_cast<const uint8_t*>(blocks1_dev), n_frames, ctx->kp_cap,
                              ctx->cfg.match_threshold, matches_dev, s);
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
-  return OKVFE_OK;
+  return ring_release(ctx, &ctx->cls_ring, cls_slot, s);
 }
 
 okvfe_status okvfe_match_motion_stereo_blocks_device(okvfe_ctx* ctx, int32_t cam, const void* block0_dev,
@@ -1380,13 +1646,22 @@ okvfe_status okvfe_match_motion_stereo_blocks_device(okvfe_ctx* ctx, int32_t cam
   okvfe_stereo_pair sp{};
   sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1;
   sp.f0 = sp.f1 = 0.5 * (dc.fu + dc.fv);  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834)
-  const PairParams pp = to_pair_params(sp);
+  PairParams pp = to_pair_params(sp);
+  int cls_slot = -1;
+  if (ctx->n_layers > 1) {
+    double table[kClassTableDoubles];
+    fill_class_table(table, sp.f0, sp.f1, true);
+    void* d_tab = nullptr;
+    okvfe_status st = ring_upload(ctx, &ctx->cls_ring, table, sizeof(table), s, &d_tab, &cls_slot);
+    if (st != OKVFE_OK) return st;
+    pp.cls = static_cast<const double*>(d_tab);
+  }
   launch_match_motion_blocks(pp, ctx->d_cams + cam, ctx->w, ctx->h, offs,
                              static_cast<const uint8_t*>(block0_dev), static_cast<const uint8_t*>(block1_dev),
                              skip0_dev, matched1_dev, ctx->kp_cap, ctx->cfg.match_threshold, matches_dev, s);
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
-  return OKVFE_OK;
+  return ring_release(ctx, &ctx->cls_ring, cls_slot, s);
 }
 
 okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0_dev, const void* block1_dev,

@@ -77,8 +77,14 @@ struct PairParams {  // one stereo pair on device
   int32_t image0, image1;
   double C0[9], r0[3], C1[9], r1[3];
   double f0, f1;
-  double cos26, cos6;  // cos(2.6 sigma), cos(6 sigma) for the (single) size class
+  double cos26, cos6;  // cos(2.6 sigma), cos(6 sigma) of size class (0, 0): keypoint size 12
+  // scale space (octaves > 0): keypoint sizes are 12 * scale(layer) and sigma depends on the sizes
+  // of the two keypoints; cls = device table [2][kSizeClasses][kSizeClasses] of cos(2.6 sigma) /
+  // cos(6 sigma) indexed by the layers (= okvfe_keypoint::octave) of keypoint 0 and keypoint 1,
+  // or null when every keypoint has size 12
+  const double* cls;
 };
+constexpr int kSizeClasses = 8;
 
 }  // namespace okvfe
 
@@ -146,7 +152,8 @@ void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, co
                                 const uint8_t* bpv0, const int32_t* n0p, int n0,
                                 const uint8_t* desc1, const double* bp1, const uint8_t* bpv1,
                                 const int32_t* n1p, int n1, int max_rows, int threshold,
-                                okvfe_stereo_match* out, hipStream_t stream);
+                                okvfe_stereo_match* out, hipStream_t stream,
+                                const okvfe_keypoint* kp0 = nullptr, const okvfe_keypoint* kp1 = nullptr);
 void launch_match_motion(const PairParams* pair, const DeviceCamera* camera, int w, int h,
                          const uint8_t* desc0, const okvfe_keypoint* kp0, const double* bp0,
                          const uint8_t* bpv0, const uint8_t* skip0, int n0, const uint8_t* desc1,
@@ -173,6 +180,15 @@ void launch_match_motion_blocks(const PairParams& pair, const DeviceCamera* came
 void launch_match_stereo_blocks(const PairParams& pair, const int offs[6], const uint8_t* blocks0,
                                 const uint8_t* blocks1, int n_frames, int kp_cap, int threshold,
                                 okvfe_stereo_match* out, hipStream_t stream);
+// scale space (k_pyramid.hip)
+void launch_halfsample(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);
+void launch_twothird(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);
+void launch_scale_filter(Candidate* cand, int cand_cap, int32_t* cand_count, int n_images,
+                         const int32_t* below, int wb, int hb, int rn_b, int rd_b, const int32_t* above,
+                         int wa, int ha, int rn_a, int rd_a, hipStream_t stream);
+void launch_merge_layers(const okvfe_keypoint* const* kps, const int32_t* const* counts, const float* scale,
+                         int n_layers, int layer_cap, int n_images, okvfe_keypoint* out, int out_cap,
+                         int32_t* out_count, hipStream_t stream);
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,
                            int32_t* best_j, uint32_t* best_d, hipStream_t stream);
 void launch_hamming_count(const uint8_t* A, int nA, const uint8_t* B, int nB, int thr,

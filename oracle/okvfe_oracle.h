@@ -91,6 +91,13 @@ int orc_nms(const int32_t* score, int w, int h, int abs_threshold,
 int orc_uniformity_select(orc_point_score* pts, int n, int w, int h, float radius,
                           int max_kpts);
 void orc_subpixel2d(const int32_t s[9], float* dx, float* dy);
+/* scale space (octaves > 0): layer images, sizes, scales and the cross-layer maximum test */
+void orc_halfsample(const uint8_t* src, int w, int h, int stride, uint8_t* dst);
+void orc_twothirdsample(const uint8_t* src, int w, int h, int stride, uint8_t* dst);
+void orc_layer_scale(int l, int* num, int* den);
+void orc_layer_size(int w, int h, int l, int* lw, int* lh);
+int orc_scale_neighbour_ok(const int32_t* other, int wo, int ho, int x, int y, int32_t s, int rn, int rd);
+/* octaves > 0: kps capacity should be 2*octaves*max_kpts */
 int orc_detect(const uint8_t* img, int w, int h, int stride, float uniformity_radius,
                int octaves, int abs_threshold, int max_kpts, orc_keypoint* kps, int cap,
                int32_t* score_out /* optional h*w */);

@@ -14,7 +14,8 @@
  *   adds) capped at maxNumKpt -> 2-D quadratic sub-pixel refinement ->
  *   cv::KeyPoint(pt, 12*scale, -1, score, layer).
  * octaves: every shipped config uses 0 = single layer at full resolution
- * (config/euroc.yaml:66, okvis_common/include/okvis/Parameters.hpp:127).
+ * (config/euroc.yaml:66, okvis_common/include/okvis/Parameters.hpp:127); octaves > 0 builds the
+ * scale space described at detect_scale_space below.
  */
 #include "okvfe_oracle.h"
 
@@ -266,10 +267,185 @@ void orc_subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
   *delta_y = dy;
 }
 
+/* ---- scale space (octaves > 0) -------------------------------------------------------------- */
+/* PARITY UNPINNED like the rest of this file.  The reference passes `octaves` to
+ * brisk::ScaleSpaceFeatureDetector (Frontend.cpp:2406-2409; its own smoke test uses 2,
+ * okvis_cv/test/TestFrame.cpp:75-77); "0 means single-scale at highest resolution"
+ * (Parameters.hpp:127).  Restated from the published BRISK scale space:
+ *   layers    2*octaves of them.  Layer 0 = the image (scale 1), layer 1 = two-third sampling of
+ *             layer 0 (scale 1.5), layer l >= 2 = half sampling of layer l-2 (scales 2, 3, 4, 6...).
+ *   half      2x2 box mean, (a+b+c+d+2)>>2;  size w/2 x h/2.
+ *   2/3       every 3x3 source block gives 2x2 pixels with the separable weights (2,1,0)/3 and
+ *             (0,1,2)/3: (sum w_x w_y s + 4) / 9;  size (w/3)*2 x (h/3)*2.
+ *   per layer the single-scale pipeline: Harris score, 8-neighbour NMS with the absolute threshold.
+ *   scale-space maximum: a 2-D maximum of layer l survives unless a STRICTLY greater score exists
+ *             in layer l-1 or l+1 within +-1 pixel (that layer's pixels) of the same image
+ *             location (pixel centres: X = s (x + 1/2) - 1/2).
+ *   then per layer: uniformity enforcement (radius in layer pixels, maxNumKpt per layer), sub-pixel
+ *             refinement, cv::KeyPoint(pt in image coordinates, 12 * scale, -1, score, layer).
+ * Output: layers in ascending order, at most 2*octaves*max_kpts keypoints. */
+void orc_halfsample(const uint8_t* src, int w, int h, int stride, uint8_t* dst /* (h/2)*(w/2) */) {
+  const int w2 = w / 2, h2 = h / 2;
+  for (int y = 0; y < h2; ++y) {
+    const uint8_t* r0 = src + (size_t)(2 * y) * stride;
+    const uint8_t* r1 = r0 + stride;
+    for (int x = 0; x < w2; ++x)
+      dst[(size_t)y * w2 + x] = (uint8_t)((r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2) >> 2);
+  }
+}
+
+void orc_twothirdsample(const uint8_t* src, int w, int h, int stride,
+                        uint8_t* dst /* ((h/3)*2)*((w/3)*2) */) {
+  const int bw = w / 3, bh = h / 3, w2 = bw * 2;
+  static const int wt[2][3] = {{2, 1, 0}, {0, 1, 2}};
+  for (int by = 0; by < bh; ++by)
+    for (int q = 0; q < 2; ++q)
+      for (int bx = 0; bx < bw; ++bx)
+        for (int p = 0; p < 2; ++p) {
+          int acc = 0;
+          for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i)
+              acc += wt[q][j] * wt[p][i] * (int)src[(size_t)(3 * by + j) * stride + 3 * bx + i];
+          dst[(size_t)(2 * by + q) * w2 + 2 * bx + p] = (uint8_t)((acc + 4) / 9);
+        }
+}
+
+/* scale of layer l as a fraction: even l: 2^(l/2); odd l: 3 * 2^((l-1)/2) / 2 */
+void orc_layer_scale(int l, int* num, int* den) {
+  if ((l & 1) == 0) {
+    *num = 1 << (l / 2);
+    *den = 1;
+  } else {
+    *num = 3 << ((l - 1) / 2);
+    *den = 2;
+  }
+}
+void orc_layer_size(int w, int h, int l, int* lw, int* lh) {
+  if (l == 0) {
+    *lw = w; *lh = h;
+  } else if (l == 1) {
+    *lw = (w / 3) * 2; *lh = (h / 3) * 2;
+  } else {
+    int pw, ph;
+    orc_layer_size(w, h, l - 2, &pw, &ph);
+    *lw = pw / 2; *lh = ph / 2;
+  }
+}
+static int floor_div(int a, int b) { /* b > 0 */
+  return a >= 0 ? a / b : -((-a + b - 1) / b);
+}
+/* 1 when no pixel of `other` (wo x ho) within +-1 px of the location corresponding to (x, y) of a
+ * layer whose scale is rn/rd times the other layer's has a strictly greater score than s */
+int orc_scale_neighbour_ok(const int32_t* other, int wo, int ho, int x, int y, int32_t s, int rn, int rd) {
+  /* x' = ((2x+1) rn/rd - 1) / 2 = N / D,  D = 2 rd */
+  const int D = 2 * rd;
+  const int Nx = (2 * x + 1) * rn - rd, Ny = (2 * y + 1) * rn - rd;
+  int u0 = -floor_div(-(Nx - D), D), u1 = floor_div(Nx + D, D);  /* ceil((N-D)/D) .. floor((N+D)/D) */
+  int v0 = -floor_div(-(Ny - D), D), v1 = floor_div(Ny + D, D);
+  if (u0 < 0) u0 = 0;
+  if (v0 < 0) v0 = 0;
+  if (u1 > wo - 1) u1 = wo - 1;
+  if (v1 > ho - 1) v1 = ho - 1;
+  for (int v = v0; v <= v1; ++v)
+    for (int u = u0; u <= u1; ++u)
+      if (other[(size_t)v * wo + u] > s) return 0;
+  return 1;
+}
+
+#define ORC_MAX_LAYERS 8
+static int detect_scale_space(const uint8_t* img, int w, int h, int stride, float uniformity_radius,
+                              int octaves, int abs_threshold, int max_kpts, orc_keypoint* kps, int cap) {
+  const int L = 2 * octaves;
+  if (L > ORC_MAX_LAYERS) return -1;
+  uint8_t* im[ORC_MAX_LAYERS];
+  int32_t* sc[ORC_MAX_LAYERS];
+  orc_point_score* pts[ORC_MAX_LAYERS];
+  int np[ORC_MAX_LAYERS], lw[ORC_MAX_LAYERS], lh[ORC_MAX_LAYERS], st[ORC_MAX_LAYERS];
+  for (int l = 0; l < L; ++l) {
+    orc_layer_size(w, h, l, &lw[l], &lh[l]);
+    if (lw[l] < 8 || lh[l] < 8) return -1;
+    if (l == 0) {
+      im[0] = (uint8_t*)img;
+      st[0] = stride;
+    } else {
+      im[l] = (uint8_t*)malloc((size_t)lw[l] * lh[l]);
+      st[l] = lw[l];
+      if (l == 1)
+        orc_twothirdsample(im[0], lw[0], lh[0], st[0], im[1]);
+      else
+        orc_halfsample(im[l - 2], lw[l - 2], lh[l - 2], st[l - 2], im[l]);
+    }
+    sc[l] = (int32_t*)malloc((size_t)lw[l] * lh[l] * sizeof(int32_t));
+    orc_harris_score(im[l], lw[l], lh[l], st[l], sc[l]);
+    int maxc = (lw[l] / 2 + 1) * (lh[l] - 3);
+    if (maxc < 16) maxc = 16;
+    pts[l] = (orc_point_score*)malloc((size_t)maxc * sizeof(orc_point_score));
+    np[l] = orc_nms(sc[l], lw[l], lh[l], abs_threshold, pts[l], maxc);
+  }
+  int nout = 0;
+  for (int l = 0; l < L; ++l) {
+    int sn, sd;
+    orc_layer_scale(l, &sn, &sd);
+    /* scale-space maxima: compare with the layers below and above */
+    int kept = 0;
+    for (int i = 0; i < np[l]; ++i) {
+      const orc_point_score p = pts[l][i];
+      int ok = 1;
+      for (int dl = -1; dl <= 1 && ok; dl += 2) {
+        const int m = l + dl;
+        if (m < 0 || m >= L) continue;
+        int mn, md;
+        orc_layer_scale(m, &mn, &md);
+        /* ratio scale_l / scale_m = (sn/sd) / (mn/md), reduced */
+        int rn = sn * md, rd = sd * mn;
+        for (int g = 2; g <= 3; ++g)
+          while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+        ok = orc_scale_neighbour_ok(sc[m], lw[m], lh[m], p.x, p.y, p.score, rn, rd);
+      }
+      if (ok) pts[l][kept++] = p;
+    }
+    kept = orc_uniformity_select(pts[l], kept, lw[l], lh[l], uniformity_radius, max_kpts);
+    const float scale = (float)sn / (float)sd;
+    for (int i = 0; i < kept && nout < cap; ++i) {
+      const int u = pts[l][i].x, v = pts[l][i].y;
+      int32_t patch[9];
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx)
+          patch[(dy + 1) * 3 + (dx + 1)] = sc[l][(size_t)(v + dy) * lw[l] + (u + dx)];
+      float ddx, ddy;
+      orc_subpixel2d(patch, &ddx, &ddy);
+      const float xl = (float)u + ddx, yl = (float)v + ddy; /* layer coordinates */
+      orc_keypoint* k = &kps[nout++];
+      float t = xl + 0.5f;
+      t = scale * t;
+      k->x = t - 0.5f;
+      t = yl + 0.5f;
+      t = scale * t;
+      k->y = t - 0.5f;
+      k->size = 12.0f * scale;
+      k->angle = -1.0f;
+      k->response = (float)pts[l][i].score;
+      k->octave = l;
+      k->class_id = -1;
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    if (l) free(im[l]);
+    free(sc[l]);
+    free(pts[l]);
+  }
+  return nout;
+}
+
 /* ---- detect(): the whole detector for one image -------------------------------------------- */
 int orc_detect(const uint8_t* img, int w, int h, int stride, float uniformity_radius, int octaves,
                int abs_threshold, int max_kpts, orc_keypoint* kps, int cap, int32_t* score_out) {
-  (void)octaves; /* single layer; see header */
+  if (octaves > 0) {
+    const int n_ss = detect_scale_space(img, w, h, stride, uniformity_radius, octaves, abs_threshold,
+                                        max_kpts, kps, cap);
+    if (score_out) orc_harris_score(img, w, h, stride, score_out);
+    return n_ss;
+  }
   size_t n = (size_t)w * (size_t)h;
   int32_t* score = score_out ? score_out : (int32_t*)malloc(n * sizeof(int32_t));
   orc_harris_score(img, w, h, stride, score);

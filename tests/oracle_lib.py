@@ -136,14 +136,36 @@ def subpixel2d(patch) -> tuple:
 def detect(img, radius, octaves, thr, max_kpts, want_score=False):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape
-    cap = max(int(max_kpts), 1) + 8
+    cap = max(int(max_kpts), 1) * max(1, 2 * int(octaves)) + 8
     if not radius > 0:
-        cap = (w // 2 + 1) * h
+        cap = (w // 2 + 1) * h * max(1, 2 * int(octaves))
     kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
     score = np.empty((h, w), dtype=np.int32) if want_score else None
     n = lib().orc_detect(_p(img), w, h, w, C.c_float(radius), int(octaves), int(thr),
                          int(max_kpts), _p(kps), cap, _p(score))
     return (kps[:n].copy(), score) if want_score else kps[:n].copy()
+
+
+def layer_size(w, h, layer):
+    lw, lh = C.c_int(), C.c_int()
+    lib().orc_layer_size(int(w), int(h), int(layer), C.byref(lw), C.byref(lh))
+    return lw.value, lh.value
+
+
+def halfsample(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2), dtype=np.uint8)
+    lib().orc_halfsample(_p(img), w, h, w, _p(out))
+    return out
+
+
+def twothirdsample(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty(((h // 3) * 2, (w // 3) * 2), dtype=np.uint8)
+    lib().orc_twothirdsample(_p(img), w, h, w, _p(out))
+    return out
 
 
 def integral(img):

@@ -241,7 +241,10 @@ def test_hamming_candidates_and_argmin(oracle):
 
 def test_error_paths():
     with pytest.raises(capi.OkvfeError) as e:
-        capi.Frontend(752, 480, 38.0, 2, 150, 700)
+        capi.Frontend(752, 480, 38.0, 5, 150, 700)  # more than 4 octaves
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.OkvfeError) as e:
+        capi.Frontend(96, 96, 38.0, 3, 150, 700)  # top layer of the scale space below 16 px
     assert e.value.status == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.OkvfeError) as e:
         capi.Frontend(752, 480, 38.0, 0, 0, 700)

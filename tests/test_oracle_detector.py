@@ -322,3 +322,32 @@ def test_match_motion_stereo_semantics(oracle):
     assert np.all(m["accepted"][ok] == 1) and np.all(m["accepted"][~ok] == 0)
     assert np.allclose(m["hp_W"][ok, :3], X[ok], atol=1e-3)
     assert np.all(m["quality"][ok] > 0)
+
+
+def test_scale_space_layers_and_samplers(oracle):
+    """octaves > 0 (oracle/orc_detect.c detect_scale_space): samplers against numpy, layer sizes,
+    keypoint sizes 12 * scale and octave = layer, layers in ascending order, per-layer cap."""
+    img = synth.corners_image(300, 210, 3)
+    a = img.astype(np.int32)
+    assert np.array_equal(oracle.halfsample(img),
+                          ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2)[:105, :150])
+    t = oracle.twothirdsample(img)
+    assert t.shape == (140, 200)
+    wl, wr = np.array([2, 1, 0]), np.array([0, 1, 2])
+    blk = a.reshape(70, 3, 100, 3).transpose(0, 2, 1, 3)  # [by, bx, j, i]
+    for q, wy in enumerate((wl, wr)):
+        for p, wx in enumerate((wl, wr)):
+            want = ((blk * wy[None, None, :, None] * wx[None, None, None, :]).sum(axis=(2, 3)) + 4) // 9
+            assert np.array_equal(t[q::2, p::2], want)
+    assert [oracle.layer_size(752, 480, l) for l in range(4)] == [(752, 480), (500, 320), (376, 240), (250, 160)]
+    k = oracle.detect(synth.corners_image(752, 480, 11), 38.0, 2, 150, 700)
+    assert np.all(np.diff(k["octave"]) >= 0) and set(np.unique(k["octave"])) == {0, 1, 2, 3}
+    scale = np.array([1.0, 1.5, 2.0, 3.0], dtype=np.float32)
+    assert np.array_equal(k["size"], 12.0 * scale[k["octave"]])
+    assert np.bincount(k["octave"]).max() <= 700
+    # a maximum of layer 0 that survives is not dominated by layer 1 around the same spot, so the
+    # single-scale detector finds at least as many layer-0 points
+    k0 = oracle.detect(synth.corners_image(752, 480, 11), 38.0, 0, 150, 700)
+    assert (k["octave"] == 0).sum() <= len(k0) + 5
+    # coordinates of every layer stay inside the image
+    assert k["x"].min() >= 0 and k["x"].max() < 752 and k["y"].min() >= 0 and k["y"].max() < 480
