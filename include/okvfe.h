@@ -359,6 +359,28 @@ okvfe_status okvfe_hamming_argmin(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, 
                                   int32_t nB, uint32_t threshold, int32_t* best_j,
                                   uint32_t* best_dist);
 
+/* = the descriptor matching of Frontend::verifyRecognisedPlace for ALL old landmarks against one
+ * camera of the current frame in one launch (Frontend.cpp:330-355): landmark l owns rows
+ * desc_begin[l] .. desc_begin[l+1]-1 of landmark_desc (its descriptors in the insertion order of
+ * :318-326); per landmark the running minimum over (descriptor, k) with strict <.  k_min[l] = 0 and
+ * dist_min[l] = match_threshold when nothing is below the threshold ("distMin < threshold" fails). */
+okvfe_status okvfe_verify_place_match(okvfe_ctx* ctx, const uint8_t* landmark_desc,
+                                      const int32_t* desc_begin /* n_landmarks + 1 */,
+                                      int32_t n_landmarks, const uint8_t* frame_desc, int32_t n_kps,
+                                      int32_t* k_min, uint32_t* dist_min);
+
+/* = DBoW2::TemplatedVocabulary<FBrisk::TDescriptor, FBrisk>::transform for n features (the
+ * quantisation behind dBow_->database.add / query, Frontend.cpp:756-766): descend from the root
+ * (node 0), at every level the child with the smallest FBrisk::distance (FBrisk.cpp:64-67; first
+ * child on ties), down to a leaf.  Tree in arrays: node i's children are
+ * child_index[child_begin[i] .. child_begin[i+1]); node_word[i] = word id of a leaf, < 0 for an
+ * inner node; node descriptors n_nodes x 48 (the root's row is unused).  Nodes must be numbered
+ * parents-first (as in DBoW2 files).  Outputs per feature: word id and (optional) leaf node. */
+okvfe_status okvfe_fbrisk_transform(okvfe_ctx* ctx, const uint8_t* descriptors, int32_t n,
+                                    const uint8_t* node_descriptors, int32_t n_nodes,
+                                    const int32_t* child_begin, const int32_t* child_index,
+                                    const int32_t* node_word, int32_t* word_ids, int32_t* leaf_nodes);
+
 /* = brisk::Hamming::PopcntofXORed(a, b, n128); host, no context. */
 uint32_t okvfe_popcnt_xor(const uint8_t* a, const uint8_t* b, int32_t n128);
 

@@ -74,7 +74,7 @@ EXPORTS = [
     "okvfe_format_keypoint_lines", "okvfe_parse_keypoint_lines", "okvfe_fbrisk_mean",
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
-    "okvfe_detect_describe_batch_host",
+    "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -455,6 +455,31 @@ class Frontend:
         self._check(lib().okvfe_hamming_argmin(self._h, _p(A), len(A), _p(B), len(B),
                                                C.c_uint32(int(thr)), _p(bj), _p(bd)))
         return bj[:len(A)], bd[:len(A)]
+
+    def verify_place_match(self, landmark_desc, desc_begin, frame_desc):
+        """Frontend::verifyRecognisedPlace descriptor matching, all landmarks in one launch."""
+        pool = np.ascontiguousarray(landmark_desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        db = np.ascontiguousarray(desc_begin, dtype=np.int32)
+        fd = np.ascontiguousarray(frame_desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        n = len(db) - 1
+        k_min = np.zeros(max(n, 1), dtype=np.int32)
+        d_min = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(lib().okvfe_verify_place_match(self._h, _p(pool), _p(db), n, _p(fd), len(fd),
+                                                   _p(k_min), _p(d_min)))
+        return k_min[:n], d_min[:n]
+
+    def fbrisk_transform(self, desc, node_desc, child_begin, child_index, node_word):
+        """DBoW2 vocabulary descent (FBrisk trait): word id and leaf node per descriptor."""
+        d = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        nd = np.ascontiguousarray(node_desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        cb = np.ascontiguousarray(child_begin, dtype=np.int32)
+        ci = np.ascontiguousarray(child_index, dtype=np.int32)
+        nw = np.ascontiguousarray(node_word, dtype=np.int32)
+        words = np.zeros(max(len(d), 1), dtype=np.int32)
+        leaves = np.zeros(max(len(d), 1), dtype=np.int32)
+        self._check(lib().okvfe_fbrisk_transform(self._h, _p(d), len(d), _p(nd), len(nd), _p(cb), _p(ci),
+                                                 _p(nw), _p(words), _p(leaves)))
+        return words[:len(d)], leaves[:len(d)]
 
     # -- stage profiling (HIP events on the launch stream) --------------------------------
     def profile_enable(self, on=True, stages=None):

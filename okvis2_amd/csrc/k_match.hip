@@ -22,6 +22,8 @@
 // are merged by (dist, segment).  Integer-ALU bound (v_xor + v_bcnt_u32_b32, 24 VALU per pair);
 // inputs are 2 x 33.6 KB per EuRoC stereo frame, so HBM is not the limit.
 #include "camera_dev.h"
+#include <algorithm>
+
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -426,6 +428,94 @@ __global__ __launch_bounds__(64) void hamming_emit_kernel(const uint8_t* __restr
       ++pos;
     }
   }
+}
+
+// ---- verifyRecognisedPlace, every landmark of one camera in ONE launch (Frontend.cpp:330-355) ----
+// One wave per landmark (grid-stride): lanes stride over the K frame descriptors, each landmark
+// descriptor is a wave-uniform row.  The reference's running minimum (strict <, descriptors outer,
+// k inner) keeps the smallest distance and, among equals, the first in that scan order: the wave
+// reduces the key (dist << 32 | scan position).  The frame descriptors are staged in LDS once per
+// workgroup when they fit.
+constexpr int kVerifyLdsRows = 1024;  // 48 KiB
+__global__ __launch_bounds__(256) void verify_place_kernel(
+    const uint8_t* __restrict__ pool, const int32_t* __restrict__ desc_begin, int n_landmarks,
+    const uint8_t* __restrict__ frame_desc, int K, uint32_t threshold, int32_t* __restrict__ k_min,
+    uint32_t* __restrict__ dist_min) {
+  __shared__ uint4 lds_desc[kVerifyLdsRows * 3];
+  const bool in_lds = K <= kVerifyLdsRows;
+  if (in_lds) {
+    const uint4* src = reinterpret_cast<const uint4*>(frame_desc);
+    for (int i = threadIdx.x; i < K * 3; i += 256) lds_desc[i] = src[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  for (int l = wave; l < n_landmarks; l += n_waves) {
+    unsigned long long best = ~0ull;
+    const int d0 = desc_begin[l], d1 = desc_begin[l + 1];
+    for (int d = d0; d < d1; ++d) {
+      const Desc12 a = load_desc(pool + (size_t)d * OKVFE_DESC_BYTES);  // same address in every lane
+      for (int k = lane; k < K; k += 64) {
+        const uint32_t* row = in_lds ? reinterpret_cast<const uint32_t*>(lds_desc + 3 * k)
+                                     : reinterpret_cast<const uint32_t*>(frame_desc + (size_t)k * OKVFE_DESC_BYTES);
+        const unsigned long long dist = (unsigned long long)hamming(a, row);
+        const unsigned long long key = (dist << 32) | (unsigned long long)((d - d0) * K + k);
+        best = key < best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) {
+      const unsigned long long o = __shfl_xor(best, dd);
+      best = o < best ? o : best;
+    }
+    if (lane == 0) {
+      const uint32_t dist = (uint32_t)(best >> 32);
+      const bool hit = best != ~0ull && dist < threshold;
+      k_min[l] = hit ? (int32_t)((uint32_t)best % (uint32_t)K) : 0;
+      dist_min[l] = hit ? dist : threshold;
+    }
+  }
+}
+
+// ---- DBoW2 vocabulary descent with the FBrisk trait (oracle: orc_voc_transform) ----------------
+// Lane = one feature; the node descriptors (819 x 48 B for the shipped 9^3 vocabulary) sit in LDS
+// when they fit.  At every level the child with the smallest Hamming distance wins, the first on
+// ties.
+constexpr int kVocLdsNodes = 1024;
+__global__ __launch_bounds__(256) void voc_transform_kernel(
+    const uint8_t* __restrict__ desc, int n, const uint8_t* __restrict__ node_desc, int n_nodes,
+    const int32_t* __restrict__ child_begin, const int32_t* __restrict__ child_index,
+    const int32_t* __restrict__ word, int32_t* __restrict__ word_out, int32_t* __restrict__ node_out) {
+  __shared__ uint4 lds_nodes[kVocLdsNodes * 3];
+  const bool in_lds = n_nodes <= kVocLdsNodes;
+  if (in_lds) {
+    const uint4* src = reinterpret_cast<const uint4*>(node_desc);
+    for (int i = threadIdx.x; i < n_nodes * 3; i += 256) lds_nodes[i] = src[i];
+    __syncthreads();
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Desc12 a = load_desc(desc + (size_t)i * OKVFE_DESC_BYTES);
+  int node = 0;
+  while (true) {
+    const int c0 = child_begin[node], c1 = child_begin[node + 1];
+    if (c1 <= c0) break;
+    int best = -1, best_d = 0x7FFFFFFF;
+    for (int c = c0; c < c1; ++c) {
+      const int id = child_index[c];
+      const uint32_t* row = in_lds ? reinterpret_cast<const uint32_t*>(lds_nodes + 3 * id)
+                                   : reinterpret_cast<const uint32_t*>(node_desc + (size_t)id * OKVFE_DESC_BYTES);
+      const int d = hamming(a, row);
+      if (d < best_d) {
+        best_d = d;
+        best = id;
+      }
+    }
+    node = best;
+  }
+  word_out[i] = word[node];
+  node_out[i] = node;
 }
 
 // ---- matchMotionStereo (Frontend.cpp:1812-1905) -------------------------------------------------
@@ -954,6 +1044,22 @@ void launch_match_stereo_arrays(const PairParams* pair, const uint8_t* desc0, co
   if (max_rows <= 0) return;
   hipLaunchKernelGGL(match_stereo_arrays_kernel, dim3((max_rows + 63) / 64), dim3(64, kStereoSegs), 0, stream,
                      pair, desc0, bp0, bpv0, n0p, n0, desc1, bp1, bpv1, n1p, n1, threshold, out, kp0, kp1);
+}
+
+void launch_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_landmarks,
+                         const uint8_t* frame_desc, int K, uint32_t threshold, int32_t* k_min,
+                         uint32_t* dist_min, hipStream_t stream) {
+  if (n_landmarks <= 0) return;
+  const int blocks = std::min((n_landmarks + 3) / 4, 2048);
+  hipLaunchKernelGGL(verify_place_kernel, dim3(blocks), dim3(256), 0, stream, pool, desc_begin, n_landmarks,
+                     frame_desc, K, threshold, k_min, dist_min);
+}
+void launch_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, int n_nodes,
+                          const int32_t* child_begin, const int32_t* child_index, const int32_t* word,
+                          int32_t* word_out, int32_t* node_out, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(voc_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, desc, n, node_desc,
+                     n_nodes, child_begin, child_index, word, word_out, node_out);
 }
 
 void launch_hamming_argmin(const uint8_t* A, int nA, const uint8_t* B, int nB, uint32_t thr,

@@ -1522,6 +1522,99 @@ okvfe_status okvfe_hamming_argmin(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, 
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_verify_place_match(okvfe_ctx* ctx, const uint8_t* landmark_desc, const int32_t* desc_begin,
+                                      int32_t n_landmarks, const uint8_t* frame_desc, int32_t n_kps,
+                                      int32_t* k_min, uint32_t* dist_min) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n_landmarks < 0 || n_kps < 0 || !desc_begin || (n_landmarks > 0 && (!k_min || !dist_min)) ||
+      (n_kps > 0 && !frame_desc))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_verify_place_match: bad argument");
+  for (int l = 0; l < n_landmarks; ++l)
+    if (desc_begin[l + 1] < desc_begin[l] || desc_begin[l] < 0)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_verify_place_match: desc_begin not monotone at %d", l);
+  if (n_landmarks == 0) return OKVFE_OK;
+  const int n_pool = desc_begin[n_landmarks];
+  if (n_pool > 0 && !landmark_desc) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_verify_place_match: null pool");
+  const uint32_t thr = (uint32_t)ctx->cfg.match_threshold;
+  if (n_kps == 0 || n_pool == 0) {  // Frontend.cpp:333-335: a camera without keypoints is skipped
+    for (int l = 0; l < n_landmarks; ++l) { k_min[l] = 0; dist_min[l] = thr; }
+    return OKVFE_OK;
+  }
+  if ((int64_t)3 * n_kps >= (int64_t)1 << 31) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "too many keypoints");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  const size_t o_pool = take((size_t)n_pool * 48), o_b = take((size_t)(n_landmarks + 1) * 4),
+               o_f = take((size_t)n_kps * 48), o_k = take((size_t)n_landmarks * 4), o_d = take((size_t)n_landmarks * 4);
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_pool, landmark_desc, (size_t)n_pool * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_b, desc_begin, (size_t)(n_landmarks + 1) * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_f, frame_desc, (size_t)n_kps * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_verify_place(base + o_pool, reinterpret_cast<int32_t*>(base + o_b), n_landmarks, base + o_f, n_kps, thr,
+                      reinterpret_cast<int32_t*>(base + o_k), reinterpret_cast<uint32_t*>(base + o_d), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(k_min, base + o_k, (size_t)n_landmarks * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipMemcpyAsync(dist_min, base + o_d, (size_t)n_landmarks * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_fbrisk_transform(okvfe_ctx* ctx, const uint8_t* descriptors, int32_t n,
+                                    const uint8_t* node_descriptors, int32_t n_nodes, const int32_t* child_begin,
+                                    const int32_t* child_index, const int32_t* node_word, int32_t* word_ids,
+                                    int32_t* leaf_nodes) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n < 0 || n_nodes < 1 || !node_descriptors || !child_begin || !node_word || (n > 0 && (!descriptors || !word_ids)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_fbrisk_transform: bad argument");
+  // the tree must be a tree: children lists monotone, indices in range and pointing downwards
+  if (child_begin[0] != 0) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_fbrisk_transform: child_begin[0] != 0");
+  for (int i = 0; i < n_nodes; ++i)
+    if (child_begin[i + 1] < child_begin[i])
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_fbrisk_transform: child_begin not monotone at %d", i);
+  const int n_child = child_begin[n_nodes];
+  if (n_child > 0 && !child_index) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_fbrisk_transform: null children");
+  {
+    std::vector<int> depth(n_nodes, -1);
+    depth[0] = 0;
+    for (int i = 0; i < n_nodes; ++i)  // nodes are numbered so that a parent precedes its children
+      for (int c = child_begin[i]; c < child_begin[i + 1]; ++c) {
+        const int id = child_index[c];
+        if (id <= i || id >= n_nodes || depth[i] < 0)
+          return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_fbrisk_transform: node %d has child %d (not a tree in id order)", i, id);
+        depth[id] = depth[i] + 1;
+      }
+  }
+  if (n == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  const size_t o_d = take((size_t)n * 48), o_n = take((size_t)n_nodes * 48), o_cb = take((size_t)(n_nodes + 1) * 4),
+               o_ci = take((size_t)n_child * 4), o_w = take((size_t)n_nodes * 4), o_wo = take((size_t)n * 4),
+               o_no = take((size_t)n * 4);
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_d, descriptors, (size_t)n * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_n, node_descriptors, (size_t)n_nodes * 48, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_cb, child_begin, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
+  if (n_child) HIP_TRY(ctx, hipMemcpyAsync(base + o_ci, child_index, (size_t)n_child * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_w, node_word, (size_t)n_nodes * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  launch_voc_transform(base + o_d, n, base + o_n, n_nodes, reinterpret_cast<int32_t*>(base + o_cb),
+                       reinterpret_cast<int32_t*>(base + o_ci), reinterpret_cast<int32_t*>(base + o_w),
+                       reinterpret_cast<int32_t*>(base + o_wo), reinterpret_cast<int32_t*>(base + o_no), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(word_ids, base + o_wo, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  if (leaf_nodes) HIP_TRY(ctx, hipMemcpyAsync(leaf_nodes, base + o_no, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
 // ---- stage profiling -------------------------------------------------------------------------
 okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;

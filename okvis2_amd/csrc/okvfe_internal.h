@@ -180,6 +180,12 @@ void launch_match_motion_blocks(const PairParams& pair, const DeviceCamera* came
 void launch_match_stereo_blocks(const PairParams& pair, const int offs[6], const uint8_t* blocks0,
                                 const uint8_t* blocks1, int n_frames, int kp_cap, int threshold,
                                 okvfe_stereo_match* out, hipStream_t stream);
+void launch_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_landmarks,
+                         const uint8_t* frame_desc, int K, uint32_t threshold, int32_t* k_min,
+                         uint32_t* dist_min, hipStream_t stream);
+void launch_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, int n_nodes,
+                          const int32_t* child_begin, const int32_t* child_index, const int32_t* word,
+                          int32_t* word_out, int32_t* node_out, hipStream_t stream);
 // scale space (k_pyramid.hip)
 void launch_halfsample(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);
 void launch_twothird(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);

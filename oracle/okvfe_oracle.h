@@ -215,6 +215,14 @@ int orc_detect_describe(const uint8_t* img, int w, int h, int stride,
                         const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
                         orc_keypoint* kps, uint8_t* desc, int cap);
 
+/* verifyRecognisedPlace for all landmarks of one camera; DBoW2 vocabulary descent (FBrisk) */
+void orc_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_landmarks,
+                      const uint8_t* frame_desc, int K, uint32_t threshold, int32_t* k_min,
+                      uint32_t* dist_min);
+void orc_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, const int32_t* child_begin,
+                       const int32_t* child_index, const int32_t* word, int32_t* word_out,
+                       int32_t* node_out);
+
 #ifdef __cplusplus
 }
 #endif

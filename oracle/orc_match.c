@@ -446,3 +446,57 @@ void orc_match_to_map_uninit(const uint8_t* desc, const double* bp, const uint8_
   }
   *ctr_out = ctr;
 }
+
+/* ---- verifyRecognisedPlace, all landmarks of one camera (Frontend.cpp:330-355) ------------------
+ * Landmark l owns pool rows desc_begin[l] .. desc_begin[l+1]-1 (its descriptors in insertion
+ * order, :318-326).  Running minimum with strict <, descriptors outer, k inner; k_min stays 0 and
+ * dist_min = threshold when nothing is below the threshold (the caller then ignores k_min). */
+void orc_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_landmarks,
+                      const uint8_t* frame_desc, int K, uint32_t threshold, int32_t* k_min,
+                      uint32_t* dist_min) {
+  for (int l = 0; l < n_landmarks; ++l) {
+    uint32_t dmin = threshold;
+    int32_t kmin = 0;
+    for (int d = desc_begin[l]; d < desc_begin[l + 1]; ++d)
+      for (int k = 0; k < K; ++k) {
+        const uint32_t dist = popc48(frame_desc + 48 * (size_t)k, pool + 48 * (size_t)d);
+        if (dist < dmin) {
+          dmin = dist;
+          kmin = k;
+        }
+      }
+    k_min[l] = kmin;
+    dist_min[l] = dmin;
+  }
+}
+
+/* ---- DBoW2 vocabulary descent with the FBrisk trait --------------------------------------------
+ * DBoW2 (external/DBoW2, un-vendored) TemplatedVocabulary<FBrisk::TDescriptor, FBrisk>::transform
+ * as published: from the root, at every level take the child with the smallest
+ * FBrisk::distance (= Hamming over 48 bytes, okvis_frontend/src/FBrisk.cpp:64-67), the FIRST child
+ * winning ties (strict <, children in stored order), until a leaf; the leaf's word id is the
+ * feature's word (features quantised at Frontend.cpp:756-766 via dBow_->database).
+ * Node n's children are child_index[child_begin[n] .. child_begin[n+1]).  word[n] < 0 for inner
+ * nodes. */
+void orc_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, const int32_t* child_begin,
+                       const int32_t* child_index, const int32_t* word, int32_t* word_out,
+                       int32_t* node_out) {
+  for (int i = 0; i < n; ++i) {
+    int node = 0;
+    while (child_begin[node + 1] > child_begin[node]) {
+      int best = child_index[child_begin[node]];
+      uint32_t best_d = popc48(desc + 48 * (size_t)i, node_desc + 48 * (size_t)best);
+      for (int c = child_begin[node] + 1; c < child_begin[node + 1]; ++c) {
+        const int id = child_index[c];
+        const uint32_t d = popc48(desc + 48 * (size_t)i, node_desc + 48 * (size_t)id);
+        if (d < best_d) {
+          best_d = d;
+          best = id;
+        }
+      }
+      node = best;
+    }
+    word_out[i] = word[node];
+    node_out[i] = node;
+  }
+}

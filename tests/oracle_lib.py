@@ -332,3 +332,41 @@ def match_to_map_uninit(desc, bp, use, previous, desc_begin, pool, e0_W, r0_W, T
                                   C.c_double(focal), C.c_double(thr), _p(bl), _p(bd), _p(hp), _p(hs),
                                   C.byref(ctr))
     return bl[:n], bd[:n], hp[:n], hs[:n], ctr.value
+
+
+def verify_place(pool, desc_begin, frame_desc, thr):
+    pool = np.ascontiguousarray(pool, dtype=np.uint8).reshape(-1, 48)
+    db = np.ascontiguousarray(desc_begin, dtype=np.int32)
+    fd = np.ascontiguousarray(frame_desc, dtype=np.uint8).reshape(-1, 48)
+    n = len(db) - 1
+    k_min = np.zeros(max(n, 1), dtype=np.int32)
+    d_min = np.zeros(max(n, 1), dtype=np.uint32)
+    lib().orc_verify_place(_p(pool), _p(db), n, _p(fd), len(fd), C.c_uint32(thr), _p(k_min), _p(d_min))
+    return k_min[:n], d_min[:n]
+
+
+def voc_tree_arrays(parent):
+    """children lists (child_begin, child_index) of a tree given parent[] (node 0 = root),
+    children in ascending node id = the order DBoW2 appends them while loading a file."""
+    parent = np.asarray(parent)
+    n = len(parent)
+    kids = [[] for _ in range(n)]
+    for i in range(1, n):
+        kids[int(parent[i])].append(i)
+    begin = np.zeros(n + 1, dtype=np.int32)
+    for i in range(n):
+        begin[i + 1] = begin[i] + len(kids[i])
+    index = np.array([c for k in kids for c in k], dtype=np.int32)
+    return begin, index
+
+
+def voc_transform(desc, node_desc, child_begin, child_index, word):
+    d = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 48)
+    nd = np.ascontiguousarray(node_desc, dtype=np.uint8).reshape(-1, 48)
+    cb = np.ascontiguousarray(child_begin, dtype=np.int32)
+    ci = np.ascontiguousarray(child_index, dtype=np.int32)
+    w = np.ascontiguousarray(word, dtype=np.int32)
+    wo = np.zeros(max(len(d), 1), dtype=np.int32)
+    no = np.zeros(max(len(d), 1), dtype=np.int32)
+    lib().orc_voc_transform(_p(d), len(d), _p(nd), _p(cb), _p(ci), _p(w), _p(wo), _p(no))
+    return wo[:len(d)], no[:len(d)]

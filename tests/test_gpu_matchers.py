@@ -321,3 +321,43 @@ def test_gated_matchers_large_and_ambiguous(oracle):
         assert np.array_equal(gotm[fld], refm[fld]), fld
     assert np.array_equal(gotm["hp_W"].view(np.uint64), refm["hp_W"].view(np.uint64))
     assert (refm["k1"] >= 0).sum() > 100
+
+
+def test_verify_place_batched_and_vocabulary_descent(oracle):
+    """okvfe_verify_place_match (Frontend.cpp:330-355, all landmarks in one launch) and
+    okvfe_fbrisk_transform (DBoW2 descent with the FBrisk trait) on the reference's real vocabulary
+    data and on GPU-made descriptors, against the oracle."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    d = np.fromfile(os.path.join(gold, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+    t = np.load(os.path.join(gold, "small_voc_tree.npz"))
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    fe.set_camera(0, cfg.cams[0])
+    rng = np.random.default_rng(11)
+    # landmarks with 1..4 descriptors each, frame of 700 descriptors incl. near-duplicates
+    frame = np.concatenate([d[:500], d[500:700] ^ (rng.random((200, 48)) < 0.02).astype(np.uint8)])
+    sizes = rng.integers(1, 5, 1500)
+    begin = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pool = d[rng.integers(0, 819, begin[-1])] ^ ((rng.random((begin[-1], 48)) < 0.03) *
+                                                  rng.integers(1, 256, (begin[-1], 48))).astype(np.uint8)
+    for K in (700, 0, 1, 1500):  # 1500 > the LDS staging limit of the kernel
+        fr = np.concatenate([frame, frame, frame])[:K]
+        rk, rd = oracle.verify_place(pool, begin, fr, cfg.match_threshold)
+        gk, gd = fe.verify_place_match(pool, begin, fr)
+        assert np.array_equal(gk, rk) and np.array_equal(gd, rd), K
+        if K == 700:
+            assert (rd < cfg.match_threshold).sum() > 300
+    gk, gd = fe.verify_place_match(pool[:0], np.zeros(1, np.int32), frame)
+    assert len(gk) == 0
+    # vocabulary descent
+    cb, ci = oracle.voc_tree_arrays(t["parent"])
+    img = synth.corners_image(cfg.w, cfg.h, 5)
+    _, feats, _, _ = fe.detect_describe(img, cam=0, gravity=(0.0, 1.0, 0.0))
+    feats = np.concatenate([feats, d, pool[:500]])
+    rw, rn = oracle.voc_transform(feats, t["desc"], cb, ci, t["word"])
+    gw, gn = fe.fbrisk_transform(feats, t["desc"], cb, ci, t["word"])
+    assert np.array_equal(gw, rw) and np.array_equal(gn, rn)
+    assert len(np.unique(rw)) > 300 and rw.min() >= 0 and rw.max() < 729
+    with pytest.raises(capi.OkvfeError):
+        fe.fbrisk_transform(feats[:4], t["desc"], cb, ci[::-1].copy(), t["word"])  # not a tree in id order

@@ -191,3 +191,64 @@ def test_fixed_atan_within_one_ulp_of_libm(oracle):
     assert ulps.max() <= 1
     assert (ulps != 0).mean() < 0.03
     assert np.isnan(oracle.atan_fixed(np.nan)[0])
+
+
+def _voc_tree():
+    t = np.load(os.path.join(GOLDEN, "small_voc_tree.npz"))
+    return t
+
+
+def test_vocabulary_descent_on_the_real_tree(oracle):
+    """The reference's DBoW2 vocabulary (resources/small_voc.yml.gz: k = 9, L = 3, 819 nodes, 729
+    words; fixture tests/golden/small_voc_tree.npz from tools/make_voc_tree_fixture.py).  Known
+    answers of the descent (DBoW2 transform with FBrisk::distance): a node descriptor fed as a
+    feature descends to that very node (distance 0 wins at its level) and, below it, keeps
+    following minimum-Hamming children; every leaf maps to its own word; a numpy restatement of the
+    descent agrees on perturbed descriptors."""
+    t = _voc_tree()
+    parent, word, desc = t["parent"], t["word"], t["desc"]
+    assert int(t["k"]) == 9 and int(t["L"]) == 3 and len(parent) == 820 and (word >= 0).sum() == 729
+    cb, ci = oracle.voc_tree_arrays(parent)
+    assert np.all(np.diff(cb)[word < 0] == 9) and np.all(np.diff(cb)[word >= 0] == 0)
+    leaves = np.flatnonzero(word >= 0)
+    w, n = oracle.voc_transform(desc[leaves], desc, cb, ci, word)
+    # a leaf descriptor reaches a leaf at distance 0 from it: its own word unless an earlier sibling
+    # chain is equally close (never the case for these cluster centres)
+    assert np.array_equal(n, leaves) and np.array_equal(w, word[leaves])
+    # numpy restatement on noisy features
+    rng = np.random.default_rng(3)
+    feats = desc[rng.integers(1, 820, 300)] ^ (rng.random((300, 48)) < 0.08).astype(np.uint8) * \
+        rng.integers(1, 256, (300, 48), dtype=np.uint8)
+    bits = np.unpackbits(desc, axis=1).astype(np.int32)
+    fb = np.unpackbits(feats, axis=1).astype(np.int32)
+    want = []
+    for i in range(len(feats)):
+        node = 0
+        while cb[node + 1] > cb[node]:
+            kids = ci[cb[node]:cb[node + 1]]
+            d = (bits[kids] != fb[i]).sum(axis=1)
+            node = int(kids[np.argmin(d)])  # argmin = first minimum
+        want.append(node)
+    w, n = oracle.voc_transform(feats, desc, cb, ci, word)
+    assert np.array_equal(n, want) and np.array_equal(w, word[n])
+
+
+def test_verify_place_running_minimum(oracle):
+    """Frontend.cpp:330-355 on the real vocabulary descriptors: per landmark the first-lowest
+    (descriptor, k) below the threshold."""
+    d = voc()
+    frame = d[:300]
+    pool = np.concatenate([d[300:420], d[10:14]])          # the last landmark contains frame rows
+    begin = np.concatenate([np.arange(0, 121, 3), [124]]).astype(np.int32)
+    k_min, d_min = oracle.verify_place(pool, begin, frame, 60)
+    bits = np.unpackbits(d, axis=1).astype(np.int32)
+    fb, pb = bits[:300], np.unpackbits(pool, axis=1).astype(np.int32)
+    for l in range(len(begin) - 1):
+        dist = (pb[begin[l]:begin[l + 1], None, :] != fb[None, :, :]).sum(axis=2)  # [desc, k]
+        m = dist.min()
+        if m < 60:
+            dd, kk = np.unravel_index(np.argmin(dist), dist.shape)  # first minimum in (desc, k) order
+            assert d_min[l] == m and k_min[l] == kk
+        else:
+            assert d_min[l] == 60 and k_min[l] == 0
+    assert d_min[-1] == 0 and k_min[-1] == 10
