@@ -327,6 +327,52 @@ okvfe_status okvfe_match_to_map(okvfe_ctx* ctx, const uint8_t* desc, const okvfe
                                 double reprojection_threshold, int32_t* best_landmark,
                                 int32_t* best_dist);
 
+/* ---- matchToMap from the raw landmark table (no host-side pooling) ---------------------------
+ * = Frontend::matchToMap up to and including its first matcher pass (Frontend.cpp:1219-1411):
+ * every landmark is projected into the current camera (FoV check, :1232-1256), its observations
+ * are scored and pooled by the three-slot "best views" buffer exactly as written at :1262-1354,
+ * and the 3-D landmarks are matched against the frame (matchToMapByThread, :1552-1589) -- all on
+ * the device, the pooled set never visits the host.
+ * Landmarks in ascending LandmarkId order (the order of the reference's std::map); landmark l owns
+ * observations obs_begin[l] .. obs_begin[l+1]-1, listed in the reference's iteration order
+ * (observations.rbegin() -> rend()). */
+typedef struct okvfe_landmark_table {
+  int32_t n_landmarks, n_observations, n_poses;
+  const double* hp_W;         /* n_landmarks x 4 homogeneous points (MapPoint::point) */
+  const double* quality;      /* n_landmarks (MapPoint::quality) */
+  const int32_t* obs_begin;   /* n_landmarks + 1 */
+  const int32_t* obs_pose;    /* n_observations: index into poses */
+  const uint8_t* obs_desc;    /* n_observations x 48: keypointDescriptor of the observing keypoint */
+  const double* obs_backproj; /* n_observations x 3: its cached back-projection (not normalised) */
+  const okvfe_pose* poses;    /* n_poses: T_WC of every observing (frame, camera) */
+} okvfe_landmark_table;
+
+/* What the pooling left per landmark (caller-allocated, n_landmarks rows; the struct pointer may
+ * be NULL): status 0 = not matched against (outside the FoV or no pooled view), 1 = 3-D, 2 = not
+ * 3-D yet (LandmarkToMatch::is3d); n_desc = pooled descriptors (0..2); obs_rows[3l + r] =
+ * observation whose descriptor is pooled row r (-1 = none; row 2 may be written but is cropped as
+ * in the reference); projection (2); e_W / r_W: 2 x 3 doubles, observing unit ray and camera
+ * centre per pooled row (LandmarkToMatch::e_W / r_W) -- together the inputs of
+ * okvfe_match_to_map_uninitialised for the status-2 landmarks. */
+typedef struct okvfe_landmark_pool {
+  int32_t* status;
+  int32_t* n_desc;
+  int32_t* obs_rows;
+  double* projection;
+  double* e_W;
+  double* r_W;
+} okvfe_landmark_pool;
+
+/* cam = camera slot with intrinsics (okvfe_set_camera); exclusive != 0 =
+ * loopClosureLandmarksToUseExclusively (view-point / scale pruning off, :1293-1303).  Outputs per
+ * keypoint as okvfe_match_to_map: landmark index (into the table, -1 = none) and distance. */
+okvfe_status okvfe_match_to_map_landmarks(okvfe_ctx* ctx, int32_t cam, const okvfe_landmark_table* table,
+                                          const okvfe_pose* T_WC1, double reprojection_threshold,
+                                          int32_t exclusive, const uint8_t* desc,
+                                          const okvfe_keypoint* kps, const uint8_t* use, int32_t n_kps,
+                                          okvfe_landmark_pool* pool_out, int32_t* best_landmark,
+                                          int32_t* best_dist);
+
 /* = Frontend::matchToMapByThreadUnitialised (Frontend.cpp:1616-1719), all keypoints in one call:
  * landmarks that are not 3-D yet.  Pool row d carries its observing unit ray e0_W[d] and camera
  * centre r0_W[d] (3 doubles each, LandmarkToMatch::e_W / r_W).  backproj = the current frame's

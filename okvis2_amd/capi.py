@@ -75,11 +75,24 @@ EXPORTS = [
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
     "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
+    "okvfe_match_to_map_landmarks",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
 
 _LIB = None
+
+
+class LandmarkTable(C.Structure):
+    _fields_ = [("n_landmarks", C.c_int32), ("n_observations", C.c_int32), ("n_poses", C.c_int32),
+                ("hp_W", C.c_void_p), ("quality", C.c_void_p), ("obs_begin", C.c_void_p),
+                ("obs_pose", C.c_void_p), ("obs_desc", C.c_void_p), ("obs_backproj", C.c_void_p),
+                ("poses", C.c_void_p)]
+
+
+class LandmarkPool(C.Structure):
+    _fields_ = [("status", C.c_void_p), ("n_desc", C.c_void_p), ("obs_rows", C.c_void_p),
+                ("projection", C.c_void_p), ("e_W", C.c_void_p), ("r_W", C.c_void_p)]
 
 
 class OkvfeError(RuntimeError):
@@ -455,6 +468,38 @@ class Frontend:
         self._check(lib().okvfe_hamming_argmin(self._h, _p(A), len(A), _p(B), len(B),
                                                C.c_uint32(int(thr)), _p(bj), _p(bd)))
         return bj[:len(A)], bd[:len(A)]
+
+    def match_to_map_landmarks(self, cam, hp_W, quality, obs_begin, obs_pose, obs_desc, obs_bp, poses,
+                               T_WC1, repr_threshold, exclusive, desc, kps, use):
+        """Frontend::matchToMap from the raw landmark table (projection + view pooling + 3-D match on
+        the device).  poses: list of (C, r).  Returns (best_landmark, best_dist, pool dict)."""
+        hp = np.ascontiguousarray(hp_W, dtype=np.float64).reshape(-1, 4)
+        q = np.ascontiguousarray(quality, dtype=np.float64)
+        ob = np.ascontiguousarray(obs_begin, dtype=np.int32)
+        op = np.ascontiguousarray(obs_pose, dtype=np.int32)
+        od = np.ascontiguousarray(obs_desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        obp = np.ascontiguousarray(obs_bp, dtype=np.float64).reshape(-1, 3)
+        P = (Pose * max(len(poses), 1))(*[make_pose(*p) for p in poses])
+        nl = len(hp)
+        t = LandmarkTable(nl, len(op), len(poses), _p(hp).value, _p(q).value, _p(ob).value,
+                          _p(op).value if len(op) else None, _p(od).value if len(od) else None,
+                          _p(obp).value if len(obp) else None, C.addressof(P))
+        pool = {"status": np.zeros(max(nl, 1), np.int32), "n_desc": np.zeros(max(nl, 1), np.int32),
+                "obs_rows": np.zeros((max(nl, 1), 3), np.int32), "projection": np.zeros((max(nl, 1), 2)),
+                "e_W": np.zeros((max(nl, 1), 2, 3)), "r_W": np.zeros((max(nl, 1), 2, 3))}
+        lp = LandmarkPool(*[_p(pool[k]).value for k in ("status", "n_desc", "obs_rows", "projection",
+                                                         "e_W", "r_W")])
+        d = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, DESC_BYTES)
+        kk = np.ascontiguousarray(kps, dtype=KEYPOINT_DTYPE)
+        u = np.ascontiguousarray(use, dtype=np.uint8)
+        n = len(kk)
+        lm = np.zeros(max(n, 1), dtype=np.int32)
+        bd = np.zeros(max(n, 1), dtype=np.int32)
+        T1 = make_pose(*T_WC1)
+        self._check(lib().okvfe_match_to_map_landmarks(
+            self._h, int(cam), C.byref(t), C.byref(T1), C.c_double(repr_threshold), int(bool(exclusive)),
+            _p(d), _p(kk), _p(u), n, C.byref(lp), _p(lm), _p(bd)))
+        return lm[:n], bd[:n], {k: v[:nl] for k, v in pool.items()}
 
     def verify_place_match(self, landmark_desc, desc_begin, frame_desc):
         """Frontend::verifyRecognisedPlace descriptor matching, all landmarks in one launch."""

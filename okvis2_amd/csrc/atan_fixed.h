@@ -15,6 +15,7 @@
 // K.C. Ng, 1993; error < 1 ulp).  Against glibc's (nearly correctly rounded) atan this differs by
 // at most 1 ulp (tests/test_oracle_pins.py::test_fixed_atan_within_one_ulp_of_libm).
 #pragma once
+#include <math.h>
 
 #if defined(__HIPCC__)
 #define OKVFE_HD __host__ __device__ inline
@@ -75,6 +76,58 @@ OKVFE_HD double atan_fixed(double x) {
     r = h - ((t * (s1 + s2) - l) - t);
   }
   return neg ? -r : r;
+}
+
+// FP64 arccosine as one fixed sequence (the published fdlibm scheme: rational approximation of
+// asin on [0, 1/2], acos(x) = 2 asin(sqrt((1 - x) / 2)) above it; error < 1 ulp).  Used where the
+// reference calls libm's acos in a comparison that decides an outcome (descriptor-view pooling
+// score, okvis_frontend/src/Frontend.cpp:1312); host code and kernels share it.
+OKVFE_HD double acos_fixed(double x) {
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+               pi = 3.14159265358979311600e+00;
+  const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01,
+               pS2 = 2.01212532134862925881e-01, pS3 = -4.00555345006794114027e-02,
+               pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00,
+               qS3 = -6.88283971605453293030e-01, qS4 = 7.70381505559019352791e-02;
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax >= 1.0) {
+    if (x == 1.0) return 0.0;
+    if (x == -1.0) return pi + 2.0 * pio2_lo;
+    return (x - x) / (x - x);  // NaN
+  }
+  if (ax < 0.5) {
+    if (ax < 6.938893903907228e-18) return pio2_hi + pio2_lo;  // 2^-57
+    const double z = x * x;
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double r = p / q;
+    return pio2_hi - (x - (pio2_lo - x * r));
+  }
+  if (x < 0.0) {
+    const double z = (1.0 + x) * 0.5;
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double s = sqrt(z);
+    const double r = p / q;
+    const double w = r * s - pio2_lo;
+    return pi - 2.0 * (s + w);
+  }
+  const double z = (1.0 - x) * 0.5;
+  const double s = sqrt(z);
+  // df = s with the low 32 bits of its mantissa cleared
+  unsigned long long bits;
+  __builtin_memcpy(&bits, &s, 8);
+  bits &= 0xFFFFFFFF00000000ull;
+  double df;
+  __builtin_memcpy(&df, &bits, 8);
+  const double c = (z - df * df) / (s + df);
+  const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const double r = p / q;
+  const double w = r * s + c;
+  return 2.0 * (df + w);
 }
 
 }  // namespace okvfe

@@ -1377,6 +1377,103 @@ okvfe_status okvfe_match_to_map(okvfe_ctx* ctx, const uint8_t* desc, const okvfe
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_match_to_map_landmarks(okvfe_ctx* ctx, int32_t cam, const okvfe_landmark_table* T,
+                                          const okvfe_pose* T_WC1, double reprojection_threshold, int32_t exclusive,
+                                          const uint8_t* desc, const okvfe_keypoint* kps, const uint8_t* use,
+                                          int32_t n_kps, okvfe_landmark_pool* pool_out, int32_t* best_landmark,
+                                          int32_t* best_dist) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!T || !T_WC1 || n_kps < 0 || !(reprojection_threshold >= 0.0) || T->n_landmarks < 0 || T->n_observations < 0 ||
+      T->n_poses < 0 || !T->obs_begin || (n_kps > 0 && (!desc || !kps || !use || !best_landmark || !best_dist)) ||
+      (T->n_landmarks > 0 && (!T->hp_W || !T->quality)) ||
+      (T->n_observations > 0 && (!T->obs_pose || !T->obs_desc || !T->obs_backproj || !T->poses)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_landmarks: bad argument");
+  if (cam < 0 || cam >= (int)ctx->h_cams.size() || !(ctx->h_cams[cam].fu > 0.0))
+    return fail(ctx, OKVFE_ERR_NOT_READY, "okvfe_match_to_map_landmarks: camera slot %d has no intrinsics (okvfe_set_camera)", cam);
+  const int nl = T->n_landmarks, no = T->n_observations;
+  for (int l = 0; l < nl; ++l)
+    if (T->obs_begin[l + 1] < T->obs_begin[l] || T->obs_begin[l] < 0 || T->obs_begin[l + 1] > no)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_landmarks: obs_begin not monotone at %d", l);
+  for (int o = 0; o < no; ++o)
+    if (T->obs_pose[o] < 0 || T->obs_pose[o] >= T->n_poses)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_landmarks: observation %d: pose index out of range", o);
+  for (int k = 0; k < n_kps; ++k) {
+    best_landmark[k] = -1;
+    best_dist[k] = ctx->cfg.match_threshold;
+  }
+  if (nl == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  // inputs
+  const size_t o_hp = take((size_t)nl * 32), o_q = take((size_t)nl * 8), o_ob = take((size_t)(nl + 1) * 4),
+               o_op = take((size_t)no * 4), o_od = take((size_t)no * 48), o_obp = take((size_t)no * 24),
+               o_poses = take((size_t)T->n_poses * sizeof(okvfe_pose));
+  const size_t o_d = take((size_t)n_kps * 48), o_k = take((size_t)n_kps * sizeof(okvfe_keypoint)), o_u = take(n_kps);
+  // pooling results
+  const size_t o_st = take((size_t)nl * 4), o_nd = take((size_t)nl * 4), o_rows = take((size_t)nl * 12),
+               o_proj = take((size_t)nl * 16), o_e = take((size_t)nl * 48), o_r = take((size_t)nl * 48);
+  // packed 3-D set + matcher outputs
+  const size_t o_idx = take((size_t)nl * 4), o_p3 = take((size_t)nl * 16), o_b3 = take((size_t)(nl + 1) * 4),
+               o_pool3 = take((size_t)nl * 2 * 48), o_n3 = take(8), o_lm = take((size_t)n_kps * 4),
+               o_bd = take((size_t)n_kps * 4);
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRY(ctx, up(o_hp, T->hp_W, (size_t)nl * 32));
+  HIP_TRY(ctx, up(o_q, T->quality, (size_t)nl * 8));
+  HIP_TRY(ctx, up(o_ob, T->obs_begin, (size_t)(nl + 1) * 4));
+  HIP_TRY(ctx, up(o_op, T->obs_pose, (size_t)no * 4));
+  HIP_TRY(ctx, up(o_od, T->obs_desc, (size_t)no * 48));
+  HIP_TRY(ctx, up(o_obp, T->obs_backproj, (size_t)no * 24));
+  HIP_TRY(ctx, up(o_poses, T->poses, (size_t)T->n_poses * sizeof(okvfe_pose)));
+  HIP_TRY(ctx, up(o_d, desc, (size_t)n_kps * 48));
+  HIP_TRY(ctx, up(o_k, kps, (size_t)n_kps * sizeof(okvfe_keypoint)));
+  HIP_TRY(ctx, up(o_u, use, n_kps));
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources
+  const DeviceCamera& dc = ctx->h_cams[cam];
+  const double focal = dc.fu + dc.fv;  // the SUM, as at Frontend.cpp:1213-1215
+  auto I = [&](size_t o) { return reinterpret_cast<int32_t*>(base + o); };
+  auto D = [&](size_t o) { return reinterpret_cast<double*>(base + o); };
+  launch_prepare_landmarks(D(o_hp), D(o_q), I(o_ob), nl, I(o_op), D(o_obp),
+                           reinterpret_cast<const okvfe_pose*>(base + o_poses), *T_WC1, ctx->d_cams + cam, ctx->w,
+                           ctx->h, reprojection_threshold, exclusive ? 1 : 0, std::cos(10.0 / focal), std::cos(0.6),
+                           I(o_st), I(o_nd), I(o_rows), D(o_proj), D(o_e), D(o_r), s);
+  launch_compact_landmarks(I(o_st), I(o_nd), I(o_rows), D(o_proj), base + o_od, nl, 1, I(o_idx), D(o_p3), I(o_b3),
+                           base + o_pool3, I(o_n3), s);
+  HIP_TRY(ctx, hipGetLastError());
+  int32_t n3[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(n3, base + o_n3, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // the matcher's grid depends on the number of 3-D landmarks only
+  if (n_kps > 0 && n3[0] > 0) {
+    launch_match_to_map(base + o_d, reinterpret_cast<okvfe_keypoint*>(base + o_k), base + o_u, n_kps, D(o_p3),
+                        I(o_b3), n3[0], base + o_pool3, reprojection_threshold * reprojection_threshold,
+                        ctx->cfg.match_threshold, I(o_lm), I(o_bd), s);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<int32_t> idx(n3[0]);
+    HIP_TRY(ctx, hipMemcpyAsync(best_landmark, base + o_lm, (size_t)n_kps * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(best_dist, base + o_bd, (size_t)n_kps * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(idx.data(), base + o_idx, (size_t)n3[0] * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (int k = 0; k < n_kps; ++k)
+      if (best_landmark[k] >= 0) best_landmark[k] = idx[best_landmark[k]];  // packed -> table index
+  }
+  if (pool_out) {
+    if (pool_out->status) HIP_TRY(ctx, hipMemcpyAsync(pool_out->status, base + o_st, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+    if (pool_out->n_desc) HIP_TRY(ctx, hipMemcpyAsync(pool_out->n_desc, base + o_nd, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+    if (pool_out->obs_rows) HIP_TRY(ctx, hipMemcpyAsync(pool_out->obs_rows, base + o_rows, (size_t)nl * 12, hipMemcpyDeviceToHost, s));
+    if (pool_out->projection) HIP_TRY(ctx, hipMemcpyAsync(pool_out->projection, base + o_proj, (size_t)nl * 16, hipMemcpyDeviceToHost, s));
+    if (pool_out->e_W) HIP_TRY(ctx, hipMemcpyAsync(pool_out->e_W, base + o_e, (size_t)nl * 48, hipMemcpyDeviceToHost, s));
+    if (pool_out->r_W) HIP_TRY(ctx, hipMemcpyAsync(pool_out->r_W, base + o_r, (size_t)nl * 48, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+  }
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_match_to_map_uninitialised(okvfe_ctx* ctx, const uint8_t* desc, const double* backproj,
                                               const uint8_t* use, const int32_t* previous_landmark,
                                               int32_t n_kps, const int32_t* desc_begin, int32_t n_landmarks,

@@ -186,6 +186,17 @@ void launch_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_l
 void launch_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, int n_nodes,
                           const int32_t* child_begin, const int32_t* child_index, const int32_t* word,
                           int32_t* word_out, int32_t* node_out, hipStream_t stream);
+// matchToMap preparation (k_map.hip)
+void launch_prepare_landmarks(const double* hp_W, const double* quality, const int32_t* obs_begin,
+                              int n_landmarks, const int32_t* obs_pose, const double* obs_bp,
+                              const okvfe_pose* poses, const okvfe_pose& T_WC1, const DeviceCamera* camera,
+                              int w, int h, double repr, int exclusive, double cos10, double cos06,
+                              int32_t* status, int32_t* n_desc, int32_t* obs_rows, double* projection,
+                              double* e_W, double* r_W, hipStream_t stream);
+void launch_compact_landmarks(const int32_t* status, const int32_t* n_desc, const int32_t* obs_rows,
+                              const double* projection, const uint8_t* obs_desc, int n_landmarks, int want,
+                              int32_t* index_out, double* proj_out, int32_t* begin_out, uint8_t* pool_out,
+                              int32_t* n_out, hipStream_t stream);
 // scale space (k_pyramid.hip)
 void launch_halfsample(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);
 void launch_twothird(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);

@@ -223,6 +223,14 @@ void orc_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, con
                        const int32_t* child_index, const int32_t* word, int32_t* word_out,
                        int32_t* node_out);
 
+/* matchToMap: landmark projection + descriptor-view pooling (Frontend.cpp:1219-1359) */
+double orc_acos_fixed(double x);
+void orc_prepare_landmarks(const double* hp_W, const double* quality, const int32_t* obs_begin,
+                           int n_landmarks, const int32_t* obs_pose, const double* obs_bp,
+                           const orc_pose* poses_old, const orc_pose* T_WC1, const orc_camera* cam,
+                           double repr_threshold, int exclusive, int32_t* status, int32_t* n_desc,
+                           int32_t* obs_rows, double* projection, double* e_W, double* r_W);
+
 #ifdef __cplusplus
 }
 #endif

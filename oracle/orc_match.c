@@ -500,3 +500,144 @@ void orc_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, con
     node_out[i] = node;
   }
 }
+
+/* ---- matchToMap: landmark projection + descriptor-view pooling (Frontend.cpp:1219-1359) ---------
+ * Per landmark (caller's order = ascending LandmarkId): FoV check by projecting the homogeneous
+ * point into the current camera (:1232-1256), then the observations in the reference's iteration
+ * order (observations.rbegin() .. rend(), i.e. the caller flattens them that way): 3-D test
+ * (:1284-1290), view-point (> 0.6 rad) and scale (> 50 %) pruning unless `exclusive`
+ * (loopClosureLandmarksToUseExclusively, :1293-1303), score, and the three-slot "keep the best"
+ * buffer EXACTLY as written at :1305-1340 -- including its quirks: the descriptor is written at row
+ * `o` (the largest slot index replaced so far), not at the replaced slot, and only the first `o`
+ * rows survive the crop at :1344, so a landmark with a single accepted observation ends with zero
+ * rows and is skipped (:1351-1354) and at most 2 rows are ever kept.
+ * acos: orc_acos_fixed (fixed IEEE sequence, <= 1 ulp from libm; the score only ranks views).
+ * Outputs per landmark: status 0 = not matched against (outside the FoV / no rows), 1 = 3-D,
+ * 2 = not 3-D yet; n_desc = rows kept; obs[r] = observation whose descriptor sits in row r;
+ * projection; e_W / r_W (3 doubles per kept row: observing ray and camera centre, :1326-1330). */
+double orc_acos_fixed(double x) {
+  static const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+                      pi = 3.14159265358979311600e+00;
+  static const double pS[6] = {1.66666666666666657415e-01, -3.25565818622400915405e-01,
+                               2.01212532134862925881e-01, -4.00555345006794114027e-02,
+                               7.91534994289814532176e-04, 3.47933107596021167570e-05};
+  static const double qS[5] = {1.0, -2.40339491173441421878e+00, 2.02094576023350569471e+00,
+                               -6.88283971605453293030e-01, 7.70381505559019352791e-02};
+  double ax, z, p, q, r, sq, w, df, c;
+  if (x != x) return x;
+  ax = x < 0.0 ? -x : x;
+  if (ax >= 1.0) {
+    if (x == 1.0) return 0.0;
+    if (x == -1.0) return pi + 2.0 * pio2_lo;
+    return (x - x) / (x - x);
+  }
+  if (ax < 0.5) {
+    if (ax < 6.938893903907228e-18) return pio2_hi + pio2_lo;
+    z = x * x;
+  } else if (x < 0.0) {
+    z = (1.0 + x) * 0.5;
+  } else {
+    z = (1.0 - x) * 0.5;
+  }
+  p = z * (pS[0] + z * (pS[1] + z * (pS[2] + z * (pS[3] + z * (pS[4] + z * pS[5])))));
+  q = 1.0 + z * (qS[1] + z * (qS[2] + z * (qS[3] + z * qS[4])));
+  r = p / q;
+  if (ax < 0.5) return pio2_hi - (x - (pio2_lo - x * r));
+  sq = sqrt(z);
+  if (x < 0.0) {
+    w = r * sq - pio2_lo;
+    return pi - 2.0 * (sq + w);
+  }
+  {
+    uint64_t bits;
+    memcpy(&bits, &sq, 8);
+    bits &= 0xFFFFFFFF00000000ull;
+    memcpy(&df, &bits, 8);
+  }
+  c = (z - df * df) / (sq + df);
+  w = r * sq + c;
+  return 2.0 * (df + w);
+}
+
+void orc_prepare_landmarks(const double* hp_W, const double* quality, const int32_t* obs_begin,
+                           int n_landmarks, const int32_t* obs_pose, const double* obs_bp,
+                           const orc_pose* poses_old, const orc_pose* T_WC1, const orc_camera* cam,
+                           double repr_threshold, int exclusive, int32_t* status, int32_t* n_desc,
+                           int32_t* obs_rows /* n*3 */, double* projection /* n*2 */,
+                           double* e_W /* n*2*3 */, double* r_W /* n*2*3 */) {
+  const double maxU = (double)cam->w + repr_threshold, maxV = (double)cam->h + repr_threshold;
+  const double focal = cam->fu + cam->fv; /* sum, as at Frontend.cpp:1213-1215 */
+  const double cos10 = cos(10.0 / focal), cos06 = cos(0.6);
+  for (int l = 0; l < n_landmarks; ++l) {
+    status[l] = 0;
+    n_desc[l] = 0;
+    obs_rows[3 * l] = obs_rows[3 * l + 1] = obs_rows[3 * l + 2] = -1;
+    projection[2 * l] = projection[2 * l + 1] = 0.0;
+    for (int i = 0; i < 6; ++i) e_W[6 * l + i] = r_W[6 * l + i] = 0.0;
+    const double* hp = hp_W + 4 * (size_t)l;
+    const double p_W[3] = {hp[0] / hp[3], hp[1] / hp[3], hp[2] / hp[3]};
+    const double r_Wv[3] = {p_W[0] - T_WC1->r[0], p_W[1] - T_WC1->r[1], p_W[2] - T_WC1->r[2]};
+    double e_Wv[3];
+    normalize3(r_Wv, e_Wv);
+    const double rn = sqrt(dot3(r_Wv, r_Wv));
+    const double r = 0.01 > rn ? 0.01 : rn;
+    double hp_C[4], head[3], kp[2];
+    inv_transform_h(T_WC1, hp, hp_C);
+    if (hp_C[3] < 0) {
+      head[0] = -hp_C[0]; head[1] = -hp_C[1]; head[2] = -hp_C[2];
+    } else {
+      head[0] = hp_C[0]; head[1] = hp_C[1]; head[2] = hp_C[2];
+    }
+    const int st = orc_cam_project(cam, head, kp, NULL);
+    if (st == 4 || st == 3) continue; /* Invalid, Behind */
+    if (kp[0] < -repr_threshold || kp[1] < -repr_threshold || kp[0] > maxU || kp[1] > maxV) continue;
+    projection[2 * l] = kp[0];
+    projection[2 * l + 1] = kp[1];
+    int is3d = 0, o = 0, rows[3] = {-1, -1, -1};
+    double best[3] = {1.0, 1.0, 1.0}, ew[3][3], rw[3][3];
+    for (int ob = obs_begin[l]; ob < obs_begin[l + 1]; ++ob) {
+      const orc_pose* To = poses_old + obs_pose[ob];
+      const double r_old[3] = {p_W[0] - To->r[0], p_W[1] - To->r[1], p_W[2] - To->r[2]};
+      if (!is3d) {
+        const double f = 0.2 / focal / quality[l];
+        const double rc[3] = {r_Wv[0] - f * r_old[0], r_Wv[1] - f * r_old[1], r_Wv[2] - f * r_old[2]};
+        double a[3], b[3];
+        normalize3(r_Wv, a);
+        normalize3(rc, b);
+        if (dot3(a, b) > cos10) is3d = 1;
+      }
+      double eo[3];
+      normalize3(r_old, eo);
+      const double cosVC = dot3(e_Wv, eo);
+      if (cosVC < cos06 && !exclusive) continue;
+      const double scaleChange = fabs(r - sqrt(dot3(r_old, r_old))) / r;
+      if (scaleChange > 0.5 && !exclusive) continue;
+      const double score = 0.5 * (orc_acos_fixed(cosVC) / 0.6 + scaleChange / 0.5);
+      double worst = 0.0;
+      int wi = 0;
+      for (int n = 0; n < 3; ++n)
+        if (best[n] > worst) {
+          worst = best[n];
+          wi = n;
+        }
+      if (score < best[wi]) {
+        rows[o] = ob;
+        double en[3];
+        normalize3(obs_bp + 3 * (size_t)ob, en);
+        rot(To->C, en, ew[o]);
+        rw[o][0] = To->r[0]; rw[o][1] = To->r[1]; rw[o][2] = To->r[2];
+        o = o > wi ? o : wi;
+        best[wi] = score;
+      }
+    }
+    if (o == 0) continue; /* "no observations -- weird" */
+    status[l] = is3d ? 1 : 2;
+    n_desc[l] = o;
+    for (int k = 0; k < 3; ++k) obs_rows[3 * l + k] = rows[k];
+    for (int k = 0; k < o && k < 2; ++k)
+      for (int i = 0; i < 3; ++i) {
+        e_W[6 * l + 3 * k + i] = ew[k][i];
+        r_W[6 * l + 3 * k + i] = rw[k][i];
+      }
+  }
+}

@@ -370,3 +370,30 @@ def voc_transform(desc, node_desc, child_begin, child_index, word):
     no = np.zeros(max(len(d), 1), dtype=np.int32)
     lib().orc_voc_transform(_p(d), len(d), _p(nd), _p(cb), _p(ci), _p(w), _p(wo), _p(no))
     return wo[:len(d)], no[:len(d)]
+
+
+def acos_fixed(x) -> np.ndarray:
+    f = lib().orc_acos_fixed
+    f.restype, f.argtypes = C.c_double, [C.c_double]
+    return np.array([f(float(v)) for v in np.atleast_1d(np.asarray(x, dtype=np.float64))])
+
+
+def prepare_landmarks(hp_W, quality, obs_begin, obs_pose, obs_bp, poses, T_WC1, cam, repr_thr, exclusive):
+    """orc_prepare_landmarks: Frontend.cpp:1219-1359 (projection + descriptor-view pooling)."""
+    hp = np.ascontiguousarray(hp_W, dtype=np.float64).reshape(-1, 4)
+    q = np.ascontiguousarray(quality, dtype=np.float64)
+    ob = np.ascontiguousarray(obs_begin, dtype=np.int32)
+    op = np.ascontiguousarray(obs_pose, dtype=np.int32)
+    obp = np.ascontiguousarray(obs_bp, dtype=np.float64).reshape(-1, 3)
+    P = (Pose * max(len(poses), 1))(*[make_pose(*p) for p in poses])
+    T1 = make_pose(*T_WC1)
+    c = make_camera(cam)
+    nl = len(hp)
+    out = {"status": np.zeros(max(nl, 1), np.int32), "n_desc": np.zeros(max(nl, 1), np.int32),
+           "obs_rows": np.zeros((max(nl, 1), 3), np.int32), "projection": np.zeros((max(nl, 1), 2)),
+           "e_W": np.zeros((max(nl, 1), 2, 3)), "r_W": np.zeros((max(nl, 1), 2, 3))}
+    lib().orc_prepare_landmarks(_p(hp), _p(q), _p(ob), nl, _p(op), _p(obp), P, C.byref(T1), C.byref(c),
+                                C.c_double(repr_thr), int(bool(exclusive)), _p(out["status"]),
+                                _p(out["n_desc"]), _p(out["obs_rows"]), _p(out["projection"]),
+                                _p(out["e_W"]), _p(out["r_W"]))
+    return {k: v[:nl] for k, v in out.items()}

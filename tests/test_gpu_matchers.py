@@ -361,3 +361,52 @@ def test_verify_place_batched_and_vocabulary_descent(oracle):
     assert len(np.unique(rw)) > 300 and rw.min() >= 0 and rw.max() < 729
     with pytest.raises(capi.OkvfeError):
         fe.fbrisk_transform(feats[:4], t["desc"], cb, ci[::-1].copy(), t["word"])  # not a tree in id order
+
+
+def test_match_to_map_from_raw_landmark_table(oracle):
+    """okvfe_match_to_map_landmarks (Frontend.cpp:1219-1411): projection, descriptor-view pooling and
+    the 3-D matcher on the device from the raw landmark / observation tables, 6000 landmarks;
+    every pooled field and every match against the oracle, then the un-initialised matcher on the
+    status-2 landmarks the pooling returned."""
+    import os
+    import map_synth
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    voc = np.fromfile(os.path.join(gold, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+    m = map_synth.make_map(6000, voc=voc)
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    fe.set_camera(0, m["cam"])
+    kps, desc, use = map_synth.make_frame(m, oracle)
+    for exclusive, thr in ((False, 20.0), (True, 150.0)):
+        ref = oracle.prepare_landmarks(m["hp"], m["quality"], m["obs_begin"], m["obs_pose"], m["obs_bp"],
+                                       m["poses"], m["T1"], m["cam"], thr, exclusive)
+        lm, bd, pool = fe.match_to_map_landmarks(0, m["hp"], m["quality"], m["obs_begin"], m["obs_pose"],
+                                                 m["obs_desc"], m["obs_bp"], m["poses"], m["T1"], thr,
+                                                 exclusive, desc, kps, use)
+        for k in ("status", "n_desc", "obs_rows"):
+            assert np.array_equal(pool[k], ref[k]), k
+        for k in ("projection", "e_W", "r_W"):
+            assert np.array_equal(pool[k].view(np.uint64), ref[k].view(np.uint64)), k
+        assert (ref["status"] == 1).sum() > 500 and (ref["status"] == 2).sum() > 100
+        assert (ref["status"] == 0).sum() > 500 and ref["n_desc"].max() == 2
+        idx, proj, begin, rows = map_synth.packed_set(ref, m["obs_desc"], 1)
+        rl, rd = oracle.match_to_map(desc, kps, use, proj, begin, rows, thr, cfg.match_threshold)
+        rl = np.where(rl >= 0, idx[np.maximum(rl, 0)], -1)
+        assert np.array_equal(lm, rl) and np.array_equal(bd, rd)
+        assert (rl >= 0).sum() > 100
+    # the status-2 landmarks feed matchToMapByThreadUnitialised unchanged
+    idx, _, begin, rows = map_synth.packed_set(pool, m["obs_desc"], 2)
+    e0 = np.concatenate([pool["e_W"][l, :pool["n_desc"][l]] for l in idx])
+    r0 = np.concatenate([pool["r_W"][l, :pool["n_desc"][l]] for l in idx])
+    bp, bv = oracle.backproject_keypoints(m["cam"], kps)
+    prev = np.full(len(kps), -1, dtype=np.int32)
+    f = 0.5 * (m["cam"].fu + m["cam"].fv)
+    got = fe.match_to_map_uninitialised(desc, bp, use & bv, prev, begin, rows, e0, r0, m["T1"], f)
+    want = oracle.match_to_map_uninit(desc, bp, use & bv, prev, begin, rows, e0, r0, m["T1"], f,
+                                      cfg.match_threshold)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # empty table
+    lm, bd, pool = fe.match_to_map_landmarks(0, m["hp"][:0], m["quality"][:0], np.zeros(1, np.int32),
+                                             m["obs_pose"][:0], m["obs_desc"][:0], m["obs_bp"][:0], m["poses"],
+                                             m["T1"], 20.0, False, desc, kps, use)
+    assert np.all(lm == -1) and np.all(bd == cfg.match_threshold)

@@ -252,3 +252,34 @@ def test_verify_place_running_minimum(oracle):
         else:
             assert d_min[l] == 60 and k_min[l] == 0
     assert d_min[-1] == 0 and k_min[-1] == 10
+
+
+def test_fixed_acos_within_one_ulp_of_libm(oracle):
+    x = np.concatenate([np.linspace(-1, 1, 20001), [0.5, -0.5, 1e-20, 0.9999999999, -0.9999999999]])
+    got, want = oracle.acos_fixed(x), np.arccos(x)
+    assert np.abs(got.view(np.int64) - want.view(np.int64)).max() <= 1
+    assert np.isnan(oracle.acos_fixed(1.5)[0])
+
+
+def test_descriptor_view_pooling_follows_the_reference_buffer_rules(oracle):
+    """Frontend.cpp:1305-1354 written out for three small cases: the three-slot buffer writes at row
+    `o`, crops to `o` rows, and drops a landmark whose single view was accepted."""
+    cam = synth.euroc_config().cams[0]
+    eye = np.eye(3).reshape(-1)
+    T1 = (eye, np.zeros(3))
+    poses = [(eye, np.array([0.05 * i, 0.0, 0.0])) for i in range(5)]
+    hp = np.array([[0.0, 0.0, 5.0, 1.0]] * 3)
+    quality = np.array([1.0, 1.0, 1.0])
+    # landmark 0: one view -> o stays 0 -> skipped; landmark 1: two views -> one row kept (the SECOND
+    # view overwrote row 0); landmark 2: four views
+    obs_begin = np.array([0, 1, 3, 7], dtype=np.int32)
+    obs_pose = np.array([1, 1, 2, 1, 2, 3, 4], dtype=np.int32)
+    obs_bp = np.tile(np.array([0.0, 0.0, 1.0]), (7, 1))
+    out = oracle.prepare_landmarks(hp, quality, obs_begin, obs_pose, obs_bp, poses, T1, cam, 20.0, False)
+    assert out["status"][0] == 0 and out["n_desc"][0] == 0
+    assert out["status"][1] in (1, 2) and out["n_desc"][1] == 1 and out["obs_rows"][1, 0] == 2
+    # four views: slots 0,1,2 filled in turn (rows 0,0->1,1->2 by the write-at-o rule), the fourth
+    # (largest view-point change = worst score) is not better than the worst slot
+    assert out["n_desc"][2] == 2 and list(out["obs_rows"][2]) == [4, 5, -1]
+    assert np.allclose(out["projection"][0], [cam.cu, cam.cv], atol=1.0)
+    assert np.allclose(out["r_W"][2, 0], poses[2][1]) and np.allclose(out["r_W"][2, 1], poses[3][1])
