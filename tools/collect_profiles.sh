@@ -8,17 +8,23 @@ R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 1"
+BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --lanes 1"
 $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- $BENCH > /tmp/prof_stats.log 2>&1
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
 # three staggered lanes (the higher-throughput mode): the same kernels sharing the GPU
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats3 -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 3 > /tmp/prof_stats3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats3 -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --lanes 3 > /tmp/prof_stats3.log 2>&1
 cp $(find /tmp/prof_stats3 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats_3lanes.csv
 grep '^{"metric"' /tmp/prof_stats3.log | tail -1 > $OUT/${TAG}_bench_3lanes.json
 # the other BASELINE shapes (informational bench lines, CPU baseline + parity leg included)
-for W in tumvi hilti; do
+for W in tumvi hilti mono640; do
   python $R/bench.py --workload $W 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_$W.json
+done
+python $R/bench.py --workload hilti --split cameras 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_hilti_split_cameras.json
+# counter calibration on K1's own access shapes (4 B/lane reads, 16 B/lane writes): known byte counts
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/cal_$C -o p -- $R/tools/ubench/fetch_calib > /tmp/cal_$C.log 2>&1
+  python $R/tools/pmc_summary.py $(find /tmp/cal_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_calib_$C.json > /dev/null
 done
 export OKVFE_PMC_CALIB=1
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -26,6 +32,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python $R/tools/pmc_summary.py $(find /tmp/prof_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_$C.json > /dev/null
 done
 unset OKVFE_PMC_CALIB
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -o p -- $BENCH --steps 3 > /tmp/prof_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -o p -- $BENCH --steps 3 > /tmp/prof_sq.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/prof_sq -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_sq.json > /dev/null
 ls -la $OUT | tail -12

@@ -40,6 +40,19 @@ _, write, write_cal = rows("WRITE_SIZE")
 CAL_KIB = 262144.0
 f_scale, w_scale = CAL_KIB / fetch_cal, CAL_KIB / write_cal
 rd, wr = fetch * f_scale * 1024.0, write * w_scale * 1024.0
+# second calibration, on K1's own access shapes (tools/ubench/fetch_calib: 1 GiB per kernel)
+calib_shapes = None
+try:
+    cf = json.load(open(os.path.join(src, f"{tag}_calib_FETCH_SIZE.json")))
+    cw = json.load(open(os.path.join(src, f"{tag}_calib_WRITE_SIZE.json")))
+    gib = 1048576.0
+    calib_shapes = {"read4_fetch_scale": gib / cf["read4"]["mean_per_dispatch"]["FETCH_SIZE"],
+                    "read16_fetch_scale": gib / cf["read16"]["mean_per_dispatch"]["FETCH_SIZE"],
+                    "write16_write_scale": gib / cw["write16"]["mean_per_dispatch"]["WRITE_SIZE"],
+                    "note": "1 GiB per kernel; read4 = one dword per lane (K1's loads), write16 = 16 B "
+                            "per lane (K1's stores): the same scales as the bitwise_not calibration"}
+except Exception:
+    pass
 out = {
     "kernel": name,
     "workload": f"{w}x{h} u8 x {n_img} images per launch (bench.py --lanes 1)",
@@ -56,6 +69,8 @@ out = {
     "hbm_bytes_per_image": (rd + wr) / n_img,
     "algorithmic_bytes_per_launch": 5 * w * h * n_img,
     "ratio_to_algorithmic": (rd + wr) / (5.0 * w * h * n_img),
+    "read_ratio": rd / (1.0 * w * h * n_img), "write_ratio": wr / (4.0 * w * h * n_img),
+    "calibration_on_k1_access_shapes": calib_shapes,
 }
 dst = os.path.join(root, "profiles", f"{tag}_k1_pmc.json")
 json.dump(out, open(dst, "w"), indent=1)
