@@ -277,7 +277,10 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // Layout: entry e of lane l of wave v at byte e * (256 * waves per block) + v * 256 + l * 4 (bank-conflict-free); a
 // lane pushes in test order.  Entries >= kScoreSlots fall outside the workgroup's LDS allocation:
 // the hardware range check discards those writes and the epilogue reads such scores from the map.
-constexpr int kScoreSlots = 16;
+#ifndef OKVFE_K1_SLOTS
+#define OKVFE_K1_SLOTS 16
+#endif
+constexpr int kScoreSlots = OKVFE_K1_SLOTS;
 // m = (m << 1) | (c >= nb); lanes that hit push c
 __device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& sp) {
   uint64_t mask, sav;
