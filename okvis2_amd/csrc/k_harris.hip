@@ -275,32 +275,39 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 // after the row loop missed the L2 (the tile's own stores had pushed them out) and cost one 64-128 B
 // HBM fetch per candidate -- 0.44 GB per 1536 images, as much as 80 % of the image bytes themselves.
 // Layout: entry e of lane l of wave v at byte e * (256 * waves per block) + v * 256 + l * 4 (bank-conflict-free); a
-// lane pushes in test order.  Entries >= kScoreSlots fall outside the workgroup's LDS allocation:
-// the hardware range check discards those writes and the epilogue reads such scores from the map.
+// lane pushes in test order.  A lane with more than kScoreSlots hits (flat or noisy content) stops
+// writing (its address is compared with the end of its slice) and the epilogue reads the scores
+// of those candidates from the score map.
 #ifndef OKVFE_K1_SLOTS
 #define OKVFE_K1_SLOTS 16
 #endif
 constexpr int kScoreSlots = OKVFE_K1_SLOTS;
 // m = (m << 1) | (c >= nb); lanes that hit push c
-__device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& sp) {
+__device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& sp, uint32_t sp_end) {
   uint64_t mask, sav;
 #ifndef OKVFE_K1_NOLDSPUSH
-  // about half of the (row, column) tests of a wave have no hit at all: the push is branched over
+  // about half of the (row, column) tests of a wave have no hit at all: the push is branched over.
+  // Lanes whose stack is full (sp >= sp_end) skip the write but still advance sp, so that slot
+  // indices stay equal to push counts.
   asm volatile(
       "v_cmp_ge_i32_e64 %[mask], %[c], %[nb]\n\t"
       "v_addc_co_u32_e64 %[m], vcc, %[m], %[m], %[mask]\n\t"
       "s_and_saveexec_b64 %[sav], %[mask]\n\t"
       "s_cbranch_execz .Lokvfe_nopush%=\n\t"
+      "v_cmp_gt_u32_e32 vcc, %[end], %[sp]\n\t"
+      "s_and_b64 exec, exec, vcc\n\t"
       "ds_write_b32 %[sp], %[c]\n\t"
+      "s_and_b64 exec, %[sav], %[mask]\n\t"
       "v_add_u32 %[sp], %[stride], %[sp]\n"
       ".Lokvfe_nopush%=:\n\t"
       "s_mov_b64 exec, %[sav]"
       : [m] "+v"(m), [sp] "+v"(sp), [mask] "=&s"(mask), [sav] "=&s"(sav)
-      : [c] "v"(c), [nb] "v"(nb), [stride] "i"(kWavesPerBlock * 256)
+      : [c] "v"(c), [nb] "v"(nb), [end] "s"(sp_end), [stride] "i"(kWavesPerBlock * 256)
       : "vcc", "scc", "memory");
 #else
   (void)sav;
   (void)sp;
+  (void)sp_end;
   asm volatile("v_cmp_ge_i32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, vcc, %0, %0, %1"
                : "+v"(m), "=&s"(mask)
                : "v"(c), "v"(nb)
@@ -386,6 +393,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   const uint32_t sp0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
                        (uint32_t)(wave * 256 + lane * 4);
   uint32_t sp = sp0;  // LDS byte address of this lane's next score slot
+  // end of the stack as ONE scalar: slot e of any lane lies below base + (e + 1) * stride
+  const uint32_t sp_end = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
+                          (uint32_t)(kScoreSlots * kWavesPerBlock * 256);
 
   // covariance row g from pixel rows a (g-1), b (g), c (g+1) -> H (horizontally smoothed); k3, k10 =
   // the (3, 10, 3) filter taps times 2^9 (mulhi24 of two such gradients then yields g*g >> 14), or
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       const int rgt[4] = {nc[1], nc[2], nc[3], nr};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        push_hit(hits[i], nc[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr), sp);
+        push_hit(hits[i], nc[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr), sp, sp_end);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -244,7 +244,7 @@ def test_error_paths():
         capi.Frontend(752, 480, 38.0, 5, 150, 700)  # more than 4 octaves
     assert e.value.status == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.OkvfeError) as e:
-        capi.Frontend(96, 96, 38.0, 3, 150, 700)  # top layer of the scale space below 16 px
+        capi.Frontend(64, 64, 38.0, 3, 150, 700)  # top layer of the scale space (10 px) below 16 px
     assert e.value.status == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.OkvfeError) as e:
         capi.Frontend(752, 480, 38.0, 0, 0, 700)
