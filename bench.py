@@ -174,15 +174,17 @@ def k1_name(h):
 def roofline_block(P, n_img_launch, harris_ms, extra):
     achieved = 5.0 * P * n_img_launch / (harris_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "round2_k1_pmc.json")
-    if os.path.exists(pmc_path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round2_*_k1_pmc.json")))
+    if cands:
+        pmc_path = cands[-1]  # newest collection of this round
         pmc = json.load(open(pmc_path))
         # same kernel, same image shape: per-image HBM bytes x the images of one launch here
         if pmc.get("algorithmic_bytes_per_launch") == 5 * P * pmc.get("images_per_launch", 0):
             traffic = pmc["hbm_bytes_per_image"] * n_img_launch
-            traffic_src = ("profiles/round2_k1_pmc.json (FETCH_SIZE/WRITE_SIZE passes at %d images "
-                           "per launch, scaled per image; rocprofv3 cannot run inside this process)"
-                           % pmc["images_per_launch"])
+            traffic_src = ("profiles/%s (FETCH_SIZE/WRITE_SIZE passes at %d images per launch, scaled "
+                           "per image; rocprofv3 cannot run inside this process)"
+                           % (os.path.basename(pmc_path), pmc["images_per_launch"]))
     r = {"kernel": k1_name(0), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
