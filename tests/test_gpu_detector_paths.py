@@ -262,3 +262,82 @@ def test_score_token_across_contexts(oracle, mode):
     out = subprocess.run([sys.executable, "-c", _TOKEN_CHILD, ROOT, str(mode)], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "TOKEN-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_candidate_overflow_is_deterministic_and_reported(oracle):
+    """An NMS candidate list that overflows max_candidates leaves THAT image without keypoints
+    (which maxima an overflowing list drops depends on atomic order) and okvfe_check_capacity names
+    it; the other images of the batch are untouched.  Every path that reads counts honours it."""
+    w, h = 752, 480
+    busy = synth.noise_image(w, h, 3)            # tens of thousands of maxima at threshold 5
+    calm = synth.corners_image(w, h, 4)
+    fe = capi.Frontend(w, h, 38.0, 0, 150, 700, max_batch=3, max_candidates=8000)
+    n_busy = len(oracle.nms(oracle.harris_score(busy), 150))
+    n_calm = len(oracle.nms(oracle.harris_score(calm), 150))
+    assert n_busy > 8000 > n_calm
+    d_img = torch.from_numpy(np.stack([calm, busy, calm])).cuda()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    fe.detect_describe_batch_device(d_img.data_ptr(), 3, None, None, st)
+    st.synchronize()
+    with pytest.raises(capi.OkvfeError) as e:
+        fe.check_capacity(3)
+    assert e.value.status == capi.ERR_CAPACITY and "image 1" in str(e.value)
+    ref = oracle.detect_describe(calm, 38.0, 0, 150, 700, oracle.MODE_GRADIENT)
+    for i in (0, 2):
+        k, d, _, _ = fe.download(i)
+        G.assert_keypoints_equal(k, ref[0])
+        assert np.array_equal(d, ref[1])
+    with pytest.raises(capi.OkvfeError) as e:
+        fe.download(1)
+    assert e.value.status == capi.ERR_CAPACITY
+    # the gather blocks (what the cross-camera matchers read) carry an EMPTY image 1, not a truncated one
+    nb = fe.gather_block_bytes()
+    blocks = torch.zeros((3, nb), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    fe.pack_gather_blocks_device(0, 3, blocks.data_ptr(), st)
+    st.synchronize()
+    host_counts = blocks[:, :4].cpu().numpy().copy().view(np.int32)[:, 0]
+    assert host_counts[1] == 0 and host_counts[0] == len(ref[0]) == host_counts[2]
+    fe.check_capacity(1)  # image 0 alone is fine
+
+
+def test_host_fed_batches_equal_device_fed(oracle):
+    """okvfe_detect_describe_batch_host (pinned host images, library-side double-buffered copy) gives
+    the same rows as the device-resident call, over several calls that alternate the two buffers
+    and with different images per call."""
+    cfg = synth.euroc_config()
+    B = 4
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                       num_cameras=2, max_batch=B)
+    for ci in range(2):
+        fe.set_camera(ci, cfg.cams[ci])
+    st = torch.cuda.Stream()
+    cam_ids = np.array([0, 1] * (B // 2), dtype=np.int32)
+    batches = []
+    for c in range(3):
+        imgs = np.stack([synth.corners_image(cfg.w, cfg.h, 900 + 10 * c + i) for i in range(B)])
+        grav = np.array([[0.01 * (c + i), 1.0, -0.02 * i] for i in range(B)], dtype=np.float32)
+        batches.append((imgs, grav, torch.from_numpy(imgs).pin_memory()))
+    got = []
+    for imgs, grav, pinned in batches:  # enqueue all three without waiting: copies overlap kernels
+        fe.detect_describe_batch_host(pinned.data_ptr(), B, cam_ids, grav, st)
+        st.synchronize()  # results live in the context until the next call
+        got.append([fe.download(i) for i in range(B)])
+    for (imgs, grav, _), rows in zip(batches, got):
+        d_img = torch.from_numpy(imgs).cuda()
+        st.wait_stream(torch.cuda.current_stream())
+        fe.detect_describe_batch_device(d_img.data_ptr(), B, cam_ids, grav, st)
+        st.synchronize()
+        for i in range(B):
+            want = fe.download(i)
+            for a, b in zip(rows[i], want):
+                assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+            assert len(want[0]) > 100
+    # back-to-back host-fed calls without a host wait in between: the last result must be right
+    for imgs, grav, pinned in batches:
+        fe.detect_describe_batch_host(pinned.data_ptr(), B, cam_ids, grav, st)
+    st.synchronize()
+    for i in range(B):
+        for a, b in zip(fe.download(i), got[-1][i]):
+            assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
