@@ -344,7 +344,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     if args.workload != "euroc" and args.batch == 768:
-        args.batch = 192
+        # frames per step that fill the 256 CUs for a whole number of workgroup rounds of the score
+        # kernel (1536 resident workgroups): 512 TUM-VI images = 6.9 rounds, 1536 VGA images = 6
+        args.batch = {"tumvi": 256, "hilti": 192, "mono640": 1536}[args.workload]
     if args.workload == "hilti" and args.split == "cameras":
         res = run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev)
         if res is not None:

@@ -328,38 +328,64 @@ constexpr int kSplitTests = 30;  // tiles of more than 32 rows: hit bits of the 
 //     neighbour of a tested row) and overwritten with zeros after the loop by the two waves that
 //     own them; rows past the image (partial last tile) are not stored;
 //   * hit bits of rows that may not be maxima (y < 2, y >= h-2) are masked in the epilogue.
-template <int kTHF, bool NMS>
+template <int kTHF, bool NMS, bool PACK = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int strips,
-    int ytiles, int n_images, NmsOut nms) {
+    int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
   constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
   static_assert(kMain % 6 == 0 && kTHF <= 61, "rows per wave: 6k (+1 with the fused NMS), <= 61");
   const int lane = threadIdx.x;
-  int image, tile;
-  xcd_tile(strips * ytiles, n_images, &image, &tile);
-  const int ytile = tile / strips;
-  const int strip = tile - ytile * strips;
   const int nd = w >> 2;
-  const int d = strip * kStripLanes + lane;
+  // PACK (narrow last strip, e.g. 7 dwords of a 1024-px row): `strips` counts the full strips
+  // only; the last strips of pack_g consecutive images share one wave, pack_u lanes each (left
+  // halo lane + store lanes), in the blocks behind the main_blocks ordinary ones.  Everything that
+  // differs between the sub-strips is per-lane already (dword index, load / store offsets, store
+  // predicate), so the row loop is the same code; only the candidate reservation of the epilogue
+  // runs once per image.
+  int image, tile, ytile, strip, d;
+  int sub = 0;          // PACK: which of the wave's images this lane works on
+  int group_images = 1;  // images addressed through this wave's buffer resources
+  bool lane_on = true;  // PACK: lane belongs to an existing image
+  const bool packed_block = PACK && (int)blockIdx.x >= main_blocks;
+  if (packed_block) {
+    const int p = (int)blockIdx.x - main_blocks;
+    const int group = p / ytiles;
+    ytile = p - group * ytiles;
+    image = group * pack_g;  // first image of the group
+    group_images = n_images - image < pack_g ? n_images - image : pack_g;
+    strip = strips;  // index of the (packed) last strip
+    sub = lane / pack_u;
+    const int j = lane - sub * pack_u;
+    lane_on = sub < group_images;
+    if (!lane_on) sub = 0;
+    d = lane_on ? strip * kStripLanes + j : nd;  // idle lanes behave like lanes past the row end
+  } else {
+    xcd_tile(strips * ytiles, n_images, &image, &tile);
+    ytile = tile / strips;
+    strip = tile - ytile * strips;
+    d = strip * kStripLanes + lane;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int ys_own = (ytile * kWavesPerBlock + wave) * kTHF;
   if (ys_own >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
   const int ye_own = ys_own + kTHF < h ? ys_own + kTHF : h;
   const int ys = NMS ? ys_own - 1 : ys_own;  // first score row computed (with NMS one above the tile)
-  const bool last_strip = strip * kStripLanes + 64 >= nd;
-  const bool store = d < nd && (strip == 0 || lane >= 1) && (last_strip || lane <= kStripLanes);
+  const bool last_strip = PACK ? packed_block : strip * kStripLanes + 64 >= nd;
+  const bool first_lane_halo = packed_block ? d == strip * kStripLanes : (strip != 0 && lane < 1);
+  const bool store = d < nd && !first_lane_halo && (last_strip || lane <= kStripLanes);
   const int dcl = d < nd ? d : nd - 1;  // clamped dword index for loads
   const size_t img_off = (size_t)image * (size_t)w * (size_t)h;
   // buffer resources (SGPR base + 32-bit per-lane offset): no 64-bit VALU address arithmetic in
   // the row loop; the row offset rides in the scalar offset operand
   const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(images + img_off), 0, w * h, 0x00027000);
+      const_cast<uint8_t*>(images + img_off), 0, w * h * group_images, 0x00027000);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      scores + img_off, 0, w * h * 4, 0x00027000);
-  const int ld_off = dcl * 4;    // byte offset of this lane's dword within a pixel row
+      scores + img_off, 0, w * h * 4 * group_images, 0x00027000);
+  const int sub_off = PACK ? sub * w * h : 0;  // pixel offset of this lane's image in the group
+  const int ld_off = dcl * 4 + sub_off;  // byte offset of this lane's dword within a pixel row
   // halo lanes (and lanes past the image) store nowhere: their per-lane offset lies outside the
   // resource, so the hardware range check drops the store (the scalar offset is not range-checked)
-  const int st_off = store ? dcl * 16 : 0x7FFFFFF0;
+  const int st_off = store ? dcl * 16 + sub_off * 4 : 0x7FFFFFF0;
   int m0 = d == 0 ? 0 : -1;        // column 0 is rim
   int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
   // keep the masks as opaque VGPR values: "x & m" then stays a 2-cycle v_and_b32 instead of being
@@ -644,17 +670,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       cnt += __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
     }
     if (!__any(cnt != 0)) return;
-    int incl = cnt;
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-      const int t = __shfl_up(incl, dd);
-      if (lane >= dd) incl += t;
+    // one reservation in the image's candidate list per wave (PACK: per image of the wave)
+    // (the sub-strip index is recomputed here instead of being kept in a register across the
+    // row loop: the PACK variant has to stay within 80 VGPRs as well)
+    int sub_e = 0;
+    if (packed_block) {
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));
+      sub_e = l2 / pack_u;
+      if (sub_e >= group_images) sub_e = 0;
     }
-    const int total = __shfl(incl, 63);
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&nms.cand_count[image], total);
-    int pos = __shfl(base, 0) + incl - cnt;
-    Candidate* outc = nms.cand + (size_t)image * nms.cand_cap;
+    const int image_l = image + sub_e;
+    int pos = 0;
+    auto reserve = [&](bool mine, int img) {
+      const int c = mine ? cnt : 0;
+      int incl = c;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const int t = __shfl_up(incl, dd);
+        if (lane >= dd) incl += t;
+      }
+      const int total = __shfl(incl, 63);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&nms.cand_count[img], total);
+      base = __shfl(base, 0);  // by all lanes: a cross-lane read of an inactive lane returns 0
+      if (mine) pos = base + incl - c;
+    };
+    if (packed_block) {
+      for (int g = 0; g < group_images; ++g) {  // wave-uniform
+        const bool mine = sub_e == g;
+        if (__any(mine && cnt != 0)) reserve(mine, image + g);
+      }
+    } else {
+      reserve(true, image);
+    }
+    Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
     __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
     int flagged = 0;
 #pragma unroll
@@ -690,14 +740,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
           if (e < kScoreSlots)
             cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
           else
-            cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, dcl * 16 + 4 * i + yy * w * 4, 0, 1);
+            cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * w * 4, 1);
           if (pos < nms.cand_cap) outc[pos] = cd;
           ++pos;
         }
       }
     }
     if ((rows_adj[0] | rows_adj[1]) != 0u && __any(flagged != 0)) {
-      if (flagged) atomicAdd(&nms.fix_count[image], flagged);
+      if (flagged) atomicAdd(&nms.fix_count[image_l], flagged);
     }
   }
 }
@@ -718,12 +768,25 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
       const char* e = getenv("OKVFE_K1_TH");  // A/B knob: rows per wave of the fused kernel (25..61)
       return e ? atoi(e) : 0;
     }();
+    // narrow last strip (1024-px rows: 7 of 64 lanes): the last strips of pack_g images share a wave
+    const int last_first = (strips - 1) * kStripLanes;      // first dword (halo lane) of the last strip
+    const int pack_u = nd - last_first;                     // halo lane + store lanes
+    const int pack_g = strips >= 2 ? 64 / pack_u : 1;
 #define OKVFE_K1_NMS_LAUNCH(TH)                                                                 \
   {                                                                                              \
     const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                    \
-    hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(strips * ytiles * n_images), block, 0,    \
-                       stream, img, w, h, score, strips, ytiles, n_images, *nms);                \
+    if (pack_g >= 2 && !no_pack) {                                                               \
+      const int main_blocks = (strips - 1) * ytiles * n_images;                                  \
+      const int groups = (n_images + pack_g - 1) / pack_g;                                       \
+      hipLaunchKernelGGL((harris_kernel<TH, true, true>), dim3(main_blocks + groups * ytiles),   \
+                         block, 0, stream, img, w, h, score, strips - 1, ytiles, n_images, *nms, \
+                         pack_g, pack_u, main_blocks);                                           \
+    } else {                                                                                     \
+      hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(strips * ytiles * n_images), block, 0,  \
+                         stream, img, w, h, score, strips, ytiles, n_images, *nms, 1, 64, 0);    \
+    }                                                                                            \
   }
+    static const bool no_pack = getenv("OKVFE_K1_NOPACK") != nullptr;  // A/B knob
     if (nms) {
       // rows per wave (6k + 1): more rows = fewer halo rows per tile (6 per tile), but longer waves
       // (tail) and a later epilogue
@@ -739,7 +802,7 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     } else {
       const int ytiles = (h + 30 * kWavesPerBlock - 1) / (30 * kWavesPerBlock);
       hipLaunchKernelGGL((harris_kernel<30, false>), dim3(strips * ytiles * n_images), block, 0, stream,
-                         img, w, h, score, strips, ytiles, n_images, NmsOut{});
+                         img, w, h, score, strips, ytiles, n_images, NmsOut{}, 1, 64, 0);
     }
 #undef OKVFE_K1_NMS_LAUNCH
   } else {

@@ -198,6 +198,42 @@ def test_batch_of_odd_size_mixed_images(oracle, n_images, mode):
     assert len(fe.download(4)[0]) == 0
 
 
+@pytest.mark.parametrize("w,h,n_images", [(1024, 150, 11), (260, 130, 23), (512, 512, 17), (1280, 100, 6)])
+def test_packed_last_strips_batches(oracle, w, h, n_images):
+    """Rows whose last 62-dword strip is narrow (1024 px: 7 dwords, 260 px: 2, 512 px: 3, 1280 px: 9):
+    the fused score+NMS kernel lets the last strips of 8 / 21 / 16 / 6 consecutive images share one
+    wave.  Batches that end inside a group, images of different kinds next to each other (plateaus
+    set the fix-up flags of a whole wave row), one flat image; every image against the oracle."""
+    fe = capi.Frontend(w, h, 12.0, 0, 60, 500, rotation_invariant=False, max_batch=n_images,
+                       max_candidates=1 << 15)
+    imgs = []
+    for i in range(n_images):
+        if i == 2:
+            imgs.append(np.full((h, w), 17, np.uint8))
+        elif i % 3 == 0:
+            imgs.append(_plateau_image(w, h, 300 + i, 2 + i % 2, 1 + i % 3))
+        elif i % 3 == 1:
+            imgs.append(synth.noise_image(w, h, 300 + i))
+        else:
+            imgs.append(synth.corners_image(w, h, 300 + i))
+    imgs = np.stack(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    fe.detect_describe_batch_device(d_img.data_ptr(), n_images, None, None,
+                                    torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    fe.check_capacity(n_images)  # raises if a candidate list overflowed
+    total = 0
+    for i in range(n_images):
+        k, d = oracle.detect_describe(imgs[i], 12.0, 0, 60, 500, oracle.MODE_UPRIGHT, None, None,
+                                      np.float32(1.0), (0.0, 1.0, 0.0))
+        g = fe.download(i)
+        G.assert_keypoints_equal(g[0], k)
+        assert np.array_equal(g[1], d)
+        total += len(k)
+    assert total > 20 * n_images
+    assert len(fe.download(2)[0]) == 0
+
+
 def test_split_batch_api_equals_combined_call():
     cfg = synth.euroc_config()
     n = 6
