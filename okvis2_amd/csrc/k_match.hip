@@ -802,7 +802,26 @@ __device__ __forceinline__ void cross3(const double a[3], const double b[3], dou
   t1 = a[0] * b[1]; t2 = a[1] * b[0]; out[2] = t1 - t2;
 }
 
-__global__ __launch_bounds__(64) void match_to_map_uninit_kernel(
+// Segments: the landmark list is cut into kUninitSegs contiguous ranges, one wave each, and every
+// wave runs the reference loop over its range from best = threshold.  The gate is a pure function
+// of (keypoint, pooled descriptor), so a range walked from a higher starting value accepts a
+// superset: its accepted pairs have strictly decreasing distances, and the ones the sequential loop
+// would have accepted with the incoming best B of the range are exactly those below B (a suffix).
+// Per range and keypoint it is therefore enough to keep
+//   * the last accepted pair (distance, landmark),
+//   * the last accepted NON-parallel pair (distance, hp): it is the stored hp of the range iff its
+//     distance is below B, otherwise the range stores none,
+//   * for the landmark the keypoint already carries (never accepted, only counted): the smallest
+//     gated distance of its descriptors below the range's running best at that point; the
+//     sequential loop counts it iff that is below B as well,
+// and to fold the ranges in order.
+constexpr int kUninitSegs = 8;
+struct UninitSegResult {
+  int best, lm, np_dist, prev_min;
+  double hp[4];
+};
+
+__global__ __launch_bounds__(64 * kUninitSegs) void match_to_map_uninit_kernel(
     const PairParams* __restrict__ pair, const uint8_t* __restrict__ desc_k,
     const double* __restrict__ bp, const uint8_t* __restrict__ use,
     const int32_t* __restrict__ previous, int n_k, const int32_t* __restrict__ desc_begin, int n_lm,
@@ -810,11 +829,13 @@ __global__ __launch_bounds__(64) void match_to_map_uninit_kernel(
     const double* __restrict__ r0_W, int threshold, int32_t* __restrict__ best_lm,
     int32_t* __restrict__ best_d, double* __restrict__ hps_W, uint8_t* __restrict__ hp_set,
     int32_t* __restrict__ ctr_total) {
+  __shared__ UninitSegResult seg_res[kUninitSegs - 1][64];
   const PairParams& P = *pair;  // C1/r1 = T_WC1; cos26/cos6 for sigma = 1/f
-  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x, seg = threadIdx.y;
+  const int k = blockIdx.x * 64 + lane;
   const bool in_range = k < n_k;
   const bool active = in_range && use[k] != 0;
-  Desc12 dk;
+  Desc12 dk = {};
   double e1_W[3] = {0, 0, 0};
   int prev = -1;
   if (active) {
@@ -824,64 +845,90 @@ __global__ __launch_bounds__(64) void match_to_map_uninit_kernel(
     rot(P.C1, en, e1_W);
     prev = previous[k];
   }
-  int best = threshold, lm = -1, ctr = 0;
-  bool have_hp = false;
+  // gate of one (keypoint, pooled descriptor) pair in the reference's order; pure
+  auto gate = [&](int d, double hp[4], bool* is_parallel) -> bool {
+    const double* e0 = e0_W + 3 * (size_t)d;
+    const double* r0 = r0_W + 3 * (size_t)d;
+    const double e0v[3] = {e0[0], e0[1], e0[2]}, r0v[3] = {r0[0], r0[1], r0[2]};
+    if (dot3(e0v, e1_W) < P.cos6) {
+      double t[3], et[3], c0[3], c1[3], n0[3], n1[3], cx[3], nn[3], nnn[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) t[i] = P.r1[i] - r0v[i];
+      normalize3(t, et);
+      cross3(e0v, et, c0);
+      normalize3(c0, n0);
+      cross3(e1_W, et, c1);
+      normalize3(c1, n1);
+      if (dot3(n0, n1) < P.cos6) return false;
+      cross3(e0v, e1_W, cx);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) nn[i] = n0[i] + n0[i];
+      normalize3(nn, nnn);
+      if (dot3(cx, nnn) > 0.0) return false;
+    }
+    bool is_valid;
+    triangulate_fast(r0v, e0v, P.r1, e1_W, P.cos26, P.cos6, hp, &is_valid, is_parallel);
+    if (!is_valid) return false;
+    if (!*is_parallel) {
+      double a[3], bb[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double p = hp[i] / hp[3];
+        a[i] = p - r0v[i];
+        bb[i] = p - P.r1[i];
+      }
+      if (sqrt(dot3(a, a)) < 0.2) is_valid = false;
+      if (sqrt(dot3(bb, bb)) < 0.2) is_valid = false;
+    }
+    return is_valid;
+  };
+  const int per_seg = (n_lm + kUninitSegs - 1) / kUninitSegs;
+  const int l_lo = min(seg * per_seg, n_lm), l_hi = min(l_lo + per_seg, n_lm);
+  int best = threshold, lm = -1, np_dist = INT_MAX, prev_min = INT_MAX;
   double hps[4] = {0, 0, 0, 0};
-  for (int l = 0; l < n_lm; ++l) {
+  for (int l = l_lo; l < l_hi; ++l) {
     const int b = desc_begin[l], e = desc_begin[l + 1];
-    bool done = !active;  // per-lane "break" out of this landmark's descriptor loop
     for (int d = b; d < e; ++d) {
       const uint32_t* dd = reinterpret_cast<const uint32_t*>(pool + (size_t)d * OKVFE_DESC_BYTES);
-      if (done) continue;
+      if (!active) continue;
       const int dist = hamming(dk, dd);
       if (dist < best) {
-        const double* e0 = e0_W + 3 * (size_t)d;
-        const double* r0 = r0_W + 3 * (size_t)d;
-        const double e0v[3] = {e0[0], e0[1], e0[2]}, r0v[3] = {r0[0], r0[1], r0[2]};
-        if (dot3(e0v, e1_W) < P.cos6) {
-          double t[3], et[3], c0[3], c1[3], n0[3], n1[3], cx[3], nn[3], nnn[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) t[i] = P.r1[i] - r0v[i];
-          normalize3(t, et);
-          cross3(e0v, et, c0);
-          normalize3(c0, n0);
-          cross3(e1_W, et, c1);
-          normalize3(c1, n1);
-          if (dot3(n0, n1) < P.cos6) continue;
-          cross3(e0v, e1_W, cx);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) nn[i] = n0[i] + n0[i];
-          normalize3(nn, nnn);
-          if (dot3(cx, nnn) > 0.0) continue;
-        }
         double hp[4];
-        bool is_valid, is_parallel;
-        triangulate_fast(r0v, e0v, P.r1, e1_W, P.cos26, P.cos6, hp, &is_valid, &is_parallel);
-        if (!is_valid) continue;
-        if (!is_parallel) {
-          double a[3], bb[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const double p = hp[i] / hp[3];
-            a[i] = p - r0v[i];
-            bb[i] = p - P.r1[i];
-          }
-          if (sqrt(dot3(a, a)) < 0.2) is_valid = false;
-          if (sqrt(dot3(bb, bb)) < 0.2) is_valid = false;
-        }
-        if (!is_valid) continue;
-        if (l == prev) {
-          ++ctr;
-          done = true;
+        bool is_parallel;
+        if (!gate(d, hp, &is_parallel)) continue;
+        if (l == prev) {  // counted, never accepted: `best` stays as it is for the whole landmark
+          prev_min = dist < prev_min ? dist : prev_min;
           continue;
         }
         best = dist;
         lm = l;
         if (!is_parallel) {
+          np_dist = dist;
           hps[0] = hp[0]; hps[1] = hp[1]; hps[2] = hp[2]; hps[3] = hp[3];
-          have_hp = true;
         }
       }
+    }
+  }
+  if (seg > 0) {
+    UninitSegResult& r = seg_res[seg - 1][lane];
+    r.best = best; r.lm = lm; r.np_dist = np_dist; r.prev_min = prev_min;
+    r.hp[0] = hps[0]; r.hp[1] = hps[1]; r.hp[2] = hps[2]; r.hp[3] = hps[3];
+  }
+  __syncthreads();
+  if (seg > 0) return;
+  // fold the ranges in landmark order; range 0 started from the threshold itself
+  int ctr = prev_min < threshold ? 1 : 0;
+  bool have_hp = np_dist != INT_MAX;
+  for (int sg = 0; sg < kUninitSegs - 1; ++sg) {
+    const UninitSegResult& r = seg_res[sg][lane];
+    if (r.prev_min < best) ++ctr;
+    if (r.best < best) {
+      if (r.np_dist < best) {
+        hps[0] = r.hp[0]; hps[1] = r.hp[1]; hps[2] = r.hp[2]; hps[3] = r.hp[3];
+        have_hp = true;
+      }
+      best = r.best;
+      lm = r.lm;
     }
   }
   if (in_range) {
@@ -895,7 +942,7 @@ __global__ __launch_bounds__(64) void match_to_map_uninit_kernel(
   }
 #pragma unroll
   for (int dlt = 32; dlt > 0; dlt >>= 1) ctr += __shfl_xor(ctr, dlt);
-  if (threadIdx.x == 0 && ctr) atomicAdd(ctr_total, ctr);
+  if (lane == 0 && ctr) atomicAdd(ctr_total, ctr);
 }
 
 // ---- gather blocks (cross-camera exchange) ---------------------------------------
@@ -999,7 +1046,7 @@ void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, c
                                 int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
                                 int32_t* ctr_total, hipStream_t stream) {
   if (n_k <= 0) return;
-  hipLaunchKernelGGL(match_to_map_uninit_kernel, dim3((n_k + 63) / 64), dim3(64), 0, stream, pair,
+  hipLaunchKernelGGL(match_to_map_uninit_kernel, dim3((n_k + 63) / 64), dim3(64, kUninitSegs), 0, stream, pair,
                      desc_k, bp, use, previous, n_k, desc_begin, n_lm, pool, e0_W, r0_W, threshold,
                      best_lm, best_d, hps_W, hp_set, ctr_total);
 }

@@ -267,6 +267,84 @@ def test_match_to_map_uninitialised(oracle):
     assert np.all(e[0] == -1) and e[4] == 0
 
 
+def test_match_to_map_uninitialised_staircase_5000_landmarks(oracle):
+    """5 000 landmarks in 8 ranges of the device kernel: every keypoint has ~14 noisy copies of its
+    descriptor spread over the whole list with different Hamming distances, so the running minimum
+    of the reference loop descends through several ranges; a third of the copies fail the
+    epipolar / triangulation gate, far points triangulate as parallel (no hp stored, the hp of an
+    EARLIER accepted pair survives), and the landmark a keypoint already carries holds several
+    copies of which only a later one lies under the running best (the counting rule)."""
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    fe = G.make_frontend(cfg)
+    rng = np.random.default_rng(2024)
+    n_k, n_lm = 300, 5000
+    focal = 0.5 * (cam.fu + cam.fv)
+    th = -0.02
+    Ry = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    T1 = (Ry.reshape(-1), np.array([0.3, 0.02, -0.04]))
+    far = rng.random(n_k) < 0.2
+    X = np.stack([rng.uniform(-2, 2, n_k), rng.uniform(-1, 1, n_k), rng.uniform(2.5, 10, n_k)], 1)
+    X[far] *= 300.0
+    Xc = (X - T1[1]) @ Ry
+    kps = np.zeros(n_k, dtype=oracle.KEYPOINT_DTYPE)
+    for i in range(n_k):
+        st, pt, _ = oracle.cam_project(cam, Xc[i])
+        kps["x"][i], kps["y"][i] = pt if st == 0 else (9.0, 9.0)
+    bp, bv = oracle.backproject_keypoints(cam, kps)
+    desc = rng.integers(0, 256, (n_k, 48), dtype=np.uint8)
+    counts = rng.integers(1, 6, n_lm)
+    desc_begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    m = int(desc_begin[-1])
+    pool = rng.integers(0, 256, (m, 48), dtype=np.uint8)
+    r0 = rng.normal(0, 0.4, (m, 3)) + np.array([-0.3, 0, 0])
+    e0 = rng.normal(0, 1, (m, 3)) + np.array([0, 0, 3.0])
+    e0 /= np.linalg.norm(e0, axis=1, keepdims=True)
+    previous = np.full(n_k, -1, dtype=np.int32)
+    taken = np.zeros(m, bool)
+
+    def plant(k, d, nbits, good):
+        bits = rng.choice(384, nbits, replace=False)
+        row = desc[k].copy()
+        for b in bits:
+            row[b >> 3] ^= np.uint8(1 << (b & 7))
+        pool[d] = row
+        ray = X[k] - r0[d]
+        ray /= np.linalg.norm(ray)
+        if not good:
+            ray = ray + rng.normal(0, 0.25, 3)
+            ray /= np.linalg.norm(ray)
+        e0[d] = ray
+        taken[d] = True
+
+    for k in range(n_k):
+        lms = rng.choice(n_lm, 14, replace=False)
+        for l in lms:
+            d = int(rng.integers(desc_begin[l], desc_begin[l + 1]))
+            if not taken[d]:
+                plant(k, d, int(rng.integers(3, 56)), rng.random() > 0.33)
+        if k % 3 == 0:  # the carried landmark: all of its descriptors are copies, distances shuffled
+            l = int(lms[rng.integers(0, 14)])
+            previous[k] = l
+            for d in range(desc_begin[l], desc_begin[l + 1]):
+                plant(k, d, int(rng.integers(3, 56)), rng.random() > 0.25)
+    use = (bv != 0) & (rng.random(n_k) > 0.05)
+    ref = oracle.match_to_map_uninit(desc, bp, use, previous, desc_begin, pool, e0, r0, T1, focal,
+                                     cfg.match_threshold)
+    got = fe.match_to_map_uninitialised(desc, bp, use, previous, desc_begin, pool, e0, r0, T1, focal)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[3], ref[3])
+    assert np.array_equal(got[2].view(np.uint64), ref[2].view(np.uint64))
+    assert got[4] == ref[4]
+    matched = ref[0] >= 0
+    # the cases the fold has to get right are all present
+    assert matched.sum() > 150 and ref[4] > 20
+    assert (matched & (ref[3] == 0)).sum() > 10   # best pair parallel, no earlier non-parallel one
+    assert (matched & (ref[3] != 0)).sum() > 100
+    per = (n_lm + 7) // 8
+    assert len(np.unique(ref[0][matched] // per)) == 8  # winners in every range
+
+
 def test_gated_matchers_large_and_ambiguous(oracle):
     """1500 keypoints per side (segments longer than the LDS chunk: the scan reloads chunks every
     round) with clusters of near-identical descriptors, so that most rows have several candidates
