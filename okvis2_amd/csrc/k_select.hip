@@ -125,6 +125,151 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
   }
 }
 
+// ---- register-blocked sort (up to 8192 keys), the production path -------------------------------
+// Same total order, different network: the ALL-ASCENDING form of the bitonic sorter (first stride
+// of a phase compares i with its mirror image i ^ (k - 1) inside the block of k, the remaining
+// strides are plain half-cleaners), so the padding keys (~0) never leave the tail [n, np) and every
+// compare-exchange whose lower index is >= n is skipped: the work follows n, not the next power
+// of two (4 450 candidates per EuRoC image used to cost a full 8192 network).  A thread keeps 16
+// keys in registers and runs up to FOUR strides on them between two LDS round trips (24 passes
+// for 8192 keys instead of 49); phases 1..4 run on the 16 keys a thread loads from the candidate
+// list before anything is written to LDS.  LDS index i lives at slot i + (i >> 4): with one pad
+// slot per 16 keys all access patterns of the passes (16 keys per lane at strides 1, 2, 4 ... ) are
+// bank-conflict free.  LDS-bandwidth / VALU bound, two workgroups per CU.
+constexpr int kRbThreads = 512;
+constexpr int kRbKeys = 16;  // per thread and pass
+__host__ __device__ __forceinline__ int rb_slot(int i) { return i + (i >> 4); }
+// Keys travel through the network as FP64 bit patterns: a compare-exchange is then v_min_f64 +
+// v_max_f64 (2 instructions) instead of two 64-bit integer compares and four selects (~14 with the
+// SGPR hazards).  A key K = (0x7FFFFFFF - score) << 32 | y << 16 | x is below 2^63; D = K - 2^62 in
+// sign-magnitude form is a finite double (|D| <= 2^62 < 0x7FF0...: never Inf / NaN) whose IEEE order
+// is the order of K.  Denormal patterns are ordinary values here (FP64 denormals are never flushed
+// on this target) and no arithmetic touches the bits.
+using RbKey = double;
+__device__ __forceinline__ RbKey rb_encode(uint64_t k) {
+  const int64_t d = (int64_t)k - (int64_t)(1ull << 62);
+  const uint64_t bits = d >= 0 ? (uint64_t)d : (0x8000000000000000ull | (uint64_t)(-d));
+  return __longlong_as_double((long long)bits);
+}
+__device__ __forceinline__ uint64_t rb_decode(RbKey v) {
+  const uint64_t bits = (uint64_t)__double_as_longlong(v);
+  const int64_t mag = (int64_t)(bits & 0x7FFFFFFFFFFFFFFFull);
+  const int64_t d = (bits >> 63) ? -mag : mag;
+  return (uint64_t)(d + (int64_t)(1ull << 62));
+}
+constexpr uint64_t kRbPadKey = 0x7FFFFFFFFFFFFFFFull;  // above every real key (score >= 1)
+__device__ __forceinline__ void rb_cswap(RbKey& a, RbKey& b) {  // ascending
+  RbKey lo, hi;
+  asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b));
+  a = lo;
+  b = hi;
+}
+// R strides (bits R-1 .. 0 of the element number m) on 2^R keys; MIRROR: the first one pairs m
+// with its complement (the keys of the upper half were fetched with mirrored low index bits)
+template <int R, bool MIRROR>
+__device__ __forceinline__ void rb_network(RbKey (&key)[kRbKeys]) {
+  constexpr int N = 1 << R;
+  if (MIRROR) {
+#pragma unroll
+    for (int m = 0; m < N / 2; ++m) rb_cswap(key[m], key[(N - 1) ^ m]);
+  }
+#pragma unroll
+  for (int b = MIRROR ? R - 2 : R - 1; b >= 0; --b) {
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+      if ((m & (1 << b)) == 0) rb_cswap(key[m], key[m | (1 << b)]);
+  }
+}
+// one LDS pass: strides 2^(q+R-1) .. 2^q of the network on np keys
+template <int R, bool MIRROR>
+__device__ __forceinline__ void rb_pass(RbKey* lds, int np, int n, int q, int tid) {
+  constexpr int N = 1 << R;
+  const int low_mask = (1 << q) - 1;
+  for (int g = tid; g < (np >> R); g += kRbThreads) {
+    const int low = g & low_mask;
+    const int base = ((g >> q) << (q + R)) | low;
+    if (base >= n) continue;  // smallest index of the group: all of its keys are padding
+    const int base_hi = MIRROR ? base ^ low_mask : base;  // upper half: mirrored low bits
+    RbKey key[kRbKeys];
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+      key[m] = lds[rb_slot(((MIRROR && m >= N / 2) ? base_hi : base) | (m << q))];
+    rb_network<R, MIRROR>(key);
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+      lds[rb_slot(((MIRROR && m >= N / 2) ? base_hi : base) | (m << q))] = key[m];
+  }
+}
+
+__global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __restrict__ cand,
+                                                             int cand_cap,
+                                                             const int32_t* __restrict__ cand_count,
+                                                             uint64_t* __restrict__ sort_ws,
+                                                             int ws_stride, int max_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RbKey* lds = reinterpret_cast<RbKey*>(smem_raw);
+  const int img = blockIdx.x;
+  int n = cand_count[img];
+  n = n > cand_cap ? 0 : n;  // overflowed list: no keypoints (see sort_kernel)
+  if (n == 0) return;
+  int lnp = 4;
+  while ((1 << lnp) < n) ++lnp;
+  const int np = 1 << lnp;
+  if (np > max_keys) return;  // left to sort_kernel (second launch)
+  const Candidate* c = cand + (size_t)img * cand_cap;
+  uint64_t* ws = sort_ws + (size_t)img * ws_stride;
+  const int tid = threadIdx.x;
+  // phases 1..4 on 16 consecutive keys straight from the candidate list
+  for (int g = tid; g < (np >> 4); g += kRbThreads) {
+    RbKey key[kRbKeys];
+#pragma unroll
+    for (int m = 0; m < kRbKeys; ++m) {
+      const int i = g * kRbKeys + m;
+      key[m] = rb_encode(i < n ? make_key(c[i]) : kRbPadKey);
+    }
+    if (g * kRbKeys < n) {
+      // phase k = 2^p inside the thread: mirror within blocks of 2^p keys, then half-cleaners
+#pragma unroll
+      for (int p = 1; p <= 4; ++p) {
+        const int blk = 1 << p;
+#pragma unroll
+        for (int m = 0; m < kRbKeys; ++m)
+          if ((m & (blk - 1)) < blk / 2) rb_cswap(key[m], key[m ^ (blk - 1)]);
+#pragma unroll
+        for (int b = p - 2; b >= 0; --b)
+#pragma unroll
+          for (int m = 0; m < kRbKeys; ++m)
+            if ((m & (1 << b)) == 0) rb_cswap(key[m], key[m | (1 << b)]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < kRbKeys; ++m) lds[rb_slot(g * kRbKeys + m)] = key[m];
+  }
+  __syncthreads();
+  for (int lk = 5; lk <= lnp; ++lk) {  // phase: blocks of 2^lk keys
+    int top = lk - 1;                  // highest stride bit still to do
+    bool mirror = true;
+    while (top >= 0) {
+      const int r = top + 1 < 4 ? top + 1 : 4;
+      const int q = top - r + 1;
+      if (mirror) {
+        rb_pass<4, true>(lds, np, n, q, tid);  // lk >= 5: the first pass always has 4 strides
+      } else {
+        switch (r) {
+          case 4: rb_pass<4, false>(lds, np, n, q, tid); break;
+          case 3: rb_pass<3, false>(lds, np, n, q, tid); break;
+          case 2: rb_pass<2, false>(lds, np, n, q, tid); break;
+          default: rb_pass<1, false>(lds, np, n, q, tid); break;
+        }
+      }
+      __syncthreads();
+      top -= r;
+      mirror = false;
+    }
+  }
+  for (int i = tid; i < n; i += kRbThreads) ws[i] = rb_decode(lds[rb_slot(i)]);
+}
+
 // 2-D quadratic sub-pixel refinement; mirrors the published BRISK Subpixel2D with 64-bit
 // coefficients (Harris scores overflow 32-bit products) and double Hessian terms.
 __device__ void subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
@@ -578,10 +723,18 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
   const bool two = ws_stride > kLdsSortKeys;
-  // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
-  hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
-                     cand, cand_cap, cand_count, sort_ws, ws_stride, 0,
-                     two ? sort_keys : 2 * kLdsSortKeys);
+  static const bool legacy = getenv("OKVFE_LEGACY_SORT") != nullptr;  // A/B knob
+  if (legacy) {
+    // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
+    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
+                       cand, cand_cap, cand_count, sort_ws, ws_stride, 0,
+                       two ? sort_keys : 2 * kLdsSortKeys);
+  } else {
+    // up to 8192 keys: register-blocked network in 68 KiB (16 keys minimum: one thread's share)
+    const int keys = sort_keys < kRbKeys ? kRbKeys : sort_keys;
+    hipLaunchKernelGGL(sort_rb_kernel, dim3(n_images), dim3(kRbThreads), (size_t)rb_slot(keys) * 8, stream,
+                       cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
+  }
   if (two)  // second launch: 8193..16384 keys in 128 KiB, larger sets in the HBM workspace
     hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)2 * kLdsSortKeys * 8,
                        stream, cand, cand_cap, cand_count, sort_ws, ws_stride, kLdsSortKeys,
