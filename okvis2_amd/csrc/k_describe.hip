@@ -8,8 +8,11 @@
 // cameras/implementation/PinholeCamera.hpp:574-593).
 //
 //   describe_setup_kernel  one thread per keypoint: border test, camera-aware matrix M.
-//   describe_kernel  one wave per keypoint, lane i = pattern point i (60 of 64 lanes), 6 waves per
-//                    SIMD.  The pixels under the keypoint's pattern go straight from the image
+//   describe_kernel  one wave per keypoint at a time, lane i = pattern point i (60 of 64 lanes),
+//                    6 waves per SIMD; 16 workgroups of 4 waves per image, each wave walks the
+//                    image's keypoints with stride 64 (per-lane pattern constants, image
+//                    parameters and the buffer resource are set up once per wave; wave-uniform
+//                    values -- keypoint, M -- live in SGPRs).  The pixels under the keypoint's pattern go straight from the image
 //                    into a dense LDS patch (buffer_load ... lds, whole rows per instruction);
 //                    every sample is a box sum with sub-pixel rim weights read from LDS
 //                    (fixed trip counts, v_sad_u8 over masked dwords); 383 pair comparisons
@@ -216,6 +219,10 @@ __device__ __forceinline__ bool camera_aware_matrix(const float* __restrict__ ra
 }
 
 constexpr int kDescWaves = 4;
+#ifndef OKVFE_DESC_BLOCKS
+#define OKVFE_DESC_BLOCKS 16
+#endif
+constexpr int kDescBlocksPerImage = OKVFE_DESC_BLOCKS;
 
 struct GlobalPx {  // direct reads from the image (fallback when the patch does not fit in LDS)
   static constexpr bool kFixedTrip = false;
@@ -292,23 +299,21 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     img = L < full ? (int)(g * 8u + (L & 7u)) : (int)(n8 + g);
     tile = (int)(slot - g * (uint32_t)tiles);
   }
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = tile * kDescWaves + wv;
+  // wave index as a scalar: everything indexed by the keypoint (slot, kp, M) is wave-uniform and
+  // belongs in SGPRs
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
   const int n = kp_count_in[img];
-  if (k >= n) return;  // whole wave exits; no block-wide barriers below
+  if (tile * kDescWaves + wv >= n) return;  // whole wave exits; no block-wide barriers below
   const uint8_t* im = images + (size_t)img * w * h;
-  const size_t slot = (size_t)img * kp_cap + k;
-  okvfe_keypoint kp = kps_in[slot];
   const ImageParams ip = prm[img];
   const int border = pat->border;
-  // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
-  bool valid = valid_tmp[slot] != 0;
   const bool active = lane < kPatternPoints;
   const int li = active ? lane : 0;
-  const float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
-  const int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];
-  const float4 M4 = *reinterpret_cast<const float4*>(desc_tmp + slot * OKVFE_DESC_BYTES);
-  float M[4] = {M4.x, M4.y, M4.z, M4.w};
+  float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
+  int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];
+  okvfe_keypoint kp;
+  float M[4];
   float xf, yf;
   int* vals = values[wv];
   uint8_t* patch = patches[wv] + kZeroRowBytes;
@@ -403,6 +408,29 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     return true;
   };
 
+  // The wave walks the image's keypoints wv, wv + tiles * kDescWaves, ...: the per-lane pattern
+  // constants, the image's parameters and the buffer resource above are set up once per wave
+  // instead of once per keypoint.
+  for (int k = tile * kDescWaves + wv; k < n; k += tiles * kDescWaves) {
+  // opaque to the optimiser: expressions of the lane constants are NOT hoisted out of the loop
+  // (they would cost ~25 more live VGPRs and push the kernel below 6 waves/SIMD)
+  asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(lane));
+  const size_t slot = (size_t)img * kp_cap + k;
+  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  kp = kps_in[slot];
+  kp.x = uni(kp.x);
+  kp.y = uni(kp.y);
+  kp.size = uni(kp.size);
+  kp.angle = uni(kp.angle);
+  kp.response = uni(kp.response);
+  kp.octave = __builtin_amdgcn_readfirstlane(kp.octave);
+  kp.class_id = __builtin_amdgcn_readfirstlane(kp.class_id);
+  // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
+  bool valid = __builtin_amdgcn_readfirstlane((int)valid_tmp[slot]) != 0;
+  {
+    const float4 M4 = *reinterpret_cast<const float4*>(desc_tmp + slot * OKVFE_DESC_BYTES);
+    M[0] = uni(M4.x); M[1] = uni(M4.y); M[2] = uni(M4.z); M[3] = uni(M4.w);
+  }
   if (valid && ip.mode == kGradient) {
     valid = sample_all(true);
     if (valid) {
@@ -468,6 +496,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     kps_tmp[slot] = kp;
     valid_tmp[slot] = valid ? 1 : 0;
   }
+  __builtin_amdgcn_wave_barrier();  // vals[] / the patch are rewritten for the next keypoint
+  }
 }
 
 // ---- compaction + back-projection -----------------------------------------------------------
@@ -530,7 +560,10 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, desc_tmp,
                      valid_tmp);
-  const int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
+  // blocks per image: enough waves to fill the machine with one image's ~300 keypoints spread
+  // over them (a wave then describes ~9 keypoints of its image in a row)
+  int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
+  if (tiles > kDescBlocksPerImage) tiles = kDescBlocksPerImage;
   const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
   hipLaunchKernelGGL(describe_kernel, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
                      w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,

@@ -512,6 +512,10 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
 //     ordering between them is needed.
 // Two workgroup barriers per round; sub-pixel refinement of the accepted points runs at the end.
 constexpr int kSelThreads = 256;
+#ifdef OKVFE_SELECT_STATS  // profiling build only (tools/select_stats.py): where do the cycles of a block go?
+__device__ unsigned long long g_sel_stats[8];
+#define OKVFE_SEL_CLOCK() (unsigned long long)__builtin_readcyclecounter()
+#endif
 constexpr int kStampIts = (kStampCells + kSelThreads - 1) / kSelThreads;
 constexpr int kRoundCap = 64;
 
@@ -548,6 +552,9 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
   const int32_t* sc = scores + (size_t)img * w * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
+#ifdef OKVFE_SELECT_STATS
+  unsigned long long st_rounds = 0, st_windows = 0, st_decide = 0, st_stamp = 0, st_t0 = OKVFE_SEL_CLOCK(), st_loop0 = 0, st_loop1 = 0;
+#endif
   if (n > 0) {  // block-uniform
     if (OCC_LDS) {
       uint4* z = reinterpret_cast<uint4*>(smem_raw);
@@ -590,7 +597,13 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
     int pos = 0;
     __syncthreads();
+#ifdef OKVFE_SELECT_STATS
+    st_loop0 = OKVFE_SEL_CLOCK();
+#endif
     while (true) {
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long st_a = OKVFE_SEL_CLOCK();
+#endif
       // the 64-candidate window would run past the resident chunk: slide it (block-uniform)
       if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
         chunk_base = pos;
@@ -605,6 +618,9 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
             refill = true;  // skipped past the chunk through windows without a passing candidate
             break;
           }
+#ifdef OKVFE_SELECT_STATS
+          ++st_windows;
+#endif
           const int idx = pos + lane;
           uint2 rec = make_uint2(0, 0);
           if (idx < n) rec = recs[idx - chunk_base];
@@ -657,6 +673,11 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
         }
       }
       __syncthreads();
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long st_b = OKVFE_SEL_CLOCK();
+      st_decide += st_b - st_a;
+      ++st_rounds;
+#endif
       const int nacc = s_round;
       pos = s_pos;
       kept = s_kept;
@@ -687,7 +708,13 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
         }
       }
       __syncthreads();
+#ifdef OKVFE_SELECT_STATS
+      st_stamp += OKVFE_SEL_CLOCK() - st_b;
+#endif
     }
+#ifdef OKVFE_SELECT_STATS
+    st_loop1 = OKVFE_SEL_CLOCK();
+#endif
   }
   for (int i = tid; i < kept; i += kSelThreads) {
     const uint64_t k = keys[acc_idx[i]];
@@ -712,9 +739,31 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     out[i] = kp;
   }
   if (tid == 0) kp_count[img] = kept;
+#ifdef OKVFE_SELECT_STATS
+  if (tid == 0) {
+    atomicAdd(&g_sel_stats[0], 1ull);
+    atomicAdd(&g_sel_stats[1], st_rounds);
+    atomicAdd(&g_sel_stats[2], st_windows);
+    atomicAdd(&g_sel_stats[3], (unsigned long long)kept);
+    atomicAdd(&g_sel_stats[4], st_decide);
+    atomicAdd(&g_sel_stats[5], st_stamp);
+    atomicAdd(&g_sel_stats[6], st_loop0 - st_t0);
+    atomicAdd(&g_sel_stats[7], OKVFE_SEL_CLOCK() - st_loop1);
+  }
+#endif
 }
 
 }  // namespace
+
+#ifdef OKVFE_SELECT_STATS
+extern "C" __attribute__((visibility("default"))) void okvfe_debug_select_stats(unsigned long long* out8, int reset) {
+  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sel_stats), sizeof(g_sel_stats));
+  if (reset) {
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stats), z, sizeof(z));
+  }
+}
+#endif
 
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
                  float radius, uint64_t* sort_ws, hipStream_t stream) {
