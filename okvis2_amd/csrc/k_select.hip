@@ -799,7 +799,8 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
-  const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024;
+  static const bool force_hbm = getenv("OKVFE_SELECT_OCC_HBM") != nullptr;  // A/B knob
+  const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024 && !force_hbm;
   // greedy kernel: occupancy + accepted indices (u16, u32 for capacities above 65536) + a sliding
   // chunk of candidate records.  Half a CU's LDS (two images per CU) when at least 128 records
   // fit, else the whole CU; grids that do not fit at all stay in the HBM workspace.
