@@ -57,6 +57,39 @@ def test_select_many_candidates_and_limit(oracle):
         G.assert_keypoints_equal(fe.detect(img), ref)
 
 
+def test_sort_network_sizes_around_its_limits(oracle):
+    """Candidate counts around the limits of the register-blocked sort: one thread's 16 keys, one
+    LDS pass, just below / above 4096 and 8192 keys (above 8192 the two-stride LDS network or the
+    HBM workspace network takes over); ties in the score (binary noise) order by (y, x)."""
+    w = 752
+    rng = np.random.default_rng(99)
+    base = (rng.integers(0, 2, (480, w)) * 255).astype(np.uint8)
+    counts = {}
+    for h in range(16, 481, 4):
+        counts[h] = len(oracle.nms(oracle.harris_score(np.ascontiguousarray(base[:h])), 1))
+    picks = []
+    for lim in (4096, 8192, 16384):
+        picks.append(max((h for h in counts if counts[h] <= lim), key=lambda h: counts[h]))
+        picks.append(min((h for h in counts if counts[h] > lim), key=lambda h: counts[h]))
+    assert any(4096 < counts[h] <= 8192 for h in picks) and any(8192 < counts[h] <= 16384 for h in picks)
+    assert any(counts[h] > 16384 for h in picks)
+    cases = [(h, 1) for h in sorted(set(picks))]
+    # a handful of candidates (up to one thread's 16 keys, and one more): thresholds from the scores
+    img64 = np.ascontiguousarray(base[:64])
+    sc = np.sort(oracle.nms(oracle.harris_score(img64), 1)["score"])[::-1]
+    for want in (1, 5, 16, 17, 40):
+        thr = int(sc[want - 1])
+        if thr > int(sc[want]):  # no tie across the cut
+            cases.append((64, thr))
+    assert len(cases) >= 8
+    for h, thr in cases:
+        img = np.ascontiguousarray(base[:h])
+        fe = capi.Frontend(w, h, 9.0, 0, thr, 4000, max_candidates=1 << 15)
+        ref = oracle.detect(img, 9.0, 0, thr, 4000)
+        assert len(ref) > 0
+        G.assert_keypoints_equal(fe.detect(img), ref)
+
+
 _CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
