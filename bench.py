@@ -530,6 +530,19 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     fill_gbps = d_sc.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    # the score kernel's own byte mix through a trivial kernel: read 1 B, write 4 B per pixel
+    # (torch's u8 -> int32 conversion of the same batch into the same buffer)
+    d_px = d_img.reshape(-1)[:d_cp.numel()].view(d_cp.shape) if d_img.numel() >= d_cp.numel() else None
+    widen_ms = None
+    if d_px is not None:
+        d_cp.copy_(d_px)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            d_cp.copy_(d_px)
+        e1.record()
+        torch.cuda.synchronize()
+        widen_ms = e0.elapsed_time(e1) / 5
     del d_sc, d_cp
 
     extras = {}
@@ -602,6 +615,11 @@ def main():
                 "isolated_frac": 5.0 * P * n_lane_img / (iso[0] / iso[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "copy_kernel_GBps": copy_gbps, "fill_kernel_GBps": fill_gbps,
                 "frac_of_copy_kernel": 5.0 * P * n_lane_img / (harris_ms * 1e-3) / 1e9 / copy_gbps,
+                "widen_kernel_ms": widen_ms,
+                "widen_kernel_note": "torch u8 -> int32 conversion of the same images into the same "
+                                     "buffer: the score kernel's algorithmic bytes (1 B in, 4 B out "
+                                     "per pixel) through a kernel that computes nothing",
+                "frac_of_widen_kernel": (widen_ms / harris_ms) if widen_ms else None,
                 "score_only_launch_ms": solo[0] / solo[1],
                 "score_only_frac": 5.0 * P * n_lane_img / (solo[0] / solo[1] * 1e-3) / 1e9
                                    / HBM_PEAK_GBPS,

@@ -347,10 +347,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   int group_images = 1;  // images addressed through this wave's buffer resources
   bool lane_on = true;  // PACK: lane belongs to an existing image
   const bool packed_block = PACK && (int)blockIdx.x >= main_blocks;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  int row_tile;  // which kTHF-row tile of the image this wave owns
+  const int ytiles_blk = ytiles;
   if (packed_block) {
     const int p = (int)blockIdx.x - main_blocks;
-    const int group = p / ytiles;
-    ytile = p - group * ytiles;
+    const int group = p / ytiles_blk;
+    ytile = p - group * ytiles_blk;
+    row_tile = ytile * kWavesPerBlock + wave;
     image = group * pack_g;  // first image of the group
     group_images = n_images - image < pack_g ? n_images - image : pack_g;
     strip = strips;  // index of the (packed) last strip
@@ -363,10 +367,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     xcd_tile(strips * ytiles, n_images, &image, &tile);
     ytile = tile / strips;
     strip = tile - ytile * strips;
+    row_tile = ytile * kWavesPerBlock + wave;
     d = strip * kStripLanes + lane;
   }
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  const int ys_own = (ytile * kWavesPerBlock + wave) * kTHF;
+  const int ys_own = row_tile * kTHF;
   if (ys_own >= h) return;  // wave-uniform; all 64 lanes of a live wave stay active (DPP sources)
   const int ye_own = ys_own + kTHF < h ? ys_own + kTHF : h;
   const int ys = NMS ? ys_own - 1 : ys_own;  // first score row computed (with NMS one above the tile)
@@ -400,6 +404,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   };
 
   int pr[3][4];      // rolling pixel rows (own 4 columns)
+#ifdef OKVFE_K1_MFMA
+  // EXPERIMENT (off by default; bit-exact, measured 0.700 ms against 0.710 ms per 1536 images):
+  // gradients on the matrix pipe.  v_mfma_i32_4x4x4i8 runs one 4x4x4 product per group of 4 lanes:
+  // D[i] of a lane = sum_k A[i][k] * B_lane[k], with row i of A supplied by lane 4b + i -- i.e. FOUR
+  // different 4-tap dot products of the lane's own B dword in one issue slot (4.2 cycles beside the
+  // vector ALU, tools/ubench/mfma4_test.hip).  B = a 4-pixel window of one pixel row (bytes - 128:
+  // both filters sum to zero, so the offset cancels exactly); rows 0/1 of A = the gx taps of the
+  // window's two centre columns, rows 2/3 = the gy taps, times 8 (i8 range); A depends on the role
+  // of the pixel row (above / centre / below).  Two windows per pixel row cover the lane's four
+  // columns: [x-1 .. x+2] and [x+1 .. x+4].  Six MFMAs per covariance row replace ~30 multiply /
+  // add / DPP instructions; the results are the same integers (x 2^9 after one shift).
+  typedef int v4i_t __attribute__((ext_vector_type(4)));
+  int win[3][2];     // rolling windows of the last three pixel rows
+  auto taps = [](int b0, int b1, int b2, int b3) {
+    return (int)((uint32_t)(b0 & 255) | ((uint32_t)(b1 & 255) << 8) | ((uint32_t)(b2 & 255) << 16) |
+                 ((uint32_t)(b3 & 255) << 24));
+  };
+  const int r4 = lane & 3;
+  // gx = [3 10 3]^T (rows) x [-1 0 1] (columns); gy = [-1 0 1]^T x [3 10 3]
+  int A_above = r4 == 0 ? taps(-24, 0, 24, 0) : r4 == 1 ? taps(0, -24, 0, 24)
+              : r4 == 2 ? taps(-24, -80, -24, 0) : taps(0, -24, -80, -24);
+  int A_centre = r4 == 0 ? taps(-80, 0, 80, 0) : r4 == 1 ? taps(0, -80, 0, 80) : 0;
+  int A_below = r4 == 0 ? taps(-24, 0, 24, 0) : r4 == 1 ? taps(0, -24, 0, 24)
+              : r4 == 2 ? taps(24, 80, 24, 0) : taps(0, 24, 80, 24);
+  asm volatile("" : "+v"(A_above), "+v"(A_centre), "+v"(A_below));
+  auto make_windows = [&](uint32_t dw, int wn[2]) {
+    const int x = (int)(dw ^ 0x80808080u);
+    const int l = from_left(x), r = from_right(x);
+    wn[0] = (int)__builtin_amdgcn_alignbyte((uint32_t)x, (uint32_t)l, 3);  // l.b3 x.b0 x.b1 x.b2
+    wn[1] = (int)__builtin_amdgcn_alignbyte((uint32_t)r, (uint32_t)x, 1);  // x.b1 x.b2 x.b3 r.b0
+  };
+#endif
   // stream 0 carries the xx and yy entries PACKED (xx | yy << 16: both are non-negative and every
   // partial sum stays below 2^16, so one 32-bit add smooths two channels); stream 1 carries xy
   int hs[2][2][4];   // horizontally smoothed entries: current / previous row
@@ -426,6 +462,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // covariance row g from pixel rows a (g-1), b (g), c (g+1) -> H (horizontally smoothed); k3, k10 =
   // the (3, 10, 3) filter taps times 2^9 (mulhi24 of two such gradients then yields g*g >> 14), or
   // 0, 0 for a rim row
+#ifdef OKVFE_K1_MFMA
+  auto cov_row = [&](const int* wa, const int* wb, const int* wc, int (*H)[4], bool inner) {
+    v4i_t acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    acc1 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_above, wa[0], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_above, wa[1], acc2, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_centre, wb[0], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_centre, wb[1], acc2, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_below, wc[0], acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_below, wc[1], acc2, 0, 0, 0);
+    // One more wait state than hipcc (ROCm 7.2) leaves between the last MFMA and the first vector
+    // instruction that reads its result: without it the shifts below read stale registers on
+    // gfx950 (tools/ubench/mfma_grad_test.hip is correct stand-alone; in this kernel the schedule
+    // is tighter).  Measured with 1 .. 16 wait states: results exact from 1 on.
+    asm volatile("s_nop 1" : "+v"(acc1), "+v"(acc2));
+    if (__builtin_expect(!inner, 0)) {  // covariance rows 0 / h-1 are rim: scalar branch, two steps per strip
+      asm volatile("" ::: "memory");
+      acc1 = v4i_t{0, 0, 0, 0};
+      acc2 = v4i_t{0, 0, 0, 0};
+    }
+    int gx[4], gy[4];
+    // x 8 from the taps, x 64 here = the 2^9 scale of the products below
+    gx[0] = (acc1[0] << 6) & m0;
+    gx[1] = acc1[1] << 6;
+    gx[2] = acc2[0] << 6;
+    gx[3] = (acc2[1] << 6) & m3;
+    gy[0] = (acc1[2] << 6) & m0;
+    gy[1] = acc1[3] << 6;
+    gy[2] = acc2[2] << 6;
+    gy[3] = (acc2[3] << 6) & m3;
+#else
   auto cov_row = [&](const int* a, const int* b, const int* c, int (*H)[4], int k3, int k10) {
     int vs[4], vd[4];
 #pragma unroll
@@ -449,6 +515,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     gy[1] = __mul24(vd[1], k10) + __mul24(vd[0] + vd[2], k3);
     gy[2] = __mul24(vd[2], k10) + __mul24(vd[1] + vd[3], k3);
     gy[3] = (__mul24(vd[3], k10) + __mul24(vd[2] + vd_r, k3)) & m3;
+#endif
     int G[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -553,8 +620,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     const uint32_t t0 = load_next(), t1 = load_next();
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) ring[i] = load_next();
+#ifdef OKVFE_K1_MFMA
+    make_windows(t0, win[0]);
+    make_windows(t1, win[1]);
+#else
     unpack4(t0, pr[0]);
     unpack4(t1, pr[1]);
+#endif
   }
   int y = ys - 2;  // score row completed by the current step (meaningful from step 2 on)
   // step j (compile-time phase PH = j % 6): pixel row ys+j, covariance row g = ys+j-1, score row
@@ -563,10 +635,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     constexpr int PH = decltype(ph)::value;
     constexpr int s_new = (PH + 2) % 3, s_a = PH % 3, s_b = (PH + 1) % 3, q = PH % 2;
     ring[(PH + kAhead) % 6] = load_next();
-    unpack4(ring[PH], pr[s_new]);
     const int g = y + 1;
     const bool inner = g >= 1 && g <= h - 2;  // scalar
+#ifdef OKVFE_K1_MEMONLY  // A/B: the kernel's loads and stores with no arithmetic (its own memory floor)
+    {
+      int sc[4];
+      unpack4(ring[PH], sc);
+      if (decltype(want_store)::value && y < h) store_row(sc, y);
+      ++y;
+      (void)inner;
+      return;
+    }
+#endif
+#ifdef OKVFE_K1_MFMA
+    make_windows(ring[PH], win[s_new]);
+    cov_row(win[s_a], win[s_b], win[s_new], hs[q], inner);
+#else
+    unpack4(ring[PH], pr[s_new]);
     cov_row(pr[s_a], pr[s_b], pr[s_new], hs[q], inner ? 3 << 9 : 0, inner ? 10 << 9 : 0);
+#endif
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -772,17 +859,21 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     const int last_first = (strips - 1) * kStripLanes;      // first dword (halo lane) of the last strip
     const int pack_u = nd - last_first;                     // halo lane + store lanes
     const int pack_g = strips >= 2 ? 64 / pack_u : 1;
+#define OKVFE_K1_TILING(TH)                                                                     \
+  const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                      \
+  const int ytiles_blk = ytiles;
+#define OKVFE_K1_SGROUPS(n) (n)
 #define OKVFE_K1_NMS_LAUNCH(TH)                                                                 \
   {                                                                                              \
-    const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                    \
+    OKVFE_K1_TILING(TH)                                                                          \
     if (pack_g >= 2 && !no_pack) {                                                               \
-      const int main_blocks = (strips - 1) * ytiles * n_images;                                  \
+      const int main_blocks = ytiles * n_images * OKVFE_K1_SGROUPS(strips - 1);                  \
       const int groups = (n_images + pack_g - 1) / pack_g;                                       \
-      hipLaunchKernelGGL((harris_kernel<TH, true, true>), dim3(main_blocks + groups * ytiles),   \
+      hipLaunchKernelGGL((harris_kernel<TH, true, true>), dim3(main_blocks + groups * ytiles_blk), \
                          block, 0, stream, img, w, h, score, strips - 1, ytiles, n_images, *nms, \
                          pack_g, pack_u, main_blocks);                                           \
     } else {                                                                                     \
-      hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(strips * ytiles * n_images), block, 0,  \
+      hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0,  \
                          stream, img, w, h, score, strips, ytiles, n_images, *nms, 1, 64, 0);    \
     }                                                                                            \
   }
@@ -800,11 +891,14 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
         default: OKVFE_K1_NMS_LAUNCH(61); break;
       }
     } else {
-      const int ytiles = (h + 30 * kWavesPerBlock - 1) / (30 * kWavesPerBlock);
-      hipLaunchKernelGGL((harris_kernel<30, false>), dim3(strips * ytiles * n_images), block, 0, stream,
+      OKVFE_K1_TILING(30)
+      (void)ytiles_blk;
+      hipLaunchKernelGGL((harris_kernel<30, false>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0, stream,
                          img, w, h, score, strips, ytiles, n_images, NmsOut{}, 1, 64, 0);
     }
 #undef OKVFE_K1_NMS_LAUNCH
+#undef OKVFE_K1_TILING
+#undef OKVFE_K1_SGROUPS
   } else {
     if (nms) return false;
     const dim3 grid((w + 255) / 256, (h + kTH * kWavesPerBlock - 1) / (kTH * kWavesPerBlock),
