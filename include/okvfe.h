@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define OKVFE_ABI_VERSION 1
+#define OKVFE_ABI_VERSION 2
 #define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
@@ -115,7 +115,15 @@ typedef struct okvfe_config {
   int32_t scale_invariant;    /* Frontend.cpp:143 default false; true is unsupported */
   int32_t match_threshold;    /* matching_threshold (Hamming bits, strict <) */
   int32_t max_candidates;     /* per-image NMS candidate capacity; 0 = worst case */
+  int32_t score_type;         /* OKVFE_SCORE_HARRIS (0): brisk::HarrisScoreCalculator, the x86
+                               * reference path and every shipped configuration (Frontend.cpp:2406);
+                               * OKVFE_SCORE_AGAST_9_16 (1): the AGAST 9-16 corner score of
+                               * brisk::BriskFeatureDetector, the reference's ARM branch
+                               * (okvis_cv/test/TestFrame.cpp:71-72), absolute_threshold = its
+                               * threshold (34 there); the rest of the detector is shared */
 } okvfe_config;
+#define OKVFE_SCORE_HARRIS 0
+#define OKVFE_SCORE_AGAST_9_16 1
 
 typedef struct okvfe_ctx okvfe_ctx;
 
@@ -235,7 +243,8 @@ okvfe_status okvfe_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_d
                                          const float* gravity_C, void* stream);
 
 /* ---- single stages on device buffers (parity tests, profiling) ----------- */
-/* K1: Harris score maps, n_images * H * W int32. */
+/* K1: score maps of the configured score_type (Harris unless the context was created with
+ * OKVFE_SCORE_AGAST_9_16), n_images * H * W int32. */
 okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev,
                                        int32_t n_images, int32_t* scores_dev, void* stream);
 

@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("OKVFE_LIB") or os.path.join(_HERE, "libokvfe.so")  # 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
     ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
-ABI_VERSION = 1
+ABI_VERSION = 2
+SCORE_HARRIS, SCORE_AGAST_9_16 = 0, 1
 DESC_BYTES = 48
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -35,7 +36,8 @@ class Config(C.Structure):
                 ("uniformity_radius", C.c_float), ("octaves", C.c_int32),
                 ("absolute_threshold", C.c_int32), ("max_keypoints", C.c_int32),
                 ("rotation_invariant", C.c_int32), ("scale_invariant", C.c_int32),
-                ("match_threshold", C.c_int32), ("max_candidates", C.c_int32)]
+                ("match_threshold", C.c_int32), ("max_candidates", C.c_int32),
+                ("score_type", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -246,11 +248,12 @@ class Frontend:
 
     def __init__(self, width, height, uniformity_radius, octaves, absolute_threshold,
                  max_keypoints, rotation_invariant=True, scale_invariant=False,
-                 match_threshold=60, max_batch=1, num_cameras=1, device=0, max_candidates=0):
+                 match_threshold=60, max_batch=1, num_cameras=1, device=0, max_candidates=0,
+                 score_type=SCORE_HARRIS):
         cfg = Config(ABI_VERSION, device, width, height, max_batch, num_cameras,
                      float(uniformity_radius), int(octaves), int(absolute_threshold),
                      int(max_keypoints), int(bool(rotation_invariant)), int(bool(scale_invariant)),
-                     int(match_threshold), int(max_candidates))
+                     int(match_threshold), int(max_candidates), int(score_type))
         self._h = C.c_void_p()
         # row capacity per image: a scale space (octaves > 0) has 2 * octaves layers and every layer
         # may deliver max_keypoints (okvfe_device_outputs.max_keypoints reports the same number)

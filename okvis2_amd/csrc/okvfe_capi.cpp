@@ -419,6 +419,9 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: max_keypoints must be in 1..4096");
   if (cfg->absolute_threshold < 1)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: absolute_threshold must be >= 1");
+  if (cfg->score_type != OKVFE_SCORE_HARRIS && cfg->score_type != OKVFE_SCORE_AGAST_9_16)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: score_type %d (0 = Harris, 1 = AGAST 9-16)",
+                cfg->score_type);
   if (cfg->match_threshold < 0 || cfg->match_threshold > 385)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: match_threshold out of range");
   if (cfg->octaves < 0 || cfg->octaves > 4)
@@ -657,7 +660,10 @@ okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev
   {
     hipStream_t s = pick_stream(ctx, stream);
     StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
-    launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
+    if (ctx->cfg.score_type == OKVFE_SCORE_AGAST_9_16)
+      launch_agast_score(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
+    else
+      launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
   }
   HIP_TRY(ctx, hipGetLastError());
   return OKVFE_OK;
@@ -728,6 +734,11 @@ okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) 
 // K1 + K2 of one layer context `L` (score map + NMS candidates), launched for `owner`
 void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipStream_t s, bool* fused) {
   int32_t* d_fix_count = L->d_cand_count + L->B;  // [0, B) candidate counts, [B, 2B) flagged counts
+  if (L->cfg.score_type == OKVFE_SCORE_AGAST_9_16) {  // score map only; the stand-alone NMS follows
+    launch_agast_score(images_dev, L->w, L->h, n_images, L->d_scores, s);
+    *fused = false;
+    return;
+  }
   *fused = launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->cfg.absolute_threshold,
                              L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count, s);
   if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);

@@ -114,6 +114,8 @@ __device__ __forceinline__ void xcd_tile(int tiles, int n_images, int* image, in
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 namespace okvfe {
 
+void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                        hipStream_t stream);
 void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                    hipStream_t stream);
 // Score map and NMS candidates in one pass (k_harris.hip); false = not applicable (unaligned

@@ -98,6 +98,11 @@ void orc_layer_scale(int l, int* num, int* den);
 void orc_layer_size(int w, int h, int l, int* lw, int* lh);
 int orc_scale_neighbour_ok(const int32_t* other, int wo, int ho, int x, int y, int32_t s, int rn, int rd);
 /* octaves > 0: kps capacity should be 2*octaves*max_kpts */
+void orc_agast_score(const uint8_t* img, int w, int h, int stride, int32_t* score /* h*w */);
+void orc_score_map(int score_type, const uint8_t* img, int w, int h, int stride, int32_t* score);
+int orc_detect_scored(const uint8_t* img, int w, int h, int stride, float uniformity_radius, int octaves,
+                      int abs_threshold, int max_kpts, orc_keypoint* kps, int cap, int32_t* score_out,
+                      int score_type);
 int orc_detect(const uint8_t* img, int w, int h, int stride, float uniformity_radius,
                int octaves, int abs_threshold, int max_kpts, orc_keypoint* kps, int cap,
                int32_t* score_out /* optional h*w */);

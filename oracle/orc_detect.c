@@ -78,6 +78,51 @@ void orc_harris_score(const uint8_t* img, int w, int h, int stride, int32_t* sco
 }
 
 /* ---- K2: 8-neighbour non-max suppression -------------------------------------------------- */
+/* ---- AGAST / FAST 9-16 corner score -----------------------------------------------------------
+ * Score calculator of brisk::BriskFeatureDetector (the reference's ARM branch,
+ * okvis_cv/test/TestFrame.cpp:71-72: BriskFeatureDetector(34, 2)); [NOT IN TREE] like the rest of
+ * the brisk library -- this follows the PUBLISHED definition (Rosten & Drummond FAST-9 on the
+ * 16-pixel Bresenham circle of radius 3; AGAST, Mair et al., decides the same predicate with a
+ * faster tree): the pixel is a corner at threshold t iff 9 contiguous circle pixels are all
+ * brighter than p + t or all darker than p - t (strict), and its score is the LARGEST such t --
+ * what the bisection of the published cornerScore converges to --, i.e.
+ *   max( max_s min_{k<9} (c[s+k] - p), max_s min_{k<9} (p - c[s+k]) ) - 1, clamped at 0.
+ * Pixels closer than 3 px to the image border score 0. */
+static const int kCircle16[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},  {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                     {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+void orc_agast_score(const uint8_t* img, int w, int h, int stride, int32_t* score) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      if (x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
+        const int p = img[(size_t)y * stride + x];
+        int d[16];
+        for (int i = 0; i < 16; ++i)
+          d[i] = (int)img[(size_t)(y + kCircle16[i][1]) * stride + (x + kCircle16[i][0])] - p;
+        int bright = -256, dark = -256;
+        for (int st = 0; st < 16; ++st) {
+          int mn = 256, mx = -256;
+          for (int k = 0; k < 9; ++k) {
+            const int v = d[(st + k) & 15];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+          }
+          if (mn > bright) bright = mn;
+          if (-mx > dark) dark = -mx;
+        }
+        s = (bright > dark ? bright : dark) - 1;
+        if (s < 0) s = 0;
+      }
+      score[(size_t)y * w + x] = s;
+    }
+}
+void orc_score_map(int score_type, const uint8_t* img, int w, int h, int stride, int32_t* score) {
+  if (score_type == 1)
+    orc_agast_score(img, w, h, stride, score);
+  else
+    orc_harris_score(img, w, h, stride, score);
+}
+
 /* Raster scan of rows 2..h-3, columns 2..w-3.  A centre passes when it is >=
  * the absolute threshold and no neighbour is strictly greater; the pixel right
  * after an accepted maximum is skipped (so of two equal horizontal neighbours
@@ -354,7 +399,8 @@ int orc_scale_neighbour_ok(const int32_t* other, int wo, int ho, int x, int y, i
 
 #define ORC_MAX_LAYERS 8
 static int detect_scale_space(const uint8_t* img, int w, int h, int stride, float uniformity_radius,
-                              int octaves, int abs_threshold, int max_kpts, orc_keypoint* kps, int cap) {
+                              int octaves, int abs_threshold, int max_kpts, orc_keypoint* kps, int cap,
+                              int score_type) {
   const int L = 2 * octaves;
   if (L > ORC_MAX_LAYERS) return -1;
   uint8_t* im[ORC_MAX_LAYERS];
@@ -376,7 +422,7 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
         orc_halfsample(im[l - 2], lw[l - 2], lh[l - 2], st[l - 2], im[l]);
     }
     sc[l] = (int32_t*)malloc((size_t)lw[l] * lh[l] * sizeof(int32_t));
-    orc_harris_score(im[l], lw[l], lh[l], st[l], sc[l]);
+    orc_score_map(score_type, im[l], lw[l], lh[l], st[l], sc[l]);
     int maxc = (lw[l] / 2 + 1) * (lh[l] - 3);
     if (maxc < 16) maxc = 16;
     pts[l] = (orc_point_score*)malloc((size_t)maxc * sizeof(orc_point_score));
@@ -440,15 +486,24 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
 /* ---- detect(): the whole detector for one image -------------------------------------------- */
 int orc_detect(const uint8_t* img, int w, int h, int stride, float uniformity_radius, int octaves,
                int abs_threshold, int max_kpts, orc_keypoint* kps, int cap, int32_t* score_out) {
+  return orc_detect_scored(img, w, h, stride, uniformity_radius, octaves, abs_threshold, max_kpts, kps, cap,
+                           score_out, 0);
+}
+
+/* score_type: 0 = Harris (the x86 reference path), 1 = AGAST 9-16 score (orc_agast_score); everything
+ * after the score map -- NMS, scale-space maxima, uniformity, cap, sub-pixel -- is shared. */
+int orc_detect_scored(const uint8_t* img, int w, int h, int stride, float uniformity_radius, int octaves,
+                      int abs_threshold, int max_kpts, orc_keypoint* kps, int cap, int32_t* score_out,
+                      int score_type) {
   if (octaves > 0) {
     const int n_ss = detect_scale_space(img, w, h, stride, uniformity_radius, octaves, abs_threshold,
-                                        max_kpts, kps, cap);
-    if (score_out) orc_harris_score(img, w, h, stride, score_out);
+                                        max_kpts, kps, cap, score_type);
+    if (score_out) orc_score_map(score_type, img, w, h, stride, score_out);
     return n_ss;
   }
   size_t n = (size_t)w * (size_t)h;
   int32_t* score = score_out ? score_out : (int32_t*)malloc(n * sizeof(int32_t));
-  orc_harris_score(img, w, h, stride, score);
+  orc_score_map(score_type, img, w, h, stride, score);
   int maxc = (w / 2 + 1) * (h - 3);
   if (maxc < 16) maxc = 16;
   orc_point_score* pts = (orc_point_score*)malloc((size_t)maxc * sizeof(orc_point_score));

@@ -133,7 +133,18 @@ def subpixel2d(patch) -> tuple:
     return dx.value, dy.value
 
 
-def detect(img, radius, octaves, thr, max_kpts, want_score=False):
+SCORE_HARRIS, SCORE_AGAST = 0, 1
+
+
+def agast_score(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h, w), dtype=np.int32)
+    lib().orc_agast_score(_p(img), w, h, w, _p(out))
+    return out
+
+
+def detect(img, radius, octaves, thr, max_kpts, want_score=False, score_type=SCORE_HARRIS):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape
     cap = max(int(max_kpts), 1) * max(1, 2 * int(octaves)) + 8
@@ -141,8 +152,8 @@ def detect(img, radius, octaves, thr, max_kpts, want_score=False):
         cap = (w // 2 + 1) * h * max(1, 2 * int(octaves))
     kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
     score = np.empty((h, w), dtype=np.int32) if want_score else None
-    n = lib().orc_detect(_p(img), w, h, w, C.c_float(radius), int(octaves), int(thr),
-                         int(max_kpts), _p(kps), cap, _p(score))
+    n = lib().orc_detect_scored(_p(img), w, h, w, C.c_float(radius), int(octaves), int(thr),
+                                int(max_kpts), _p(kps), cap, _p(score), int(score_type))
     return (kps[:n].copy(), score) if want_score else kps[:n].copy()
 
 
@@ -188,8 +199,8 @@ def describe(img, kps, mode, rays=None, jac=None, fu=1.0, direction=(0.0, 1.0, 0
 
 
 def detect_describe(img, radius, octaves, thr, max_kpts, mode, rays=None, jac=None, fu=1.0,
-                    direction=(0.0, 1.0, 0.0)):
-    kps = detect(img, radius, octaves, thr, max_kpts)
+                    direction=(0.0, 1.0, 0.0), score_type=SCORE_HARRIS):
+    kps = detect(img, radius, octaves, thr, max_kpts, score_type=score_type)
     return describe(img, kps, mode, rays, jac, fu, direction)
 
 
