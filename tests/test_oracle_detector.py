@@ -351,3 +351,44 @@ def test_scale_space_layers_and_samplers(oracle):
     assert (k["octave"] == 0).sum() <= len(k0) + 5
     # coordinates of every layer stay inside the image
     assert k["x"].min() >= 0 and k["x"].max() < 752 and k["y"].min() >= 0 and k["y"].max() < 480
+
+
+CIRCLE16 = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3),
+            (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def test_agast_score_known_answers(oracle):
+    """The published FAST / AGAST 9-16 predicate on hand-made circles: the score is the largest
+    threshold t at which 9 contiguous circle pixels are all > p + t or all < p - t."""
+    def scene(centre, values):
+        img = np.full((16, 16), centre, np.uint8)
+        for (dx, dy), v in zip(CIRCLE16, values):
+            img[8 + dy, 8 + dx] = v
+        return img
+
+    # 9 contiguous brighter by 50, start anywhere on the circle (wrap-around included)
+    for start in (0, 5, 11, 15):
+        vals = [150 if (i - start) % 16 < 9 else 100 for i in range(16)]
+        assert oracle.agast_score(scene(100, vals))[8, 8] == 49
+    # only 8 contiguous: not a corner at any threshold
+    vals = [150 if i < 8 else 100 for i in range(16)]
+    assert oracle.agast_score(scene(100, vals))[8, 8] == 0
+    # darker arc; the weakest pixel of the arc sets the score
+    vals = [60 if 3 <= i < 12 else 100 for i in range(16)]
+    vals[7] = 90
+    assert oracle.agast_score(scene(100, vals))[8, 8] == 9
+    # a longer arc does not raise the score; bright and dark arcs: the better one wins
+    vals = [200] * 12 + [0] * 4
+    assert oracle.agast_score(scene(100, vals))[8, 8] == 99
+    vals = [130] * 9 + [100] * 7
+    vals2 = [20] * 9 + [100] * 7
+    assert oracle.agast_score(scene(100, vals))[8, 8] == 29 and oracle.agast_score(scene(100, vals2))[8, 8] == 79
+    # difference of exactly 1: corner only at t = 0 -> score 0 (thresholds start at 1)
+    assert oracle.agast_score(scene(100, [101] * 16))[8, 8] == 0
+    assert oracle.agast_score(scene(100, [102] * 16))[8, 8] == 1
+    # saturated point and the 3-pixel border rule
+    img = np.zeros((16, 16), np.uint8)
+    img[8, 8] = 255
+    img[2, 2] = 255
+    s = oracle.agast_score(img)
+    assert s[8, 8] == 254 and s[2, 2] == 0 and s[:3].max() == 0 and s[:, -3:].max() == 0
