@@ -436,6 +436,30 @@ okvfe_status okvfe_fbrisk_transform(okvfe_ctx* ctx, const uint8_t* descriptors, 
                                     const int32_t* child_begin, const int32_t* child_index,
                                     const int32_t* node_word, int32_t* word_ids, int32_t* leaf_nodes);
 
+/* = the weighting / normalisation half of DBoW2::TemplatedVocabulary::transform(features, BowVector)
+ * (behind dBow_->database.add / query, Frontend.cpp:756-766), for the word ids okvfe_fbrisk_transform
+ * returned: TF_IDF / TF (weighting 0 / 1) sum the word's stored weight per occurrence in feature
+ * order, IDF / BINARY (2 / 3) keep the first; words of weight <= 0 are skipped; with
+ * normalise_l1 != 0 (the L1 scoring of the shipped vocabulary) the vector is divided by its L1 norm
+ * (summed in ascending word order), otherwise TF_IDF / TF divide by the number of distinct words.
+ * Host helper (a few thousand features at most).  Output: ascending word ids + values; n_out is the
+ * number of distinct words even when it exceeds cap (then OKVFE_ERR_CAPACITY). */
+okvfe_status okvfe_bow_vector(const int32_t* word_ids, int32_t n_features, const double* word_weight,
+                              int32_t n_words, int32_t weighting, int32_t normalise_l1,
+                              int32_t* ids_out, double* values_out, int32_t cap, int32_t* n_out);
+/* = DBoW2::TemplatedDatabase::query with L1 scoring (queryL1) against ALL stored entries in one
+ * launch: entry e owns db_ids / db_values [db_begin[e], db_begin[e+1]) (ascending word ids, the
+ * BowVector it was added with).  Per entry, over the common words in ascending word order:
+ * value += |q - d| - |q| - |d|, score = -value / 2 (1 = identical, 0 = nothing in common) -- the
+ * same additions in the same order as the inverted-file walk of the reference, so the doubles are
+ * bit-identical.  scores[e] = -1 for entries without a common word (DBoW2 does not list them).
+ * The reference then sorts the listed entries by id (Frontend.cpp:760-765): this array is already
+ * in id order. */
+okvfe_status okvfe_bow_query_l1(okvfe_ctx* ctx, const int32_t* db_begin /* n_entries + 1 */,
+                                const int32_t* db_ids, const double* db_values, int32_t n_entries,
+                                const int32_t* q_ids, const double* q_values, int32_t n_q,
+                                double* scores /* n_entries */);
+
 /* = brisk::Hamming::PopcntofXORed(a, b, n128); host, no context. */
 uint32_t okvfe_popcnt_xor(const uint8_t* a, const uint8_t* b, int32_t n128);
 

@@ -77,7 +77,7 @@ EXPORTS = [
     "okvfe_match_to_map_uninitialised", "okvfe_pack_gather_blocks_device",
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
     "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
-    "okvfe_match_to_map_landmarks",
+    "okvfe_match_to_map_landmarks", "okvfe_bow_vector", "okvfe_bow_query_l1",
 ]
 
 STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
@@ -170,6 +170,21 @@ def make_pose(Cm, r) -> Pose:
     for i in range(3):
         p.r[i] = float(r[i])
     return p
+
+
+def bow_vector(word_ids, word_weight, weighting=0, normalise_l1=True):
+    """DBoW2 BowVector of a feature set from its word ids (okvfe_fbrisk_transform) and the
+    vocabulary's word weights: (ascending word ids, values).  Host helper."""
+    w = np.ascontiguousarray(word_ids, dtype=np.int32)
+    ww = np.ascontiguousarray(word_weight, dtype=np.float64)
+    ids = np.zeros(len(ww), dtype=np.int32)
+    vals = np.zeros(len(ww), dtype=np.float64)
+    n = C.c_int32()
+    st = lib().okvfe_bow_vector(_p(w), len(w), _p(ww), len(ww), int(weighting), int(bool(normalise_l1)),
+                                _p(ids), _p(vals), len(ww), C.byref(n))
+    if st != OK:
+        raise OkvfeError(st, "okvfe_bow_vector")
+    return ids[:n.value].copy(), vals[:n.value].copy()
 
 
 def popcnt_xor(a, b, n128=3) -> int:
@@ -528,6 +543,20 @@ class Frontend:
         self._check(lib().okvfe_fbrisk_transform(self._h, _p(d), len(d), _p(nd), len(nd), _p(cb), _p(ci),
                                                  _p(nw), _p(words), _p(leaves)))
         return words[:len(d)], leaves[:len(d)]
+
+    def bow_query_l1(self, db_begin, db_ids, db_values, q_ids, q_values):
+        """DBoW2 database query with L1 scoring against all entries: score per entry (-1 = no
+        common word)."""
+        b = np.ascontiguousarray(db_begin, dtype=np.int32)
+        ids = np.ascontiguousarray(db_ids, dtype=np.int32)
+        vals = np.ascontiguousarray(db_values, dtype=np.float64)
+        qi = np.ascontiguousarray(q_ids, dtype=np.int32)
+        qv = np.ascontiguousarray(q_values, dtype=np.float64)
+        n = len(b) - 1
+        scores = np.zeros(max(n, 1), dtype=np.float64)
+        self._check(lib().okvfe_bow_query_l1(self._h, _p(b), _p(ids), _p(vals), n, _p(qi), _p(qv), len(qi),
+                                             _p(scores)))
+        return scores[:n]
 
     # -- stage profiling (HIP events on the launch stream) --------------------------------
     def profile_enable(self, on=True, stages=None):

@@ -1010,6 +1010,44 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_motion_blocks_kernel(
   match_motion_rows(pair, *camera, w, h, I0, I1, threshold, out);
 }
 
+
+// ---- DBoW2 database query, L1 scoring (TemplatedDatabase::queryL1 behind Frontend.cpp:756-766) ----
+// One thread per database entry: merge-join of the entry's BowVector with the query's (both in
+// ascending word order), value += |q - d| - |q| - |d| over the common words in that order -- the
+// order in which the reference's inverted-file walk reaches this entry -- then score = -value / 2.
+// A few hundred words per vector, a few thousand entries: latency-bound, one small launch.
+__global__ __launch_bounds__(256) void bow_query_l1_kernel(const int32_t* __restrict__ db_begin,
+                                                           const int32_t* __restrict__ db_ids,
+                                                           const double* __restrict__ db_values, int n_entries,
+                                                           const int32_t* __restrict__ q_ids,
+                                                           const double* __restrict__ q_values, int n_q,
+                                                           double* __restrict__ scores) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_entries) return;
+  int i = db_begin[e];
+  const int i_end = db_begin[e + 1];
+  int j = 0;
+  double value = 0.0;
+  bool any = false;
+  while (i < i_end && j < n_q) {
+    const int a = db_ids[i], b = q_ids[j];
+    if (a == b) {
+      const double d = db_values[i], q = q_values[j];
+      double t = fabs(q - d);
+      t = t - fabs(q);
+      t = t - fabs(d);
+      value = value + t;
+      any = true;
+      ++i;
+      ++j;
+    } else if (a < b) {
+      ++i;
+    } else {
+      ++j;
+    }
+  }
+  scores[e] = any ? -value / 2.0 : -1.0;
+}
 }  // namespace
 
 void launch_match_motion_blocks(const PairParams& pair, const DeviceCamera* camera, int w, int h,
@@ -1101,6 +1139,14 @@ void launch_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_l
   hipLaunchKernelGGL(verify_place_kernel, dim3(blocks), dim3(256), 0, stream, pool, desc_begin, n_landmarks,
                      frame_desc, K, threshold, k_min, dist_min);
 }
+void launch_bow_query_l1(const int32_t* db_begin, const int32_t* db_ids, const double* db_values, int n_entries,
+                         const int32_t* q_ids, const double* q_values, int n_q, double* scores,
+                         hipStream_t stream) {
+  if (n_entries <= 0) return;
+  hipLaunchKernelGGL(bow_query_l1_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, stream, db_begin, db_ids,
+                     db_values, n_entries, q_ids, q_values, n_q, scores);
+}
+
 void launch_voc_transform(const uint8_t* desc, int n, const uint8_t* node_desc, int n_nodes,
                           const int32_t* child_begin, const int32_t* child_index, const int32_t* word,
                           int32_t* word_out, int32_t* node_out, hipStream_t stream) {

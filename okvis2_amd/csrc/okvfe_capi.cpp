@@ -1724,6 +1724,101 @@ okvfe_status okvfe_fbrisk_transform(okvfe_ctx* ctx, const uint8_t* descriptors, 
 }
 
 // ---- stage profiling -------------------------------------------------------------------------
+okvfe_status okvfe_bow_vector(const int32_t* word_ids, int32_t n_features, const double* word_weight,
+                              int32_t n_words, int32_t weighting, int32_t normalise_l1, int32_t* ids_out,
+                              double* values_out, int32_t cap, int32_t* n_out) {
+  if (n_features < 0 || n_words < 1 || !word_weight || !n_out || weighting < 0 || weighting > 3 ||
+      (n_features > 0 && !word_ids) || cap < 0 || (cap > 0 && (!ids_out || !values_out)))
+    return OKVFE_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < n_features; ++i)
+    if (word_ids[i] < 0 || word_ids[i] >= n_words) return OKVFE_ERR_INVALID_ARGUMENT;
+  // value per word in feature order (the sums are sequential additions of the same weight, as
+  // BowVector::addWeight performs them), then the words in ascending order
+  const bool sums = weighting == 0 || weighting == 1;  // TF_IDF, TF
+  std::vector<double> acc(n_words, 0.0);
+  std::vector<uint8_t> seen(n_words, 0);
+  for (int i = 0; i < n_features; ++i) {
+    const int id = word_ids[i];
+    const double wgt = word_weight[id];
+    if (!(wgt > 0)) continue;
+    if (!seen[id]) {
+      seen[id] = 1;
+      acc[id] = wgt;
+    } else if (sums) {
+      acc[id] = acc[id] + wgt;
+    }
+  }
+  int n = 0;
+  for (int id = 0; id < n_words; ++id) n += seen[id];
+  *n_out = n;
+  if (n > cap) return OKVFE_ERR_CAPACITY;
+  int k = 0;
+  for (int id = 0; id < n_words; ++id)
+    if (seen[id]) {
+      ids_out[k] = id;
+      values_out[k] = acc[id];
+      ++k;
+    }
+  if (normalise_l1) {
+    double norm = 0.0;
+    for (int i = 0; i < n; ++i) norm = norm + std::fabs(values_out[i]);
+    if (norm > 0.0)
+      for (int i = 0; i < n; ++i) values_out[i] = values_out[i] / norm;
+  } else if (sums && n > 0) {
+    const double nd = (double)n;
+    for (int i = 0; i < n; ++i) values_out[i] = values_out[i] / nd;
+  }
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_bow_query_l1(okvfe_ctx* ctx, const int32_t* db_begin, const int32_t* db_ids,
+                                const double* db_values, int32_t n_entries, const int32_t* q_ids,
+                                const double* q_values, int32_t n_q, double* scores) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n_entries < 0 || n_q < 0 || !db_begin || (n_entries > 0 && !scores) || (n_q > 0 && (!q_ids || !q_values)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_bow_query_l1: bad argument");
+  if (db_begin[0] != 0) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_bow_query_l1: db_begin[0] != 0");
+  for (int e = 0; e < n_entries; ++e) {
+    if (db_begin[e + 1] < db_begin[e])
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_bow_query_l1: db_begin not monotone at %d", e);
+    for (int i = db_begin[e] + 1; i < db_begin[e + 1]; ++i)
+      if (db_ids[i] <= db_ids[i - 1])
+        return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_bow_query_l1: entry %d is not in ascending word order", e);
+  }
+  for (int j = 1; j < n_q; ++j)
+    if (q_ids[j] <= q_ids[j - 1])
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_bow_query_l1: query is not in ascending word order");
+  if (n_entries == 0) return OKVFE_OK;
+  const int m = db_begin[n_entries];
+  if (m > 0 && (!db_ids || !db_values)) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_bow_query_l1: null database");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = ctx->stream;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + std::max<size_t>(bytes, 1), 256); return o; };
+  const size_t o_b = take((size_t)(n_entries + 1) * 4), o_i = take((size_t)m * 4), o_v = take((size_t)m * 8),
+               o_qi = take((size_t)n_q * 4), o_qv = take((size_t)n_q * 8), o_s = take((size_t)n_entries * 8);
+  okvfe_status st = ensure_scratch(ctx, off);
+  if (st != OKVFE_OK) return st;
+  uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  HIP_TRY(ctx, hipMemcpyAsync(base + o_b, db_begin, (size_t)(n_entries + 1) * 4, hipMemcpyHostToDevice, s));
+  if (m) {
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_i, db_ids, (size_t)m * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_v, db_values, (size_t)m * 8, hipMemcpyHostToDevice, s));
+  }
+  if (n_q) {
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_qi, q_ids, (size_t)n_q * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_qv, q_values, (size_t)n_q * 8, hipMemcpyHostToDevice, s));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable host buffers: the copies above have completed
+  launch_bow_query_l1(reinterpret_cast<int32_t*>(base + o_b), reinterpret_cast<int32_t*>(base + o_i),
+                      reinterpret_cast<double*>(base + o_v), n_entries, reinterpret_cast<int32_t*>(base + o_qi),
+                      reinterpret_cast<double*>(base + o_qv), n_q, reinterpret_cast<double*>(base + o_s), s);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(scores, base + o_s, (size_t)n_entries * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));

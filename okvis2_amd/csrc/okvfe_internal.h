@@ -114,6 +114,9 @@ __device__ __forceinline__ void xcd_tile(int tiles, int n_images, int* image, in
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 namespace okvfe {
 
+void launch_bow_query_l1(const int32_t* db_begin, const int32_t* db_ids, const double* db_values, int n_entries,
+                         const int32_t* q_ids, const double* q_values, int n_q, double* scores,
+                         hipStream_t stream);
 void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                         hipStream_t stream);
 void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,

@@ -239,4 +239,8 @@ void orc_prepare_landmarks(const double* hp_W, const double* quality, const int3
 #ifdef __cplusplus
 }
 #endif
+int orc_bow_vector(const int32_t* word_ids, int n_features, const double* word_weight, int n_words, int weighting,
+                   int normalise_l1, int32_t* ids_out /* n_words */, double* values_out /* n_words */);
+void orc_bow_query_l1(const int32_t* db_begin, const int32_t* db_ids, const double* db_values, int n_entries,
+                      const int32_t* q_ids, const double* q_values, int n_q, int n_words, double* scores);
 #endif /* OKVFE_ORACLE_H_ */

@@ -15,6 +15,7 @@
 #include "okvfe_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 uint32_t orc_popcnt_xor(const uint8_t* a, const uint8_t* b, int n128) {
@@ -640,4 +641,75 @@ void orc_prepare_landmarks(const double* hp_W, const double* quality, const int3
         r_W[6 * l + 3 * k + i] = rw[k][i];
       }
   }
+}
+
+
+/* ---- DBoW2 bag-of-words vector and L1 database query (behind dBow_->database.add / query,
+ * Frontend.cpp:756-766).  DBoW2 is an un-vendored submodule of the reference (external/DBoW2,
+ * .gitmodules); this follows its published TemplatedVocabulary::transform(features, BowVector) and
+ * TemplatedDatabase::queryL1: addWeight / addIfNotExist per feature in order, division by the
+ * number of distinct words when the scoring does not normalise, L1 normalisation in ascending word
+ * order; the query walks the query words in ascending order and, per word, the inverted-file row in
+ * ascending entry order: value[entry] += |q - d| - |q| - |d|; score = -value / 2.  Entries without
+ * a common word are not listed (-1 here). */
+int orc_bow_vector(const int32_t* word_ids, int n_features, const double* word_weight, int n_words, int weighting,
+                   int normalise_l1, int32_t* ids_out, double* values_out) {
+  double* acc = (double*)calloc((size_t)n_words, sizeof(double));
+  unsigned char* seen = (unsigned char*)calloc((size_t)n_words, 1);
+  const int sums = weighting == 0 || weighting == 1;
+  for (int i = 0; i < n_features; ++i) {
+    const int id = word_ids[i];
+    const double w = word_weight[id];
+    if (!(w > 0)) continue;
+    if (!seen[id]) { seen[id] = 1; acc[id] = w; }
+    else if (sums) acc[id] = acc[id] + w;
+  }
+  int n = 0;
+  for (int id = 0; id < n_words; ++id)
+    if (seen[id]) { ids_out[n] = id; values_out[n] = acc[id]; ++n; }
+  if (normalise_l1) {
+    double norm = 0.0;
+    for (int i = 0; i < n; ++i) norm = norm + fabs(values_out[i]);
+    if (norm > 0.0) for (int i = 0; i < n; ++i) values_out[i] = values_out[i] / norm;
+  } else if (sums && n > 0) {
+    const double nd = (double)n;
+    for (int i = 0; i < n; ++i) values_out[i] = values_out[i] / nd;
+  }
+  free(acc);
+  free(seen);
+  return n;
+}
+
+void orc_bow_query_l1(const int32_t* db_begin, const int32_t* db_ids, const double* db_values, int n_entries,
+                      const int32_t* q_ids, const double* q_values, int n_q, int n_words, double* scores) {
+  /* the inverted file: row of word w = (entry, value) pairs in ascending entry order */
+  int32_t* row_begin = (int32_t*)calloc((size_t)n_words + 1, sizeof(int32_t));
+  const int m = db_begin[n_entries];
+  for (int i = 0; i < m; ++i) row_begin[db_ids[i] + 1]++;
+  for (int w = 0; w < n_words; ++w) row_begin[w + 1] += row_begin[w];
+  int32_t* fill = (int32_t*)malloc((size_t)n_words * sizeof(int32_t));
+  memcpy(fill, row_begin, (size_t)n_words * sizeof(int32_t));
+  int32_t* row_entry = (int32_t*)malloc((size_t)(m > 0 ? m : 1) * sizeof(int32_t));
+  double* row_value = (double*)malloc((size_t)(m > 0 ? m : 1) * sizeof(double));
+  for (int e = 0; e < n_entries; ++e)
+    for (int i = db_begin[e]; i < db_begin[e + 1]; ++i) {
+      const int pos = fill[db_ids[i]]++;
+      row_entry[pos] = e;
+      row_value[pos] = db_values[i];
+    }
+  double* value = (double*)calloc((size_t)(n_entries > 0 ? n_entries : 1), sizeof(double));
+  unsigned char* hit = (unsigned char*)calloc((size_t)(n_entries > 0 ? n_entries : 1), 1);
+  for (int j = 0; j < n_q; ++j) {
+    const double q = q_values[j];
+    for (int r = row_begin[q_ids[j]]; r < row_begin[q_ids[j] + 1]; ++r) {
+      const double d = row_value[r];
+      double t = fabs(q - d);
+      t = t - fabs(q);
+      t = t - fabs(d);
+      value[row_entry[r]] = value[row_entry[r]] + t;
+      hit[row_entry[r]] = 1;
+    }
+  }
+  for (int e = 0; e < n_entries; ++e) scores[e] = hit[e] ? -value[e] / 2.0 : -1.0;
+  free(row_begin); free(fill); free(row_entry); free(row_value); free(value); free(hit);
 }

@@ -408,3 +408,25 @@ def prepare_landmarks(hp_W, quality, obs_begin, obs_pose, obs_bp, poses, T_WC1, 
                                 _p(out["n_desc"]), _p(out["obs_rows"]), _p(out["projection"]),
                                 _p(out["e_W"]), _p(out["r_W"]))
     return {k: v[:nl] for k, v in out.items()}
+
+
+def bow_vector(word_ids, word_weight, weighting=0, normalise_l1=True):
+    w = np.ascontiguousarray(word_ids, dtype=np.int32)
+    ww = np.ascontiguousarray(word_weight, dtype=np.float64)
+    ids = np.zeros(len(ww), dtype=np.int32)
+    vals = np.zeros(len(ww), dtype=np.float64)
+    n = lib().orc_bow_vector(_p(w), len(w), _p(ww), len(ww), int(weighting), int(bool(normalise_l1)),
+                             _p(ids), _p(vals))
+    return ids[:n].copy(), vals[:n].copy()
+
+
+def bow_query_l1(db_begin, db_ids, db_values, q_ids, q_values, n_words):
+    b = np.ascontiguousarray(db_begin, dtype=np.int32)
+    ids = np.ascontiguousarray(db_ids, dtype=np.int32)
+    vals = np.ascontiguousarray(db_values, dtype=np.float64)
+    qi = np.ascontiguousarray(q_ids, dtype=np.int32)
+    qv = np.ascontiguousarray(q_values, dtype=np.float64)
+    n = len(b) - 1
+    scores = np.zeros(max(n, 1), dtype=np.float64)
+    lib().orc_bow_query_l1(_p(b), _p(ids), _p(vals), n, _p(qi), _p(qv), len(qi), int(n_words), _p(scores))
+    return scores[:n]

@@ -97,3 +97,50 @@ def test_synthetic_inputs_are_deterministic():
     for mk in (synth.euroc_config, synth.mono640_config, synth.tumvi1024_config, synth.hilti_config):
         cfg = mk()
         assert all(c.w == cfg.w and c.h == cfg.h for c in cfg.cams)
+
+
+def test_bow_vector_host_helper_against_the_oracle_and_a_plain_restatement(oracle):
+    """okvfe_bow_vector (DBoW2 transform's weighting / normalisation half) on the reference's real
+    vocabulary weights: every weighting mode, with and without L1 normalisation, against the C
+    oracle and against a dictionary restatement written here."""
+    import os
+    voc = np.load(os.path.join(os.path.dirname(__file__), "golden", "small_voc_tree.npz"))
+    word, weight = voc["word"], voc["weight"]
+    n_words = int(word.max()) + 1
+    ww = np.zeros(n_words)
+    ww[word[word >= 0]] = weight[word >= 0]
+    assert int(voc["weighting"]) == 0 and int(voc["scoring"]) == 0   # TF_IDF, L1_NORM
+    ww[5] = 0.0  # a stopped word: skipped
+    rng = np.random.default_rng(4)
+    for n_feat in (0, 1, 37, 700, 3000):
+        ids_in = rng.integers(0, n_words, n_feat)
+        for weighting in (0, 1, 2, 3):
+            for norm in (True, False):
+                got = capi.bow_vector(ids_in, ww, weighting, norm)
+                ref = oracle.bow_vector(ids_in, ww, weighting, norm)
+                assert np.array_equal(got[0], ref[0])
+                assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64))
+                acc = {}
+                for x in ids_in:
+                    x = int(x)
+                    if not ww[x] > 0:
+                        continue
+                    if x not in acc:
+                        acc[x] = ww[x]
+                    elif weighting in (0, 1):
+                        acc[x] = acc[x] + ww[x]
+                keys = sorted(acc)
+                vals = np.array([acc[k] for k in keys], dtype=np.float64)
+                if norm:
+                    s = 0.0
+                    for t in vals:
+                        s = s + abs(t)
+                    if s > 0:
+                        vals = vals / s
+                elif weighting in (0, 1) and len(vals):
+                    vals = vals / float(len(vals))
+                assert np.array_equal(np.array(keys, dtype=np.int32), got[0])
+                assert np.array_equal(vals.view(np.uint64), got[1].view(np.uint64))
+                assert 5 not in got[0]
+    with pytest.raises(capi.OkvfeError):
+        capi.bow_vector([n_words], ww)

@@ -441,6 +441,79 @@ def test_verify_place_batched_and_vocabulary_descent(oracle):
         fe.fbrisk_transform(feats[:4], t["desc"], cb, ci[::-1].copy(), t["word"])  # not a tree in id order
 
 
+def test_place_recognition_query_descent_bow_vector_l1_scores(oracle):
+    """dBow_->database.query(features, ...) of Frontend.cpp:756-766 end to end on the device path:
+    vocabulary descent (okvfe_fbrisk_transform) -> BowVector (okvfe_bow_vector) -> L1 scores against
+    every stored keyframe in one launch (okvfe_bow_query_l1), on the reference's real 9^3 vocabulary
+    (node weights included) with keyframes made of GPU descriptors; scores as bit patterns against
+    the oracle's inverted-file walk."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    t = np.load(os.path.join(gold, "small_voc_tree.npz"))
+    word, weight = t["word"], t["weight"]
+    n_words = int(word.max()) + 1
+    ww = np.zeros(n_words)
+    ww[word[word >= 0]] = weight[word >= 0]
+    cb, ci = oracle.voc_tree_arrays(t["parent"])
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    fe.set_camera(0, cfg.cams[0])
+    rng = np.random.default_rng(21)
+    # 40 "places" (images), 6 keyframes each: the place's descriptors with a few bits flipped and a
+    # random subset dropped -> 240 database entries; queries = fresh views of some places
+    places = []
+    for pl in range(40):
+        _, feats, _, _ = fe.detect_describe(synth.corners_image(cfg.w, cfg.h, 900 + pl), cam=0,
+                                            gravity=(0.0, 1.0, 0.0))
+        places.append(feats)
+
+    def view(pl):
+        f = places[pl]
+        keep = rng.random(len(f)) > 0.25
+        flips = ((rng.random(f.shape) < 0.01) * rng.integers(1, 256, f.shape)).astype(np.uint8)
+        return (f ^ flips)[keep]
+
+    def bow(feats):
+        w, _ = fe.fbrisk_transform(feats, t["desc"], cb, ci, t["word"])
+        rw, _ = oracle.voc_transform(feats, t["desc"], cb, ci, t["word"])
+        assert np.array_equal(w, rw)
+        v = capi.bow_vector(w, ww, int(t["weighting"]), True)
+        r = oracle.bow_vector(rw, ww, int(t["weighting"]), True)
+        assert np.array_equal(v[0], r[0]) and np.array_equal(v[1].view(np.uint64), r[1].view(np.uint64))
+        return v
+
+    entries, owner = [], []
+    for pl in range(40):
+        for _ in range(6):
+            entries.append(bow(view(pl)))
+            owner.append(pl)
+    entries.append((np.zeros(0, np.int32), np.zeros(0)))  # a keyframe without features
+    owner.append(-1)
+    begin = np.concatenate([[0], np.cumsum([len(e[0]) for e in entries])]).astype(np.int32)
+    ids = np.concatenate([e[0] for e in entries]).astype(np.int32)
+    vals = np.concatenate([e[1] for e in entries])
+    owner = np.array(owner)
+    hits = 0
+    for pl in (0, 7, 19, 39):
+        q = bow(view(pl))
+        got = fe.bow_query_l1(begin, ids, vals, q[0], q[1])
+        ref = oracle.bow_query_l1(begin, ids, vals, q[0], q[1], n_words)
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+        assert got[-1] == -1.0 and np.all(got[:-1] >= 0.0) and np.all(got[:-1] <= 1.0 + 1e-12)
+        best = np.argsort(-got)[:6]
+        hits += int((owner[best] == pl).sum())
+    assert hits >= 20  # the six views of the queried place rank on top
+    # a stored vector queried with itself: identical vectors score 1 up to the rounding of the norm
+    e0 = entries[0]
+    self_score = fe.bow_query_l1(begin, ids, vals, e0[0], e0[1])[0]
+    assert abs(self_score - 1.0) < 1e-12
+    # empty query, empty database
+    assert np.all(fe.bow_query_l1(begin, ids, vals, np.zeros(0, np.int32), np.zeros(0)) == -1.0)
+    assert len(fe.bow_query_l1(np.zeros(1, np.int32), ids[:0], vals[:0], q[0], q[1])) == 0
+    with pytest.raises(capi.OkvfeError):
+        fe.bow_query_l1(begin, ids[::-1].copy(), vals, q[0], q[1])  # not in ascending word order
+
+
 def test_match_to_map_from_raw_landmark_table(oracle):
     """okvfe_match_to_map_landmarks (Frontend.cpp:1219-1411): projection, descriptor-view pooling and
     the 3-D matcher on the device from the raw landmark / observation tables, 6000 landmarks;
