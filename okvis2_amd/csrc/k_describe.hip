@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
     int w, int h, const Pattern* __restrict__ pat, const ImageParams* __restrict__ prm,
     const float* const* __restrict__ rays, const float* const* __restrict__ jac,
     const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
-    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
+    okvfe_keypoint* __restrict__ kps_tmp, uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
   const int img = blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= kp_count_in[img]) return;
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
   }
   *reinterpret_cast<float4*>(desc_tmp + slot * OKVFE_DESC_BYTES) = make_float4(M[0], M[1], M[2], M[3]);
   valid_tmp[slot] = valid ? 1 : 0;
+  kps_tmp[slot] = kp;  // the record travels on from here; describe_kernel only rewrites the angle
 }
 
 // One wave per keypoint, lane i = pattern point i.  The pixels under the keypoint's pattern
@@ -285,6 +286,12 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     uint32_t inv_tiles) {
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchBufBytes];
   __shared__ int values[kDescWaves][64];
+  // the 383 short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
+  // they were a third dependent round trip in every keypoint's chain
+  __shared__ uint16_t short_pairs[384];
+  for (int t = threadIdx.x; t < 384; t += 64 * kDescWaves)
+    short_pairs[t] = t < pat->n_short ? (uint16_t)(pat->short_i[t] | (pat->short_j[t] << 8)) : (uint16_t)0;
+  __syncthreads();
   // all keypoint blocks of an image run on the same XCD (block L -> XCD L % 8), so its pixels
   // are fetched from HBM into ONE L2 instead of into all eight
   // (two thirds of the blocks find no keypoint in their slots and leave right here, so the
@@ -331,6 +338,41 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     by1 = __builtin_amdgcn_readfirstlane(by1);
     const int px0 = bx0 & ~3;
     const int pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
+#ifndef OKVFE_DESC_NO_X4
+    // 16 bytes per lane (buffer_load_dwordx4 ... lds, new on gfx950): a quarter of the load
+    // instructions for the same pixels.  The staging is bound by the number of vector-memory
+    // requests in flight at L2 latency, not by bytes (stage-only 0.43 ms of the kernel's 0.51 with
+    // dword requests), so fewer, wider requests are what shortens it.  Rows are padded to 16 B.
+    const int nq = (pw + 15) >> 4;  // 16-byte chunks per patch row
+    if (dword_ok && nq >= 1 && nq * 16 <= kZeroRowBytes - 8) {
+      const int pitch = nq * 16;
+      const uint32_t inv = (65536u + (uint32_t)nq - 1u) / (uint32_t)nq;
+      const int R = (int)((64u * inv) >> 16);
+      const int trips = (ph + R - 1) / R;
+      if (trips * R * pitch <= kPatchDataBytes) {  // wave-uniform
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rr = ((uint32_t)lane * inv) >> 16;
+        const uint32_t c = (uint32_t)lane - rr * (uint32_t)nq;
+        const uint32_t src_lane = rr * (uint32_t)w + c * 16u;
+        const int src0 = by0 * w + px0;
+#ifndef OKVFE_DESC_NOSTAGE
+        if ((int)rr < R) {
+          for (int it = 0; it < trips; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * R * pitch), 16,
+                (int)src_lane, src0 + it * R * w, 0, 0);
+        }
+#endif
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        ppx->patch = patch;
+        ppx->x0 = px0;
+        ppx->y0 = by0;
+        ppx->pitch = pitch;
+        return true;
+      }
+    }
+#endif
     const int ndw = (pw + 3) >> 2;  // dwords per patch row
     const int pitch = ndw * 4;
     if (pitch > kZeroRowBytes - 8 || ndw < 1) return false;  // wave-uniform
@@ -349,12 +391,14 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       const uint32_t c = (uint32_t)lane - rr * (uint32_t)ndw;
       const uint32_t src_lane = rr * (uint32_t)w + c * 4u;
       const int src0 = by0 * w + px0;
+#ifndef OKVFE_DESC_NOSTAGE  // A/B: box sums on whatever the LDS holds (no image traffic)
       if ((int)rr < R) {
         for (int it = 0; it < trips; ++it)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
               img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * R * pitch), 4,
               (int)src_lane, src0 + it * R * w, 0, 0);
       }
+#endif
       __builtin_amdgcn_s_waitcnt(0);
     } else {
       if (ph * pitch > kPatchDataBytes) return false;
@@ -397,7 +441,11 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     PatchPx ppx;
     int v = 0;
     if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
+#ifdef OKVFE_DESC_STAGEONLY  // A/B: patch staging without the box sums
+      v = ppx.patch[lane];
+#else
       if (active) v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
+#endif
     } else {
       const GlobalPx gpx{im, w};
       if (active) v = smoothed_intensity(gpx, xf, yf, sg, bsc, bsc2);
@@ -411,26 +459,33 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   // The wave walks the image's keypoints wv, wv + tiles * kDescWaves, ...: the per-lane pattern
   // constants, the image's parameters and the buffer resource above are set up once per wave
   // instead of once per keypoint.
-  for (int k = tile * kDescWaves + wv; k < n; k += tiles * kDescWaves) {
+  // (x, y), M and the valid flag of a keypoint are loaded ONE KEYPOINT AHEAD: with the pattern
+  // tables in LDS the chain of a keypoint is then a single global round trip (the patch) instead of
+  // three.  The loads are wave-uniform; their values move to SGPRs when the keypoint's turn comes.
+  const int k_step = tiles * kDescWaves;
+  float2 nxt_xy = make_float2(0.f, 0.f);
+  float4 nxt_M = make_float4(0.f, 0.f, 0.f, 0.f);
+  int nxt_valid = 0;
+  auto fetch = [&](int kk) {
+    const size_t sl = (size_t)img * kp_cap + kk;
+    nxt_xy = *reinterpret_cast<const float2*>(&kps_in[sl].x);
+    nxt_M = *reinterpret_cast<const float4*>(desc_tmp + sl * OKVFE_DESC_BYTES);
+    nxt_valid = (int)valid_tmp[sl];
+  };
+  fetch(tile * kDescWaves + wv);
+  for (int k = tile * kDescWaves + wv; k < n; k += k_step) {
   // opaque to the optimiser: expressions of the lane constants are NOT hoisted out of the loop
   // (they would cost ~25 more live VGPRs and push the kernel below 6 waves/SIMD)
   asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(lane));
   const size_t slot = (size_t)img * kp_cap + k;
   auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-  kp = kps_in[slot];
-  kp.x = uni(kp.x);
-  kp.y = uni(kp.y);
-  kp.size = uni(kp.size);
-  kp.angle = uni(kp.angle);
-  kp.response = uni(kp.response);
-  kp.octave = __builtin_amdgcn_readfirstlane(kp.octave);
-  kp.class_id = __builtin_amdgcn_readfirstlane(kp.class_id);
+  kp.x = uni(nxt_xy.x);
+  kp.y = uni(nxt_xy.y);
   // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
-  bool valid = __builtin_amdgcn_readfirstlane((int)valid_tmp[slot]) != 0;
-  {
-    const float4 M4 = *reinterpret_cast<const float4*>(desc_tmp + slot * OKVFE_DESC_BYTES);
-    M[0] = uni(M4.x); M[1] = uni(M4.y); M[2] = uni(M4.z); M[3] = uni(M4.w);
-  }
+  bool valid = __builtin_amdgcn_readfirstlane(nxt_valid) != 0;
+  M[0] = uni(nxt_M.x); M[1] = uni(nxt_M.y); M[2] = uni(nxt_M.z); M[3] = uni(nxt_M.w);
+  if (k + k_step < n) fetch(k + k_step);  // scalar branch
+  bool new_angle = false;
   if (valid && ip.mode == kGradient) {
     valid = sample_all(true);
     if (valid) {
@@ -468,6 +523,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         best_k = bk;
       }
       kp.angle = (float)best_k * 0.3515625f;
+      new_angle = true;
       M[0] = pat->rot_cosf[best_k];
       M[1] = -pat->rot_sinf[best_k];
       M[2] = pat->rot_sinf[best_k];
@@ -479,9 +535,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     unsigned long long words[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const int b = j * 64 + lane;
-      bool bit = false;
-      if (b < pat->n_short) bit = vals[pat->short_i[b]] > vals[pat->short_j[b]];
+      const uint32_t pr = short_pairs[j * 64 + lane];  // slots past n_short hold 0 | 0: bit 0
+      const bool bit = vals[pr & 255u] > vals[pr >> 8];
       words[j] = __ballot(bit);
     }
     if (lane < 6) {
@@ -493,7 +548,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     }
   }
   if (lane == 0) {
-    kps_tmp[slot] = kp;
+    if (new_angle) kps_tmp[slot].angle = kp.angle;  // the rest of the record: describe_setup_kernel
     valid_tmp[slot] = valid ? 1 : 0;
   }
   __builtin_amdgcn_wave_barrier();  // vals[] / the patch are rewritten for the next keypoint
@@ -558,7 +613,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      hipStream_t stream) {
   if (n_images <= 0) return;
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
-                     stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, desc_tmp,
+                     stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
                      valid_tmp);
   // blocks per image: enough waves to fill the machine with one image's ~300 keypoints spread
   // over them (a wave then describes ~9 keypoints of its image in a row)
