@@ -364,9 +364,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     if (!lane_on) sub = 0;
     d = lane_on ? strip * kStripLanes + j : nd;  // idle lanes behave like lanes past the row end
   } else {
+#if defined(OKVFE_K1_MAP) && OKVFE_K1_MAP == 1   // A/B: plain image-major order (an image's blocks spread over all XCDs)
+    image = (int)blockIdx.x / (strips * ytiles);
+    tile = (int)blockIdx.x - image * (strips * ytiles);
+#elif defined(OKVFE_K1_MAP) && OKVFE_K1_MAP == 2  // A/B: tile-major order (the same tile of consecutive images back to back)
+    tile = (int)blockIdx.x / n_images;
+    image = (int)blockIdx.x - tile * n_images;
+#else
     xcd_tile(strips * ytiles, n_images, &image, &tile);
+#endif
+#if defined(OKVFE_K1_MAP) && OKVFE_K1_MAP == 3  // A/B: strip-major tile order inside an image
+    strip = tile / ytiles;
+    ytile = tile - strip * ytiles;
+#else
     ytile = tile / strips;
     strip = tile - ytile * strips;
+#endif
     row_tile = ytile * kWavesPerBlock + wave;
     d = strip * kStripLanes + lane;
   }
