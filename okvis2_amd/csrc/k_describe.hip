@@ -19,8 +19,10 @@
 //                    become 6 wave ballots -> 6 x u64 = 48 bytes.  All blocks of an image run
 //                    on one XCD.  No integral image: the 4 B/px integral pass of the classic
 //                    CPU formulation (5 B/px of HBM traffic) is gone.
-//                    VALU / latency bound (~510 VALU per keypoint); ~4.2 KB in + 48 B out per
-//                    keypoint, 0.19 GB of HBM reads per 512 EuRoC images.
+//                    Latency / LDS bound (~340 VALU per keypoint; ONE global round trip per
+//                    keypoint: its patch, 16 B per lane; the short-pair table sits in LDS, the next
+//                    keypoint's position / M / valid flag are requested a keypoint ahead);
+//                    ~4.2 KB in + 48 B out per keypoint, 0.19 GB of HBM reads per 512 EuRoC images.
 //   compact_kernel   removes the keypoints the extractor dropped (order preserved) and
 //                    back-projects the survivors in FP64 (Gauss-Newton undistortion).
 #include <limits.h>
