@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FRAMES, DISTINCT = 768, 16
+DISTINCT = 16
 
 
 def _run(fe, cfg, d_img, n_frames, grav, pairs, d_match):
@@ -51,9 +51,13 @@ def _digest(res, matches):
     return h.hexdigest()
 
 
-def test_full_size_batch_replicas_permutation_idempotence(oracle):
+@pytest.mark.parametrize("workload,FRAMES", [("euroc", 768), ("tumvi", 256)])
+def test_full_size_batch_replicas_permutation_idempotence(oracle, workload, FRAMES):
+    """euroc: BASELINE configs[2] at the bench's batch (768 stereo frames of 752x480); tumvi:
+    configs[3] (256 stereo frames of 1024x1024, equidistant cameras: packed last strips of the score
+    kernel, occupancy grid of radius 50, up to 1000 keypoints per image)."""
     import bench
-    cfg = synth.euroc_config()
+    cfg = synth.euroc_config() if workload == "euroc" else synth.tumvi1024_config()
     imgs, base = bench.make_inputs(cfg, FRAMES, DISTINCT, 4242)
     fe = G.make_frontend(cfg, max_batch=2 * FRAMES, num_cameras=2)
     for ci, cam in enumerate(cfg.cams):
