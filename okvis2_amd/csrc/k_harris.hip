@@ -585,7 +585,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   auto store_row = [&](const int sc[4], int y) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = {sc[0], sc[1], sc[2], sc[3]};
-#ifndef OKVFE_K1_NOSTORE
+#if defined(OKVFE_K1_ALIGNED_STORE_EXPERIMENT)
+    // bandwidth experiment only (results are garbage): every lane stores, strips are 1024 B apart and
+    // rows 3072 B apart, so that every store instruction writes eight whole 128-byte lines
+#if OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 1   // 1024-byte segments, rows 3072 B apart: whole lines only
+    if (y < h - 12)
+      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (strip * 64 + lane) * 16, y * 3072, OKVFE_K1_STORE_AUX);
+#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 2  // 1024-byte segments at 64-byte (not 128-byte) aligned rows
+    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (strip * 64 + lane) * 16, y * 3008, OKVFE_K1_STORE_AUX);
+#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 3  // the real 62 / 63-lane segments, each in its own 1024-byte slot
+    if (y < h - 12)
+      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, store ? (strip * 64 + lane) * 16 : 0x7FFFFFF0, y * 3072,
+                                             OKVFE_K1_STORE_AUX);
+#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 5  // the real segments (62 / 63 lanes, contiguous), rows padded to 3072 B
+    if (y < h - 12) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * 3072, OKVFE_K1_STORE_AUX);
+#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 6  // like 5 and the last strip also writes the 64-byte pad of the row
+    if (y < h - 12)
+      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (store || (last_strip && d < nd + 4)) ? d * 16 : 0x7FFFFFF0,
+                                             y * 3072, OKVFE_K1_STORE_AUX);
+#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 4  // like 3, segments shifted to start on a line (lane - 1)
+    if (y < h - 12)
+      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
+                                             store ? (strip * 64 + lane - (strip ? 1 : 0)) * 16 : 0x7FFFFFF0, y * 3072,
+                                             OKVFE_K1_STORE_AUX);
+#endif
+#elif !defined(OKVFE_K1_NOSTORE)
     __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, OKVFE_K1_STORE_AUX);
 #else
     if (v.x == 0x12345678 && v.y == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, 0);
@@ -653,7 +677,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
 #ifdef OKVFE_K1_MEMONLY  // A/B: the kernel's loads and stores with no arithmetic (its own memory floor)
     {
       int sc[4];
+#ifdef OKVFE_K1_MEMONLY_NOLOADUSE  // stores of a constant: the loads are dead (and removed by the compiler)
+      sc[0] = sc[1] = sc[2] = sc[3] = y;
+#else
       unpack4(ring[PH], sc);
+#endif
       if (decltype(want_store)::value && y < h) store_row(sc, y);
       ++y;
       (void)inner;
