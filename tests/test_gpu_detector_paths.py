@@ -141,6 +141,35 @@ def test_legacy_select_kernel_for_grids_outside_lds(oracle):
     assert out.returncode == 0 and "LEGACY-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+_KNOB_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from okvis2_amd import capi, synth
+import oracle_lib as O, gpu_common as G
+for (w, h, radius, thr, maxk) in ((752, 480, 38.0, 150, 700), (1024, 128, 20.0, 60, 500), (512, 256, 12.0, 40, 800)):
+    for seed in (1, 2):
+        img = synth.corners_image(w, h, seed) if seed == 1 else synth.noise_image(w, h, seed)
+        fe = capi.Frontend(w, h, radius, 0, thr, maxk, max_candidates=1 << 15)
+        ref = O.detect(img, radius, 0, thr, maxk)
+        assert len(ref) > 10
+        G.assert_keypoints_equal(fe.detect(img), ref)
+print("KNOB-OK")
+"""
+
+
+@pytest.mark.parametrize("knob", ["OKVFE_LEGACY_SORT", "OKVFE_K1_NOPACK", "OKVFE_SELECT_OCC_HBM",
+                                  "OKVFE_LEGACY_SELECT"])
+def test_ab_knobs_keep_their_paths_exact(oracle, knob):
+    """The A/B switches the profiling notes refer to (read once per process, hence a child process
+    each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
+    grid in HBM, one-accept-per-round selection.  Each must stay bit-exact."""
+    env = dict(os.environ)
+    env[knob] = "1"
+    out = subprocess.run([sys.executable, "-c", _KNOB_CHILD, ROOT], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "KNOB-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_profile_stage_mask():
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg, max_batch=2)
