@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define OKVFE_ABI_VERSION 2
+#define OKVFE_ABI_VERSION 3
 #define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
@@ -207,11 +207,18 @@ typedef struct okvfe_device_outputs {
   const uint8_t* descriptors;    /* [max_batch][max_keypoints][48] */
   const double* backproj;        /* [max_batch][max_keypoints][3] */
   const uint8_t* backproj_valid; /* [max_batch][max_keypoints] */
-  const int32_t* scores;         /* [max_batch][H][W] Harris score maps */
+  const int32_t* scores;         /* [max_batch][H][score_pitch] score maps of the last detect call (layer 0);
+                                  * pixel (x, y) at y * score_pitch + okvfe_score_column(ctx, x) */
   const int32_t* detect_counts;  /* [max_batch] keypoints before descriptor-stage removal */
   const int32_t* candidate_counts; /* [max_batch] NMS maxima found (may exceed capacity) */
+  int32_t score_pitch;           /* ints per score-map row (>= W: the fused score+NMS kernel pads rows so that
+                                  * every wave stores whole 128-byte lines) */
+  int32_t score_strips;          /* 0 / 1: dense rows; >= 2: column x sits at okvfe_score_column(ctx, x) */
 } okvfe_device_outputs;
 okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out);
+/* Column of pixel x within a row of okvfe_device_outputs.scores (x itself for dense maps).  For a
+ * dense copy of the score map use okvfe_harris_score_device. */
+int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x);
 
 /* NMS candidate capacity check of the last batch (synchronises; one small copy): an image whose
  * score map had more maxima than the context's candidate capacity (okvfe_config.max_candidates)

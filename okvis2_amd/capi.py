@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("OKVFE_LIB") or os.path.join(_HERE, "libokvfe.so")  # 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
     ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
-ABI_VERSION = 2
+ABI_VERSION = 3
 SCORE_HARRIS, SCORE_AGAST_9_16 = 0, 1
 DESC_BYTES = 48
 
@@ -59,14 +59,15 @@ class DeviceOutputs(C.Structure):
     _fields_ = [("max_keypoints", C.c_int32), ("counts", C.c_void_p), ("keypoints", C.c_void_p),
                 ("descriptors", C.c_void_p), ("backproj", C.c_void_p),
                 ("backproj_valid", C.c_void_p), ("scores", C.c_void_p),
-                ("detect_counts", C.c_void_p), ("candidate_counts", C.c_void_p)]
+                ("detect_counts", C.c_void_p), ("candidate_counts", C.c_void_p),
+                ("score_pitch", C.c_int32), ("score_strips", C.c_int32)]
 
 
 EXPORTS = [
     "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
     "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
     "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_describe_batch_device",
-    "okvfe_get_device_outputs", "okvfe_download_image_result", "okvfe_harris_score_device",
+    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_download_image_result", "okvfe_harris_score_device",
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",

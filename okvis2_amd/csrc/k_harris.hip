@@ -248,6 +248,11 @@ __device__ __forceinline__ int from_right(int v) {  // value of lane+1
 }
 
 constexpr int kStripLanes = 62;
+// Gradients on the matrix pipe (v_mfma_i32_4x4x4i8) unless built with -DOKVFE_K1_VALU_GRAD (A/B):
+// bit-exact, and with the slotted score layout 0.658 -> 0.635 ms per 1536 EuRoC images.
+#if !defined(OKVFE_K1_VALU_GRAD) && !defined(OKVFE_K1_MFMA)
+#define OKVFE_K1_MFMA 1
+#endif
 #ifndef OKVFE_K1_WAVES
 #define OKVFE_K1_WAVES __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
@@ -330,7 +335,7 @@ constexpr int kSplitTests = 30;  // tiles of more than 32 rows: hit bits of the 
 //   * hit bits of rows that may not be maxima (y < 2, y >= h-2) are masked in the epilogue.
 template <int kTHF, bool NMS, bool PACK = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
-    const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int strips,
+    const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
     int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
   constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
   static_assert(kMain % 6 == 0 && kTHF <= 61, "rows per wave: 6k (+1 with the fused NMS), <= 61");
@@ -396,13 +401,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // the row loop; the row offset rides in the scalar offset operand
   const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(images + img_off), 0, w * h * group_images, 0x00027000);
+  // score map: `pitch` ints per row, slotted layout (okvfe_internal.h, ScoreLayout): strip s of a row
+  // has the 1024-byte slot s, lane l of the strip writes bytes [16 l, 16 l + 16) of it
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      scores + img_off, 0, w * h * 4 * group_images, 0x00027000);
-  const int sub_off = PACK ? sub * w * h : 0;  // pixel offset of this lane's image in the group
-  const int ld_off = dcl * 4 + sub_off;  // byte offset of this lane's dword within a pixel row
-  // halo lanes (and lanes past the image) store nowhere: their per-lane offset lies outside the
-  // resource, so the hardware range check drops the store (the scalar offset is not range-checked)
-  const int st_off = store ? dcl * 16 + sub_off * 4 : 0x7FFFFFF0;
+      scores + (size_t)image * (size_t)pitch * (size_t)h, 0, pitch * h * 4 * group_images, 0x00027000);
+  const int ld_off = dcl * 4 + (PACK ? sub * w * h : 0);  // byte offset of this lane's dword within a pixel row
+  // EVERY lane whose slot position lies inside the row stores -- halo lanes and lanes past the
+  // image write pad columns nobody reads -- so that a store instruction covers whole 128-byte
+  // lines; lanes outside the row (and idle lanes of a packed wave) get a per-lane offset outside the
+  // resource, which the hardware range check drops (the scalar offset is not range-checked)
+  // (the stand-alone score kernel, NMS = false, writes the dense map: pitch == w, owners only)
+  // and so does the fused kernel under the OKVFE_K1_DENSE A/B knob (pitch == w)
+  const bool slotted = NMS && pitch != w;
+  const int slot_q = slotted ? d + 2 * strip : d;  // quad position within the (padded) row
+  const bool st_on = slotted ? (lane_on && slot_q * 4 < pitch) : store;
+  const int st_off = st_on ? slot_q * 16 + (PACK ? sub * pitch * h * 4 : 0) : 0x7FFFFFF0;
   int m0 = d == 0 ? 0 : -1;        // column 0 is rim
   int m3 = d == nd - 1 ? 0 : -1;   // column w-1 is rim
   // keep the masks as opaque VGPR values: "x & m" then stays a 2-cycle v_and_b32 instead of being
@@ -418,8 +431,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
 
   int pr[3][4];      // rolling pixel rows (own 4 columns)
 #ifdef OKVFE_K1_MFMA
-  // EXPERIMENT (off by default; bit-exact, measured 0.700 ms against 0.710 ms per 1536 images):
-  // gradients on the matrix pipe.  v_mfma_i32_4x4x4i8 runs one 4x4x4 product per group of 4 lanes:
+  // Gradients on the matrix pipe (default; -DOKVFE_K1_VALU_GRAD builds the vector-ALU form).  v_mfma_i32_4x4x4i8 runs one 4x4x4 product per group of 4 lanes:
   // D[i] of a lane = sum_k A[i][k] * B_lane[k], with row i of A supplied by lane 4b + i -- i.e. FOUR
   // different 4-tap dot products of the lane's own B dword in one issue slot (4.2 cycles beside the
   // vector ALU, tools/ubench/mfma4_test.hip).  B = a 4-pixel window of one pixel row (bytes - 128:
@@ -585,34 +597,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   auto store_row = [&](const int sc[4], int y) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = {sc[0], sc[1], sc[2], sc[3]};
-#if defined(OKVFE_K1_ALIGNED_STORE_EXPERIMENT)
-    // bandwidth experiment only (results are garbage): every lane stores, strips are 1024 B apart and
-    // rows 3072 B apart, so that every store instruction writes eight whole 128-byte lines
-#if OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 1   // 1024-byte segments, rows 3072 B apart: whole lines only
-    if (y < h - 12)
-      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (strip * 64 + lane) * 16, y * 3072, OKVFE_K1_STORE_AUX);
-#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 2  // 1024-byte segments at 64-byte (not 128-byte) aligned rows
-    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (strip * 64 + lane) * 16, y * 3008, OKVFE_K1_STORE_AUX);
-#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 3  // the real 62 / 63-lane segments, each in its own 1024-byte slot
-    if (y < h - 12)
-      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, store ? (strip * 64 + lane) * 16 : 0x7FFFFFF0, y * 3072,
-                                             OKVFE_K1_STORE_AUX);
-#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 5  // the real segments (62 / 63 lanes, contiguous), rows padded to 3072 B
-    if (y < h - 12) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * 3072, OKVFE_K1_STORE_AUX);
-#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 6  // like 5 and the last strip also writes the 64-byte pad of the row
-    if (y < h - 12)
-      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, (store || (last_strip && d < nd + 4)) ? d * 16 : 0x7FFFFFF0,
-                                             y * 3072, OKVFE_K1_STORE_AUX);
-#elif OKVFE_K1_ALIGNED_STORE_EXPERIMENT == 4  // like 3, segments shifted to start on a line (lane - 1)
-    if (y < h - 12)
-      __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc,
-                                             store ? (strip * 64 + lane - (strip ? 1 : 0)) * 16 : 0x7FFFFFF0, y * 3072,
-                                             OKVFE_K1_STORE_AUX);
-#endif
-#elif !defined(OKVFE_K1_NOSTORE)
-    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, OKVFE_K1_STORE_AUX);
+#if !defined(OKVFE_K1_NOSTORE)
+    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, OKVFE_K1_STORE_AUX);
 #else
-    if (v.x == 0x12345678 && v.y == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * w * 4, 0);
+    if (v.x == 0x12345678 && v.y == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, 0);
 #endif
   };
   // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc): optionally test centre row y-1, then
@@ -868,7 +856,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
           if (e < kScoreSlots)
             cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
           else
-            cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * w * 4, 1);
+            cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * pitch * 4, 1);
           if (pos < nms.cand_cap) outc[pos] = cd;
           ++pos;
         }
@@ -882,16 +870,35 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
 
 }  // namespace
 
+static int harris_strips(int w) {  // strips of 62 quads (+ halo lanes) covering a row; the last may be narrow
+  const int nd = w >> 2;
+  int strips = 1;
+  while ((strips - 1) * kStripLanes + 64 < nd) ++strips;  // last strip must reach dword nd-1
+  return strips;
+}
+
+ScoreLayout harris_nms_layout(int w, int h) {
+  (void)h;
+  static const bool off = getenv("OKVFE_NO_FUSED_NMS") != nullptr;  // A/B knob for profiling
+  if (off || w % 4 != 0) return ScoreLayout{w, 0};
+  const int strips = harris_strips(w);
+  static const bool dense = getenv("OKVFE_K1_DENSE") != nullptr;  // A/B knob: fused kernel, dense map
+  if (strips == 1 || dense) return ScoreLayout{w, 1};
+  const int pitch = ((w + 8 * (strips - 1)) + 31) & ~31;
+  return ScoreLayout{pitch, strips};
+}
+
 static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, int32_t* score,
-                               const NmsOut* nms, hipStream_t stream) {
+                               ScoreLayout layout, const NmsOut* nms, hipStream_t stream) {
   if (n_images <= 0) return true;
   const dim3 block(64, kWavesPerBlock, 1);
   const bool aligned = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) &&
                        ((reinterpret_cast<uintptr_t>(score) & 15) == 0);
   if (aligned) {
     const int nd = w >> 2;
-    int strips = 1;
-    while ((strips - 1) * kStripLanes + 64 < nd) ++strips;  // last strip must reach dword nd-1
+    const int strips = harris_strips(w);
+    // the caller's map must be the fused kernel's layout (or dense: strips == 1, pitch == w)
+    if (nms && !(layout.strips == strips || (layout.strips == 1 && layout.pitch == w))) return false;
     static const int th_env = [] {
       const char* e = getenv("OKVFE_K1_TH");  // A/B knob: rows per wave of the fused kernel (25..61)
       return e ? atoi(e) : 0;
@@ -911,11 +918,11 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
       const int main_blocks = ytiles * n_images * OKVFE_K1_SGROUPS(strips - 1);                  \
       const int groups = (n_images + pack_g - 1) / pack_g;                                       \
       hipLaunchKernelGGL((harris_kernel<TH, true, true>), dim3(main_blocks + groups * ytiles_blk), \
-                         block, 0, stream, img, w, h, score, strips - 1, ytiles, n_images, *nms, \
+                         block, 0, stream, img, w, h, score, layout.pitch, strips - 1, ytiles, n_images, *nms, \
                          pack_g, pack_u, main_blocks);                                           \
     } else {                                                                                     \
       hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0,  \
-                         stream, img, w, h, score, strips, ytiles, n_images, *nms, 1, 64, 0);    \
+                         stream, img, w, h, score, layout.pitch, strips, ytiles, n_images, *nms, 1, 64, 0);    \
     }                                                                                            \
   }
     static const bool no_pack = getenv("OKVFE_K1_NOPACK") != nullptr;  // A/B knob
@@ -935,7 +942,7 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
       OKVFE_K1_TILING(30)
       (void)ytiles_blk;
       hipLaunchKernelGGL((harris_kernel<30, false>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0, stream,
-                         img, w, h, score, strips, ytiles, n_images, NmsOut{}, 1, 64, 0);
+                         img, w, h, score, w, strips, ytiles, n_images, NmsOut{}, 1, 64, 0);
     }
 #undef OKVFE_K1_NMS_LAUNCH
 #undef OKVFE_K1_TILING
@@ -951,16 +958,15 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
 
 void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                    hipStream_t stream) {
-  (void)launch_harris_impl(img, w, h, n_images, score, nullptr, stream);
+  (void)launch_harris_impl(img, w, h, n_images, score, ScoreLayout{w, 0}, nullptr, stream);
 }
 
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
-                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
-                       int32_t* fix_count, hipStream_t stream) {
-  static const bool off = getenv("OKVFE_NO_FUSED_NMS") != nullptr;  // A/B knob for profiling
-  if (off) return false;
+                       ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
+                       int32_t* cand_count, int32_t* fix_count, hipStream_t stream) {
+  if (layout.strips < 1) return false;
   const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count};
-  return launch_harris_impl(img, w, h, n_images, score, &nms, stream);
+  return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream);
 }
 
 }  // namespace okvfe

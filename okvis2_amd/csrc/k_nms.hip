@@ -23,30 +23,44 @@
 namespace okvfe {
 namespace {
 
-__device__ __forceinline__ bool passes(const int32_t* __restrict__ s, int w, int x, int y, int thr) {
-  const int32_t* c = s + (size_t)y * w + x;
-  const int v = c[0];
+// score-map accessors: Dense = pitch w, Slotted = the fused kernel's layout (okvfe_internal.h)
+struct DenseMap {
+  const int32_t* __restrict__ s;
+  int w;
+  __device__ __forceinline__ int at(int x, int y) const { return s[(size_t)y * w + x]; }
+};
+struct LayoutMap {
+  const int32_t* __restrict__ s;
+  ScoreLayout L;
+  __device__ __forceinline__ int at(int x, int y) const { return s[score_index(L, x, y)]; }
+};
+
+template <class Map>
+__device__ __forceinline__ bool passes(const Map& m, int x, int y, int thr) {
+  const int v = m.at(x, y);
   if (v < thr) return false;
-  if (c[1] > v || c[-1] > v) return false;
-  const int32_t* p1 = c + w;
-  const int32_t* p2 = c - w;
-  if (p1[0] > v || p2[0] > v) return false;
-  if (p1[1] > v || p1[-1] > v || p2[1] > v || p2[-1] > v) return false;
+  if (m.at(x + 1, y) > v || m.at(x - 1, y) > v) return false;
+  if (m.at(x, y + 1) > v || m.at(x, y - 1) > v) return false;
+  if (m.at(x + 1, y + 1) > v || m.at(x - 1, y + 1) > v || m.at(x + 1, y - 1) > v || m.at(x - 1, y - 1) > v)
+    return false;
   return true;
 }
 
 // accepted(x) of the raster scan for a pixel that passes: parity of the run of passing pixels
 // immediately to its left
-__device__ __forceinline__ bool accepted_slow(const int32_t* __restrict__ s, int w, int x, int y,
-                                              int thr) {
-  if (x < 2 || x >= w - 2 || !passes(s, w, x, y, thr)) return false;
+template <class Map>
+__device__ __forceinline__ bool accepted_slow(const Map& m, int w, int x, int y, int thr) {
+  if (x < 2 || x >= w - 2 || !passes(m, x, y, thr)) return false;
   int run = 0;
   int xx = x - 1;
-  while (xx >= 2 && passes(s, w, xx, y, thr)) {
+  while (xx >= 2 && passes(m, xx, y, thr)) {
     ++run;
     --xx;
   }
   return (run & 1) == 0;
+}
+__device__ __forceinline__ bool accepted_slow(const int32_t* __restrict__ s, int w, int x, int y, int thr) {
+  return accepted_slow(DenseMap{s, w}, w, x, y, thr);
 }
 
 // ---- generic kernel (any width): one lane = 4 pixels of one row ---------------------------------
@@ -237,7 +251,8 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
 // Settles the candidates the fused score+NMS kernel flagged (runs of horizontally adjacent equal
 // maxima): with the score map complete, accepted_slow applies the raster-scan rule exactly; the
 // rejected ones are removed from the (unordered) list.  One block per image, idle unless flagged.
-__global__ __launch_bounds__(256) void nms_fixup_kernel(const int32_t* __restrict__ scores, int w,
+__global__ __launch_bounds__(256) void nms_fixup_kernel(const int32_t* __restrict__ scores,
+                                                        ScoreLayout layout, int w,
                                                         int h, int thr, Candidate* __restrict__ cand,
                                                         int cand_cap,
                                                         int32_t* __restrict__ cand_count,
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(256) void nms_fixup_kernel(const int32_t* __restric
   __shared__ int s_base;
   const int img = blockIdx.x;
   if (fix_count[img] == 0) return;
-  const int32_t* s = scores + (size_t)img * w * h;
+  const LayoutMap s{scores + (size_t)img * layout.pitch * h, layout};
   Candidate* c = cand + (size_t)img * cand_cap;
   const int total = cand_count[img];
   const int n = total < cand_cap ? total : cand_cap;
@@ -283,11 +298,11 @@ __global__ __launch_bounds__(256) void nms_fixup_kernel(const int32_t* __restric
 
 }  // namespace
 
-void launch_nms_fixup(const int32_t* score, int w, int h, int n_images, int abs_threshold,
-                      Candidate* cand, int cand_cap, int32_t* cand_count,
+void launch_nms_fixup(const int32_t* score, ScoreLayout layout, int w, int h, int n_images,
+                      int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
                       const int32_t* fix_count, hipStream_t stream) {
   if (n_images <= 0) return;
-  hipLaunchKernelGGL(nms_fixup_kernel, dim3(n_images), dim3(256), 0, stream, score, w, h,
+  hipLaunchKernelGGL(nms_fixup_kernel, dim3(n_images), dim3(256), 0, stream, score, layout, w, h,
                      abs_threshold, cand, cand_cap, cand_count, fix_count);
 }
 

@@ -67,8 +67,8 @@ __device__ __forceinline__ int floor_div(int a, int b) {  // b > 0
 }
 // no strictly greater score within +-1 px (other layer's pixels) of the corresponding location;
 // rn / rd = scale of this layer / scale of the other one (oracle: orc_scale_neighbour_ok)
-__device__ bool neighbour_ok(const int32_t* __restrict__ other, int wo, int ho, int x, int y, int32_t s,
-                             int rn, int rd) {
+__device__ bool neighbour_ok(const int32_t* __restrict__ other, const ScoreLayout& lo, int wo, int ho, int x,
+                             int y, int32_t s, int rn, int rd) {
   const int D = 2 * rd;
   const int Nx = (2 * x + 1) * rn - rd, Ny = (2 * y + 1) * rn - rd;
   int u0 = -floor_div(-(Nx - D), D), u1 = floor_div(Nx + D, D);
@@ -79,7 +79,7 @@ __device__ bool neighbour_ok(const int32_t* __restrict__ other, int wo, int ho, 
   v1 = min(v1, ho - 1);
   for (int v = v0; v <= v1; ++v)
     for (int u = u0; u <= u1; ++u)
-      if (other[(size_t)v * wo + u] > s) return false;
+      if (other[score_index(lo, u, v)] > s) return false;
   return true;
 }
 
@@ -87,8 +87,8 @@ __device__ bool neighbour_ok(const int32_t* __restrict__ other, int wo, int ho, 
 // their relative order (which is arbitrary anyway: the sort that follows fixes the order).
 __global__ __launch_bounds__(256) void scale_filter_kernel(
     Candidate* __restrict__ cand, int cand_cap, int32_t* __restrict__ cand_count,
-    const int32_t* __restrict__ below, int wb, int hb, int rn_b, int rd_b,
-    const int32_t* __restrict__ above, int wa, int ha, int rn_a, int rd_a) {
+    const int32_t* __restrict__ below, ScoreLayout lb, int wb, int hb, int rn_b, int rd_b,
+    const int32_t* __restrict__ above, ScoreLayout la, int wa, int ha, int rn_a, int rd_a) {
   __shared__ int wave_cnt[4];
   __shared__ int s_base;
   const int img = blockIdx.x;
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void scale_filter_kernel(
   Candidate* c = cand + (size_t)img * cand_cap;
   const int total = cand_count[img];
   const int n = total > cand_cap ? 0 : total;  // an overflowed list is dropped downstream anyway
-  const int32_t* sb = below ? below + (size_t)img * wb * hb : nullptr;
-  const int32_t* sa = above ? above + (size_t)img * wa * ha : nullptr;
+  const int32_t* sb = below ? below + (size_t)img * lb.pitch * hb : nullptr;
+  const int32_t* sa = above ? above + (size_t)img * la.pitch * ha : nullptr;
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int base = 0; base < n; base += 256) {
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void scale_filter_kernel(
     if (i < n) {
       cd = c[i];
       keep = true;
-      if (sb) keep = neighbour_ok(sb, wb, hb, cd.x, cd.y, cd.score, rn_b, rd_b);
-      if (keep && sa) keep = neighbour_ok(sa, wa, ha, cd.x, cd.y, cd.score, rn_a, rd_a);
+      if (sb) keep = neighbour_ok(sb, lb, wb, hb, cd.x, cd.y, cd.score, rn_b, rd_b);
+      if (keep && sa) keep = neighbour_ok(sa, la, wa, ha, cd.x, cd.y, cd.score, rn_a, rd_a);
     }
     const unsigned long long b = __ballot(keep);
     if (lane == 0) wave_cnt[wv] = __popcll(b);
@@ -171,11 +171,12 @@ void launch_twothird(const uint8_t* src, int w, int h, int n_images, uint8_t* ds
                      dst, bw, bh);
 }
 void launch_scale_filter(Candidate* cand, int cand_cap, int32_t* cand_count, int n_images,
-                         const int32_t* below, int wb, int hb, int rn_b, int rd_b, const int32_t* above,
-                         int wa, int ha, int rn_a, int rd_a, hipStream_t stream) {
+                         const int32_t* below, ScoreLayout lb, int wb, int hb, int rn_b, int rd_b,
+                         const int32_t* above, ScoreLayout la, int wa, int ha, int rn_a, int rd_a,
+                         hipStream_t stream) {
   if (n_images <= 0) return;
   hipLaunchKernelGGL(scale_filter_kernel, dim3(n_images), dim3(256), 0, stream, cand, cand_cap, cand_count,
-                     below, wb, hb, rn_b, rd_b, above, wa, ha, rn_a, rd_a);
+                     below, lb, wb, hb, rn_b, rd_b, above, la, wa, ha, rn_a, rd_a);
 }
 void launch_merge_layers(const okvfe_keypoint* const* kps, const int32_t* const* counts, const float* scale,
                          int n_layers, int layer_cap, int n_images, okvfe_keypoint* out, int out_cap,

@@ -364,7 +364,7 @@ __device__ void subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
 
 template <bool OCC_LDS>
 __global__ __launch_bounds__(kThreads) void select_kernel(
-    const int32_t* __restrict__ scores, int w, int h, const Candidate* __restrict__ cand,
+    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, const Candidate* __restrict__ cand,
     int cand_cap, const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws,
     int ws_stride, float radius, int max_kpts, const float* __restrict__ lut,
     uint8_t* __restrict__ occ_ws, size_t occ_image_bytes, int occ_rows, int occ_cols,
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
   // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
   n = n > cand_cap ? 0 : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * w * h;
+  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
 
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx)
-        patch[(dy + 1) * 3 + (dx + 1)] = sc[(size_t)(v + dy) * w + (u + dx)];
+        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
     float ddx, ddy;
     subpixel2d(patch, &ddx, &ddy);
     okvfe_keypoint kp;
@@ -525,7 +525,7 @@ constexpr int kRoundCap = 64;
 // AccT: type of the accepted-candidate indices kept in LDS (u16 while the candidate capacity allows).
 template <bool OCC_LDS, typename AccT>
 __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
-    const int32_t* __restrict__ scores, int w, int h, int cand_cap,
+    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int occ_cols, int occ_bytes16,
     int acc_bytes16, int chunk_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
   // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
   n = n > cand_cap ? 0 : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * w * h;
+  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
 #ifdef OKVFE_SELECT_STATS
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx)
-        patch[(dy + 1) * 3 + (dx + 1)] = sc[(size_t)(v + dy) * w + (u + dx)];
+        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
     float ddx, ddy;
     subpixel2d(patch, &ddx, &ddy);
     okvfe_keypoint kp;
@@ -790,7 +790,7 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
                        2 * kLdsSortKeys);
 }
 
-void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
+void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_image_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
@@ -818,7 +818,7 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
       const size_t lds = fixed + chunk * 8;
 #define OKVFE_SELECT_LAUNCH(LDS, T, BYTES, OCC, PITCH)                                           \
   hipLaunchKernelGGL((select_greedy_kernel<LDS, T>), dim3(n_images), dim3(kSelThreads), BYTES,   \
-                     stream, score, w, h, cand_cap, cand_count, sort_ws, ws_stride, radius,      \
+                     stream, score, layout, w, h, cand_cap, cand_count, sort_ws, ws_stride, radius, \
                      max_kpts, lut, occ_cols, (int)occ_bytes, (int)acc_bytes, (int)chunk, kps,   \
                      kp_cap, kp_count, OCC, PITCH)
       if (wide)
@@ -843,13 +843,13 @@ void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* 
 #undef OKVFE_SELECT_LAUNCH
   if (occ_lds) {
     hipLaunchKernelGGL(select_kernel<true>, dim3(n_images), dim3(kThreads), occ_bytes, stream,
-                       score, w, h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius,
+                       score, layout, w, h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius,
                        max_kpts, lut, occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap,
                        kp_count);
   } else {
     if (radius > 0.0f)
       (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
-    hipLaunchKernelGGL(select_kernel<false>, dim3(n_images), dim3(kThreads), 0, stream, score, w,
+    hipLaunchKernelGGL(select_kernel<false>, dim3(n_images), dim3(kThreads), 0, stream, score, layout, w,
                        h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
                        occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap, kp_count);
   }

@@ -33,6 +33,7 @@ struct okvfe_ctx {
 
   std::vector<void*> allocs;
   int32_t* d_scores = nullptr;
+  ScoreLayout score_layout{0, 0};  // of d_scores: slotted where the fused score+NMS kernel applies
   Candidate* d_cand = nullptr;
   int32_t* d_cand_count = nullptr;
   uint64_t* d_sort_ws = nullptr;
@@ -484,7 +485,10 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     const bool detects = n_layers == 1;  // a scale-space parent detects in its children
     const bool describes = !child;
     if (detects) {
-      A(d_scores, P * B);
+      // AGAST score maps and maps of the unfused fall-back are dense; the fused Harris kernel
+      // writes its slotted layout (okvfe_internal.h)
+      c->score_layout = cfg->score_type == OKVFE_SCORE_HARRIS ? harris_nms_layout(c->w, c->h) : ScoreLayout{c->w, 0};
+      A(d_scores, (size_t)c->score_layout.pitch * c->h * B);
       A(d_cand, (size_t)c->cand_cap * B);
       A(d_cand_count, 2 * B);
       A(d_sort_ws, (size_t)c->ws_stride * B);
@@ -550,6 +554,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
       }
       // single-scale views of the parent (score map of the full-resolution layer etc.)
       c->d_scores = c->layers[0]->d_scores;
+      c->score_layout = c->layers[0]->score_layout;
       c->d_cand_count = c->layers[0]->d_cand_count;
       c->cand_cap = c->layers[0]->cand_cap;
     }
@@ -739,14 +744,16 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
     *fused = false;
     return;
   }
-  *fused = launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->cfg.absolute_threshold,
-                             L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count, s);
+  // a slotted score layout exists only where the fused kernel applies (decided at creation)
+  *fused = L->score_layout.strips >= 1 &&
+           launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->score_layout,
+                             L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count, s);
   if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
 }
 void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
   int32_t* d_fix_count = L->d_cand_count + L->B;
   if (fused)
-    launch_nms_fixup(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
+    launch_nms_fixup(L->d_scores, L->score_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
                      L->d_cand_count, d_fix_count, s);
   else
     launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
@@ -756,7 +763,7 @@ void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
   launch_sort(L->d_cand, L->cand_cap, L->d_cand_count, n_images, L->cfg.uniformity_radius, L->d_sort_ws, s);
 }
 void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
-  launch_select(L->d_scores, L->w, L->h, n_images, L->d_cand, L->cand_cap, L->d_cand_count,
+  launch_select(L->d_scores, L->score_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap, L->d_cand_count,
                 L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ, L->occ_image_bytes,
                 L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count, L->d_sort_ws, s);
 }
@@ -821,6 +828,7 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
         int sn, sd;
         layer_scale(l, &sn, &sd);
         const int32_t *below = nullptr, *above = nullptr;
+        ScoreLayout lb{0, 0}, la{0, 0};
         int rb[2] = {1, 1}, ra[2] = {1, 1};
         auto ratio = [&](int m, int out[2]) {  // scale_l / scale_m, reduced
           int mn, md;
@@ -830,10 +838,10 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
             while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
           out[0] = rn; out[1] = rd;
         };
-        if (l > 0) { below = ctx->layers[l - 1]->d_scores; ratio(l - 1, rb); }
-        if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; ratio(l + 1, ra); }
-        launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below,
-                            l > 0 ? ctx->layer_w[l - 1] : 0, l > 0 ? ctx->layer_h[l - 1] : 0, rb[0], rb[1], above,
+        if (l > 0) { below = ctx->layers[l - 1]->d_scores; lb = ctx->layers[l - 1]->score_layout; ratio(l - 1, rb); }
+        if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; la = ctx->layers[l + 1]->score_layout; ratio(l + 1, ra); }
+        launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below, lb,
+                            l > 0 ? ctx->layer_w[l - 1] : 0, l > 0 ? ctx->layer_h[l - 1] : 0, rb[0], rb[1], above, la,
                             l + 1 < L ? ctx->layer_w[l + 1] : 0, l + 1 < L ? ctx->layer_h[l + 1] : 0, ra[0], ra[1], s);
       }
     }
@@ -1003,7 +1011,13 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
   out->scores = ctx->d_scores;
   out->detect_counts = ctx->d_det_count;
   out->candidate_counts = ctx->d_cand_count;
+  out->score_pitch = ctx->score_layout.pitch;
+  out->score_strips = ctx->score_layout.strips;
   return OKVFE_OK;
+}
+
+int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x) {
+  return ctx ? score_col(ctx->score_layout, x) : x;
 }
 
 okvfe_status okvfe_check_capacity(okvfe_ctx* ctx, int32_t n_images, int32_t* first_overflowed) {

@@ -86,6 +86,31 @@ struct PairParams {  // one stereo pair on device
 };
 constexpr int kSizeClasses = 8;
 
+// Layout of a context's int32 score map in HBM.
+//   dense   (strips <= 1): pixel (x, y) at y * pitch + x, pitch == w;
+//   slotted (strips >= 2): what the fused score+NMS kernel (k_harris.hip) writes.  A wave of that
+//     kernel owns a strip of 62 dwords-of-pixels (quads) of a row plus one halo lane on either side;
+//     in the slotted layout every strip has a 1024-byte slot of its own in the row and ALL 64 lanes
+//     store, so that each store instruction writes eight whole 128-byte lines (partial-line stores
+//     cost the memory system as much as whole lines: profiles/round2_k1_store_pattern.txt).  Quad
+//     d = x >> 2 belongs to strip s(d) = d <= 62 ? 0 : min((d - 1) / 62, strips - 1) and sits at
+//     column x + 8 * s(d); the 2 * s quads in between are pad (halo-lane values, never read).
+//     pitch = 4 * (w / 4 + 2 * (strips - 1)) rounded up to 32 ints (128 bytes).
+struct ScoreLayout {
+  int32_t pitch;   // ints per row
+  int32_t strips;  // 0 / 1 = dense
+};
+__host__ __device__ inline int score_col(const ScoreLayout& L, int x) {
+  if (L.strips <= 1) return x;
+  const int d = x >> 2;
+  int s = d <= 62 ? 0 : (d - 1) / 62;
+  s = s > L.strips - 1 ? L.strips - 1 : s;
+  return x + 8 * s;
+}
+__host__ __device__ inline size_t score_index(const ScoreLayout& L, int x, int y) {
+  return (size_t)y * (size_t)L.pitch + (size_t)score_col(L, x);
+}
+
 }  // namespace okvfe
 
 // XCD-aware tile mapping (device): the dispatcher is observed to place linear workgroup id L on
@@ -125,16 +150,18 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 // width, >32 rows per wave): the caller then runs launch_harris + launch_nms.  Must be followed by
 // launch_nms_fixup.
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
-                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
-                       int32_t* fix_count, hipStream_t stream);
-void launch_nms_fixup(const int32_t* score, int w, int h, int n_images, int abs_threshold,
-                      Candidate* cand, int cand_cap, int32_t* cand_count,
+                       ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
+                       int32_t* cand_count, int32_t* fix_count, hipStream_t stream);
+// the layout launch_harris_nms writes for w x h images (dense when the fused kernel does not apply)
+ScoreLayout harris_nms_layout(int w, int h);
+void launch_nms_fixup(const int32_t* score, ScoreLayout layout, int w, int h, int n_images,
+                      int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
                       const int32_t* fix_count, hipStream_t stream);
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
                  float radius, uint64_t* sort_ws, hipStream_t stream);
-void launch_select(const int32_t* score, int w, int h, int n_images, Candidate* cand,
+void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
@@ -206,8 +233,9 @@ void launch_compact_landmarks(const int32_t* status, const int32_t* n_desc, cons
 void launch_halfsample(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);
 void launch_twothird(const uint8_t* src, int w, int h, int n_images, uint8_t* dst, hipStream_t stream);
 void launch_scale_filter(Candidate* cand, int cand_cap, int32_t* cand_count, int n_images,
-                         const int32_t* below, int wb, int hb, int rn_b, int rd_b, const int32_t* above,
-                         int wa, int ha, int rn_a, int rd_a, hipStream_t stream);
+                         const int32_t* below, ScoreLayout lb, int wb, int hb, int rn_b, int rd_b,
+                         const int32_t* above, ScoreLayout la, int wa, int ha, int rn_a, int rd_a,
+                         hipStream_t stream);
 void launch_merge_layers(const okvfe_keypoint* const* kps, const int32_t* const* counts, const float* scale,
                          int n_layers, int layer_cap, int n_images, okvfe_keypoint* out, int out_cap,
                          int32_t* out_count, hipStream_t stream);
