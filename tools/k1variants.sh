@@ -6,8 +6,8 @@ cd $(dirname $0)/../okvis2_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
-  /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c k_harris.hip -o build/k_harris_$name.o
-  objs=$(ls build/*.o | grep -v k_harris)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libokvfe_$name.so build/k_harris_$name.o $objs
+  /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c k_harris.hip -o /tmp/k_harris_$name.o
+  objs=$(ls build/*.hip.o build/*.cpp.o | grep -v k_harris)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libokvfe_$name.so /tmp/k_harris_$name.o $objs
   echo built libokvfe_$name.so
 done

@@ -11,6 +11,6 @@ if [ -n "$sedx" ]; then sed "$sedx" $file > /tmp/variant_$name.hip; src=/tmp/var
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -I. -I../../include"
 mkdir -p /tmp/variant_obj
 /opt/rocm/bin/hipcc $FLAGS $defs -x hip -c $src -o /tmp/variant_obj/$name.o
-objs=$(ls build/*.o | grep -v "build/$file.o")
+objs=$(ls build/*.hip.o build/*.cpp.o | grep -v "build/$file.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libokvfe_$name.so /tmp/variant_obj/$name.o $objs
 echo built libokvfe_$name.so
