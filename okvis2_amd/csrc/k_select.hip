@@ -754,104 +754,107 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
 }
 
 
-// ---- lazy-occupancy selection: one WAVE per image, no grid, no barriers -------------------------
+// ---- lazy-occupancy selection: no grid, one workgroup of 4 waves per image ----------------------
 // The occupancy grid of the reference is only ever READ at the cells of candidates: a candidate
 // passes when its level is not below the grid value at its own cell, and that value is
 // min(255, sum over the points accepted so far within 15 cells of ceil(weight(offset) * 0.99 *
 // level(point))) -- every stamp adds a non-negative integer with u8 saturation, so the saturating
 // adds collapse into one clamp of the plain sum, in any order.  This kernel therefore keeps no grid:
 // accepted points go into spatial bins of 16 x 16 cells (singly linked lists in LDS, heads swapped in
-// with one LDS atomic), and a candidate's occupancy is evaluated on demand from the <= 3 x 3 bins
-// around its cell: nine list walks in flight per lane, ONE 4-byte link word per step, the weight
-// from a 64 x 64 table indexed by the biased offset (zero outside the stamp, so there is no range
-// test), the level from a sentinel-terminated array.  A window of 64 candidates is evaluated at
-// once; passing candidates without another passing candidate of the window within 15 cells are
-// accepted in one step, the others in order (a newly accepted point adds its weight to the later
-// lanes within reach, which re-evaluate their test) -- a window never restarts.
-// A workgroup = 4 waves = 4 images sharing the weight table; LDS per image ~ 14.5 KB for EuRoC,
-// and no workgroup barrier after the table load.
+// with one LDS atomic), and a candidate's occupancy is evaluated on demand from the 3 x 3 bins
+// around its cell.  Per window of 64 candidates (lane = candidate):
+//   walk (4 waves): the nine bin lists of a candidate are split over the waves (2 + 2 + 2 + 3),
+//     all of a wave's lists in flight per lane, ONE 4-byte link word per step; the weight comes
+//     from a 64 x 64 table indexed by the biased offset (zero outside the stamp: no range test),
+//     the level from an array with a zero sentinel (finished walks read it: no branch).  Partial
+//     sums go to LDS.
+//   accept (wave 0): passing candidates without another passing candidate of the window within 15
+//     cells are accepted in one step, the others in order (a newly accepted point adds its weight
+//     to the later lanes within reach, which re-evaluate their test) -- a window never restarts.
+//     Meanwhile waves 1-2 convert the next chunk of sorted keys into candidate records.
+// Two workgroup barriers per window.  LDS per image: table 16 KB + bin heads + 8 B per keypoint slot
+// + 128 candidate records ~ 25 KB for EuRoC: six images per CU (the grid kernel: two), and the
+// serial chain per image is ~3x shorter (the grid kernel paid ~3.4 k cycles per accepted point in
+// LDS round trips and barriers).
 // Slot layout: link = 4 * ((cy & 15) << 6 | (cx & 15)) in bits 0..11, (LDS address of the next
 // slot's link word) >> 2 in bits 16..31 (bits 12..15 zero, so link >> 14 IS that address); the
 // level array sits at a fixed distance; slot `cap` is the terminator (level 0, linked to itself).
 constexpr int kLazyChunk = 128;
+constexpr int kLazyLutBytes = 64 * 64 * 4;
+constexpr int kLazyThreads = 256;
 __device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
   return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>((uintptr_t)addr);
 }
 __device__ __forceinline__ float lds_f32(uint32_t addr) {
   return *reinterpret_cast<__attribute__((address_space(3))) const float*>((uintptr_t)addr);
 }
-constexpr int kLazyLutBytes = 64 * 64 * 4;
-constexpr int kLazyWaves = 4;
-
-__host__ __device__ inline size_t lazy_wave_bytes(int nbins, int cap) {
-
-  return (((size_t)nbins * 4 + 15) & ~(size_t)15) + 4 * (((size_t)(cap + 1) * 4 + 15) & ~(size_t)15) +
-         (size_t)kLazyChunk * 16;
+__host__ __device__ inline size_t lazy_align16(size_t v) { return (v + 15) & ~(size_t)15; }
+// table | heads of the bordered bin grid | link, level (cap + 1 slots each) | record chunk | partial sums
+__host__ __device__ inline size_t lazy_lds_bytes(int bins_x, int bins_y, int cap) {
+  return (size_t)kLazyLutBytes + lazy_align16((size_t)(bins_x + 2) * (bins_y + 2) * 4) +
+         2 * lazy_align16((size_t)(cap + 1) * 4) + (size_t)kLazyChunk * 16 + 4 * 64 * 4;
 }
 
-__global__ __launch_bounds__(64 * kLazyWaves) void select_lazy_kernel(
-    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int n_images, int cand_cap,
+__global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void select_lazy_kernel(
+    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
     okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int nbins = bins_x * bins_y;
+  __shared__ int s_kept;
+  const int bpitch = bins_x + 2;  // bordered bin grid: the border bins stay empty, so no range checks
+  const int nbins = bpitch * (bins_y + 2);
+  const size_t cap4 = lazy_align16((size_t)(cap + 1) * 4);
   float* lut_s = reinterpret_cast<float*>(smem_raw);
-
-  for (int i = threadIdx.x; i < 64 * 64; i += 64 * kLazyWaves) {
-    const int dx = (i & 63) - 32, dy = (i >> 6) - 32;
-    const bool in = dx >= -15 && dx <= 15 && dy >= -15 && dy <= 15;
-    lut_s[i] = in ? lut[(dy + 15) * 31 + (dx + 15)] : 0.0f;
-  }
-  __syncthreads();
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const int img = blockIdx.x * kLazyWaves + wave;
-  if (img >= n_images) return;
-  const size_t cap4 = ((size_t)(cap + 1) * 4 + 15) & ~(size_t)15;
-  unsigned char* q0 = smem_raw + kLazyLutBytes + (size_t)wave * lazy_wave_bytes(nbins, cap);
+  unsigned char* q0 = smem_raw + kLazyLutBytes;
   uint32_t* head = reinterpret_cast<uint32_t*>(q0);
-  q0 += ((size_t)nbins * 4 + 15) & ~(size_t)15;
-
+  q0 += lazy_align16((size_t)nbins * 4);
   uint32_t* link = reinterpret_cast<uint32_t*>(q0);
   float* pnsc = reinterpret_cast<float*>(q0 + cap4);
-  uint32_t* ppix = reinterpret_cast<uint32_t*>(q0 + 2 * cap4);
-  int32_t* pscore = reinterpret_cast<int32_t*>(q0 + 3 * cap4);
-  uint4* recs = reinterpret_cast<uint4*>(q0 + 4 * cap4);
+  uint4* recs = reinterpret_cast<uint4*>(q0 + 2 * cap4);
+  float* part = reinterpret_cast<float*>(q0 + 2 * cap4 + (size_t)kLazyChunk * 16);  // [4][64]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int img = blockIdx.x;
   int n = cand_count[img];
-
+  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
+  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
   n = n > cand_cap ? 0 : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
   const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
-
-  if (n > 0) {
-
+  if (n > 0) {  // block-uniform
+    // weight(dx, dy) at [(dy + 32) << 6 | (dx + 32)], zero outside the 31 x 31 stamp
+    for (int i = tid; i < 64 * 64; i += kLazyThreads) {
+      const int dx = (i & 63) - 32, dy = (i >> 6) - 32;
+      const bool in = dx >= -15 && dx <= 15 && dy >= -15 && dy <= 15;
+      lut_s[i] = in ? lut[(dy + 15) * 31 + (dx + 15)] : 0.0f;
+    }
     const uint32_t link_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)link;
     const uint32_t end_addr = link_addr + 4u * (uint32_t)cap;
     const uint32_t nsc_delta = (uint32_t)cap4;
     const uint32_t lut_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lut_s;
-    for (int i = lane; i < nbins; i += 64) head[i] = end_addr;
-    if (lane == 0) {
+    for (int i = tid; i < nbins; i += kLazyThreads) head[i] = end_addr;
+    if (tid == 0) {
       pnsc[cap] = 0.0f;
       link[cap] = (end_addr >> 2) << 16;
+      s_kept = 0;
     }
     const float scaling = (float)(15.0 / (double)radius);
     const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-
-    uint64_t kq[kLazyChunk / 64];
+    // candidates [base, base + kLazyChunk): keys are requested one chunk ahead (threads 64..191, one
+    // key each), converted into records {cell, level, pixel, score} when their chunk is next
+    uint64_t kq = 0;
+    const bool converter = tid >= 64 && tid < 64 + kLazyChunk;
     auto request = [&](int base) {
-#pragma unroll
-      for (int r = 0; r < kLazyChunk / 64; ++r) {
-        const int i = base + r * 64 + lane;
-        kq[r] = i < n ? keys[i] : 0ull;
-      }
+      const int i = base + tid - 64;
+      kq = (converter && i < n) ? keys[i] : 0ull;
     };
     auto convert = [&]() {
-#pragma unroll
-      for (int r = 0; r < kLazyChunk / 64; ++r) {
-        const uint64_t k = kq[r];
+      if (converter) {
+        const uint64_t k = kq;
         const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
         const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
         const float fy = (float)y * scaling;
@@ -860,160 +863,199 @@ __global__ __launch_bounds__(64 * kLazyWaves) void select_lazy_kernel(
         const int cx = (int)(fx + 16.0f);
         const float q = (float)score / max_score;
         const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
-        recs[r * 64 + lane] = make_uint4(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1),
-                                         (uint32_t)(k & 0xFFFFFFFFu), (uint32_t)score);
+        recs[tid - 64] = make_uint4(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1),
+                                    (uint32_t)(k & 0xFFFFFFFFu), (uint32_t)score);
       }
     };
     request(0);
+    convert();
+    request(kLazyChunk);
+    // this wave's share of the nine bin lists: chains c = first, first + 4 (, first + 8)
+    const int first = (wave + 1) & 3;  // wave 0 (which also runs the acceptance) and waves 1, 2 walk two lists
+    const int nch = first == 0 ? 3 : 2;
+    int hoff[3];       // offset of the chain's bin from the candidate's bin in the bordered grid
+    uint32_t boff4[3];  // table offset of the chain's bin: 4 * ((16 oy) << 6 + 16 ox)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = first + 4 * k < 9 ? first + 4 * k : first;
+      const int ox = (c % 3) - 1, oy = (c / 3) - 1;
+      hoff[k] = oy * bpitch + ox;
+      boff4[k] = (uint32_t)(((16 * oy) << 6) + 16 * ox) << 2;
+    }
     const int limit = min(min(max_kpts, kp_cap), cap);
-    for (int pos = 0; pos < n && kept < limit; pos += 64) {
-
-      if ((pos & (kLazyChunk - 1)) == 0) {
-        convert();
-        request(pos + kLazyChunk);
-      }
-
+    __syncthreads();
+#ifdef OKVFE_SELECT_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ST_T() OKVFE_SEL_CLOCK()
+#endif
+    for (int pos = 0; pos < n; pos += 64) {  // block-uniform
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long t0 = ST_T();
+      ++st[2];
+#endif
       const int idx = pos + lane;
       const bool valid = idx < n;
-      const uint4 rec = recs[idx & (kLazyChunk - 1)];
+      uint4 rec = recs[idx & (kLazyChunk - 1)];
+      if (!valid) rec.x = 0u;  // a cell inside the grid; the lane never passes
       const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
       const float level = __uint_as_float(rec.y);
       const int bx = cx >> 4, by = cy >> 4;
-
+      const int bin = (by + 1) * bpitch + (bx + 1);
+      // The weight table is indexed by (dy + 32) << 6 | (dx + 32): for the bin at offset (ox, oy)
+      // that is cc - (link & 0xFFC) / 4 with cc = (cy & 15 + 32 - 16 oy) << 6 | (cx & 15 + 32 - 16 ox)
+      // -- both fields stay in [1, 63], so there is no borrow between them.
       const uint32_t lcode = ((uint32_t)(cy & 15) << 6) | (uint32_t)(cx & 15);
       const uint32_t cc4 = lut_addr + ((lcode + ((32u << 6) | 32u)) << 2);
-      uint32_t hp[9], lk[9];
+      uint32_t hp[3], lk[3];
 #pragma unroll
-      for (int b = 0; b < 9; ++b) {
-        const int qx = bx + (b % 3) - 1, qy = by + (b / 3) - 1;
-        const bool inb = valid && qx >= 0 && qx < bins_x && qy >= 0 && qy < bins_y;
-        hp[b] = inb ? head[qy * bins_x + qx] : end_addr;
-      }
+      for (int k = 0; k < 3; ++k) hp[k] = (k < nch) ? head[bin + hoff[k]] : end_addr;
 #pragma unroll
-      for (int b = 0; b < 9; ++b) lk[b] = lds_u32(hp[b]);
-      float occf = 0.0f;
+      for (int k = 0; k < 3; ++k) lk[k] = lds_u32(hp[k]);
+      float occf = 0.0f;  // sums of small integers: exact in float
       while (true) {
-        bool alive = false;
-#pragma unroll
-        for (int b = 0; b < 9; ++b) alive |= hp[b] != end_addr;
+        const bool alive = hp[0] != end_addr || hp[1] != end_addr || hp[2] != end_addr;
         if (!__any(alive)) break;
-
-        float wgt[9], lev[9];
-        uint32_t nlk[9], nhp[9];
+        float wgt[3], lev[3];
+        uint32_t nlk[3], nhp[3];
 #pragma unroll
-        for (int b = 0; b < 9; ++b) {
-          const uint32_t boff4 = (uint32_t)(((16 * ((b / 3) - 1)) << 6) + 16 * ((b % 3) - 1)) << 2;
-          wgt[b] = 0.0f;
-          lev[b] = 0.0f;
-          nhp[b] = hp[b];
-          nlk[b] = lk[b];
-          if (hp[b] != end_addr) {
-            wgt[b] = lds_f32(cc4 - boff4 - (lk[b] & 0xFFCu));
-            lev[b] = lds_f32(hp[b] + nsc_delta);
-            nhp[b] = lk[b] >> 14;
-            nlk[b] = lds_u32(nhp[b]);
-          }
+        for (int k = 0; k < 3; ++k) {
+          wgt[k] = lds_f32(cc4 - boff4[k] - (lk[k] & 0xFFCu));
+          lev[k] = lds_f32(hp[k] + nsc_delta);
+          nhp[k] = lk[k] >> 14;
+          nlk[k] = lds_u32(nhp[k]);
         }
 #pragma unroll
-        for (int b = 0; b < 9; ++b) {
-          occf += ceilf(wgt[b] * lev[b]);
-          hp[b] = nhp[b];
-          lk[b] = nlk[b];
+        for (int k = 0; k < 3; ++k) {
+          occf += ceilf(wgt[k] * lev[k]);  // 0 for finished walks (level 0) and points out of reach (weight 0)
+          hp[k] = nhp[k];
+          lk[k] = nlk[k];
         }
       }
-      int occ = (int)occf;
-      bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
-      const float nsc = (float)(0.99 * (double)level);
-      unsigned long long rem = __ballot(pass), accm = 0;
-
-      int nacc = 0;
-      if (rem != 0) {
-
-        bool linked = false;
-        for (unsigned long long r2 = rem; r2 != 0; r2 &= r2 - 1) {
-          const int j = (int)__ffsll((long long)r2) - 1;
-          const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, j);
-          const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
-          linked |= lane != j && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
-        }
-        const unsigned long long seq = __ballot(linked && pass);
-        const int room = limit - kept;
-        if (__popcll(rem) <= room) {
-
-          accm = rem & ~seq;
-          nacc = __popcll(accm);
-          rem = seq;
-        }
-        while (rem != 0 && kept + nacc < limit) {
-          const int first = (int)__ffsll((long long)rem) - 1;
-          accm |= 1ull << first;
-          ++nacc;
-          const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, first);
-          const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), first));
-          const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
-          const bool near = pass && lane > first && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
-          if (__any(near)) {
-            if (near) {
-              occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * wnsc);
-              pass = !(level < (float)(occ > 255 ? 255 : occ));
+      part[wave * 64 + lane] = occf;
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long t1 = ST_T();
+#endif
+      __syncthreads();
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long t2 = ST_T();
+#endif
+      if (wave == 0) {
+        int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
+        bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
+        const float nsc = (float)(0.99 * (double)level);
+        unsigned long long rem = __ballot(pass), accm = 0;
+        int nacc = 0;
+        if (rem != 0) {
+          // which passing candidates have another passing candidate of the window within 15 cells?
+          // (vector work only: no scalar round trip per candidate)
+          bool linked = false;
+          for (unsigned long long r2 = rem; r2 != 0; r2 &= r2 - 1) {
+            const int j = (int)__ffsll((long long)r2) - 1;
+            const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, j);
+            const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
+            linked |= lane != j && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
+          }
+          const unsigned long long seq = __ballot(linked && pass);
+          const int room = limit - kept;
+          if (__popcll(rem) <= room) {
+            // the unlinked ones neither change nor are changed by anything in this window: accepted
+            // at once; the linked ones go through the ordered loop below
+            accm = rem & ~seq;
+            nacc = __popcll(accm);
+            rem = seq;
+          }  // else: the cap falls inside this window -- everything in order
+          while (rem != 0 && kept + nacc < limit) {  // one iteration per accepted point
+            const int f = (int)__ffsll((long long)rem) - 1;
+            accm |= 1ull << f;
+            ++nacc;
+            const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
+            const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
+            const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
+            const bool near = pass && lane > f && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
+            if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
+              if (near) {
+                occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * wnsc);
+                pass = !(level < (float)(occ > 255 ? 255 : occ));
+              }
+              rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
+            } else {
+              rem &= rem - 1;
             }
-            rem &= __ballot(pass) & ~(((2ull << first) - 1ull));
-          } else {
-            rem &= rem - 1;
           }
+          if ((accm >> lane) & 1) {
+            const int slot = kept + __popcll(accm & ((1ull << lane) - 1ull));
+            const uint32_t addr = link_addr + 4u * (uint32_t)slot;
+            const uint32_t prev = atomicExch(&head[bin], addr);
+            link[slot] = (lcode << 2) | ((prev >> 2) << 16);
+            pnsc[slot] = nsc;
+            // pixel position and score wait in the output record for the sub-pixel pass
+            okvfe_keypoint kp;
+            kp.x = (float)(int)(rec.z & 0xFFFF);
+            kp.y = (float)(int)(rec.z >> 16);
+            kp.size = 12.0f;
+            kp.angle = -1.0f;
+            kp.response = (float)(int32_t)rec.w;
+            kp.octave = 0;
+            kp.class_id = (int32_t)rec.w;  // the exact score (response is its float image)
+            out[slot] = kp;
+          }
+          kept += nacc;
+          if (lane == 0) s_kept = kept;
         }
-        if ((accm >> lane) & 1) {
-          const int slot = kept + __popcll(accm & ((1ull << lane) - 1ull));
-          const uint32_t addr = link_addr + 4u * (uint32_t)slot;
-          const uint32_t prev = atomicExch(&head[by * bins_x + bx], addr);
-          link[slot] = (lcode << 2) | ((prev >> 2) << 16);
-          pnsc[slot] = nsc;
-          ppix[slot] = rec.z;
-          pscore[slot] = (int32_t)rec.w;
-        }
-        kept += nacc;
+      } else if (((pos + 64) & (kLazyChunk - 1)) == 0) {
+        // the next window starts a new chunk: every wave holds this window's records in registers
+        convert();
+        request(pos + 64 + kLazyChunk);
       }
-
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long t3 = ST_T();
+#endif
+      __syncthreads();
+#ifdef OKVFE_SELECT_STATS
+      const unsigned long long t4 = ST_T();
+      st[4] += t1 - t0; st[5] += t3 - t2; st[6] += (t2 - t1) + (t4 - t3);
+#endif
+      kept = s_kept;
+      if (kept >= limit) break;  // block-uniform
     }
+#ifdef OKVFE_SELECT_STATS
+    if (tid == 0) {
+      atomicAdd(&g_sel_stats[0], 1ull);
+      atomicAdd(&g_sel_stats[2], st[2]);
+      atomicAdd(&g_sel_stats[3], (unsigned long long)kept);
+      atomicAdd(&g_sel_stats[4], st[4]);
+      atomicAdd(&g_sel_stats[5], st[5]);
+      atomicAdd(&g_sel_stats[6], st[6]);
+    }
+#endif
   }
-
-  auto load_patch = [&](int i, int32_t patch[9], uint32_t* pix, int* score) {
-    const int ii = i < kept ? i : 0;
-    *pix = kept > 0 ? ppix[ii] : 0u;
-    *score = kept > 0 ? pscore[ii] : 0;
-    const int v = (int)(*pix >> 16), u = (int)(*pix & 0xFFFF);
-    if (i < kept) {
+  // ---- K4: sub-pixel refinement and keypoint emission (all four waves)
+#ifdef OKVFE_SELECT_STATS
+  const unsigned long long ts0 = OKVFE_SEL_CLOCK();
+#endif
+  __syncthreads();
+  for (int i = tid; i < kept; i += kLazyThreads) {
+    okvfe_keypoint kp = out[i];
+    const int u = (int)kp.x, v = (int)kp.y;
+    int32_t patch[9];
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
+    for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx)
-          patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
-    }
-  };
-  int32_t patch[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t pix = 0;
-  int score = 0;
-  if (kept > 0) load_patch(lane, patch, &pix, &score);
-  for (int i = lane; i < kept; i += 64) {
-    int32_t cur[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) cur[t] = patch[t];
-    const uint32_t cpix = pix;
-    const int cscore = score;
-    load_patch(i + 64, patch, &pix, &score);
+      for (int dx = -1; dx <= 1; ++dx)
+        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
     float ddx, ddy;
-    subpixel2d(cur, &ddx, &ddy);
-    okvfe_keypoint kp;
-    kp.x = (float)(int)(cpix & 0xFFFF) + ddx;
-    kp.y = (float)(int)(cpix >> 16) + ddy;
-    kp.size = 12.0f;
-    kp.angle = -1.0f;
-    kp.response = (float)cscore;
-    kp.octave = 0;
+    subpixel2d(patch, &ddx, &ddy);
+    kp.x = (float)u + ddx;
+    kp.y = (float)v + ddy;
+    kp.response = (float)kp.class_id;
     kp.class_id = -1;
     out[i] = kp;
   }
-  if (lane == 0) kp_count[img] = kept;
+  if (tid == 0) kp_count[img] = kept;
+#ifdef OKVFE_SELECT_STATS
+  __syncthreads();
+  if (tid == 0) atomicAdd(&g_sel_stats[7], OKVFE_SEL_CLOCK() - ts0);
+#endif
 }
 
 }  // namespace
@@ -1075,17 +1117,19 @@ void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
     // lazy occupancy (no grid): any image size / radius whose bin heads and keypoint slots fit in LDS
     const int bins_x = (occ_cols + 15) >> 4, bins_y = (occ_rows + 15) >> 4;
     const int cap = max_kpts < kp_cap ? max_kpts : kp_cap;
-    const size_t lds = kLazyLutBytes + kLazyWaves * lazy_wave_bytes(bins_x * bins_y, cap);
-    if (lds <= 160 * 1024 && occ_cols <= 65535 && occ_rows <= 65535) {
+    const size_t lds = lazy_lds_bytes(bins_x, bins_y, cap);
+    constexpr size_t kLazyMaxLds = 159 * 1024;  // the kernel also has a few bytes of static LDS
+    if (lds <= kLazyMaxLds && occ_cols <= 65535 && occ_rows <= 65535) {
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
+          (void)hipGetLastError();  // launches above 64 KiB will then fail loudly on their own
         attr_set = true;
       }
-      hipLaunchKernelGGL(select_lazy_kernel, dim3((n_images + kLazyWaves - 1) / kLazyWaves), dim3(64 * kLazyWaves), lds,
-                         stream, score, layout, w, h, n_images, cand_cap, cand_count, sort_ws, ws_stride, radius,
-                         max_kpts, lut, bins_x, bins_y, cap, kps, kp_cap, kp_count);
+      hipLaunchKernelGGL(select_lazy_kernel, dim3(n_images), dim3(kLazyThreads), lds, stream, score, layout, w, h,
+                         cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, bins_x, bins_y, cap, kps,
+                         kp_cap, kp_count);
       return;
     }
   }
