@@ -39,7 +39,7 @@ namespace {
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
 constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
-constexpr int kZeroRowBytes = 96;
+constexpr int kZeroRowBytes = 160;  // >= the widest patch row (152 B) + the 3-dword reads past a box
 constexpr int kPatchBufBytes = 6144;
 constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
@@ -449,8 +449,52 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       if (active) v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
 #endif
     } else {
-      const GlobalPx gpx{im, w};
-      if (active) v = smoothed_intensity(gpx, xf, yf, sg, bsc, bsc2);
+      // The patch does not fit in the wave's LDS buffer (wide-angle cameras stretch the camera-aware
+      // pattern towards the image rim: fu = 350 on 640 px gives |M| up to ~1.6).  It is staged in
+      // horizontal BANDS instead: a band holds as many rows as fit, every lane computes its sample in
+      // the first band that contains all rows of its box, and the next band starts at the topmost
+      // row still needed (a box is at most 12 rows tall, a band at least 39).  Only patches wider
+      // than 152 px fall back to direct image reads.
+      const int px0 = __builtin_amdgcn_readfirstlane(bx0) & ~3;
+      const int pitch16 = ((__builtin_amdgcn_readfirstlane(bx1) - px0 + 1 + 15) >> 4) << 4;
+      int rows_fit = 0;  // whole trips of R rows (stage_patch: R = 64 / chunks per row)
+      if (pitch16 <= kZeroRowBytes - 8) {
+        const int R = 64 / (pitch16 >> 4);
+        rows_fit = (kPatchDataBytes / (R * pitch16)) * R;
+      }
+      // rows this lane's box touches (one spare row either side, inside the staged rectangle)
+      const int fy0 = __builtin_amdgcn_readfirstlane(by0), fy1 = __builtin_amdgcn_readfirstlane(by1);
+      int ly0 = (int)floorf(yf - sg) - 1, ly1 = (int)ceilf(yf + sg) + 1;
+      ly0 = ly0 < fy0 ? fy0 : ly0;
+      ly1 = ly1 > fy1 ? fy1 : ly1;
+      bool done = !active;
+      int band0 = __builtin_amdgcn_readfirstlane(by0);
+      bool banded = rows_fit >= 24 && dword_ok;
+      while (banded && !__all(done)) {
+        int band1 = band0 + rows_fit - 1;
+        band1 = band1 > by1 ? by1 : band1;
+        if (!stage_patch(bx0, bx1, band0, band1, &ppx)) {  // cannot happen for rows_fit rows; stay exact anyway
+          banded = false;
+          break;
+        }
+        const bool mine = !done && ly0 >= band0 && ly1 <= band1;
+        if (mine) {
+          v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
+          done = true;
+        }
+        if (band1 >= by1) break;
+        // next band: the topmost row a remaining lane needs (wave minimum), at least one row further
+        int need = done ? INT_MAX : ly0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) need = min(need, __shfl_xor(need, d));
+        need = __builtin_amdgcn_readfirstlane(need);
+        if (need == INT_MAX) break;
+        band0 = need > band0 ? need : band0 + 1;
+      }
+      if (!__all(done)) {  // too wide for the buffer (or a box that fits no band): direct reads
+        const GlobalPx gpx{im, w};
+        if (!done) v = smoothed_intensity(gpx, xf, yf, sg, bsc, bsc2);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     vals[lane] = v;
