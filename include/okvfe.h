@@ -265,7 +265,7 @@ typedef enum okvfe_stage {
   OKVFE_STAGE_NMS = 1,      /* K2 */
   OKVFE_STAGE_SORT = 2,     /* K3 sort */
   OKVFE_STAGE_SELECT = 3,   /* K3 uniformity + K4 sub-pixel */
-  OKVFE_STAGE_INTEGRAL = 4, /* K5 */
+  OKVFE_STAGE_MAP = 4,      /* map matchers on device blocks: matchToMap / uninitialised / verifyRecognisedPlace */
   OKVFE_STAGE_DESCRIBE = 5, /* K6 */
   OKVFE_STAGE_COMPACT = 6,  /* compaction + back-projection */
   OKVFE_STAGE_MATCH = 7,    /* K7 gated stereo match */
@@ -527,6 +527,46 @@ okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0
                                               const void* block1_dev, const okvfe_pose* T_WC0,
                                               const okvfe_pose* T_WC1, double f0, double f1,
                                               okvfe_stereo_match* matches_dev, void* stream);
+
+/* ---- cross-camera gather collective (RCCL over xGMI) ---------------------- */
+/* The one exchange step of the path (okvis_frontend/src/Frontend.cpp:1990-2026 needs the keypoints
+ * of BOTH cameras of a pair; with one camera per GPU they live on different ranks): an all-gather of
+ * the ranks' gather blocks, issued from C on the caller's stream.  The library loads RCCL at first
+ * use (dlopen of librccl.so.1: the copy already mapped by the process -- e.g. torch's -- is the
+ * one found); a process that never calls these needs no RCCL.
+ *   okvfe_comm_unique_id   ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank
+ *                          (any side channel: MPI, a socket, torch.distributed.broadcast, a file);
+ *   okvfe_comm_create      ncclCommInitRank on `device` (collective over all ranks).  world == 1 with
+ *                          id == NULL makes a local communicator that never touches RCCL;
+ *   okvfe_comm_wrap        adopts an ncclComm_t the caller already owns (not destroyed by
+ *                          okvfe_comm_destroy);
+ *   okvfe_gather_blocks    ncclAllGather(send, recv, bytes_per_rank, ncclUint8) on `stream`
+ *                          (a hipStream_t; NULL = the HIP null stream): recv_dev holds world x
+ *                          bytes_per_rank bytes, rank-major.  Asynchronous: ordered by the stream. */
+typedef struct okvfe_comm okvfe_comm;
+#define OKVFE_COMM_ID_BYTES 128
+okvfe_status okvfe_comm_unique_id(uint8_t id[OKVFE_COMM_ID_BYTES]);
+okvfe_status okvfe_comm_create(const uint8_t* id /* OKVFE_COMM_ID_BYTES or NULL */, int32_t world,
+                               int32_t rank, int32_t device, okvfe_comm** out);
+okvfe_status okvfe_comm_wrap(void* nccl_comm, int32_t world, int32_t rank, okvfe_comm** out);
+void okvfe_comm_destroy(okvfe_comm* comm);
+int32_t okvfe_comm_world(const okvfe_comm* comm);
+int32_t okvfe_comm_rank(const okvfe_comm* comm);
+const char* okvfe_comm_last_error(void);
+okvfe_status okvfe_gather_blocks(okvfe_comm* comm, const void* send_dev, void* recv_dev,
+                                 size_t bytes_per_rank, void* stream);
+
+/* ---- device utilities for hosts without HIP headers ----------------------- */
+/* The C++ mirror (okvis2_amd/host/) is dependency-free; these let it own streams and device
+ * buffers (gather blocks, match rows).  Plain hipMalloc / hipStream / hipMemcpyAsync underneath. */
+okvfe_status okvfe_device_alloc(int32_t device, size_t bytes, void** out_dev);
+void okvfe_device_free(void* dev);
+okvfe_status okvfe_stream_create(int32_t device, void** out_stream);
+void okvfe_stream_destroy(void* stream);
+okvfe_status okvfe_stream_synchronize(void* stream);
+okvfe_status okvfe_copy_to_device(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+okvfe_status okvfe_copy_to_host(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+okvfe_status okvfe_device_fill(void* dst_dev, int32_t byte_value, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

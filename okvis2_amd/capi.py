@@ -79,9 +79,13 @@ EXPORTS = [
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
     "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
     "okvfe_match_to_map_landmarks", "okvfe_bow_vector", "okvfe_bow_query_l1",
+    "okvfe_comm_unique_id", "okvfe_comm_create", "okvfe_comm_wrap", "okvfe_comm_destroy",
+    "okvfe_comm_world", "okvfe_comm_rank", "okvfe_comm_last_error", "okvfe_gather_blocks",
+    "okvfe_device_alloc", "okvfe_device_free", "okvfe_stream_create", "okvfe_stream_destroy",
+    "okvfe_stream_synchronize", "okvfe_copy_to_device", "okvfe_copy_to_host", "okvfe_device_fill",
 ]
 
-STAGES = ["harris", "nms", "sort", "select", "integral", "describe", "compact", "match"]
+STAGES = ["harris", "nms", "sort", "select", "map", "describe", "compact", "match"]
 
 _LIB = None
 
@@ -127,6 +131,11 @@ def lib():
         L.okvfe_gather_block_bytes.argtypes = [C.c_void_p]
         L.okvfe_destroy.argtypes = [C.c_void_p]
         L.okvfe_destroy.restype = None
+        L.okvfe_comm_last_error.restype = C.c_char_p
+        L.okvfe_comm_destroy.argtypes = [C.c_void_p]
+        L.okvfe_comm_destroy.restype = None
+        L.okvfe_gather_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.okvfe_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
 
@@ -140,6 +149,60 @@ def _p(a):
 
 
 STREAM_LEGACY_DEFAULT = 1  # OKVFE_STREAM_LEGACY_DEFAULT (= hipStreamLegacy)
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """okvfe_comm: the RCCL communicator of the cross-camera gather, driven through the C ABI
+    (okvfe_comm_create = ncclCommInitRank, okvfe_gather_blocks = ncclAllGather on the caller's
+    stream).  Comm.local() is the world-1 communicator that never touches RCCL."""
+
+    def __init__(self, handle, world, rank):
+        self._h, self.world, self.rank = handle, world, rank
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        st = lib().okvfe_comm_unique_id(buf)
+        if st != 0:
+            raise OkvfeError(st, lib().okvfe_comm_last_error().decode())
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, comm_id, world: int, rank: int, device: int):
+        h = C.c_void_p()
+        idbuf = None
+        if comm_id is not None:
+            idbuf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        st = lib().okvfe_comm_create(C.cast(idbuf, C.c_void_p) if idbuf is not None else None,
+                                     int(world), int(rank), int(device), C.byref(h))
+        if st != 0:
+            raise OkvfeError(st, lib().okvfe_comm_last_error().decode())
+        return cls(h, world, rank)
+
+    @classmethod
+    def local(cls):
+        return cls.create(None, 1, 0, 0)
+
+    def gather(self, send_ptr, recv_ptr, bytes_per_rank: int, stream=None):
+        """raw stream handle: torch.cuda.Stream.cuda_stream (0 / None = the HIP null stream)"""
+        raw = getattr(stream, "cuda_stream", stream)
+        st = lib().okvfe_gather_blocks(self._h, _p(send_ptr), _p(recv_ptr), int(bytes_per_rank),
+                                       C.c_void_p(int(raw)) if raw else None)
+        if st != 0:
+            raise OkvfeError(st, lib().okvfe_comm_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().okvfe_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 
 def _s(stream):

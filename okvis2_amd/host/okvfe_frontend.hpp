@@ -55,7 +55,9 @@ class Context {
     const okvfe_status st = okvfe_create(&cfg, &c);
     if (st != OKVFE_OK) throw Exception(st, okvfe_last_error(nullptr));
     ctx_ = c;
-    max_keypoints_ = cfg.max_keypoints;
+    // row capacity per image: with a scale space (octaves > 0) every layer may deliver max_keypoints
+    okvfe_device_outputs o{};
+    max_keypoints_ = okvfe_get_device_outputs(c, &o) == OKVFE_OK ? o.max_keypoints : cfg.max_keypoints;
   }
   ~Context() { okvfe_destroy(ctx_); }
   Context(const Context&) = delete;
@@ -223,7 +225,121 @@ class HipFrontend {
     return out;
   }
 
+  // the k0 x k1 loops of Frontend::matchMotionStereo for one camera: older frame f0 against the
+  // current frame f1 (Frontend.cpp:1789-1905).  skip0[k0] != 0: k0 is left out (:1814-1841);
+  // matched1[k1] != 0: the current keypoint already carries a landmark (:1795-1798); either may be
+  // empty.  quality of a row = acos(cos_quality) (:1887-1889).
+  std::vector<okvfe_motion_match> matchMotionStereo(size_t cameraIndex, const FrameData& f0,
+                                                    const okvfe_pose& T_WC0, const FrameData& f1,
+                                                    const okvfe_pose& T_WC1,
+                                                    const std::vector<uint8_t>& skip0 = {},
+                                                    const std::vector<uint8_t>& matched1 = {}) {
+    if (cameraIndex >= cameras_.size())
+      throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "Camera index exceeds number of cameras.");
+    std::lock_guard<std::mutex> lock(mutexes_[cameraIndex]);
+    std::vector<okvfe_motion_match> out(f0.keypoints.size());
+    const std::vector<double> b0 = flat(f0.backProjections), b1 = flat(f1.backProjections);
+    contexts_[cameraIndex]->check(okvfe_match_motion_stereo(
+        contexts_[cameraIndex]->get(), &cameras_[cameraIndex], f0.descriptors.data.data(), f0.keypoints.data(),
+        b0.data(), f0.backProjectionsValid.data(), skip0.empty() ? nullptr : skip0.data(),
+        int32_t(f0.keypoints.size()), f1.descriptors.data.data(), f1.keypoints.data(), b1.data(),
+        f1.backProjectionsValid.data(), matched1.empty() ? nullptr : matched1.data(),
+        int32_t(f1.keypoints.size()), &T_WC0, &T_WC1, out.data()));
+    return out;
+  }
+
+  struct MapMatches {  // per keypoint of the frame: landmark index (-1 = none) and distance
+    std::vector<int32_t> landmark, distance;
+  };
+  // Frontend::matchToMap up to and including its first matcher pass (Frontend.cpp:1219-1411): the
+  // landmark table is projected, pooled and matched on the GPU.  use[k] == 0 skips keypoint k.
+  MapMatches matchToMap(size_t cameraIndex, const FrameData& frame, const okvfe_landmark_table& table,
+                        const okvfe_pose& T_WC1, double reprojectionThreshold, bool exclusive,
+                        const std::vector<uint8_t>& use = {}, okvfe_landmark_pool* poolOut = nullptr) {
+    if (cameraIndex >= cameras_.size())
+      throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "Camera index exceeds number of cameras.");
+    std::lock_guard<std::mutex> lock(mutexes_[cameraIndex]);
+    if (!extractors_[cameraIndex].isCameraAware()) extractors_[cameraIndex].setCamera(cameras_[cameraIndex]);
+    const size_t n = frame.keypoints.size();
+    MapMatches m{std::vector<int32_t>(n, -1), std::vector<int32_t>(n, 0)};
+    const std::vector<uint8_t> all(n, 1);
+    contexts_[cameraIndex]->check(okvfe_match_to_map_landmarks(
+        contexts_[cameraIndex]->get(), 0, &table, &T_WC1, reprojectionThreshold, exclusive ? 1 : 0,
+        frame.descriptors.data.data(), frame.keypoints.data(), use.empty() ? all.data() : use.data(), int32_t(n),
+        poolOut, m.landmark.data(), m.distance.data()));
+    return m;
+  }
+  // Frontend::matchToMapByThread on an already pooled 3-D landmark set (Frontend.cpp:1552-1589)
+  MapMatches matchToMapPooled(size_t cameraIndex, const FrameData& frame, const std::vector<uint8_t>& use,
+                              const std::vector<double>& projections, const std::vector<int32_t>& descBegin,
+                              const std::vector<uint8_t>& pool, double reprojectionThreshold) {
+    std::lock_guard<std::mutex> lock(mutexes_[cameraIndex]);
+    const size_t n = frame.keypoints.size();
+    MapMatches m{std::vector<int32_t>(n, -1), std::vector<int32_t>(n, 0)};
+    const std::vector<uint8_t> all(n, 1);
+    contexts_[cameraIndex]->check(okvfe_match_to_map(
+        contexts_[cameraIndex]->get(), frame.descriptors.data.data(), frame.keypoints.data(),
+        use.empty() ? all.data() : use.data(), int32_t(n), projections.data(), descBegin.data(),
+        int32_t(descBegin.size()) - 1, pool.data(), reprojectionThreshold, m.landmark.data(), m.distance.data()));
+    return m;
+  }
+
+  struct UninitialisedMatches {
+    MapMatches matches;
+    std::vector<std::array<double, 4>> hp_W;  // written where hpSet[k]
+    std::vector<uint8_t> hpSet;
+    int32_t alreadyMatched = 0;  // ctrs of Frontend.cpp:1702
+  };
+  // Frontend::matchToMapByThreadUnitialised (Frontend.cpp:1616-1719): landmarks without a 3-D
+  // position yet; pool row d carries its observing unit ray e0_W[d] and camera centre r0_W[d].
+  UninitialisedMatches matchToMapUninitialised(size_t cameraIndex, const FrameData& frame,
+                                               const std::vector<uint8_t>& use,
+                                               const std::vector<int32_t>& previousLandmark,
+                                               const std::vector<int32_t>& descBegin,
+                                               const std::vector<uint8_t>& pool, const std::vector<double>& e0_W,
+                                               const std::vector<double>& r0_W, const okvfe_pose& T_WC1) {
+    std::lock_guard<std::mutex> lock(mutexes_[cameraIndex]);
+    const size_t n = frame.keypoints.size();
+    UninitialisedMatches u;
+    u.matches = MapMatches{std::vector<int32_t>(n, -1), std::vector<int32_t>(n, 0)};
+    std::vector<double> hp(4 * n + 4);
+    u.hpSet.assign(n, 0);
+    const std::vector<double> bp = flat(frame.backProjections);
+    const double focal = 0.5 * (cameras_[cameraIndex].fu + cameras_[cameraIndex].fv);
+    contexts_[cameraIndex]->check(okvfe_match_to_map_uninitialised(
+        contexts_[cameraIndex]->get(), frame.descriptors.data.data(), bp.data(), use.data(),
+        previousLandmark.data(), int32_t(n), descBegin.data(), int32_t(descBegin.size()) - 1, pool.data(),
+        e0_W.data(), r0_W.data(), &T_WC1, focal, u.matches.landmark.data(), u.matches.distance.data(), hp.data(),
+        u.hpSet.data(), &u.alreadyMatched));
+    u.hp_W.resize(n);
+    for (size_t k = 0; k < n; ++k) u.hp_W[k] = {hp[4 * k], hp[4 * k + 1], hp[4 * k + 2], hp[4 * k + 3]};
+    return u;
+  }
+
+  struct PlaceMatches {  // per old landmark: best keypoint of the frame and its distance
+    std::vector<int32_t> kMin;
+    std::vector<uint32_t> distMin;
+  };
+  // the descriptor matching of Frontend::verifyRecognisedPlace for all old landmarks against one
+  // camera of the current frame (Frontend.cpp:330-355)
+  PlaceMatches verifyRecognisedPlace(size_t cameraIndex, const std::vector<uint8_t>& landmarkDescriptors,
+                                     const std::vector<int32_t>& descBegin, const FrameData& frame) {
+    std::lock_guard<std::mutex> lock(mutexes_[cameraIndex]);
+    const size_t nl = descBegin.empty() ? 0 : descBegin.size() - 1;
+    PlaceMatches p{std::vector<int32_t>(nl, 0), std::vector<uint32_t>(nl, 0)};
+    contexts_[cameraIndex]->check(okvfe_verify_place_match(
+        contexts_[cameraIndex]->get(), landmarkDescriptors.data(), descBegin.data(), int32_t(nl),
+        frame.descriptors.data.data(), int32_t(frame.keypoints.size()), p.kMin.data(), p.distMin.data()));
+    return p;
+  }
+
  private:
+  static std::vector<double> flat(const std::vector<std::array<double, 3>>& v) {
+    std::vector<double> b(v.size() * 3 + 3);
+    for (size_t k = 0; k < v.size(); ++k)
+      for (int i = 0; i < 3; ++i) b[3 * k + size_t(i)] = v[k][size_t(i)];
+    return b;
+  }
   std::vector<okvfe_camera> cameras_;
   std::vector<std::mutex> mutexes_;
   std::vector<std::shared_ptr<Context>> contexts_;

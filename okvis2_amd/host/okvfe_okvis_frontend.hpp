@@ -27,6 +27,20 @@
 
 namespace okvfe {
 
+// Hook for the estimator-side association (Frontend::dataAssociationAndInitialization,
+// okvis_frontend/src/Frontend.cpp:558-1014): a maintainer who has moved the matcher loops of that
+// function onto HipFrontend::matchMotionStereo / matchToMap / matchToMapUninitialised /
+// verifyRecognisedPlace installs one; it gets the GPU front-end and the wrapped reference
+// front-end (for everything it does not take over).  Without a hook the call is forwarded.
+class AssociationHook {
+ public:
+  virtual ~AssociationHook() = default;
+  virtual bool dataAssociationAndInitialization(HipFrontend& gpu, okvis::ViFrontendInterface& reference,
+                                                okvis::Estimator& estimator, const okvis::ViParameters& params,
+                                                std::shared_ptr<okvis::MultiFrame> framesInOut,
+                                                bool* asKeyframe) = 0;
+};
+
 class HipViFrontend : public okvis::ViFrontendInterface {
  public:
   // rest: the reference front-end that keeps serving the estimator-side virtuals
@@ -59,8 +73,12 @@ class HipViFrontend : public okvis::ViFrontendInterface {
   bool dataAssociationAndInitialization(okvis::Estimator& estimator, const okvis::ViParameters& params,
                                         std::shared_ptr<okvis::MultiFrame> framesInOut,
                                         bool* asKeyframe) override {
+    if (hook_) return hook_->dataAssociationAndInitialization(gpu_, *rest_, estimator, params, framesInOut, asKeyframe);
     return rest_->dataAssociationAndInitialization(estimator, params, framesInOut, asKeyframe);
   }
+  // installs (or, with nullptr, removes) the association hook; reports whether the GPU matchers run
+  void setAssociationHook(std::shared_ptr<AssociationHook> hook) { hook_ = std::move(hook); }
+  bool associationOnGpu() const { return bool(hook_); }
 
   bool propagation(const okvis::ImuMeasurementDeque& imuMeasurements, const okvis::ImuParameters& imuParams,
                    okvis::kinematics::Transformation& T_WS_propagated, okvis::SpeedAndBias& speedAndBiases,
@@ -76,6 +94,7 @@ class HipViFrontend : public okvis::ViFrontendInterface {
  private:
   std::unique_ptr<okvis::ViFrontendInterface> rest_;
   HipFrontend gpu_;
+  std::shared_ptr<AssociationHook> hook_;
 };
 
 }  // namespace okvfe

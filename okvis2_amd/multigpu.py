@@ -116,7 +116,7 @@ class CrossCameraMatcher:
     Results: {(i, j): uint8 tensor [frames, max_keypoints, sizeof(okvfe_stereo_match)]}."""
 
     def __init__(self, engines: dict, n_cams: int, n_frames: int, poses_T_WC, focal, overlap,
-                 world: int, rank: int, device, group=None):
+                 world: int, rank: int, device, group=None, comm="auto"):
         import torch
         self.torch = torch
         self.n_cams, self.n_frames, self.world, self.rank = n_cams, n_frames, world, rank
@@ -143,6 +143,16 @@ class CrossCameraMatcher:
         self.mine = [(i, j) for (i, j, o) in self.schedule if o == rank]
         self.out = {p: torch.zeros((n_frames, self.kp_cap, capi.STEREO_MATCH_DTYPE.itemsize),
                                    dtype=torch.uint8, device=self.device) for p in self.mine}
+        # The collective: on the GPU it is issued from C -- okvfe_gather_blocks = ncclAllGather on the
+        # main stream, through a communicator made with okvfe_comm_create (the 128-byte id travels by
+        # torch.distributed.broadcast); comm=None keeps torch.distributed's all_gather_into_tensor
+        # (the CPU / gloo tests), a capi.Comm is used as given.
+        self.comm = None
+        if comm == "auto":
+            if self.cuda:
+                self.comm = self._make_comm()
+        elif comm is not None:
+            self.comm = comm
         if self.cuda:
             self.main = torch.cuda.Stream(device=self.device)
             self.cam_streams = {c: torch.cuda.Stream(device=self.device) for c in self.local_cams}
@@ -182,7 +192,26 @@ class CrossCameraMatcher:
                 self.out[(i, j)].data_ptr(), self.main)
         return self.gathered, self.out
 
+    def _make_comm(self):
+        """One RCCL communicator over the ranks of `group`, created through the C ABI."""
+        import torch.distributed as dist
+        torch = self.torch
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if not (dist.is_available() and dist.is_initialized()) or self.world == 1:
+            return capi.Comm.create(capi.Comm.unique_id(), 1, 0, dev_index)  # RCCL with one rank
+        id_t = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            id_t.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(id_t, src=src, group=self.group)
+        return capi.Comm.create(bytes(id_t.cpu().numpy().tobytes()), self.world, self.rank, dev_index)
+
     def _gather(self):
+        if self.comm is not None:  # C path: ncclAllGather on the current (main) stream
+            st = self.main.cuda_stream if self.cuda else None
+            self.comm.gather(self.local.data_ptr(), self.gathered.data_ptr(),
+                             self.local.numel() * self.local.element_size(), st)
+            return
         import torch.distributed as dist
         if self.world == 1 and not dist.is_initialized():
             self.gathered.copy_(self.local)

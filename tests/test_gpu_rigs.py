@@ -99,6 +99,88 @@ def test_hilti_rig_five_cameras_nine_pairs_cross_camera_matcher(oracle):
         dist.destroy_process_group()
 
 
+def test_hilti_rig_cpp_cross_camera_matcher_rccl_through_c_abi(oracle, tmp_path):
+    """The same rig through the C++ host class okvfe::CrossCameraMatcher
+    (okvis2_amd/host/okvfe_cross_camera.hpp, tests/cpp/cross_camera_cli.cpp): communicator from
+    okvfe_comm_unique_id / okvfe_comm_create (ncclCommInitRank with one rank), the gather issued from C
+    (okvfe_gather_blocks = ncclAllGather), everything on one stream, two steps; blocks and match rows
+    against the oracle."""
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "tests", "cpp", "cross_camera_cli")
+    assert os.path.exists(cli), "run __graft_entry__.build() first"
+    cfg = synth.hilti_config()
+    pairs = synth.rig_overlap_pairs(cfg, capi.camera_overlap)
+    nfr = 2
+    rays = [capi.build_awareness_maps(c)[0] for c in cfg.cams]
+    frames, poses_f = [], []
+    for f in range(nfr):
+        a = 0.15 * f
+        C_WS = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+        frames.append(synth.render_rig(cfg, rays, 60 + f, r_S=np.array([0.1 * f, 0.0, 0.0])))
+        poses_f.append(synth.rig_poses(cfg, C_WS, np.array([0.1 * f, 0.0, 0.0])))
+    poses = poses_f[0]
+    focal = [0.5 * (c.fu + c.fv) for c in cfg.cams]
+    grav = {c: np.stack([synth.gravity_in_camera(poses_f[f][c][0]) for f in range(nfr)]).astype(np.float32)
+            for c in range(5)}
+    req, resp = tmp_path / "req.bin", tmp_path / "resp.bin"
+    with open(req, "wb") as f:
+        f.write(struct.pack("<iiii", cfg.w, cfg.h, 5, nfr))
+        f.write(struct.pack("<f", cfg.uniformity_radius))
+        f.write(struct.pack("<iii", cfg.abs_threshold, cfg.match_threshold, cfg.max_kpts))
+        ov = np.zeros((5, 5), np.uint8)
+        for (i, j) in pairs:
+            ov[i, j] = 1
+        f.write(ov.tobytes())
+        for c in range(5):
+            cam = cfg.cams[c]
+            f.write(struct.pack("<4d", cam.fu, cam.fv, cam.cu, cam.cv))
+            f.write(struct.pack("<i", cam.dist_type))
+            f.write(struct.pack("<4d", *cam.d))
+            f.write(np.asarray(poses[c][0], dtype=np.float64).tobytes())
+            f.write(np.asarray(poses[c][1], dtype=np.float64).tobytes())
+            f.write(grav[c].tobytes())
+            f.write(np.stack([frames[fr][c] for fr in range(nfr)]).tobytes())
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = (os.path.join(root, "okvis2_amd") + ":" + os.path.dirname(torch.__file__) + "/lib:/opt/rocm/lib:"
+                              + env.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([cli, "run", str(req), str(resp)], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    buf = open(resp, "rb").read()
+    n_pairs, cap = struct.unpack_from("<ii", buf, 0)
+    off = 8
+    assert n_pairs == len(pairs) and cap == cfg.max_kpts
+    rows = {}
+    msz = capi.STEREO_MATCH_DTYPE.itemsize
+    for _ in range(n_pairs):
+        i, j = struct.unpack_from("<ii", buf, off)
+        off += 8
+        rows[(i, j)] = np.frombuffer(buf, capi.STEREO_MATCH_DTYPE, nfr * cap, off).reshape(nfr, cap)
+        off += nfr * cap * msz
+    bb = multigpu.block_layout(cap)["total"]
+    ref = [[_oracle_camera(oracle, cfg, c, frames[f][c], grav[c][f]) for c in range(5)] for f in range(nfr)]
+    for c in range(5):
+        blocks = np.frombuffer(buf, np.uint8, nfr * bb, off).reshape(nfr, bb)
+        off += nfr * bb
+        for f in range(nfr):
+            k, d, bp, bv = multigpu.unpack_block_host(blocks[f], cap)
+            rk, rd, rbp, rbv = ref[f][c]
+            G.assert_keypoints_equal(k, rk)
+            assert np.array_equal(d, rd) and np.array_equal(bv, rbv)
+            assert np.array_equal(bp.view(np.uint64), rbp.view(np.uint64))
+    assert off == len(buf)
+    total = 0
+    for (i, j) in pairs:
+        for f in range(nfr):
+            (k0, d0, b0, v0), (k1, d1, b1, v1) = ref[f][i], ref[f][j]
+            want = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, poses[i], poses[j], focal[i], focal[j],
+                                       cfg.match_threshold)
+            assert np.array_equal(rows[(i, j)][f, :len(k0)].view(np.uint8), want.view(np.uint8)), (i, j, f)
+            total += int((want["k1"] >= 0).sum())
+    assert total > 100
+
+
 def test_tumvi_1024_stereo_detect_describe_match(oracle):
     """config/tumvi_slam_1024.yaml: both equidistant 1024x1024 cameras + matchStereo, 2 stereo
     frames through okvfe_detect_describe_batch_device / okvfe_match_stereo_batch_device."""
