@@ -528,6 +528,47 @@ okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0
                                               const okvfe_pose* T_WC1, double f0, double f1,
                                               okvfe_stereo_match* matches_dev, void* stream);
 
+/* ---- device-resident, batched map matchers ---------------------------------- */
+/* The map-side loops of the front-end on data that never leaves the GPU: frame f of the batch is
+ * gather block f (okvfe_pack_gather_blocks_device: keypoints, descriptors, back-projections and the
+ * keypoint count of one image), the pooled landmark set lives in device memory, ONE launch serves
+ * all frames, nothing synchronises the host.  Row capacity of every per-keypoint array = the
+ * context's okvfe_device_outputs.max_keypoints (K); rows >= a frame's keypoint count are untouched.
+ * The pooled set is what okvfe_match_to_map / okvfe_match_to_map_uninitialised take, as device
+ * pointers (e.g. uploaded once per keyframe with okvfe_copy_to_device). */
+typedef struct okvfe_map_device {
+  int32_t n_landmarks;        /* L */
+  const int32_t* desc_begin;  /* device, L + 1: landmark l owns pool rows desc_begin[l] .. desc_begin[l+1]-1 */
+  const uint8_t* pool;        /* device, desc_begin[L] x 48 pooled descriptors */
+  const double* projections;  /* device, n_frames x L x 2 (frame-major): 3-D landmarks projected into frame f
+                               * (Frontend.cpp:1232-1256); only okvfe_match_to_map_blocks_device reads it */
+  const double* e0_W;         /* device, desc_begin[L] x 3: observing unit ray per pool row (LandmarkToMatch::e_W) */
+  const double* r0_W;         /* device, desc_begin[L] x 3: observing camera centre per pool row */
+} okvfe_map_device;
+/* = Frontend::matchToMapByThread (Frontend.cpp:1552-1589) for n_frames frames.  use_dev: device
+ * n_frames x K flags or NULL (every keypoint).  Outputs (device, n_frames x K): landmark index
+ * (-1 = none) and distance (match_threshold if none). */
+okvfe_status okvfe_match_to_map_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
+                                              const uint8_t* use_dev, const okvfe_map_device* map,
+                                              double reprojection_threshold, int32_t* best_landmark_dev,
+                                              int32_t* best_dist_dev, void* stream);
+/* = Frontend::matchToMapByThreadUnitialised (Frontend.cpp:1616-1719) for n_frames frames.
+ * T_WC1: HOST array of n_frames poses (the one thing that crosses PCIe: 96 bytes per frame, through
+ * the context's pinned parameter ring); previous_landmark_dev: device n_frames x K or NULL (-1);
+ * outputs device: best_landmark / best_dist n_frames x K, hps_W n_frames x K x 4, hp_set
+ * n_frames x K, already_matched n_frames (zeroed by this call). */
+okvfe_status okvfe_match_to_map_uninitialised_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
+                                                            const uint8_t* use_dev, const int32_t* previous_landmark_dev,
+                                                            const okvfe_map_device* map, const okvfe_pose* T_WC1,
+                                                            double focal_length, int32_t* best_landmark_dev,
+                                                            int32_t* best_dist_dev, double* hps_W_dev, uint8_t* hp_set_dev,
+                                                            int32_t* already_matched_dev, void* stream);
+/* = the descriptor matching of Frontend::verifyRecognisedPlace (Frontend.cpp:330-355) of all L old
+ * landmarks against n_frames frames.  Outputs device n_frames x L as okvfe_verify_place_match. */
+okvfe_status okvfe_verify_place_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
+                                              const okvfe_map_device* map, int32_t* k_min_dev,
+                                              uint32_t* dist_min_dev, void* stream);
+
 /* ---- cross-camera gather collective (RCCL over xGMI) ---------------------- */
 /* The one exchange step of the path (okvis_frontend/src/Frontend.cpp:1990-2026 needs the keypoints
  * of BOTH cameras of a pair; with one camera per GPU they live on different ranks): an all-gather of

@@ -55,6 +55,12 @@ class StereoPair(C.Structure):
                 ("f0", C.c_double), ("f1", C.c_double)]
 
 
+class MapDevice(C.Structure):
+    """okvfe_map_device: the pooled landmark set in device memory (all members device pointers)."""
+    _fields_ = [("n_landmarks", C.c_int32), ("desc_begin", C.c_void_p), ("pool", C.c_void_p),
+                ("projections", C.c_void_p), ("e0_W", C.c_void_p), ("r0_W", C.c_void_p)]
+
+
 class DeviceOutputs(C.Structure):
     _fields_ = [("max_keypoints", C.c_int32), ("counts", C.c_void_p), ("keypoints", C.c_void_p),
                 ("descriptors", C.c_void_p), ("backproj", C.c_void_p),
@@ -79,6 +85,8 @@ EXPORTS = [
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
     "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
     "okvfe_match_to_map_landmarks", "okvfe_bow_vector", "okvfe_bow_query_l1",
+    "okvfe_match_to_map_blocks_device", "okvfe_match_to_map_uninitialised_blocks_device",
+    "okvfe_verify_place_blocks_device",
     "okvfe_comm_unique_id", "okvfe_comm_create", "okvfe_comm_wrap", "okvfe_comm_destroy",
     "okvfe_comm_world", "okvfe_comm_rank", "okvfe_comm_last_error", "okvfe_gather_blocks",
     "okvfe_device_alloc", "okvfe_device_free", "okvfe_stream_create", "okvfe_stream_destroy",
@@ -637,6 +645,38 @@ class Frontend:
         n = (C.c_int32 * len(STAGES))()
         self._check(lib().okvfe_profile_read(self._h, ms, n))
         return {STAGES[i]: (ms[i], n[i]) for i in range(len(STAGES))}
+
+    # -- device-resident, batched map matchers (frame f = gather block f) -----------------
+    @staticmethod
+    def make_map_device(n_landmarks, desc_begin_ptr, pool_ptr, projections_ptr=None, e0_ptr=None,
+                        r0_ptr=None) -> MapDevice:
+        m = MapDevice()
+        m.n_landmarks = int(n_landmarks)
+        m.desc_begin, m.pool = int(desc_begin_ptr), int(pool_ptr) if pool_ptr else None
+        m.projections = int(projections_ptr) if projections_ptr else None
+        m.e0_W = int(e0_ptr) if e0_ptr else None
+        m.r0_W = int(r0_ptr) if r0_ptr else None
+        return m
+
+    def match_to_map_blocks_device(self, blocks_ptr, n_frames, use_ptr, map_dev, repr_thr, best_lm_ptr,
+                                   best_d_ptr, stream=None):
+        self._check(lib().okvfe_match_to_map_blocks_device(
+            self._h, _p(blocks_ptr), int(n_frames), _p(use_ptr), C.byref(map_dev), C.c_double(repr_thr),
+            _p(best_lm_ptr), _p(best_d_ptr), _s(stream)))
+
+    def match_to_map_uninitialised_blocks_device(self, blocks_ptr, n_frames, use_ptr, previous_ptr, map_dev,
+                                                 poses_T_WC1, focal, best_lm_ptr, best_d_ptr, hps_ptr,
+                                                 hp_set_ptr, ctr_ptr, stream=None):
+        P = (Pose * int(n_frames))(*[make_pose(*T) for T in poses_T_WC1])
+        self._check(lib().okvfe_match_to_map_uninitialised_blocks_device(
+            self._h, _p(blocks_ptr), int(n_frames), _p(use_ptr), _p(previous_ptr), C.byref(map_dev), P,
+            C.c_double(focal), _p(best_lm_ptr), _p(best_d_ptr), _p(hps_ptr), _p(hp_set_ptr), _p(ctr_ptr),
+            _s(stream)))
+
+    def verify_place_blocks_device(self, blocks_ptr, n_frames, map_dev, k_min_ptr, dist_min_ptr, stream=None):
+        self._check(lib().okvfe_verify_place_blocks_device(
+            self._h, _p(blocks_ptr), int(n_frames), C.byref(map_dev), _p(k_min_ptr), _p(dist_min_ptr),
+            _s(stream)))
 
     # -- gather blocks --------------------------------------------------------------------
     def gather_block_bytes(self) -> int:

@@ -436,12 +436,28 @@ __global__ __launch_bounds__(64) void hamming_emit_kernel(const uint8_t* __restr
 // k inner) keeps the smallest distance and, among equals, the first in that scan order: the wave
 // reduces the key (dist << 32 | scan position).  The frame descriptors are staged in LDS once per
 // workgroup when they fit.
+// Device-resident batches of the map matchers (okvfe_*_blocks_device): frame f = blockIdx.y takes its
+// keypoints / descriptors / back-projections and its keypoint count from gather block f (the layout
+// of okvfe_pack_gather_blocks_device), per-frame inputs and outputs advance by the strides below.
+// blocks == nullptr is the classic single-frame call on plain arrays.
+struct MapBatch {
+  const uint8_t* blocks;
+  int o_kps, o_desc, o_bp, block_bytes, kp_cap;
+  size_t frame_stride;  // matchToMap: doubles per frame in `projections` (0 = one set for all frames)
+};
 constexpr int kVerifyLdsRows = 1024;  // 48 KiB
 __global__ __launch_bounds__(256) void verify_place_kernel(
     const uint8_t* __restrict__ pool, const int32_t* __restrict__ desc_begin, int n_landmarks,
     const uint8_t* __restrict__ frame_desc, int K, uint32_t threshold, int32_t* __restrict__ k_min,
-    uint32_t* __restrict__ dist_min) {
+    uint32_t* __restrict__ dist_min, MapBatch mb) {
   __shared__ uint4 lds_desc[kVerifyLdsRows * 3];
+  if (mb.blocks) {  // frame blockIdx.y of a device-resident batch
+    const uint8_t* base = mb.blocks + (size_t)blockIdx.y * mb.block_bytes;
+    K = *reinterpret_cast<const int32_t*>(base);
+    frame_desc = base + mb.o_desc;
+    k_min += (size_t)blockIdx.y * n_landmarks;
+    dist_min += (size_t)blockIdx.y * n_landmarks;
+  }
   const bool in_lds = K <= kVerifyLdsRows;
   if (in_lds) {
     const uint4* src = reinterpret_cast<const uint4*>(frame_desc);
@@ -709,13 +725,23 @@ __global__ __launch_bounds__(64 * kMapSegs) void match_to_map_kernel(
     const uint8_t* __restrict__ desc_k, const okvfe_keypoint* __restrict__ kps,
     const uint8_t* __restrict__ use, int n_k, const double* __restrict__ projections,
     const int32_t* __restrict__ desc_begin, int n_lm, const uint8_t* __restrict__ pool,
-    double thr_sq, int threshold, int32_t* __restrict__ best_lm, int32_t* __restrict__ best_d) {
+    double thr_sq, int threshold, int32_t* __restrict__ best_lm, int32_t* __restrict__ best_d, MapBatch mb) {
   __shared__ uint4 seg_desc[kMapSegs][kMapChunkDesc * 3];
   __shared__ int2 seg_best[kMapSegs - 1][64];
+  if (mb.blocks) {  // frame blockIdx.y of a device-resident batch
+    const uint8_t* base = mb.blocks + (size_t)blockIdx.y * mb.block_bytes;
+    n_k = *reinterpret_cast<const int32_t*>(base);
+    desc_k = base + mb.o_desc;
+    kps = reinterpret_cast<const okvfe_keypoint*>(base + mb.o_kps);
+    if (use) use += (size_t)blockIdx.y * mb.kp_cap;
+    projections += (size_t)blockIdx.y * mb.frame_stride;
+    best_lm += (size_t)blockIdx.y * mb.kp_cap;
+    best_d += (size_t)blockIdx.y * mb.kp_cap;
+  }
   const int lane = threadIdx.x, seg = threadIdx.y;
   const int k = blockIdx.x * 64 + lane;
   const bool in_range = k < n_k;
-  const bool active = in_range && use[k] != 0;
+  const bool active = in_range && (use == nullptr || use[k] != 0);
   Desc12 dk = {};
   double kx = 0.0, ky = 0.0;
   if (active) {
@@ -828,13 +854,27 @@ __global__ __launch_bounds__(64 * kUninitSegs) void match_to_map_uninit_kernel(
     const uint8_t* __restrict__ pool, const double* __restrict__ e0_W,
     const double* __restrict__ r0_W, int threshold, int32_t* __restrict__ best_lm,
     int32_t* __restrict__ best_d, double* __restrict__ hps_W, uint8_t* __restrict__ hp_set,
-    int32_t* __restrict__ ctr_total) {
+    int32_t* __restrict__ ctr_total, MapBatch mb) {
   __shared__ UninitSegResult seg_res[kUninitSegs - 1][64];
+  if (mb.blocks) {  // frame blockIdx.y of a device-resident batch: its own pose record, block and rows
+    const uint8_t* base = mb.blocks + (size_t)blockIdx.y * mb.block_bytes;
+    pair += blockIdx.y;
+    n_k = *reinterpret_cast<const int32_t*>(base);
+    desc_k = base + mb.o_desc;
+    bp = reinterpret_cast<const double*>(base + mb.o_bp);
+    if (use) use += (size_t)blockIdx.y * mb.kp_cap;
+    if (previous) previous += (size_t)blockIdx.y * mb.kp_cap;
+    best_lm += (size_t)blockIdx.y * mb.kp_cap;
+    best_d += (size_t)blockIdx.y * mb.kp_cap;
+    hps_W += 4 * (size_t)blockIdx.y * mb.kp_cap;
+    hp_set += (size_t)blockIdx.y * mb.kp_cap;
+    ctr_total += blockIdx.y;
+  }
   const PairParams& P = *pair;  // C1/r1 = T_WC1; cos26/cos6 for sigma = 1/f
   const int lane = threadIdx.x, seg = threadIdx.y;
   const int k = blockIdx.x * 64 + lane;
   const bool in_range = k < n_k;
-  const bool active = in_range && use[k] != 0;
+  const bool active = in_range && (use == nullptr || use[k] != 0);
   Desc12 dk = {};
   double e1_W[3] = {0, 0, 0};
   int prev = -1;
@@ -843,7 +883,7 @@ __global__ __launch_bounds__(64 * kUninitSegs) void match_to_map_uninit_kernel(
     double en[3];
     normalize3(bp + 3 * (size_t)k, en);
     rot(P.C1, en, e1_W);
-    prev = previous[k];
+    prev = previous ? previous[k] : -1;
   }
   // gate of one (keypoint, pooled descriptor) pair in the reference's order; pure
   auto gate = [&](int d, double hp[4], bool* is_parallel) -> bool {
@@ -1086,7 +1126,19 @@ void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, c
   if (n_k <= 0) return;
   hipLaunchKernelGGL(match_to_map_uninit_kernel, dim3((n_k + 63) / 64), dim3(64, kUninitSegs), 0, stream, pair,
                      desc_k, bp, use, previous, n_k, desc_begin, n_lm, pool, e0_W, r0_W, threshold,
-                     best_lm, best_d, hps_W, hp_set, ctr_total);
+                     best_lm, best_d, hps_W, hp_set, ctr_total, MapBatch{});
+}
+void launch_match_to_map_uninit_blocks(const PairParams* pairs, const int offs[6], const uint8_t* blocks,
+                                       int n_frames, int kp_cap, const uint8_t* use, const int32_t* previous,
+                                       const int32_t* desc_begin, int n_lm, const uint8_t* pool,
+                                       const double* e0_W, const double* r0_W, int threshold, int32_t* best_lm,
+                                       int32_t* best_d, double* hps_W, uint8_t* hp_set, int32_t* ctr_total,
+                                       hipStream_t stream) {
+  if (n_frames <= 0 || kp_cap <= 0) return;
+  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, 0};
+  hipLaunchKernelGGL(match_to_map_uninit_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64, kUninitSegs), 0,
+                     stream, pairs, nullptr, nullptr, use, previous, 0, desc_begin, n_lm, pool, e0_W, r0_W,
+                     threshold, best_lm, best_d, hps_W, hp_set, ctr_total, mb);
 }
 
 void launch_match_motion(const PairParams* pair, const DeviceCamera* camera, int w, int h,
@@ -1108,7 +1160,17 @@ void launch_match_to_map(const uint8_t* desc_k, const okvfe_keypoint* kps, const
   if (n_k <= 0) return;
   hipLaunchKernelGGL(match_to_map_kernel, dim3((n_k + 63) / 64), dim3(64, kMapSegs), 0, stream, desc_k, kps,
                      use, n_k, projections, desc_begin, n_lm, pool, thr_sq, threshold, best_lm,
-                     best_d);
+                     best_d, MapBatch{});
+}
+void launch_match_to_map_blocks(const int offs[6], const uint8_t* blocks, int n_frames, int kp_cap,
+                                const uint8_t* use, const double* projections, size_t proj_stride,
+                                const int32_t* desc_begin, int n_lm, const uint8_t* pool, double thr_sq,
+                                int threshold, int32_t* best_lm, int32_t* best_d, hipStream_t stream) {
+  if (n_frames <= 0 || kp_cap <= 0) return;
+  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, proj_stride};
+  hipLaunchKernelGGL(match_to_map_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64, kMapSegs), 0, stream,
+                     nullptr, nullptr, use, 0, projections, desc_begin, n_lm, pool, thr_sq, threshold, best_lm,
+                     best_d, mb);
 }
 
 void launch_match_stereo(const PairParams* pairs, int n_pairs, const okvfe_keypoint* kps,
@@ -1137,7 +1199,16 @@ void launch_verify_place(const uint8_t* pool, const int32_t* desc_begin, int n_l
   if (n_landmarks <= 0) return;
   const int blocks = std::min((n_landmarks + 3) / 4, 2048);
   hipLaunchKernelGGL(verify_place_kernel, dim3(blocks), dim3(256), 0, stream, pool, desc_begin, n_landmarks,
-                     frame_desc, K, threshold, k_min, dist_min);
+                     frame_desc, K, threshold, k_min, dist_min, MapBatch{});
+}
+void launch_verify_place_blocks(const uint8_t* pool, const int32_t* desc_begin, int n_landmarks, const int offs[6],
+                                const uint8_t* blocks, int n_frames, int kp_cap, uint32_t threshold,
+                                int32_t* k_min, uint32_t* dist_min, hipStream_t stream) {
+  if (n_landmarks <= 0 || n_frames <= 0) return;
+  const int blocks_x = std::min((n_landmarks + 3) / 4, 2048);
+  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, 0};
+  hipLaunchKernelGGL(verify_place_kernel, dim3(blocks_x, n_frames), dim3(256), 0, stream, pool, desc_begin,
+                     n_landmarks, nullptr, 0, threshold, k_min, dist_min, mb);
 }
 void launch_bow_query_l1(const int32_t* db_begin, const int32_t* db_ids, const double* db_values, int n_entries,
                          const int32_t* q_ids, const double* q_values, int n_q, double* scores,

@@ -1937,6 +1937,112 @@ okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* 
   return ring_release(ctx, &ctx->cls_ring, cls_slot, s);
 }
 
+// ---- device-resident, batched map matchers (frame f = gather block f) --------------------------
+namespace {
+okvfe_status map_args_ok(okvfe_ctx* ctx, const char* who, const void* blocks, int n_frames, const okvfe_map_device* map) {
+  if (!blocks || !map || n_frames < 1 || map->n_landmarks < 0 || !map->desc_begin ||
+      (map->n_landmarks > 0 && !map->pool))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
+  return OKVFE_OK;
+}
+}  // namespace
+
+okvfe_status okvfe_match_to_map_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
+                                              const uint8_t* use_dev, const okvfe_map_device* map,
+                                              double reprojection_threshold, int32_t* best_landmark_dev,
+                                              int32_t* best_dist_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  okvfe_status st = map_args_ok(ctx, "okvfe_match_to_map_blocks_device", blocks_dev, n_frames, map);
+  if (st != OKVFE_OK) return st;
+  if (!best_landmark_dev || !best_dist_dev || !(reprojection_threshold >= 0.0) ||
+      (map->n_landmarks > 0 && !map->projections))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_blocks_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  {
+    StageTimer t(ctx, OKVFE_STAGE_MAP, s);
+    launch_match_to_map_blocks(offs, static_cast<const uint8_t*>(blocks_dev), n_frames, ctx->kp_cap, use_dev,
+                               map->projections, (size_t)map->n_landmarks * 2, map->desc_begin, map->n_landmarks,
+                               map->pool, reprojection_threshold * reprojection_threshold, ctx->cfg.match_threshold,
+                               best_landmark_dev, best_dist_dev, s);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_match_to_map_uninitialised_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
+                                                            const uint8_t* use_dev, const int32_t* previous_landmark_dev,
+                                                            const okvfe_map_device* map, const okvfe_pose* T_WC1,
+                                                            double focal_length, int32_t* best_landmark_dev,
+                                                            int32_t* best_dist_dev, double* hps_W_dev, uint8_t* hp_set_dev,
+                                                            int32_t* already_matched_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  okvfe_status st = map_args_ok(ctx, "okvfe_match_to_map_uninitialised_blocks_device", blocks_dev, n_frames, map);
+  if (st != OKVFE_OK) return st;
+  if (!T_WC1 || !(focal_length > 0.0) || !best_landmark_dev || !best_dist_dev || !hps_W_dev || !hp_set_dev ||
+      !already_matched_dev || (map->n_landmarks > 0 && (!map->e0_W || !map->r0_W)))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_to_map_uninitialised_blocks_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  // one pose record per frame, through the pinned parameter ring (one asynchronous copy, no host sync)
+  std::vector<PairParams> pp((size_t)n_frames);
+  const double sigma = 1.0 / focal_length;  // Frontend.cpp:1636
+  const double c26 = std::cos(2.6 * sigma), c6 = std::cos(6.0 * sigma);
+  for (int f = 0; f < n_frames; ++f) {
+    pp[(size_t)f] = PairParams{};
+    std::memcpy(pp[(size_t)f].C1, T_WC1[f].C, sizeof(pp[(size_t)f].C1));
+    std::memcpy(pp[(size_t)f].r1, T_WC1[f].r, sizeof(pp[(size_t)f].r1));
+    pp[(size_t)f].cos26 = c26;
+    pp[(size_t)f].cos6 = c6;
+  }
+  void* d_pairs = nullptr;
+  int slot = -1;
+  st = ring_upload(ctx, &ctx->pair_ring, pp.data(), pp.size() * sizeof(PairParams), s, &d_pairs, &slot);
+  if (st != OKVFE_OK) return st;
+  hipError_t e = hipMemsetAsync(already_matched_dev, 0, (size_t)n_frames * sizeof(int32_t), s);
+  if (e == hipSuccess) {
+    StageTimer t(ctx, OKVFE_STAGE_MAP, s);
+    launch_match_to_map_uninit_blocks(static_cast<const PairParams*>(d_pairs), offs,
+                                      static_cast<const uint8_t*>(blocks_dev), n_frames, ctx->kp_cap, use_dev,
+                                      previous_landmark_dev, map->desc_begin, map->n_landmarks, map->pool, map->e0_W,
+                                      map->r0_W, ctx->cfg.match_threshold, best_landmark_dev, best_dist_dev, hps_W_dev,
+                                      hp_set_dev, already_matched_dev, s);
+    e = hipGetLastError();
+  }
+  const okvfe_status rel = ring_release(ctx, &ctx->pair_ring, slot, s);  // on every path: the slot has a reader or not
+  HIP_TRY(ctx, e);
+  ctx->last_stream = s;
+  return rel;
+}
+
+okvfe_status okvfe_verify_place_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
+                                              const okvfe_map_device* map, int32_t* k_min_dev,
+                                              uint32_t* dist_min_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  okvfe_status st = map_args_ok(ctx, "okvfe_verify_place_blocks_device", blocks_dev, n_frames, map);
+  if (st != OKVFE_OK) return st;
+  if (!k_min_dev || !dist_min_dev)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_verify_place_blocks_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const BlockLayout L = block_layout(ctx->kp_cap);
+  const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  {
+    StageTimer t(ctx, OKVFE_STAGE_MAP, s);
+    launch_verify_place_blocks(map->pool, map->desc_begin, map->n_landmarks, offs,
+                               static_cast<const uint8_t*>(blocks_dev), n_frames, ctx->kp_cap,
+                               (uint32_t)ctx->cfg.match_threshold, k_min_dev, dist_min_dev, s);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_match_motion_stereo_blocks_device(okvfe_ctx* ctx, int32_t cam, const void* block0_dev,
                                                      const void* block1_dev, const uint8_t* skip0_dev,
                                                      const uint8_t* matched1_dev, const okvfe_pose* T_WC0,

@@ -202,6 +202,20 @@ void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, c
                                 const double* e0_W, const double* r0_W, int threshold,
                                 int32_t* best_lm, int32_t* best_d, double* hps_W, uint8_t* hp_set,
                                 int32_t* ctr_total, hipStream_t stream);
+// device-resident batches of the map matchers (frame f reads gather block f; k_match.hip, MapBatch)
+void launch_match_to_map_blocks(const int offs[6], const uint8_t* blocks, int n_frames, int kp_cap,
+                                const uint8_t* use, const double* projections, size_t proj_stride,
+                                const int32_t* desc_begin, int n_lm, const uint8_t* pool, double thr_sq,
+                                int threshold, int32_t* best_lm, int32_t* best_d, hipStream_t stream);
+void launch_match_to_map_uninit_blocks(const PairParams* pairs, const int offs[6], const uint8_t* blocks,
+                                       int n_frames, int kp_cap, const uint8_t* use, const int32_t* previous,
+                                       const int32_t* desc_begin, int n_lm, const uint8_t* pool,
+                                       const double* e0_W, const double* r0_W, int threshold, int32_t* best_lm,
+                                       int32_t* best_d, double* hps_W, uint8_t* hp_set, int32_t* ctr_total,
+                                       hipStream_t stream);
+void launch_verify_place_blocks(const uint8_t* pool, const int32_t* desc_begin, int n_landmarks, const int offs[6],
+                                const uint8_t* blocks, int n_frames, int kp_cap, uint32_t threshold,
+                                int32_t* k_min, uint32_t* dist_min, hipStream_t stream);
 void launch_pack_blocks(const int offs[6], int first, int n, int kp_cap, const int32_t* counts,
                         const okvfe_keypoint* kps, const uint8_t* desc, const double* bp,
                         const uint8_t* bpv, uint8_t* blocks, hipStream_t stream);
