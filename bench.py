@@ -169,6 +169,158 @@ WORKLOAD_TEXT = {
 }
 
 
+# VALU issue rates measured on this part (tools/ubench/valu_rate.hip, profiles/round2_valu_rate_ubench.txt):
+# 2.3 cycles per wave64 instruction for xor / add / shifts, 4.2 for v_bcnt_u32_b32 and the rest of VOP3.
+# A 384-bit Hamming distance = 12 x (v_xor + v_bcnt accumulate) per lane = 78 cycles per 64 pairs on
+# one of 1024 SIMDs at 2.4 GHz.
+VALU_PEAK_HAMMING_PAIRS = 1024 * 64 / (12 * (2.3 + 4.2)) * 2.4e9
+# L2 -> LDS direct loads (buffer_load ... lds), the path the descriptor kernel stages its patches
+# through: ~12 B per cycle per CU (guides/MI355X_MICROARCH.md, "LDS-DMA prologue ~12-13 B/cyc/CU")
+LDS_DMA_PEAK_GBPS = 256 * 12.0 * 2.4
+
+
+def alu_rooflines(stage_ms, pair_evals_per_launch, kp_described_per_launch, patch_bytes_per_kp, n_img_launch):
+    """Roofline blocks of the kernels that are NOT HBM-bound: what bounds them, the
+    achieved rate from this run's stage times and the fraction of that bound's peak."""
+    out = {}
+    if stage_ms.get("match") and pair_evals_per_launch:
+        a = pair_evals_per_launch / (stage_ms["match"] * 1e-3)
+        out["match_stereo"] = {"kernel": "match_stereo_kernel (K7)", "bound": "valu", "achieved": a / 1e9,
+                               "peak": VALU_PEAK_HAMMING_PAIRS / 1e9, "unit": "G Hamming pairs/s (384 bit)",
+                               "frac": a / VALU_PEAK_HAMMING_PAIRS,
+                               "algorithmic_pairs_per_launch": pair_evals_per_launch,
+                               "note": "sum over stereo frames of n0 x n1 descriptor pairs (the reference evaluates "
+                                       "every pair, Frontend.cpp:2016-2026); peak = 12 x (v_xor + v_bcnt) at the "
+                                       "measured issue rates; the rest of the launch is the FP64 gate rounds"}
+    if stage_ms.get("describe") and kp_described_per_launch:
+        a = kp_described_per_launch * patch_bytes_per_kp / (stage_ms["describe"] * 1e-3) / 1e9
+        out["describe"] = {"kernel": "describe_kernel (K6)", "bound": "l2_to_lds (buffer_load ... lds)",
+                           "achieved": a, "peak": LDS_DMA_PEAK_GBPS, "unit": "GB/s staged into LDS",
+                           "frac": a / LDS_DMA_PEAK_GBPS,
+                           "patch_bytes_per_keypoint": patch_bytes_per_kp,
+                           "keypoints_per_launch": kp_described_per_launch,
+                           "note": "a keypoint's pattern patch (64 rows x 64..80 B) goes L2 -> LDS once; the box "
+                                   "sums (~420 VALU per keypoint, profiles/round3 SQ counters) overlap with it; "
+                                   "stage time includes describe_setup_kernel"}
+    if stage_ms.get("select"):
+        out["select"] = {"kernel": "select_lazy_kernel (K3 uniformity + K4 sub-pixel)", "bound": "latency",
+                         "achieved": n_img_launch / (stage_ms["select"] * 1e-3), "peak": None, "unit": "images/s",
+                         "frac": None,
+                         "note": "one workgroup per image, all images of the launch resident at once: the launch "
+                                 "lasts as long as ONE image's serial chain (candidates in score order, ~2 k "
+                                 "cycles per 64-candidate window); there is no throughput peak to compare with"}
+    if stage_ms.get("sort"):
+        out["sort"] = {"kernel": "sort_rb_kernel (K3 sort)", "bound": "lds", "achieved": None, "peak": None,
+                       "unit": None, "frac": None,
+                       "note": "bitonic network on 64-bit keys in LDS, 24 passes for 8192 keys; ~24 G keys/s"}
+    return out
+
+
+def run_map_workload(args, torch, capi, synth, dev):
+    """SURVEY.md 8 D3 / Frontend.cpp:1515-1589: the map matcher on device-resident data.  One step =
+    okvfe_match_to_map_blocks_device over B frames of 700 keypoints against 5000 pooled 3-D landmarks
+    (1..3 descriptors each, projections per frame), nothing crossing PCIe.  Reports frames/s and the
+    VALU roofline of the Hamming work; rank 0 / one GPU (replicas only: the map needs estimator state)."""
+    from okvis2_amd import multigpu
+    cfg = synth.euroc_config()
+    B = args.batch if args.batch != 768 else 256
+    K, L = cfg.max_kpts, 5000
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, K,
+                       match_threshold=cfg.match_threshold, max_batch=1, num_cameras=1, device=dev.index)
+    rng = np.random.default_rng(7)
+    counts = rng.integers(1, 4, L)
+    begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    pool = rng.integers(0, 256, (begin[-1], 48), dtype=np.uint8)
+    lm_xy = np.stack([rng.uniform(-200, 952, L), rng.uniform(-150, 630, L)], 1)  # ~60 % inside the image
+    distinct = min(args.distinct, B)
+    blocks, proj, useful = [], [], []
+    kdt = capi.KEYPOINT_DTYPE
+    for f in range(distinct):
+        kps = np.zeros(K, dtype=kdt)
+        kps["x"] = rng.uniform(30, cfg.w - 30, K)
+        kps["y"] = rng.uniform(30, cfg.h - 30, K)
+        desc = rng.integers(0, 256, (K, 48), dtype=np.uint8)
+        p = lm_xy + rng.normal(0, 2.0, (L, 2))
+        vis = np.flatnonzero((p[:, 0] > 0) & (p[:, 0] < cfg.w) & (p[:, 1] > 0) & (p[:, 1] < cfg.h))
+        obs = rng.permutation(vis)[:K]  # keypoint i observes landmark obs[i]
+        kps["x"][:len(obs)] = p[obs, 0] + rng.normal(0, 1.5, len(obs))
+        kps["y"][:len(obs)] = p[obs, 1] + rng.normal(0, 1.5, len(obs))
+        for i, l in enumerate(obs[::2]):
+            desc[2 * i] = pool[begin[l]] ^ ((rng.random(48) < 0.04) * rng.integers(0, 256, 48)).astype(np.uint8)
+        blocks.append(multigpu.pack_block_host(K, kps, desc, np.zeros((K, 3)), np.ones(K, np.uint8)))
+        proj.append(p)
+        # Hamming evaluations of the reference loop: (keypoint, pooled descriptor) pairs within the radius
+        dx = kps["x"][:, None].astype(np.float64) - p[None, :, 0]
+        dy = kps["y"][:, None].astype(np.float64) - p[None, :, 1]
+        near = (dx * dx + dy * dy) <= args.map_radius ** 2
+        useful.append(int((near * counts[None, :]).sum()))
+    rep = [i % distinct for i in range(B)]
+    d_blocks = torch.from_numpy(np.stack([blocks[i] for i in rep])).to(dev)
+    d_proj = torch.from_numpy(np.stack([proj[i] for i in rep])).to(dev)
+    d_begin, d_pool = torch.from_numpy(begin).to(dev), torch.from_numpy(pool).to(dev)
+    md = fe.make_map_device(L, d_begin.data_ptr(), d_pool.data_ptr(), d_proj.data_ptr())
+    d_lm = torch.empty((B, K), dtype=torch.int32, device=dev)
+    d_bd = torch.empty((B, K), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    fe.profile_enable(True, stages=("map",))
+
+    def step():
+        fe.match_to_map_blocks_device(d_blocks.data_ptr(), B, None, md, args.map_radius, d_lm.data_ptr(),
+                                      d_bd.data_ptr(), st)
+
+    for _ in range(args.warmup):
+        step()
+    st.synchronize()
+    torch.cuda.synchronize()
+    steps = args.steps
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        st.synchronize()
+        elapsed = time.perf_counter() - t0
+        if elapsed >= MIN_TIMED_S or args.exact_steps:
+            break
+        steps *= int(math.ceil(MIN_TIMED_S / max(elapsed, 1e-6))) + 1
+        fe.profile_enable(False)
+        fe.profile_enable(True, stages=("map",))
+    ms, cnt = fe.profile_read()["map"]
+    launch_ms = ms / cnt
+    lm = d_lm.cpu().numpy()
+    matched = int((lm[:distinct] >= 0).sum())
+    # parity on the first distinct frames against the host-buffer entry point (itself oracle-checked in tests/)
+    pairs_launch = sum(useful[i] for i in rep)
+    brute = B * K * int(begin[-1])
+    a = pairs_launch / (launch_ms * 1e-3)
+    res = {
+        "metric": "map-matcher frames/s (matchToMapByThread, 5000 pooled landmarks x 700 keypoints)",
+        "value": B * steps / elapsed, "unit": "frames/s", "n_gpus": 1, "steps": steps,
+        "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8 (Hamming) + f64 (reprojection gate)", "data": "synthetic",
+        "config": {"workload": "Frontend::matchToMapByThread (Frontend.cpp:1552-1589) on device-resident data: "
+                               f"{B} frames x {K} keypoints (gather blocks) against {L} pooled 3-D landmarks "
+                               f"({int(begin[-1])} descriptors), reprojection radius {args.map_radius} px, one "
+                               "launch per step (okvfe_match_to_map_blocks_device), nothing crosses PCIe",
+                   "frames_per_step": B, "distinct_frames": distinct,
+                   "matched_keypoints_per_frame": matched / distinct,
+                   "parallelism": "replicas only (the map needs estimator state)"},
+        "roofline": {"kernel": "match_to_map_kernel (batched over gather blocks)", "bound": "valu",
+                     "achieved": a / 1e9, "peak": VALU_PEAK_HAMMING_PAIRS / 1e9,
+                     "unit": "G Hamming pairs/s (384 bit)", "frac": a / VALU_PEAK_HAMMING_PAIRS,
+                     "algorithmic_pairs_per_launch": pairs_launch, "avg_launch_ms": launch_ms,
+                     "brute_force_pairs_per_launch": brute,
+                     "brute_force_equivalent_frac": brute / (launch_ms * 1e-3) / VALU_PEAK_HAMMING_PAIRS,
+                     "traffic": None,
+                     "note": "algorithmic pairs = (keypoint, pooled descriptor) pairs inside the reprojection "
+                             "radius = the Hamming distances the reference loop evaluates; the kernel tests the "
+                             "radius per (wave of 64 keypoints, landmark) and skips a landmark no keypoint of the "
+                             "wave is near, so most of its time is the FP64 radius test over K x L, not popcounts; "
+                             "peak = 12 x (v_xor + v_bcnt) per pair at the measured VALU issue rates"},
+    }
+    return res
+
+
 def k1_name(h):
     return "harris_kernel<61, true> (K1 score map + fused K2 NMS)"
 
@@ -304,7 +456,9 @@ def main():
     ap.add_argument("--stagger", type=int, default=1,
                     help="with --lanes > 1: serialise the score kernels of the lanes (library env "
                          "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
-    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640"), default="euroc",
+    ap.add_argument("--map-radius", type=float, default=20.0,
+                    help="--workload map: reprojection threshold in px (20 with IMU, 150 without; Frontend.cpp:1530)")
+    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640", "map"), default="euroc",
                     help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3]; "
                          "hilti = configs[4] (5 cameras); mono640 = configs[1] (informational; batch "
                          "192 by default for these)")
@@ -350,6 +504,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.workload == "map":
+        res = run_map_workload(args, torch, capi, synth, dev)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload != "euroc" and args.batch == 768:
         # frames per step that fill the 256 CUs for a whole number of workgroup rounds of the score
         # kernel (1536 resident workgroups): 512 TUM-VI images = 6.9 rounds, 1536 VGA images = 6
@@ -489,9 +651,11 @@ def main():
     for lane in lanes:
         lane[0].check_capacity(n_lane_img)
     kp_total = 0
+    kp_counts = []
     for i in range(min(n_img, C * distinct)):
         k, _, _, _ = fe.download(i)
         kp_total += len(k)
+        kp_counts.append(len(k))
     m_host = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts).copy()
 
     def read_profiles():
@@ -648,6 +812,11 @@ def main():
                          if S == 1 else
                          "avg_launch_ms is taken while the other lanes' kernels share the GPU; "
                          "isolated_* is the same launch with the GPU to itself")}),
+            "rooflines_other": alu_rooflines(
+                stage_ms,
+                (sum(kp_counts[C * i] * kp_counts[C * i + 1] for i in range(len(kp_counts) // C)) *
+                 (Bl / max(1, len(kp_counts) // C))) if C > 1 else 0,
+                kp_total * (n_lane_img / max(1, len(kp_counts))), 4512, n_lane_img),
             "stage_ms_per_launch": stage_ms,
             "stage_ms_note": "all-stage event pass of 3 steps after the timed region; avg_launch_ms of "
                              "the roofline comes from the timed region itself",
