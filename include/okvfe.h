@@ -528,6 +528,32 @@ okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0
                                               const okvfe_pose* T_WC1, double f0, double f1,
                                               okvfe_stereo_match* matches_dev, void* stream);
 
+/* ---- sampling pattern as data ------------------------------------------------ */
+/* The extractor's sampling pattern is DATA: the pattern the library builds at okvfe_create restates
+ * the published BRISK geometry (the BRISK2 pattern of the reference's
+ * `brisk` submodule could not be read here); a pattern confirmed against a real brisk build --
+ * sample offsets, smoothing half-widths, the short pairs IN BIT ORDER, the long pairs of the
+ * orientation estimate -- is installed with okvfe_set_pattern and replaces it without touching a
+ * kernel.  Limits of the kernels: <= 60 sample points (one lane each), <= 384 short pairs (bit b of
+ * the 48-byte row = value[short_i[b]] > value[short_j[b]]; unused bits stay 0), <= 1100 long pairs,
+ * border >= the farthest sample + its half-width + 1.  okvfe_set_pattern synchronises the context. */
+#define OKVFE_PATTERN_POINTS 60
+#define OKVFE_PATTERN_SHORT_PAIRS 384
+#define OKVFE_PATTERN_LONG_PAIRS 1100
+typedef struct okvfe_pattern {
+  int32_t n_points;
+  float px[OKVFE_PATTERN_POINTS], py[OKVFE_PATTERN_POINTS]; /* offsets from the keypoint, upright, px */
+  float sigma_half[OKVFE_PATTERN_POINTS];                   /* half side of the smoothing box */
+  int32_t n_short;
+  uint8_t short_i[OKVFE_PATTERN_SHORT_PAIRS], short_j[OKVFE_PATTERN_SHORT_PAIRS];
+  int32_t n_long;
+  uint8_t long_i[OKVFE_PATTERN_LONG_PAIRS], long_j[OKVFE_PATTERN_LONG_PAIRS];
+  int32_t long_wdx[OKVFE_PATTERN_LONG_PAIRS], long_wdy[OKVFE_PATTERN_LONG_PAIRS]; /* round(2048 d / |d|^2) */
+  int32_t border; /* keypoints closer than this to the image rim are removed */
+} okvfe_pattern;
+okvfe_status okvfe_get_pattern(const okvfe_ctx* ctx, okvfe_pattern* out);
+okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* pattern);
+
 /* ---- device-resident, batched map matchers ---------------------------------- */
 /* The map-side loops of the front-end on data that never leaves the GPU: frame f of the batch is
  * gather block f (okvfe_pack_gather_blocks_device: keypoints, descriptors, back-projections and the

@@ -55,6 +55,15 @@ class StereoPair(C.Structure):
                 ("f0", C.c_double), ("f1", C.c_double)]
 
 
+class PatternData(C.Structure):
+    """okvfe_pattern: the extractor's sampling pattern as data (okvfe_get_pattern / okvfe_set_pattern)."""
+    _fields_ = [("n_points", C.c_int32), ("px", C.c_float * 60), ("py", C.c_float * 60),
+                ("sigma_half", C.c_float * 60), ("n_short", C.c_int32),
+                ("short_i", C.c_uint8 * 384), ("short_j", C.c_uint8 * 384),
+                ("n_long", C.c_int32), ("long_i", C.c_uint8 * 1100), ("long_j", C.c_uint8 * 1100),
+                ("long_wdx", C.c_int32 * 1100), ("long_wdy", C.c_int32 * 1100), ("border", C.c_int32)]
+
+
 class MapDevice(C.Structure):
     """okvfe_map_device: the pooled landmark set in device memory (all members device pointers)."""
     _fields_ = [("n_landmarks", C.c_int32), ("desc_begin", C.c_void_p), ("pool", C.c_void_p),
@@ -85,6 +94,7 @@ EXPORTS = [
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
     "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
     "okvfe_match_to_map_landmarks", "okvfe_bow_vector", "okvfe_bow_query_l1",
+    "okvfe_get_pattern", "okvfe_set_pattern",
     "okvfe_match_to_map_blocks_device", "okvfe_match_to_map_uninitialised_blocks_device",
     "okvfe_verify_place_blocks_device",
     "okvfe_comm_unique_id", "okvfe_comm_create", "okvfe_comm_wrap", "okvfe_comm_destroy",
@@ -645,6 +655,15 @@ class Frontend:
         n = (C.c_int32 * len(STAGES))()
         self._check(lib().okvfe_profile_read(self._h, ms, n))
         return {STAGES[i]: (ms[i], n[i]) for i in range(len(STAGES))}
+
+    # -- sampling pattern as data ----------------------------------------------------------
+    def get_pattern(self) -> PatternData:
+        p = PatternData()
+        self._check(lib().okvfe_get_pattern(self._h, C.byref(p)))
+        return p
+
+    def set_pattern(self, pattern: PatternData):
+        self._check(lib().okvfe_set_pattern(self._h, C.byref(pattern)))
 
     # -- device-resident, batched map matchers (frame f = gather block f) -----------------
     @staticmethod

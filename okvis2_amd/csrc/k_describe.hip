@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   const uint8_t* im = images + (size_t)img * w * h;
   const ImageParams ip = prm[img];
   const int border = pat->border;
-  const bool active = lane < kPatternPoints;
+  const bool active = lane < pat->n_points;  // <= kPatternPoints (okvfe_set_pattern may install fewer samples)
   const int li = active ? lane : 0;
   float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
   int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];

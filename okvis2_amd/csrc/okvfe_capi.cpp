@@ -1937,6 +1937,80 @@ okvfe_status okvfe_match_stereo_blocks_batch_device(okvfe_ctx* ctx, const void* 
   return ring_release(ctx, &ctx->cls_ring, cls_slot, s);
 }
 
+// ---- sampling pattern as data ---------------------------------------------------------------------
+okvfe_status okvfe_get_pattern(const okvfe_ctx* ctx, okvfe_pattern* out) {
+  if (!ctx || !out) return OKVFE_ERR_INVALID_ARGUMENT;
+  const Pattern& P = ctx->host_pattern;
+  std::memset(out, 0, sizeof(*out));
+  out->n_points = P.n_points;
+  std::memcpy(out->px, P.px, sizeof(out->px));
+  std::memcpy(out->py, P.py, sizeof(out->py));
+  std::memcpy(out->sigma_half, P.sigma_half, sizeof(out->sigma_half));
+  out->n_short = P.n_short;
+  std::memcpy(out->short_i, P.short_i, sizeof(out->short_i));
+  std::memcpy(out->short_j, P.short_j, sizeof(out->short_j));
+  out->n_long = P.n_long;
+  std::memcpy(out->long_i, P.long_i, sizeof(out->long_i));
+  std::memcpy(out->long_j, P.long_j, sizeof(out->long_j));
+  std::memcpy(out->long_wdx, P.long_wdx, sizeof(out->long_wdx));
+  std::memcpy(out->long_wdy, P.long_wdy, sizeof(out->long_wdy));
+  out->border = P.border;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* p) {
+  if (!ctx || !p) return OKVFE_ERR_INVALID_ARGUMENT;
+  static_assert(OKVFE_PATTERN_POINTS == kPatternPoints && OKVFE_PATTERN_LONG_PAIRS == kMaxLongPairs, "pattern limits");
+  if (p->n_points < 1 || p->n_points > kPatternPoints || p->n_short < 0 || p->n_short > OKVFE_PATTERN_SHORT_PAIRS ||
+      p->n_long < 0 || p->n_long > kMaxLongPairs)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_pattern: %d points, %d short, %d long pairs (limits %d / %d / %d)",
+                p->n_points, p->n_short, p->n_long, kPatternPoints, OKVFE_PATTERN_SHORT_PAIRS, kMaxLongPairs);
+  float reach = 0.0f;
+  for (int i = 0; i < p->n_points; ++i) {
+    if (!(p->sigma_half[i] > 0.0f) || !std::isfinite(p->px[i]) || !std::isfinite(p->py[i]))
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_pattern: sample %d: half-width %g", i, (double)p->sigma_half[i]);
+    reach = std::max(reach, std::sqrt(p->px[i] * p->px[i] + p->py[i] * p->py[i]) + p->sigma_half[i]);
+  }
+  if ((float)p->border < reach + 1.0f || p->border > 120)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_pattern: border %d, samples reach %.2f px", p->border, (double)reach);
+  for (int b = 0; b < p->n_short; ++b)
+    if (p->short_i[b] >= p->n_points || p->short_j[b] >= p->n_points)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_pattern: short pair %d names sample %d / %d", b, p->short_i[b], p->short_j[b]);
+  for (int l = 0; l < p->n_long; ++l)
+    if (p->long_i[l] >= p->n_points || p->long_j[l] >= p->n_points)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_pattern: long pair %d names sample %d / %d", l, p->long_i[l], p->long_j[l]);
+  Pattern& P = ctx->host_pattern;  // rotation tables stay: they do not depend on the pattern
+  P.n_points = p->n_points;
+  std::memcpy(P.px, p->px, sizeof(P.px));
+  std::memcpy(P.py, p->py, sizeof(P.py));
+  std::memcpy(P.sigma_half, p->sigma_half, sizeof(P.sigma_half));
+  P.n_short = p->n_short;
+  std::memset(P.short_i, 0, sizeof(P.short_i));
+  std::memset(P.short_j, 0, sizeof(P.short_j));
+  std::memcpy(P.short_i, p->short_i, (size_t)p->n_short);
+  std::memcpy(P.short_j, p->short_j, (size_t)p->n_short);
+  P.n_long = p->n_long;
+  std::memcpy(P.long_i, p->long_i, sizeof(P.long_i));
+  std::memcpy(P.long_j, p->long_j, sizeof(P.long_j));
+  std::memcpy(P.long_wdx, p->long_wdx, sizeof(P.long_wdx));
+  std::memcpy(P.long_wdy, p->long_wdy, sizeof(P.long_wdy));
+  P.border = p->border;
+  for (int i = 0; i < kPatternPoints; ++i) {  // same float sequence as build_pattern (host_tables.cpp)
+    const float sg = i < P.n_points ? P.sigma_half[i] : 1.0f;
+    float area = 4.0f * sg;
+    area = area * sg;
+    const int scaling = static_cast<int>(4194304.0f / area);
+    const float s2 = static_cast<float>(scaling) * area;
+    P.box_scaling[i] = scaling;
+    P.box_scaling2[i] = static_cast<int>(s2 / 1024.0f);
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_pattern, &P, sizeof(Pattern), hipMemcpyHostToDevice));
+  return OKVFE_OK;
+}
+
 // ---- device-resident, batched map matchers (frame f = gather block f) --------------------------
 namespace {
 okvfe_status map_args_ok(okvfe_ctx* ctx, const char* who, const void* blocks, int n_frames, const okvfe_map_device* map) {

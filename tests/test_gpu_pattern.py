@@ -1,0 +1,127 @@
+"""GPU: the sampling pattern is data (okvfe_get_pattern / okvfe_set_pattern): a pattern with other
+sample offsets, half-widths, pair tables and bit order than the built-in restatement is installed on
+the GPU and in the oracle, and detect + describe stay byte-equal in all three extraction modes -- the
+route by which a pattern confirmed against a real `brisk` build (tools/ref_compare) replaces the
+restatement without touching a kernel.  Also: the default pattern round-trips, bad patterns are
+rejected."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gpu_common as G
+from okvis2_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_orc(oracle, p):
+    """orc_pattern with the fields of an okvfe_pattern (rotation tables from the oracle's own build)"""
+    q = type(oracle.pattern())()
+    C.memmove(C.byref(q), C.byref(oracle.pattern()), C.sizeof(q))
+    for f in ("n_points", "n_short", "n_long", "border"):
+        setattr(q, f, getattr(p, f))
+    for f in ("px", "py", "sigma_half", "short_i", "short_j", "long_i", "long_j", "long_wdx", "long_wdy"):
+        C.memmove(getattr(q, f), getattr(p, f), C.sizeof(getattr(p, f)))
+    return q
+
+
+def test_default_pattern_round_trips_and_equals_the_oracles(oracle):
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    p, o = fe.get_pattern(), oracle.pattern()
+    assert p.n_points == o.n_points == 60 and p.n_short == o.n_short == 383 and p.border == o.border
+    for f in ("px", "py", "sigma_half", "short_i", "short_j", "long_wdx", "long_wdy"):
+        assert bytes(getattr(p, f)) == bytes(getattr(o, f)), f
+    fe.set_pattern(p)  # installing what is there changes nothing
+    img = synth.corners_image(cfg.w, cfg.h, 31)
+    k, d, _, _ = fe.detect_describe(img)
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_GRADIENT)
+    G.assert_keypoints_equal(k, rk)
+    assert np.array_equal(d, rd)
+
+
+def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch):
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    rng = np.random.default_rng(5)
+    base = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts).get_pattern()
+    p = capi.PatternData()
+    C.memmove(C.byref(p), C.byref(base), C.sizeof(p))
+    # 52 samples (the last 8 of the outer ring dropped), offsets shrunk and rotated by 7 degrees,
+    # half-widths changed, pairs re-derived from the kept samples in a permuted bit order with some
+    # pairs flipped, 300 of them; long pairs re-weighted
+    n = 52
+    a = np.deg2rad(7.0)
+    px, py = np.array(base.px[:n]) * 0.93, np.array(base.py[:n]) * 0.93
+    p.n_points = n
+    for i in range(n):
+        p.px[i] = np.float32(np.cos(a) * px[i] - np.sin(a) * py[i])
+        p.py[i] = np.float32(np.sin(a) * px[i] + np.cos(a) * py[i])
+        p.sigma_half[i] = np.float32(base.sigma_half[i] * (0.9 if i % 3 else 1.05))
+    pairs = [(base.short_i[b], base.short_j[b]) for b in range(base.n_short)
+             if base.short_i[b] < n and base.short_j[b] < n]
+    order = rng.permutation(len(pairs))[:300]
+    p.n_short = len(order)
+    for b, o in enumerate(order):
+        i, j = pairs[o]
+        if b % 5 == 0:
+            i, j = j, i
+        p.short_i[b], p.short_j[b] = i, j
+    for b in range(p.n_short, 384):
+        p.short_i[b] = p.short_j[b] = 0
+    longs = [(base.long_i[l], base.long_j[l], base.long_wdx[l], base.long_wdy[l]) for l in range(base.n_long)
+             if base.long_i[l] < n and base.long_j[l] < n]
+    p.n_long = len(longs)
+    for l, (i, j, wx, wy) in enumerate(longs):
+        p.long_i[l], p.long_j[l], p.long_wdx[l], p.long_wdy[l] = i, j, wx + (l % 3) - 1, wy - (l % 2)
+    p.border = base.border
+    q = _to_orc(oracle, p)
+    monkeypatch.setattr(oracle, "pattern", lambda: q)  # oracle.describe / detect_describe read it per call
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                       rotation_invariant=True)
+    fe.set_camera(0, cam)
+    fe.set_pattern(p)
+    rays, jac = oracle.awareness_maps(cam)
+    img = synth.corners_image(cfg.w, cfg.h, 32)
+    k, d, _, _ = fe.detect_describe(img, cam=0, gravity=(0.1, 0.97, -0.1))
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.1, 0.97, -0.1))
+    G.assert_keypoints_equal(k, rk)
+    assert np.array_equal(d, rd) and len(k) > 100
+    assert np.all(np.unpackbits(d, axis=1, bitorder="little")[:, p.n_short:] == 0)
+    k, d, _, _ = fe.detect_describe(img)  # gradient orientation through the new long pairs
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_GRADIENT)
+    G.assert_keypoints_equal(k, rk)
+    assert np.array_equal(d, rd)
+    fu = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                       rotation_invariant=False)
+    fu.set_pattern(p)
+    k, d, _, _ = fu.detect_describe(img)
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_UPRIGHT)
+    G.assert_keypoints_equal(k, rk)
+    assert np.array_equal(d, rd)
+    # the built-in pattern gives other descriptors: the data really is what the kernel reads
+    kb, db, _, _ = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                 rotation_invariant=False).detect_describe(img)
+    assert len(kb) == len(k) and not np.array_equal(db, d)
+
+
+def test_bad_patterns_are_rejected():
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    for edit in ("points", "pair", "border", "sigma"):
+        p = fe.get_pattern()
+        if edit == "points":
+            p.n_points = 61
+        elif edit == "pair":
+            p.short_i[5] = 60
+        elif edit == "border":
+            p.border = 5
+        else:
+            p.sigma_half[3] = 0.0
+        with pytest.raises(capi.OkvfeError):
+            fe.set_pattern(p)
