@@ -81,6 +81,172 @@ def compare_hamming(oracle, DUMP):
         assert oracle.popcnt_xor(dref[0], dref[r]) == ham[r]
 
 
+def _rounded(k):
+    return np.stack([np.floor(k["x"] + 0.5).astype(np.int32), np.floor(k["y"] + 0.5).astype(np.int32)], 1)
+
+
+def stage_report(oracle, DUMP):
+    """Walks the pipeline stage by stage on every case of a dump and returns [(stage, ok, detail)] in
+    pipeline order; the first entry with ok == False is where this repo's restatement and the dumped
+    arithmetic part ways.  Stages whose files are absent (a dump made with
+    -DOKVFE_REF_DUMP_NO_INTERNALS has no score map / raw maxima) are reported as skipped."""
+    rep = []
+
+    def add(stage, ok, detail=""):
+        rep.append((stage, ok, detail))
+
+    # 0. popcount
+    try:
+        compare_hamming(oracle, DUMP)
+        add("hamming (PopcntofXORed)", True)
+    except AssertionError as e:
+        add("hamming (PopcntofXORed)", False, str(e))
+    cases = _cases(DUMP)
+    single = [c for c in cases if c["octaves"] == 0]
+    # 1. score map
+    bad, seen = None, 0
+    for c in single:
+        f = os.path.join(DUMP, c["name"] + ".score.i32")
+        if not os.path.exists(f):
+            continue
+        seen += 1
+        img = _pgm(os.path.join(DUMP, c["image"]))
+        ref = np.fromfile(f, dtype=np.int32).reshape(c["h"], c["w"])
+        got = oracle.harris_score(img)
+        inner = (slice(2, c["h"] - 2), slice(2, c["w"] - 2))
+        if not np.array_equal(got[inner], ref[inner]):
+            d = np.argwhere(got[inner] != ref[inner])
+            y, x = d[0] + 2
+            ratio = np.median(ref[inner][ref[inner] != 0] / np.maximum(got[inner][ref[inner] != 0], 1))
+            bad = (f"{c['name']}: {len(d)} of {got[inner].size} scores differ, first at (x={x}, y={y}): "
+                   f"ours {got[y, x]} reference {ref[y, x]}; median reference/ours ratio {ratio:.4g} "
+                   "(a constant ratio = a different score scale: shift / normalisation of the binomial)")
+            break
+    add("score map (HarrisScoreCalculator)", None if seen == 0 else bad is None, bad or ("not in the dump" if seen == 0 else ""))
+    # 2. raw 2-D maxima (NMS rule, threshold meaning, tie handling)
+    bad, seen = None, 0
+    for c in single:
+        f = os.path.join(DUMP, c["name"] + ".maxima.bin")
+        if not os.path.exists(f):
+            continue
+        seen += 1
+        img = _pgm(os.path.join(DUMP, c["image"]))
+        ref = np.fromfile(f, dtype=np.int32).reshape(-1, 3)
+        got = oracle.nms(oracle.harris_score(img), c["thr"])
+        g = {(int(p["x"]), int(p["y"])): int(p["score"]) for p in got}
+        r = {(int(x), int(y)): int(sc) for x, y, sc in ref}
+        if g != r:
+            only_g, only_r = sorted(set(g) - set(r)), sorted(set(r) - set(g))
+            bad = (f"{c['name']}: {len(g)} maxima here, {len(r)} in the reference; only here {only_g[:3]}, only "
+                   f"there {only_r[:3]}" + ("" if only_g or only_r else "; same positions, scores differ"))
+            break
+    add("2-D maxima (Get2dMaxima)", None if seen == 0 else bad is None, bad or ("not in the dump" if seen == 0 else ""))
+    # 3. maxima + sub-pixel without uniformity (public API: radius 0, no cap)
+    bad, seen = None, 0
+    for c in single:
+        f = os.path.join(DUMP, c["name"] + ".kps_nouniform.bin")
+        if not os.path.exists(f):
+            continue
+        seen += 1
+        img = _pgm(os.path.join(DUMP, c["image"]))
+        ref = np.fromfile(f, dtype=KP)
+        got = oracle.detect(img, 0.0, 0, c["thr"], 100000000)
+        gs = set(map(tuple, _rounded(got)))
+        rs = set(map(tuple, _rounded(ref)))
+        if gs != rs:
+            bad = f"{c['name']}: maxima sets differ ({len(gs)} vs {len(rs)}; only here {sorted(gs - rs)[:3]}, only there {sorted(rs - gs)[:3]})"
+            break
+        go, ro = np.lexsort((got["x"], got["y"])), np.lexsort((ref["x"], ref["y"]))
+        gx, rx = got[go], ref[ro]
+        if not (np.array_equal(gx["x"].view(np.uint32), rx["x"].view(np.uint32)) and
+                np.array_equal(gx["y"].view(np.uint32), rx["y"].view(np.uint32))):
+            i = int(np.flatnonzero((gx["x"] != rx["x"]) | (gx["y"] != rx["y"]))[0])
+            bad = (f"{c['name']}: same maxima, sub-pixel positions differ, first ({gx['x'][i]:.6f}, {gx['y'][i]:.6f}) "
+                   f"vs ({rx['x'][i]:.6f}, {rx['y'][i]:.6f})")
+            break
+        if not np.array_equal(gx["response"].view(np.uint32), rx["response"].view(np.uint32)):
+            bad = f"{c['name']}: responses differ"
+            break
+    add("maxima + sub-pixel, no uniformity", None if seen == 0 else bad is None, bad or ("not in the dump" if seen == 0 else ""))
+    # 4. uniformity: the accepted set and its ORDER, then the final records
+    bad = None
+    for c in cases:
+        img = _pgm(os.path.join(DUMP, c["image"]))
+        ref = np.fromfile(os.path.join(DUMP, c["name"] + ".kps.bin"), dtype=KP)
+        got = oracle.detect(img, c["radius"], c["octaves"], c["thr"], c["maxk"])
+        gr, rr = _rounded(got), _rounded(ref)
+        if set(map(tuple, gr)) != set(map(tuple, rr)):
+            bad = f"{c['name']}: accepted sets differ ({len(got)} vs {len(ref)} keypoints)"
+            break
+        if not np.array_equal(gr, rr):
+            i = int(np.flatnonzero((gr != rr).any(axis=1))[0])
+            bad = f"{c['name']}: same accepted set, ORDER differs from position {i} on (tie order of the sort / raster order)"
+            break
+        for f in ("x", "y", "size", "response"):
+            if not np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)):
+                bad = f"{c['name']}: field {f} differs"
+                break
+        if bad is None and not np.array_equal(got["octave"], ref["octave"]):
+            bad = f"{c['name']}: octave differs"
+        if bad:
+            break
+    add("uniformity, cap, keypoint records", bad is None, bad or "")
+    # 5. extractor probes: pattern positions / half-widths / pairs / bit order
+    bad, seen = None, 0
+    pf = os.path.join(DUMP, "probes.txt")
+    if os.path.exists(pf):
+        for line in open(pf):
+            if not line.strip() or line.startswith("#"):
+                continue
+            t = line.split()
+            stem = t[0][:-4]
+            f = os.path.join(DUMP, stem + ".desc.bin")
+            if not os.path.exists(f):
+                continue
+            seen += 1
+            img = _pgm(os.path.join(DUMP, t[0]))
+            kp = np.zeros(1, dtype=KP)
+            kp["x"], kp["y"], kp["size"], kp["angle"], kp["response"], kp["class_id"] = float(t[3]), float(t[4]), 12.0, -1.0, 1000.0, -1
+            k, d = oracle.describe(img, kp, oracle.MODE_UPRIGHT)
+            ref = np.fromfile(f, dtype=np.uint8)
+            if len(ref) == 0 or len(k) == 0:
+                if (len(ref) == 0) != (len(k) == 0):
+                    bad = f"{stem}: the keypoint is {'kept' if len(k) else 'removed'} here, {'kept' if len(ref) else 'removed'} there (border rule)"
+                    break
+                continue
+            if not np.array_equal(d[0], ref):
+                bits = np.flatnonzero(np.unpackbits(d[0] ^ ref, bitorder="little"))
+                bad = (f"{stem}: {len(bits)} of 384 bits differ, first bits {bits[:8].tolist()} (few bits near one sample = "
+                       "a half-width / position; many = pair table or bit order)")
+                break
+    add("extractor probes (pattern, pairs, bit order)", None if seen == 0 else bad is None, bad or ("not in the dump" if seen == 0 else ""))
+    # 6. descriptors of the real cases (orientation / camera-aware warp on top of the pattern)
+    try:
+        compare_extractor(oracle, DUMP)
+        add("descriptors of the cases", True)
+    except AssertionError as e:
+        add("descriptors of the cases", False, str(e))
+    return rep
+
+
+def first_divergence(rep):
+    for stage, ok, detail in rep:
+        if ok is False:
+            return f"FIRST DIVERGING STAGE: {stage} -- {detail}"
+    return None
+
+
+@needs_dump
+def test_stage_by_stage_against_the_reference_dump(oracle):
+    """THE pin: every stage of detector and extractor against what the real brisk produced; the
+    failure message names the first stage that differs and how."""
+    rep = stage_report(oracle, DUMP)
+    for stage, ok, detail in rep:
+        print(f"{'ok  ' if ok else ('skip' if ok is None else 'DIFF')} {stage} {detail}")
+    msg = first_divergence(rep)
+    assert msg is None, msg
+
+
 @needs_dump
 def test_detector_keypoints_match_reference(oracle):
     compare_detector(oracle, DUMP)
@@ -117,6 +283,11 @@ def test_compare_harness_on_a_self_dump(oracle, tmp_path):
                      f"0.1 0.98 -0.05 {'m.rays.f32' if mode == 2 else '-'} {'m.jac.f32' if mode == 2 else '-'}")
         k = oracle.detect(img, 20.0, 0, 50, 300)
         k.tofile(os.path.join(d, name + ".kps.bin"))
+        sc = oracle.harris_score(img)
+        sc.astype(np.int32).tofile(os.path.join(d, name + ".score.i32"))
+        mx = oracle.nms(sc, 50)
+        np.stack([mx["x"], mx["y"], mx["score"]], 1).astype(np.int32).tofile(os.path.join(d, name + ".maxima.bin"))
+        oracle.detect(img, 0.0, 0, 50, 100000000).tofile(os.path.join(d, name + ".kps_nouniform.bin"))
         if mode == 2:
             kk, dd = oracle.describe(img, k, oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu),
                                      (0.1, 0.98, -0.05))
@@ -130,7 +301,31 @@ def test_compare_harness_on_a_self_dump(oracle, tmp_path):
             first = False
         assert len(kk) > 20
     open(os.path.join(d, "manifest.txt"), "w").write("# self dump\n" + "\n".join(lines) + "\n")
+    with open(os.path.join(d, "probes.txt"), "w") as pf:  # a few of the extractor probes
+        for pname, pimg in make_inputs.probes()[::9]:
+            make_inputs.write_pgm(os.path.join(d, pname + ".pgm"), pimg)
+            pf.write(f"{pname}.pgm {make_inputs.PROBE_SIZE} {make_inputs.PROBE_SIZE} {make_inputs.PROBE_KP[0]:.1f} "
+                     f"{make_inputs.PROBE_KP[1]:.1f}\n")
+            kp = np.zeros(1, dtype=KP)
+            kp["x"], kp["y"], kp["size"], kp["angle"], kp["response"], kp["class_id"] = (*make_inputs.PROBE_KP, 12.0, -1.0, 1000.0, -1)
+            _, pd = oracle.describe(pimg, kp, oracle.MODE_UPRIGHT)
+            pd.tofile(os.path.join(d, pname + ".desc.bin"))
     open(os.path.join(d, "dump_done.txt"), "w").write("2 cases\n")
     compare_detector(oracle, d)
     compare_extractor(oracle, d)
     compare_hamming(oracle, d)
+    rep = stage_report(oracle, d)
+    assert [ok for _, ok, _ in rep] == [True] * 7, rep
+    # ... and the report NAMES the stage when one is made to differ: a score map at another scale
+    # (the un-normalised binomial sum is the restatement's most likely deviation), a flipped pair
+    sc2 = np.fromfile(os.path.join(d, "a.score.i32"), dtype=np.int32) // 16
+    sc2.tofile(os.path.join(d, "a.score.i32"))
+    msg = first_divergence(stage_report(oracle, d))
+    assert msg and msg.startswith("FIRST DIVERGING STAGE: score map") and "ratio" in msg, msg
+    oracle.harris_score(_pgm(os.path.join(d, "a.pgm"))).astype(np.int32).tofile(os.path.join(d, "a.score.i32"))
+    first_probe = sorted(f for f in os.listdir(d) if f.startswith("probe_") and f.endswith(".desc.bin"))[0]
+    pb = np.fromfile(os.path.join(d, first_probe), dtype=np.uint8)
+    pb[3] ^= 0x10
+    pb.tofile(os.path.join(d, first_probe))
+    msg = first_divergence(stage_report(oracle, d))
+    assert msg and msg.startswith("FIRST DIVERGING STAGE: extractor probes") and "[28]" in msg, msg

@@ -46,9 +46,46 @@ def cases():
     return out
 
 
+PROBE_SIZE, PROBE_KP = 128, (64.0, 64.0)
+
+
+def probes():
+    """(name, image): images that make the extractor reveal its pattern around ONE keypoint at
+    PROBE_KP.  A 5x5 bright blob at (r, phi) raises exactly the samples whose smoothing box covers
+    it, so the set of bits it flips names the samples near (r, phi), i.e. positions, half-widths,
+    pairs and bit order; edges at 16 orientations and a few noise images exercise the comparisons
+    on graded input."""
+    out = []
+    n = PROBE_SIZE
+    yy, xx = np.mgrid[0:n, 0:n]
+    k = 0
+    for r in (0.0, 3.0, 6.0, 9.0, 12.0, 15.5, 19.0, 22.5, 26.0):
+        for a in range(1 if r == 0.0 else 24):
+            phi = 2.0 * np.pi * a / 24.0
+            cx, cy = PROBE_KP[0] + r * np.cos(phi), PROBE_KP[1] + r * np.sin(phi)
+            img = np.full((n, n), 20, np.uint8)
+            img[(np.abs(xx - cx) <= 2.0) & (np.abs(yy - cy) <= 2.0)] = 235
+            out.append((f"probe_{k:03d}", img))
+            k += 1
+    for a in range(16):
+        phi = 2.0 * np.pi * a / 16.0
+        side = (xx - PROBE_KP[0]) * np.cos(phi) + (yy - PROBE_KP[1]) * np.sin(phi)
+        out.append((f"probe_{k:03d}", np.where(side > 0.5, 200, 40).astype(np.uint8)))
+        k += 1
+    for seed in range(8):
+        out.append((f"probe_{k:03d}", synth.noise_image(n, n, 900 + seed)))
+        k += 1
+    return out
+
+
 def main():
     out_dir = sys.argv[1]
     os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "probes.txt"), "w") as f:
+        f.write("# file W H kx ky\n")
+        for name, img in probes():
+            write_pgm(os.path.join(out_dir, name + ".pgm"), img)
+            f.write(f"{name}.pgm {PROBE_SIZE} {PROBE_SIZE} {PROBE_KP[0]:.1f} {PROBE_KP[1]:.1f}\n")
     lines = ["# name image W H radius octaves abs_threshold max_kpts rot_inv scale_inv mode fu gx gy gz "
              "rays jac"]
     maps_done = {}

@@ -22,9 +22,27 @@
 //   (PopcntofXORed of descriptor 0 against all descriptors of the first case) and
 //   <dir>/dump_done.txt.  Plain little-endian binary: no OpenCV / numpy container involved.
 //
+// Per-STAGE dumps (so that a difference is located, not just detected):
+//   <name>.score.i32        W x H int32: HarrisScoreCalculator's score map          [internals]
+//   <name>.maxima.bin       n x {x, y, score} int32: Get2dMaxima(absoluteThreshold) [internals]
+//   <name>.kps_nouniform.bin  the detector with uniformityRadius 0 and an unreachable cap: every
+//                           2-D maximum after sub-pixel refinement, no uniformity     [public API]
+//   <name>.kps.bin          final keypoints: order = acceptance order of the uniformity stage
+//   probe_<k>.desc.bin      the extractor on the probe images of make_inputs.py (a bright blob /
+//                           an edge / noise around ONE externally given keypoint, upright mode): 48
+//                           bytes each.  They identify sample positions, smoothing widths, the short
+//                           pairs and their BIT ORDER without any access to brisk's tables.
+// [internals] need brisk's internal headers (brisk/internal/harris-score-calculator.h: class
+// brisk::HarrisScoreCalculator with SetImage / Score / Get2dMaxima and PointWithScore{score, x, y});
+// they are compiled unless -DOKVFE_REF_DUMP_NO_INTERNALS is given -- if a brisk checkout names these
+// differently, adapt the ~10 lines inside the #ifndef below, nothing else depends on them.
+//
 // This file cannot be compiled in the build container (no OpenCV, no brisk); it is written against
-// the API surface the reference's own call sites use and nothing else.
+// the API surface the reference's own call sites use (plus the internals named above).
 #include <brisk/brisk.h>
+#ifndef OKVFE_REF_DUMP_NO_INTERNALS
+#include <brisk/internal/harris-score-calculator.h>
+#endif
 
 #include <opencv2/core/core.hpp>
 #include <opencv2/features2d/features2d.hpp>
@@ -113,6 +131,34 @@ int main(int argc, char** argv) {
       be->setCameraProperties(rays, jac, fu);
       be->setExtractionDirection(cv::Vec3f(gx, gy, gz));
     }
+#ifndef OKVFE_REF_DUMP_NO_INTERNALS
+    if (octaves == 0) {  // stage dumps of the single-scale detector: score map and raw 2-D maxima
+      brisk::HarrisScoreCalculator hsc;
+      hsc.SetImage(image);
+      {
+        std::ofstream f(dir + "/" + name + ".score.i32", std::ios::binary);
+        for (int y = 0; y < h; ++y)
+          for (int x = 0; x < w; ++x) {
+            const int32_t v = (x >= 2 && y >= 2 && x < w - 2 && y < h - 2) ? int32_t(hsc.Score(x, y)) : 0;
+            f.write(reinterpret_cast<const char*>(&v), 4);
+          }
+      }
+      std::vector<brisk::ScoreCalculator<int>::PointWithScore> maxima;
+      hsc.Get2dMaxima(maxima, abs_thr);
+      std::ofstream f(dir + "/" + name + ".maxima.bin", std::ios::binary);
+      for (const auto& m : maxima) {
+        const int32_t r[3] = {int32_t(m.x), int32_t(m.y), int32_t(m.score)};
+        f.write(reinterpret_cast<const char*>(r), 12);
+      }
+    }
+#endif
+    {  // every maximum, sub-pixel refined, no uniformity enforcement, no cap
+      std::shared_ptr<cv::FeatureDetector> raw(
+          new brisk::ScaleSpaceFeatureDetector<brisk::HarrisScoreCalculator>(0, octaves, abs_thr, 100000000));
+      std::vector<cv::KeyPoint> all;
+      raw->detect(image, all);
+      write_keypoints(dir + "/" + name + ".kps_nouniform.bin", all);
+    }
     std::vector<cv::KeyPoint> keypoints;
     detector->detect(image, keypoints);  // Frame.hpp:152
     write_keypoints(dir + "/" + name + ".kps.bin", keypoints);
@@ -140,6 +186,32 @@ int main(int argc, char** argv) {
     std::cout << name << ": " << keypoints.size() << " keypoints described\n";
     ++cases;
   }
-  std::ofstream(dir + "/dump_done.txt") << cases << " cases\n";
+  // extractor probes: probes.txt = one line "file.pgm W H kx ky" per probe (make_inputs.py)
+  int probes = 0;
+  {
+    std::ifstream pl(dir + "/probes.txt");
+    std::string pline;
+    std::shared_ptr<cv::DescriptorExtractor> upright(new brisk::BriskDescriptorExtractor(false, false));
+    while (pl && std::getline(pl, pline)) {
+      if (pline.empty() || pline[0] == '#') continue;
+      std::istringstream is(pline);
+      std::string file;
+      int w, h;
+      float kx, ky;
+      is >> file >> w >> h >> kx >> ky;
+      cv::Mat image = cv::imread(dir + "/" + file, cv::IMREAD_GRAYSCALE);
+      if (image.empty()) {
+        std::cerr << "cannot read probe " << file << "\n";
+        return 1;
+      }
+      std::vector<cv::KeyPoint> kp(1, cv::KeyPoint(kx, ky, 12.0f, -1.0f, 1000.0f, 0, -1));
+      cv::Mat d;
+      upright->compute(image, kp, d);
+      std::ofstream f(dir + "/" + file.substr(0, file.size() - 4) + ".desc.bin", std::ios::binary);
+      if (d.rows == 1) f.write(reinterpret_cast<const char*>(d.ptr<uchar>(0)), 48);  // empty file = keypoint removed
+      ++probes;
+    }
+  }
+  std::ofstream(dir + "/dump_done.txt") << cases << " cases, " << probes << " probes\n";
   return 0;
 }
