@@ -133,6 +133,10 @@ typedef struct orc_camera {
 
 /* fixed-sequence FP64 atan used by the equidistant model (see orc_camera.c header) */
 double orc_atan_fixed(double x);
+/* 1 = libm atan / acos (the reference's calls) instead of the fixed sequences (default 0) */
+void orc_set_libm(int on);
+int orc_get_libm(void);
+double orc_atan_eval(double x);
 int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], double J[4]);
 int orc_cam_undistort(const orc_camera* c, const double pd[2], double out[2]);
 int orc_cam_backproject(const orc_camera* c, const double pt[2], double dir[3]);

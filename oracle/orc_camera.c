@@ -35,6 +35,15 @@
 #include <string.h>
 
 /* fdlibm-style atan (K.C. Ng's published scheme): break points 7/16, 11/16, 19/16, 39/16 */
+/* Transcendental back end of the oracle: 0 (default) = the fixed IEEE sequences the device evaluates
+ * (bit-exact against the GPU), 1 = libm's atan / acos, i.e. what the REFERENCE calls
+ * (EquidistantDistortion.hpp:98,138; Frontend.cpp:1312).  tests/test_oracle_libm_variant.py measures
+ * what the <= 1 ulp between the two changes downstream (back-projections, gates, match rows). */
+static int g_orc_use_libm = 0;
+void orc_set_libm(int on) { g_orc_use_libm = on != 0; }
+int orc_get_libm(void) { return g_orc_use_libm; }
+double orc_atan_eval(double x) { return g_orc_use_libm ? atan(x) : orc_atan_fixed(x); }
+
 double orc_atan_fixed(double x) {
   static const double hi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
                                9.82793723247329054082e-01, 1.57079632679489655800e+00};
@@ -118,7 +127,7 @@ int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], doubl
   {
     const double k1 = c->d[0], k2 = c->d[1], k3 = c->d[2], k4 = c->d[3];
     const double r = sqrt(u0 * u0 + u1 * u1);
-    const double theta = orc_atan_fixed(r);
+    const double theta = orc_atan_eval(r);
     const double theta2 = theta * theta;
     const double theta4 = theta2 * theta2;
     const double theta6 = theta4 * theta2;
@@ -133,7 +142,7 @@ int orc_cam_distort(const orc_camera* c, const double u[2], double out[2], doubl
         t2 = u0 * u0;
         t3 = u1 * u1;
         t4 = t2 + t3;
-        t6 = orc_atan_fixed(sqrt(t4));
+        t6 = orc_atan_eval(sqrt(t4));
         t7 = t6 * t6;
         t8 = 1.0 / sqrt(t4);
         t9 = t7 * t7;

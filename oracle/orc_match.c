@@ -613,7 +613,7 @@ void orc_prepare_landmarks(const double* hp_W, const double* quality, const int3
       if (cosVC < cos06 && !exclusive) continue;
       const double scaleChange = fabs(r - sqrt(dot3(r_old, r_old))) / r;
       if (scaleChange > 0.5 && !exclusive) continue;
-      const double score = 0.5 * (orc_acos_fixed(cosVC) / 0.6 + scaleChange / 0.5);
+      const double score = 0.5 * ((orc_get_libm() ? acos(cosVC) : orc_acos_fixed(cosVC)) / 0.6 + scaleChange / 0.5);
       double worst = 0.0;
       int wi = 0;
       for (int n = 0; n < 3; ++n)
