@@ -124,6 +124,15 @@ typedef struct okvfe_config {
 } okvfe_config;
 #define OKVFE_SCORE_HARRIS 0
 #define OKVFE_SCORE_AGAST_9_16 1
+/* 2: the published BRISK scale-space detector = brisk::BriskFeatureDetector(threshold, octaves)
+ * (okvis_cv/test/TestFrame.cpp:71-72): absolute_threshold = the AGAST threshold, octaves as there;
+ * AGAST 9-16 scores on the octaves c_i and intra-octaves d_i, the FAST 5-8 score of c0 as the layer
+ * below the first octave, maxima over the 3 x 3 neighbourhood and the +-1 px patches of the layers
+ * above and below, 2-D sub-pixel fit, and a parabola over the three layers' scores for the CONTINUOUS
+ * scale (keypoint.size = 12 x scale, response = the parabola's maximum, octave = layer index).  No
+ * uniformity stage (uniformity_radius is ignored); the strongest max_keypoints maxima per layer are
+ * kept, (score desc, y, x).  With octaves == 0 it is OKVFE_SCORE_AGAST_9_16. */
+#define OKVFE_SCORE_BRISK_SCALESPACE 2
 
 typedef struct okvfe_ctx okvfe_ctx;
 

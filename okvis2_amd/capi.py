@@ -18,7 +18,7 @@ OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
     ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
 ABI_VERSION = 3
-SCORE_HARRIS, SCORE_AGAST_9_16 = 0, 1
+SCORE_HARRIS, SCORE_AGAST_9_16, SCORE_BRISK_SCALESPACE = 0, 1, 2
 DESC_BYTES = 48
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),

@@ -89,7 +89,42 @@ __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restr
   }
 }
 
+// FAST 5-8 score of c0: the virtual intra-octave below the first octave of the published BRISK
+// scale space (oracle: orc_fast58_score).  One thread per pixel, direct reads (a small fraction of
+// the 9-16 kernel's work; the 3 x 3 neighbourhood comes out of L1 / L2).
+__global__ __launch_bounds__(256) void fast58_score_kernel(const uint8_t* __restrict__ images, int w, int h,
+                                                           int32_t* __restrict__ scores) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const uint8_t* img = images + (size_t)blockIdx.z * w * h;
+  int s = 0;
+  if (x >= 1 && y >= 1 && x < w - 1 && y < h - 1) {
+    const uint8_t* c = img + (size_t)y * w + x;
+    const int p = c[0];
+    // ring in the oracle's order: (0,1) (1,1) (1,0) (1,-1) (0,-1) (-1,-1) (-1,0) (-1,1)
+    int d[8];
+    d[0] = c[w] - p;       d[1] = c[w + 1] - p;  d[2] = c[1] - p;   d[3] = c[-w + 1] - p;
+    d[4] = c[-w] - p;      d[5] = c[-w - 1] - p; d[6] = c[-1] - p;  d[7] = c[w - 1] - p;
+    int bright = -256, most = 256;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int mn = min(min3i(d[st], d[(st + 1) & 7], d[(st + 2) & 7]), min(d[(st + 3) & 7], d[(st + 4) & 7]));
+      const int mx = max(max3i_(d[st], d[(st + 1) & 7], d[(st + 2) & 7]), max(d[(st + 3) & 7], d[(st + 4) & 7]));
+      bright = max(bright, mn);
+      most = min(most, mx);
+    }
+    s = max(bright, -most) - 1;
+    s = s < 0 ? 0 : s;
+  }
+  scores[(size_t)blockIdx.z * w * h + (size_t)y * w + x] = s;
+}
+
 }  // namespace
+
+void launch_fast58_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
+  if (n_images <= 0) return;
+  hipLaunchKernelGGL(fast58_score_kernel, dim3((w + 255) / 256, h, n_images), dim3(256), 0, stream, img, w, h, score);
+}
 
 void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
   if (n_images <= 0) return;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void merge_layers_kernel(MergeLayers m, okvfe_
       t = k.y + 0.5f;
       t = s * t;
       k.y = t - 0.5f;
-      k.size = 12.0f * s;
+      k.size = k.size * s;  // layer keypoints carry 12 (x the relative scale of the BRISK scale space)
       k.octave = l;
       if (off + i < out_cap) out[(size_t)img * out_cap + off + i] = k;
     }

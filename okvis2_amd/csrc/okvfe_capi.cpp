@@ -33,6 +33,7 @@ struct okvfe_ctx {
 
   std::vector<void*> allocs;
   int32_t* d_scores = nullptr;
+  int32_t* d_virtual = nullptr;  // scale-space parent, OKVFE_SCORE_BRISK_SCALESPACE: FAST 5-8 map of layer 0
   ScoreLayout score_layout{0, 0};  // of d_scores: slotted where the fused score+NMS kernel applies
   Candidate* d_cand = nullptr;
   int32_t* d_cand_count = nullptr;
@@ -420,9 +421,10 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: max_keypoints must be in 1..4096");
   if (cfg->absolute_threshold < 1)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: absolute_threshold must be >= 1");
-  if (cfg->score_type != OKVFE_SCORE_HARRIS && cfg->score_type != OKVFE_SCORE_AGAST_9_16)
-    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: score_type %d (0 = Harris, 1 = AGAST 9-16)",
-                cfg->score_type);
+  if (cfg->score_type != OKVFE_SCORE_HARRIS && cfg->score_type != OKVFE_SCORE_AGAST_9_16 &&
+      cfg->score_type != OKVFE_SCORE_BRISK_SCALESPACE)
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT,
+                "okvfe_create: score_type %d (0 = Harris, 1 = AGAST 9-16, 2 = BRISK scale space)", cfg->score_type);
   if (cfg->match_threshold < 0 || cfg->match_threshold > 385)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: match_threshold out of range");
   if (cfg->octaves < 0 || cfg->octaves > 4)
@@ -552,6 +554,11 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
         }
         c->d_layer_img.push_back(img);
       }
+      if (cfg->score_type == OKVFE_SCORE_BRISK_SCALESPACE) {  // FAST 5-8 map of c0: the layer below the first octave
+        void* q = nullptr;
+        HIP_TRY(c, hipMalloc(&q, (size_t)c->w * c->h * B * sizeof(int32_t)));
+        c->d_virtual = static_cast<int32_t*>(q);
+      }
       // single-scale views of the parent (score map of the full-resolution layer etc.)
       c->d_scores = c->layers[0]->d_scores;
       c->score_layout = c->layers[0]->score_layout;
@@ -583,6 +590,7 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   for (okvfe_ctx* ch : ctx->layers) okvfe_destroy(ch);
   for (uint8_t* p : ctx->d_layer_img)
     if (p) (void)hipFree(p);
+  if (ctx->d_virtual) (void)hipFree(ctx->d_virtual);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (float* p : ctx->cam_rays)
     if (p) (void)hipFree(p);
@@ -665,7 +673,7 @@ okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev
   {
     hipStream_t s = pick_stream(ctx, stream);
     StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
-    if (ctx->cfg.score_type == OKVFE_SCORE_AGAST_9_16)
+    if (ctx->cfg.score_type != OKVFE_SCORE_HARRIS)
       launch_agast_score(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
     else
       launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
@@ -739,7 +747,7 @@ okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) 
 // K1 + K2 of one layer context `L` (score map + NMS candidates), launched for `owner`
 void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipStream_t s, bool* fused) {
   int32_t* d_fix_count = L->d_cand_count + L->B;  // [0, B) candidate counts, [B, 2B) flagged counts
-  if (L->cfg.score_type == OKVFE_SCORE_AGAST_9_16) {  // score map only; the stand-alone NMS follows
+  if (L->cfg.score_type != OKVFE_SCORE_HARRIS) {  // AGAST score map only; the stand-alone NMS follows
     launch_agast_score(images_dev, L->w, L->h, n_images, L->d_scores, s);
     *fused = false;
     return;
@@ -817,6 +825,7 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
         layer_score_nms(ch, img[l], n_images, s, &f);
         fused[l] = f;
       }
+      if (ctx->d_virtual) launch_fast58_score(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_virtual, s);
     }
     if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
     {
@@ -839,19 +848,56 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
           out[0] = rn; out[1] = rd;
         };
         if (l > 0) { below = ctx->layers[l - 1]->d_scores; lb = ctx->layers[l - 1]->score_layout; ratio(l - 1, rb); }
+        if (l == 0 && ctx->d_virtual) { below = ctx->d_virtual; lb = ScoreLayout{ctx->layer_w[0], 0}; }  // same grid: ratio 1
         if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; la = ctx->layers[l + 1]->score_layout; ratio(l + 1, ra); }
         launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below, lb,
-                            l > 0 ? ctx->layer_w[l - 1] : 0, l > 0 ? ctx->layer_h[l - 1] : 0, rb[0], rb[1], above, la,
+                            l > 0 ? ctx->layer_w[l - 1] : (below ? ctx->layer_w[0] : 0),
+                            l > 0 ? ctx->layer_h[l - 1] : (below ? ctx->layer_h[0] : 0), rb[0], rb[1], above, la,
                             l + 1 < L ? ctx->layer_w[l + 1] : 0, l + 1 < L ? ctx->layer_h[l + 1] : 0, ra[0], ra[1], s);
       }
     }
+    const bool brisk_ss = ctx->cfg.score_type == OKVFE_SCORE_BRISK_SCALESPACE;
     {
       StageTimer t(ctx, OKVFE_STAGE_SORT, s);
-      for (int l = 0; l < L; ++l) layer_sort(ctx->layers[l], n_images, s);
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        if (brisk_ss)  // always ordered (score desc, y, x): there is no uniformity radius to switch the sort on
+          launch_sort(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, 1.0f, ch->d_sort_ws, s);
+        else
+          layer_sort(ch, n_images, s);
+      }
     }
     {
       StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
-      for (int l = 0; l < L; ++l) layer_select(ctx->layers[l], n_images, s);
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        if (!brisk_ss) {
+          layer_select(ch, n_images, s);
+          continue;
+        }
+        // strongest maxima + continuous scale from the scores of the layers below and above
+        int sn, sd;
+        layer_scale(l, &sn, &sd);
+        auto ratio2 = [&](int m, int out[2]) {
+          int mn, md;
+          layer_scale(m, &mn, &md);
+          int rn = sn * md, rd = sd * mn;
+          for (int g = 2; g <= 3; ++g)
+            while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+          out[0] = rn; out[1] = rd;
+        };
+        int rb2[2] = {1, 1}, ra2[2] = {1, 1};
+        const int32_t* below = l == 0 ? ctx->d_virtual : ctx->layers[l - 1]->d_scores;
+        const int wb = l == 0 ? ctx->layer_w[0] : ctx->layer_w[l - 1], hb = l == 0 ? ctx->layer_h[0] : ctx->layer_h[l - 1];
+        if (l > 0) ratio2(l - 1, rb2);
+        const int32_t* above = l + 1 < L ? ctx->layers[l + 1]->d_scores : nullptr;
+        if (above) ratio2(l + 1, ra2);
+        const double rel_b = (l & 1) ? 2.0 / 3.0 : 0.75, rel_a = (l & 1) ? 4.0 / 3.0 : 1.5;
+        launch_brisk_refine(ch->d_scores, ch->w, ch->h, n_images, ch->cand_cap, ch->d_cand_count, ch->d_sort_ws,
+                            ch->cfg.max_keypoints, below, wb, hb, rb2[0], rb2[1], above,
+                            above ? ctx->layer_w[l + 1] : 0, above ? ctx->layer_h[l + 1] : 0, ra2[0], ra2[1], rel_b,
+                            rel_a, ch->d_kps_det, ch->kp_cap, ch->d_det_count, s);
+      }
       const okvfe_keypoint* kps[8];
       const int32_t* counts[8];
       float scale[8];

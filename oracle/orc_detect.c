@@ -116,8 +116,77 @@ void orc_agast_score(const uint8_t* img, int w, int h, int stride, int32_t* scor
       score[(size_t)y * w + x] = s;
     }
 }
+/* FAST 5-8 score: the same predicate on the 8-pixel ring of radius 1 with arcs of 5 -- what the
+ * published BRISK detector evaluates on c0 to stand in for the (virtual) intra-octave below the
+ * first octave (Leutenegger et al., ICCV 2011, section 3.1).  Border of 1 px scores 0. */
+static const int kRing8[8][2] = {{0, 1}, {1, 1}, {1, 0}, {1, -1}, {0, -1}, {-1, -1}, {-1, 0}, {-1, 1}};
+void orc_fast58_score(const uint8_t* img, int w, int h, int stride, int32_t* score) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int s = 0;
+      if (x >= 1 && y >= 1 && x < w - 1 && y < h - 1) {
+        const int p = img[(size_t)y * stride + x];
+        int d[8];
+        for (int i = 0; i < 8; ++i) d[i] = (int)img[(size_t)(y + kRing8[i][1]) * stride + (x + kRing8[i][0])] - p;
+        int bright = -256, dark = -256;
+        for (int st = 0; st < 8; ++st) {
+          int mn = 256, mx = -256;
+          for (int k = 0; k < 5; ++k) {
+            const int v = d[(st + k) & 7];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+          }
+          if (mn > bright) bright = mn;
+          if (-mx > dark) dark = -mx;
+        }
+        s = (bright > dark ? bright : dark) - 1;
+        if (s < 0) s = 0;
+      }
+      score[(size_t)y * w + x] = s;
+    }
+}
+
+/* Continuous scale of a scale-space maximum (published BRISK, section 3.1: "a 1D parabola is fitted
+ * along the scale axis"): the parabola through (r_b, s_b), (1, s), (r_a, s_a) -- r = scale of the layer
+ * below / above relative to the keypoint's layer -- evaluated in double in this fixed order; its
+ * vertex, clamped to [r_b, r_a], is the relative scale, the parabola's value there the refined score.
+ * A missing neighbour layer, or a parabola that does not open downwards, keeps (1, s). */
+void orc_scale_refine(double rb, int have_b, int32_t sb, int32_t s, double ra, int have_a, int32_t sa,
+                      float* rel_scale, float* score) {
+  *rel_scale = 1.0f;
+  *score = (float)s;
+  if (!have_b || !have_a) return;
+  const double y0 = (double)sb, y1 = (double)s, y2 = (double)sa;
+  double d10 = y1 - y0;
+  double h10 = 1.0 - rb;
+  d10 = d10 / h10;
+  double d21 = y2 - y1;
+  double h21 = ra - 1.0;
+  d21 = d21 / h21;
+  double a = d21 - d10;
+  double h20 = ra - rb;
+  a = a / h20;
+  if (!(a < 0.0)) return;
+  double t = 1.0 + rb;
+  t = a * t;
+  const double b = d10 - t;
+  double v = -b;
+  double a2 = 2.0 * a;
+  v = v / a2;
+  v = v < rb ? rb : (v > ra ? ra : v);
+  /* value at the vertex: y1 + (v - 1) * (d10 + a * (v - rb)) (Newton form) */
+  double u = v - rb;
+  u = a * u;
+  u = d10 + u;
+  double dv = v - 1.0;
+  u = dv * u;
+  u = y1 + u;
+  *rel_scale = (float)v;
+  *score = (float)u;
+}
+
 void orc_score_map(int score_type, const uint8_t* img, int w, int h, int stride, int32_t* score) {
-  if (score_type == 1)
+  if (score_type == 1 || score_type == 2)
     orc_agast_score(img, w, h, stride, score);
   else
     orc_harris_score(img, w, h, stride, score);
@@ -397,6 +466,24 @@ int orc_scale_neighbour_ok(const int32_t* other, int wo, int ho, int x, int y, i
   return 1;
 }
 
+/* largest score of `other` within the same +-1 px window (the value the scale parabola takes for
+ * the neighbouring layer) */
+int32_t orc_scale_neighbour_max(const int32_t* other, int wo, int ho, int x, int y, int rn, int rd) {
+  const int D = 2 * rd;
+  const int Nx = (2 * x + 1) * rn - rd, Ny = (2 * y + 1) * rn - rd;
+  int u0 = -floor_div(-(Nx - D), D), u1 = floor_div(Nx + D, D);
+  int v0 = -floor_div(-(Ny - D), D), v1 = floor_div(Ny + D, D);
+  if (u0 < 0) u0 = 0;
+  if (v0 < 0) v0 = 0;
+  if (u1 > wo - 1) u1 = wo - 1;
+  if (v1 > ho - 1) v1 = ho - 1;
+  int32_t m = 0;
+  for (int v = v0; v <= v1; ++v)
+    for (int u = u0; u <= u1; ++u)
+      if (other[(size_t)v * wo + u] > m) m = other[(size_t)v * wo + u];
+  return m;
+}
+
 #define ORC_MAX_LAYERS 8
 static int detect_scale_space(const uint8_t* img, int w, int h, int stride, float uniformity_radius,
                               int octaves, int abs_threshold, int max_kpts, orc_keypoint* kps, int cap,
@@ -428,6 +515,17 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
     pts[l] = (orc_point_score*)malloc((size_t)maxc * sizeof(orc_point_score));
     np[l] = orc_nms(sc[l], lw[l], lh[l], abs_threshold, pts[l], maxc);
   }
+  /* score_type 2 = the published BRISK scale-space detector (brisk::BriskFeatureDetector(threshold,
+   * octaves), okvis_cv/test/TestFrame.cpp:71-72): AGAST 9-16 scores on every layer, the FAST 5-8 score
+   * of c0 as the virtual layer below it, 2-D maxima that are also maxima against the +-1 px patches of
+   * the layers below and above, strongest first up to max_kpts per layer (no uniformity), 2-D sub-pixel
+   * fit in the layer, and a 1-D parabola over the three layers' scores for the continuous scale
+   * (size = 12 * layer scale * relative scale; response = the parabola's value). */
+  int32_t* sc_virtual = NULL;
+  if (score_type == 2) {
+    sc_virtual = (int32_t*)malloc((size_t)lw[0] * lh[0] * sizeof(int32_t));
+    orc_fast58_score(im[0], lw[0], lh[0], st[0], sc_virtual);
+  }
   int nout = 0;
   for (int l = 0; l < L; ++l) {
     int sn, sd;
@@ -437,6 +535,7 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
     for (int i = 0; i < np[l]; ++i) {
       const orc_point_score p = pts[l][i];
       int ok = 1;
+      if (score_type == 2 && l == 0) ok = orc_scale_neighbour_ok(sc_virtual, lw[0], lh[0], p.x, p.y, p.score, 1, 1);
       for (int dl = -1; dl <= 1 && ok; dl += 2) {
         const int m = l + dl;
         if (m < 0 || m >= L) continue;
@@ -450,7 +549,12 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
       }
       if (ok) pts[l][kept++] = p;
     }
-    kept = orc_uniformity_select(pts[l], kept, lw[l], lh[l], uniformity_radius, max_kpts);
+    if (score_type == 2) { /* strongest first: (score desc, y, x) -- the total order of the uniformity stage */
+      qsort(pts[l], (size_t)kept, sizeof(orc_point_score), cmp_points);
+      if (kept > max_kpts) kept = max_kpts;
+    } else {
+      kept = orc_uniformity_select(pts[l], kept, lw[l], lh[l], uniformity_radius, max_kpts);
+    }
     const float scale = (float)sn / (float)sd;
     for (int i = 0; i < kept && nout < cap; ++i) {
       const int u = pts[l][i].x, v = pts[l][i].y;
@@ -473,8 +577,38 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
       k->response = (float)pts[l][i].score;
       k->octave = l;
       k->class_id = -1;
+      if (score_type == 2) { /* continuous scale from the three layers' scores */
+        double rb = 0.75, ra = 1.5; /* octave c_i: d_(i-1) below (3/4), d_i above (3/2) */
+        if (l & 1) { rb = 2.0 / 3.0; ra = 4.0 / 3.0; } /* intra-octave d_i: c_i below, c_(i+1) above */
+        int have_b = 1, have_a = l + 1 < L;
+        int32_t sb = 0, sa = 0;
+        if (l == 0) {
+          sb = orc_scale_neighbour_max(sc_virtual, lw[0], lh[0], u, v, 1, 1);
+        } else {
+          int mn, md;
+          orc_layer_scale(l - 1, &mn, &md);
+          int rn = sn * md, rd = sd * mn;
+          for (int g = 2; g <= 3; ++g)
+            while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+          sb = orc_scale_neighbour_max(sc[l - 1], lw[l - 1], lh[l - 1], u, v, rn, rd);
+        }
+        if (have_a) {
+          int mn, md;
+          orc_layer_scale(l + 1, &mn, &md);
+          int rn = sn * md, rd = sd * mn;
+          for (int g = 2; g <= 3; ++g)
+            while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+          sa = orc_scale_neighbour_max(sc[l + 1], lw[l + 1], lh[l + 1], u, v, rn, rd);
+        }
+        float rel, resp;
+        orc_scale_refine(rb, have_b, sb, pts[l][i].score, ra, have_a, sa, &rel, &resp);
+        float sz = 12.0f * rel; /* basic size 12 at the layer's own scale, times the relative scale ... */
+        k->size = sz * scale;   /* ... times the layer scale */
+        k->response = resp;
+      }
     }
   }
+  free(sc_virtual);
   for (int l = 0; l < L; ++l) {
     if (l) free(im[l]);
     free(sc[l]);

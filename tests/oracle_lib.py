@@ -133,7 +133,7 @@ def subpixel2d(patch) -> tuple:
     return dx.value, dy.value
 
 
-SCORE_HARRIS, SCORE_AGAST = 0, 1
+SCORE_HARRIS, SCORE_AGAST, SCORE_BRISK_SCALESPACE = 0, 1, 2
 
 
 def agast_score(img: np.ndarray) -> np.ndarray:

@@ -74,6 +74,70 @@ def test_agast_detector_and_descriptors(oracle, octaves, radius, maxk):
     assert total > 100
 
 
+@pytest.mark.parametrize("octaves,maxk", [(2, 450), (1, 120), (3, 2000)])
+def test_brisk_scale_space_detector(oracle, octaves, maxk):
+    """score_type OKVFE_SCORE_BRISK_SCALESPACE = brisk::BriskFeatureDetector(34, octaves), the call of
+    okvis_cv/test/TestFrame.cpp:71-72, as the published method: AGAST 9-16 on octaves and intra-octaves,
+    FAST 5-8 below c0, scale-space maxima, sub-pixel, parabola over the three layers' scores ->
+    continuous size.  Keypoints (positions, sizes, responses as float bit patterns, layer) against the
+    oracle; descriptors on top (the extractor is not scale invariant: base pattern at the keypoint)."""
+    w, h = 752, 480
+    total, refined = 0, 0
+    for kind, seed in (("corners", 5), ("noise", 6)):
+        img = synth.noise_image(w, h, seed) if kind == "noise" else synth.corners_image(w, h, seed)
+        fe = capi.Frontend(w, h, 0.0, octaves, 34, maxk, rotation_invariant=False,
+                           score_type=capi.SCORE_BRISK_SCALESPACE, max_candidates=1 << 16)
+        ref = oracle.detect(img, 0.0, octaves, 34, maxk, score_type=oracle.SCORE_BRISK_SCALESPACE)
+        got = fe.detect(img)
+        G.assert_keypoints_equal(got, ref)
+        assert np.array_equal(got["size"].view(np.uint32), ref["size"].view(np.uint32))
+        assert np.array_equal(got["response"].view(np.uint32), ref["response"].view(np.uint32))
+        k, d = oracle.detect_describe(img, 0.0, octaves, 34, maxk, oracle.MODE_UPRIGHT, None, None,
+                                      np.float32(1.0), (0.0, 1.0, 0.0), score_type=oracle.SCORE_BRISK_SCALESPACE)
+        gk, gd = fe.detect_describe(img)[:2]
+        G.assert_keypoints_equal(gk, k)
+        assert np.array_equal(gd, d)
+        total += len(ref)
+        layers = np.unique(ref["octave"])
+        assert len(layers) >= 2 and layers.max() < 2 * octaves
+        for l in layers:  # sizes are continuous: not just 12 x the layer scale
+            sc = 12.0 * ((1.5 if l & 1 else 1.0) * 2 ** (l // 2))
+            sz = ref["size"][ref["octave"] == l]
+            refined += int((np.abs(sz - sc) > 1e-3).sum())
+            lo, hi = (2.0 / 3.0, 4.0 / 3.0) if l & 1 else (0.75, 1.5)
+            assert np.all(sz >= sc * lo - 1e-3) and np.all(sz <= sc * hi + 1e-3)
+            assert np.sum(ref["octave"] == l) <= maxk
+    assert total > 200 and refined > 50
+
+
+def test_fast58_and_scale_refine_oracle_known_answers(oracle):
+    """Known answers of the two new oracle pieces: FAST 5-8 (ring of 8, arcs of 5) and the parabola."""
+    import ctypes as C
+    img = np.full((9, 9), 50, np.uint8)
+    img[4, 4] = 120  # isolated bright pixel: all 8 ring pixels darker by 70 -> score 69
+    out = np.zeros((9, 9), np.int32)
+    oracle.lib().orc_fast58_score(img.ctypes.data_as(C.c_void_p), 9, 9, 9, out.ctypes.data_as(C.c_void_p))
+    assert out[4, 4] == 69 and out[0, 0] == 0 and out[4, 5] == 0
+    img[:] = 50
+    img[:, 5:] = 90  # straight edge: only 3 contiguous ring pixels differ -> no corner on either side
+    oracle.lib().orc_fast58_score(img.ctypes.data_as(C.c_void_p), 9, 9, 9, out.ctypes.data_as(C.c_void_p))
+    assert out[4, 4] == 0 and out[4, 5] == 0
+    img[:] = 50
+    img[5:, 5:] = 90  # a bright quadrant: its corner pixel sees 5 contiguous ring pixels darker by 40
+    oracle.lib().orc_fast58_score(img.ctypes.data_as(C.c_void_p), 9, 9, 9, out.ctypes.data_as(C.c_void_p))
+    assert out[5, 5] == 39 and out[4, 4] == 0
+    rel, sc = C.c_float(), C.c_float()
+    f = oracle.lib().orc_scale_refine
+    f.argtypes = [C.c_double, C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_int32, C.POINTER(C.c_float),
+                  C.POINTER(C.c_float)]
+    f(0.75, 1, 40, 50, 1.5, 1, 40, C.byref(rel), C.byref(sc))  # symmetric in value, not in abscissa
+    assert 1.0 < rel.value < 1.5 and sc.value >= 50.0
+    f(0.75, 1, 60, 50, 1.5, 1, 20, C.byref(rel), C.byref(sc))  # rising towards the layer below: clamped there
+    assert rel.value == pytest.approx(0.75) and sc.value == pytest.approx(60.0)
+    f(0.75, 1, 10, 50, 1.5, 0, 0, C.byref(rel), C.byref(sc))   # top layer: no refinement
+    assert rel.value == 1.0 and sc.value == 50.0
+
+
 def test_agast_batch(oracle):
     cfg = synth.mono640_config()
     n = 9
