@@ -1047,16 +1047,35 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         unsigned long long rem = __ballot(pass), accm = 0;
         int nacc = 0;
         if (rem != 0) {
-          // which passing candidates have another passing candidate of the window within 15 cells?
-          // (vector work only: no scalar round trip per candidate)
+          // Which passing candidates may have another passing candidate of the window within 15
+          // cells?  Two such candidates sit in the same or in adjacent bins (a bin is 16 cells wide):
+          // every passing lane counts itself into the top byte of its bin's head word (the address
+          // below it needs 18 bits; the walks of the other waves never overlap with this phase), reads
+          // the nine counts around it and removes itself again -- two LDS round trips whatever the
+          // number of passing lanes.  Conservative (adjacent bins may be farther apart than 15 cells):
+          // the ordered loop below treats the flagged lanes exactly.
           bool linked = false;
-          for (unsigned long long r2 = rem; r2 != 0; r2 &= r2 - 1) {
-            const int j = (int)__ffsll((long long)r2) - 1;
-            const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, j);
-            const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
-            linked |= lane != j && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
+          if (pass) {
+            atomicAdd(&head[bin], 1u << 24);
           }
+          __builtin_amdgcn_wave_barrier();
+          if (pass) {
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) {
+              const uint32_t c = head[bin + ((b / 3) - 1) * bpitch + (b % 3) - 1] >> 24;
+              cnt += b == 4 ? c - 1u : c;  // own bin: the others in it
+            }
+            linked = cnt != 0;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (pass) atomicSub(&head[bin], 1u << 24);
           const unsigned long long seq = __ballot(linked && pass);
+#ifdef OKVFE_SELECT_STATS
+          st[0] += __popcll(rem);
+          st[1] += __popcll(seq);
+          st[3] += ST_T() - t2;
+#endif
           const int room = limit - kept;
           if (__popcll(rem) <= room) {
             // the unlinked ones neither change nor are changed by anything in this window: accepted
@@ -1123,6 +1142,8 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     if (tid == 0) {
       atomicAdd(&g_sel_stats[0], 1ull);
       atomicAdd(&g_sel_stats[2], st[2]);
+      atomicAdd(&g_sel_stats[1], (st[0] << 20) | st[1]);
+      atomicAdd(&g_sel_stats[7], st[3]);
       atomicAdd(&g_sel_stats[3], (unsigned long long)kept);
       atomicAdd(&g_sel_stats[4], st[4]);
       atomicAdd(&g_sel_stats[5], st[5]);
