@@ -321,6 +321,7 @@ __device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& s
 }
 
 constexpr int kSplitTests = 30;  // tiles of more than 32 rows: hit bits of the first 30 tested rows
+constexpr int kCandStage = 170;  // candidate records staged per wave (2040 B)
 
 // One wave = one strip x kTHF rows, ONE branch-free code path for every tile: a prologue,
 // kMain / 6 groups of six identical steps (the rolling buffers have periods 2 and 3, so after six
@@ -477,6 +478,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   uint32_t hits[4] = {0u, 0u, 0u, 0u}, hitsA[4] = {0u, 0u, 0u, 0u};
   constexpr int n_a = (NMS && kTHF > 32) ? kSplitTests : 0;  // tests recorded in hitsA
   __shared__ int32_t score_stack[NMS ? kScoreSlots * kWavesPerBlock * 64 : 1];
+  // candidate records of a wave are collected here and written out as ONE contiguous run: 12-byte
+  // records stored straight from the lanes land in scattered 32-byte sectors (the WRITE_SIZE counter
+  // showed ~110 KB per image of extra write traffic, 7 % of the score map) -- the common case (a
+  // wave's candidates fit) goes through LDS, larger sets keep the direct stores
+  __shared__ Candidate cand_stage[NMS ? kWavesPerBlock : 1][NMS ? kCandStage : 1];
   const uint32_t sp0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
                        (uint32_t)(wave * 256 + lane * 4);
   uint32_t sp = sp0;  // LDS byte address of this lane's next score slot
@@ -798,6 +804,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     }
     const int image_l = image + sub_e;
     int pos = 0;
+    int wave_base = 0, wave_total = 0;  // the wave's run in the image's list (unpacked waves)
     auto reserve = [&](bool mine, int img) {
       const int c = mine ? cnt : 0;
       int incl = c;
@@ -811,6 +818,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       if (lane == 0) base = atomicAdd(&nms.cand_count[img], total);
       base = __shfl(base, 0);  // by all lanes: a cross-lane read of an inactive lane returns 0
       if (mine) pos = base + incl - c;
+      wave_base = base;
+      wave_total = total;
     };
     if (packed_block) {
       for (int g = 0; g < group_images; ++g) {  // wave-uniform
@@ -822,6 +831,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     }
     Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
     __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
+    const bool staged = !packed_block && wave_total <= kCandStage;  // wave-uniform
+    Candidate* stage = cand_stage[wave];
     int flagged = 0;
 #pragma unroll
     for (int set = 0; set < 2; ++set) {
@@ -857,10 +868,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
             cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
           else
             cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * pitch * 4, 1);
-          if (pos < nms.cand_cap) outc[pos] = cd;
+          if (staged)
+            stage[pos - wave_base] = cd;
+          else if (pos < nms.cand_cap)
+            outc[pos] = cd;
           ++pos;
         }
       }
+    }
+    if (staged) {  // the wave's records as one contiguous run: lane = record, 12 bytes each
+      __builtin_amdgcn_wave_barrier();
+      for (int r = lane; r < wave_total; r += 64)
+        if (wave_base + r < nms.cand_cap) outc[wave_base + r] = stage[r];
     }
     if ((rows_adj[0] | rows_adj[1]) != 0u && __any(flagged != 0)) {
       if (flagged) atomicAdd(&nms.fix_count[image_l], flagged);

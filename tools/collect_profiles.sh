@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats3 -o p --
 cp $(find /tmp/prof_stats3 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats_3lanes.csv
 grep '^{"metric"' /tmp/prof_stats3.log | tail -1 > $OUT/${TAG}_bench_3lanes.json
 # the other BASELINE shapes (informational bench lines, CPU baseline + parity leg included)
-for W in tumvi hilti mono640; do
+for W in tumvi hilti mono640 map; do
   python $R/bench.py --workload $W 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_$W.json
 done
 python $R/bench.py --workload hilti --split cameras 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_hilti_split_cameras.json
@@ -31,7 +31,18 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -o p -- $BENCH --steps 3 > /tmp/prof_$C.log 2>&1
   python $R/tools/pmc_summary.py $(find /tmp/prof_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_$C.json > /dev/null
 done
+# the same two passes on the other image shapes (their own traffic figures instead of EuRoC's)
+for W in tumvi mono640; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_${W}_$C -o p -- $BENCH --steps 3 --workload $W > /tmp/prof_${W}_$C.log 2>&1
+    python $R/tools/pmc_summary.py $(find /tmp/prof_${W}_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_${W}_pmc_$C.json > /dev/null
+  done
+done
 unset OKVFE_PMC_CALIB
+# K1 against its own byte-mover floor on the same (slotted) score layout, and the A/B knobs
+if [ -f $R/okvis2_amd/libokvfe_memonly.so ]; then
+  ( cd $R && ROUNDS=2 bash tools/k1ab_env.sh - -:OKVFE_K1_DENSE=1 memonly memonly:OKVFE_K1_DENSE=1 valu 2>&1 | sort ) > $OUT/${TAG}_k1_floor.txt
+fi
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -o p -- $BENCH --steps 3 > /tmp/prof_sq.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/prof_sq -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_sq.json > /dev/null
 ls -la $OUT | tail -12
