@@ -444,6 +444,7 @@ struct MapBatch {
   const uint8_t* blocks;
   int o_kps, o_desc, o_bp, block_bytes, kp_cap;
   size_t frame_stride;  // matchToMap: doubles per frame in `projections` (0 = one set for all frames)
+  const int32_t* perm;  // matchToMap: [frames][kp_cap] keypoint order by image region (keypoint_order_kernel) or null
 };
 constexpr int kVerifyLdsRows = 1024;  // 48 KiB
 __global__ __launch_bounds__(256) void verify_place_kernel(
@@ -711,6 +712,52 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_motion_kernel(
 // std::map); per landmark the image-distance gate |projection - keypoint|^2 <= thr^2, then its
 // <= 3 descriptors in order with the running minimum "dist < distances[k]" (strict, first-lowest
 // wins).  Returns per keypoint the distance and the landmark INDEX (or -1).
+// Keypoints of a frame ordered by image region (bands of 96 rows, then x): 64 consecutive entries of
+// the order cover ~10 % of the image, so a wave of match_to_map_kernel can discard most landmarks by
+// ONE vector test of 64 projections against its keypoints' bounding box instead of one scalar-loop
+// iteration per landmark.  One workgroup per frame, bitonic network on <= 4096 keys in LDS; more
+// keypoints (or none) keep the identity order.  The order only groups lanes: results do not depend on it.
+constexpr int kOrderMax = 4096;
+__global__ __launch_bounds__(256) void keypoint_order_kernel(MapBatch mb, int32_t* __restrict__ perm) {
+  __shared__ uint64_t keys[kOrderMax];
+  const uint8_t* base = mb.blocks + (size_t)blockIdx.x * mb.block_bytes;
+  const int n = *reinterpret_cast<const int32_t*>(base);
+  int32_t* out = perm + (size_t)blockIdx.x * mb.kp_cap;
+  if (n <= 0 || n > kOrderMax) {
+    for (int i = threadIdx.x; i < mb.kp_cap; i += 256) out[i] = i;
+    return;
+  }
+  const okvfe_keypoint* kps = reinterpret_cast<const okvfe_keypoint*>(base + mb.o_kps);
+  int np = 64;
+  while (np < n) np <<= 1;
+  for (int i = threadIdx.x; i < np; i += 256) {
+    uint64_t key = ~0ull;
+    if (i < n) {
+      const float x = kps[i].x, y = kps[i].y;
+      const uint32_t band = (uint32_t)(y > 0.0f ? (y < 65535.0f ? y : 65535.0f) : 0.0f) / 96u;
+      const uint32_t xq = (uint32_t)(x > 0.0f ? (x < 65535.0f ? x : 65535.0f) : 0.0f);
+      key = ((uint64_t)band << 40) | ((uint64_t)xq << 16) | (uint64_t)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= np; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < np / 2; t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < mb.kp_cap; i += 256) out[i] = i < n ? (int32_t)(keys[i] & 0xFFFFu) : i;
+}
+
 // Lane = keypoint; the landmark list is cut into kMapSegs contiguous segments (one wave each) and
 // walked in chunks of 64: lane j of the wave fetches landmark j's projection and descriptor range
 // (coalesced), v_readlane broadcasts them, and the chunk's descriptors are staged in LDS.  The
@@ -739,8 +786,10 @@ __global__ __launch_bounds__(64 * kMapSegs) void match_to_map_kernel(
     best_d += (size_t)blockIdx.y * mb.kp_cap;
   }
   const int lane = threadIdx.x, seg = threadIdx.y;
-  const int k = blockIdx.x * 64 + lane;
-  const bool in_range = k < n_k;
+  const int pos = blockIdx.x * 64 + lane;
+  const bool in_range = pos < n_k;
+  // region order of the frame's keypoints (device batches): lanes of a wave are image neighbours
+  const int k = (in_range && mb.perm) ? mb.perm[(size_t)blockIdx.y * mb.kp_cap + pos] : pos;
   const bool active = in_range && (use == nullptr || use[k] != 0);
   Desc12 dk = {};
   double kx = 0.0, ky = 0.0;
@@ -749,6 +798,20 @@ __global__ __launch_bounds__(64 * kMapSegs) void match_to_map_kernel(
     kx = (double)kps[k].x;
     ky = (double)kps[k].y;
   }
+  // bounding box of the wave's keypoints, grown by the radius (+1 px for the float rounding): a
+  // landmark outside it is near no keypoint of the wave.  NaN coordinates pass (as they pass the
+  // reference's "!(dd > thr)").
+  float bx0 = active ? (float)kx : INFINITY, bx1 = active ? (float)kx : -INFINITY;
+  float by0 = active ? (float)ky : INFINITY, by1 = active ? (float)ky : -INFINITY;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    bx0 = fminf(bx0, __shfl_xor(bx0, d));
+    bx1 = fmaxf(bx1, __shfl_xor(bx1, d));
+    by0 = fminf(by0, __shfl_xor(by0, d));
+    by1 = fmaxf(by1, __shfl_xor(by1, d));
+  }
+  const float rad = sqrtf((float)thr_sq) * 1.0001f + 1.0f;
+  bx0 -= rad; by0 -= rad; bx1 += rad; by1 += rad;
   const int per_seg = (n_lm + kMapSegs - 1) / kMapSegs;
   const int l_lo = min(seg * per_seg, n_lm), l_hi = min(l_lo + per_seg, n_lm);
   uint4* chunk = seg_desc[seg];
@@ -764,6 +827,11 @@ __global__ __launch_bounds__(64 * kMapSegs) void match_to_map_kernel(
       b = desc_begin[l0 + lane];
       e = desc_begin[l0 + lane + 1];
     }
+    // ONE vector test for the 64 landmarks of the chunk: inside the wave's box?
+    const float fpx = (float)px, fpy = (float)py;
+    const unsigned long long cmask =
+        __ballot(lane < cnt && !(fpx < bx0) && !(fpx > bx1) && !(fpy < by0) && !(fpy > by1));
+    if (cmask == 0) continue;  // wave-uniform: nothing of this chunk is near the wave
     const int d_lo = __builtin_amdgcn_readfirstlane(b);
     const int d_hi = __builtin_amdgcn_readlane(e, cnt - 1);
     // descriptors of the chunk in LDS when they fit (always, with <= 3 per landmark)
@@ -774,7 +842,8 @@ __global__ __launch_bounds__(64 * kMapSegs) void match_to_map_kernel(
       for (int i = lane; i < (d_hi - d_lo) * 3; i += 64) chunk[i] = src[i];
     }
     __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < cnt; ++j) {
+    for (unsigned long long cm = cmask; cm != 0; cm &= cm - 1) {
+      const int j = (int)__ffsll((long long)cm) - 1;
       const double lpx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(px), j),
                                           __builtin_amdgcn_readlane(__double2loint(px), j));
       const double lpy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(py), j),
@@ -1135,7 +1204,7 @@ void launch_match_to_map_uninit_blocks(const PairParams* pairs, const int offs[6
                                        int32_t* best_d, double* hps_W, uint8_t* hp_set, int32_t* ctr_total,
                                        hipStream_t stream) {
   if (n_frames <= 0 || kp_cap <= 0) return;
-  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, 0};
+  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, 0, nullptr};
   hipLaunchKernelGGL(match_to_map_uninit_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64, kUninitSegs), 0,
                      stream, pairs, nullptr, nullptr, use, previous, 0, desc_begin, n_lm, pool, e0_W, r0_W,
                      threshold, best_lm, best_d, hps_W, hp_set, ctr_total, mb);
@@ -1165,9 +1234,14 @@ void launch_match_to_map(const uint8_t* desc_k, const okvfe_keypoint* kps, const
 void launch_match_to_map_blocks(const int offs[6], const uint8_t* blocks, int n_frames, int kp_cap,
                                 const uint8_t* use, const double* projections, size_t proj_stride,
                                 const int32_t* desc_begin, int n_lm, const uint8_t* pool, double thr_sq,
-                                int threshold, int32_t* best_lm, int32_t* best_d, hipStream_t stream) {
+                                int threshold, int32_t* best_lm, int32_t* best_d, int32_t* perm_ws,
+                                hipStream_t stream) {
   if (n_frames <= 0 || kp_cap <= 0) return;
-  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, proj_stride};
+  MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, proj_stride, nullptr};
+  if (perm_ws) {  // [n_frames][kp_cap] workspace: order the frames' keypoints by image region first
+    hipLaunchKernelGGL(keypoint_order_kernel, dim3(n_frames), dim3(256), 0, stream, mb, perm_ws);
+    mb.perm = perm_ws;
+  }
   hipLaunchKernelGGL(match_to_map_kernel, dim3((kp_cap + 63) / 64, n_frames), dim3(64, kMapSegs), 0, stream,
                      nullptr, nullptr, use, 0, projections, desc_begin, n_lm, pool, thr_sq, threshold, best_lm,
                      best_d, mb);
@@ -1206,7 +1280,7 @@ void launch_verify_place_blocks(const uint8_t* pool, const int32_t* desc_begin, 
                                 int32_t* k_min, uint32_t* dist_min, hipStream_t stream) {
   if (n_landmarks <= 0 || n_frames <= 0) return;
   const int blocks_x = std::min((n_landmarks + 3) / 4, 2048);
-  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, 0};
+  const MapBatch mb{blocks, offs[1], offs[2], offs[3], offs[5], kp_cap, 0, nullptr};
   hipLaunchKernelGGL(verify_place_kernel, dim3(blocks_x, n_frames), dim3(256), 0, stream, pool, desc_begin,
                      n_landmarks, nullptr, 0, threshold, k_min, dist_min, mb);
 }

@@ -33,7 +33,9 @@ struct okvfe_ctx {
 
   std::vector<void*> allocs;
   int32_t* d_scores = nullptr;
-  int32_t* d_virtual = nullptr;  // scale-space parent, OKVFE_SCORE_BRISK_SCALESPACE: FAST 5-8 map of layer 0
+  int32_t* d_virtual = nullptr;
+  int32_t* d_map_perm = nullptr;  // okvfe_match_to_map_blocks_device: keypoint order per frame [frames][kp_cap]
+  size_t map_perm_frames = 0;  // scale-space parent, OKVFE_SCORE_BRISK_SCALESPACE: FAST 5-8 map of layer 0
   ScoreLayout score_layout{0, 0};  // of d_scores: slotted where the fused score+NMS kernel applies
   Candidate* d_cand = nullptr;
   int32_t* d_cand_count = nullptr;
@@ -231,6 +233,10 @@ okvfe_status ring_upload(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, const void* sr
   uint8_t* d = r->d + (size_t)slot * r->slot_bytes;
   std::memcpy(h, src, bytes);
   HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+  // guarded from here on: an early return between upload and ring_release still leaves an event
+  // behind the copy (ring_release moves it behind the slot's last reader)
+  HIP_TRY(ctx, hipEventRecord(r->done[slot], s));
+  r->pending[slot] = true;
   *d_out = d;
   *slot_out = slot;
   return OKVFE_OK;
@@ -591,6 +597,7 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   for (uint8_t* p : ctx->d_layer_img)
     if (p) (void)hipFree(p);
   if (ctx->d_virtual) (void)hipFree(ctx->d_virtual);
+  if (ctx->d_map_perm) (void)hipFree(ctx->d_map_perm);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (float* p : ctx->cam_rays)
     if (p) (void)hipFree(p);
@@ -1020,14 +1027,33 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
   hipStream_t s = pick_stream(ctx, stream);
   const size_t P = (size_t)ctx->w * ctx->h;
   if (!ctx->feed_stream) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->feed_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    // the feed state becomes visible only when ALL of it exists: a failed allocation leaves the
+    // context as it was (the next call tries again) instead of a stream without buffers
+    hipStream_t fs = nullptr;
+    uint8_t* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
       void* q = nullptr;
-      HIP_TRY(ctx, hipMalloc(&q, P * (size_t)ctx->B));
-      ctx->d_feed[i] = static_cast<uint8_t*>(q);
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->feed_copied[i], hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->feed_consumed[i], hipEventDisableTiming));
+      e = hipMalloc(&q, P * (size_t)ctx->B);
+      buf[i] = static_cast<uint8_t*>(q);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[2 * i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[2 * i + 1], hipEventDisableTiming);
     }
+    if (e != hipSuccess) {
+      for (hipEvent_t v : ev)
+        if (v) (void)hipEventDestroy(v);
+      for (uint8_t* b : buf)
+        if (b) (void)hipFree(b);
+      if (fs) (void)hipStreamDestroy(fs);
+      HIP_TRY(ctx, e);
+    }
+    for (int i = 0; i < 2; ++i) {
+      ctx->d_feed[i] = buf[i];
+      ctx->feed_copied[i] = ev[2 * i];
+      ctx->feed_consumed[i] = ev[2 * i + 1];
+    }
+    ctx->feed_stream = fs;
   }
   const int slot = (int)(ctx->feed_next++ & 1u);
   // the buffer is rewritten only after the kernels of the batch that used it two calls ago
@@ -2081,12 +2107,21 @@ okvfe_status okvfe_match_to_map_blocks_device(okvfe_ctx* ctx, const void* blocks
   hipStream_t s = pick_stream(ctx, stream);
   const BlockLayout L = block_layout(ctx->kp_cap);
   const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
+  if ((size_t)n_frames > ctx->map_perm_frames) {  // workspace of the region order: grown on demand (synchronises once)
+    if (ctx->d_map_perm) HIP_TRY(ctx, hipFree(ctx->d_map_perm));
+    ctx->d_map_perm = nullptr;
+    ctx->map_perm_frames = 0;
+    void* q = nullptr;
+    HIP_TRY(ctx, hipMalloc(&q, (size_t)n_frames * ctx->kp_cap * sizeof(int32_t)));
+    ctx->d_map_perm = static_cast<int32_t*>(q);
+    ctx->map_perm_frames = (size_t)n_frames;
+  }
   {
     StageTimer t(ctx, OKVFE_STAGE_MAP, s);
     launch_match_to_map_blocks(offs, static_cast<const uint8_t*>(blocks_dev), n_frames, ctx->kp_cap, use_dev,
                                map->projections, (size_t)map->n_landmarks * 2, map->desc_begin, map->n_landmarks,
                                map->pool, reprojection_threshold * reprojection_threshold, ctx->cfg.match_threshold,
-                               best_landmark_dev, best_dist_dev, s);
+                               best_landmark_dev, best_dist_dev, ctx->d_map_perm, s);
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;

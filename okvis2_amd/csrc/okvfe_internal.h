@@ -211,7 +211,8 @@ void launch_match_to_map_uninit(const PairParams* pair, const uint8_t* desc_k, c
 void launch_match_to_map_blocks(const int offs[6], const uint8_t* blocks, int n_frames, int kp_cap,
                                 const uint8_t* use, const double* projections, size_t proj_stride,
                                 const int32_t* desc_begin, int n_lm, const uint8_t* pool, double thr_sq,
-                                int threshold, int32_t* best_lm, int32_t* best_d, hipStream_t stream);
+                                int threshold, int32_t* best_lm, int32_t* best_d, int32_t* perm_ws,
+                                hipStream_t stream);
 void launch_match_to_map_uninit_blocks(const PairParams* pairs, const int offs[6], const uint8_t* blocks,
                                        int n_frames, int kp_cap, const uint8_t* use, const int32_t* previous,
                                        const int32_t* desc_begin, int n_lm, const uint8_t* pool,
