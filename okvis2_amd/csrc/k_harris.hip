@@ -320,8 +320,8 @@ __device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& s
 #endif
 }
 
-constexpr int kSplitTests = 30;  // tiles of more than 32 rows: hit bits of the first 30 tested rows
-constexpr int kCandStage = 170;  // candidate records staged per wave (2040 B)
+constexpr int kSplitTests = 30;  // tiles of more than 32 rows: a set of hit masks per 30 tested rows (the last takes the rest)
+constexpr int kCandStage = 128;  // candidate records staged per wave (1536 B) when the mask sets leave no room to reuse
 
 // One wave = one strip x kTHF rows, ONE branch-free code path for every tile: a prologue,
 // kMain / 6 groups of six identical steps (the rolling buffers have periods 2 and 3, so after six
@@ -339,7 +339,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
     int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
   constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
-  static_assert(kMain % 6 == 0 && kTHF <= 61, "rows per wave: 6k (+1 with the fused NMS), <= 61");
+  static_assert(kMain % 6 == 0 && kTHF <= 121, "rows per wave: 6k (+1 with the fused NMS), <= 121");
+  // hit masks: one set of four 32-bit masks per kSplitTests tested rows; finished sets are parked in
+  // LDS (4 dwords per lane each), so only ONE set lives in registers whatever the tile height
+  constexpr int kSets = (NMS && kTHF > 32) ? (kTHF - 32 + kSplitTests - 1) / kSplitTests + 1 : 1;
+  constexpr int kLastTests = kTHF - kSplitTests * (kSets - 1);  // tests of the last set (<= 32)
+  static_assert(kLastTests >= 1 && kLastTests <= 32, "last mask set");
+  // stack depth per lane: fewer slots for the tall tiles (their three parked sets take the LDS)
+  constexpr int kSlots = kSets > 2 ? 12 : kScoreSlots;
   const int lane = threadIdx.x;
   const int nd = w >> 2;
   // PACK (narrow last strip, e.g. 7 dwords of a 1024-px row): `strips` counts the full strips
@@ -475,20 +482,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
 
   // NMS state: scores + edge neighbours of the previous row, horizontal 3-max of the last two
   int nc[4] = {0, 0, 0, 0}, nh[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, nl = 0, nr = 0;
-  uint32_t hits[4] = {0u, 0u, 0u, 0u}, hitsA[4] = {0u, 0u, 0u, 0u};
-  constexpr int n_a = (NMS && kTHF > 32) ? kSplitTests : 0;  // tests recorded in hitsA
-  __shared__ int32_t score_stack[NMS ? kScoreSlots * kWavesPerBlock * 64 : 1];
+  uint32_t hits[4] = {0u, 0u, 0u, 0u};
+  __shared__ uint32_t hit_sets[NMS && kSets > 1 ? kWavesPerBlock * (kSets - 1) * 4 * 64 : 1];  // [wave][set][column][lane]
+  __shared__ int32_t score_stack[NMS ? kSlots * kWavesPerBlock * 64 : 1];
   // candidate records of a wave are collected here and written out as ONE contiguous run: 12-byte
   // records stored straight from the lanes land in scattered 32-byte sectors (the WRITE_SIZE counter
   // showed ~110 KB per image of extra write traffic, 7 % of the score map) -- the common case (a
   // wave's candidates fit) goes through LDS, larger sets keep the direct stores
-  __shared__ Candidate cand_stage[NMS ? kWavesPerBlock : 1][NMS ? kCandStage : 1];
+  // (tiles with three parked mask sets reuse that LDS for the records once the sets are back in registers)
+  constexpr int kStageCap = kSets > 2 ? (kSets - 1) * 4 * 64 * 4 / 12 : kCandStage;
+  __shared__ Candidate cand_stage[NMS && kSets <= 2 ? kWavesPerBlock : 1][NMS && kSets <= 2 ? kCandStage : 1];
   const uint32_t sp0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
                        (uint32_t)(wave * 256 + lane * 4);
   uint32_t sp = sp0;  // LDS byte address of this lane's next score slot
   // end of the stack as ONE scalar: slot e of any lane lies below base + (e + 1) * stride
   const uint32_t sp_end = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
-                          (uint32_t)(kScoreSlots * kWavesPerBlock * 256);
+                          (uint32_t)(kSlots * kWavesPerBlock * 256);
 
   // covariance row g from pixel rows a (g-1), b (g), c (g+1) -> H (horizontally smoothed); k3, k10 =
   // the (3, 10, 3) filter taps times 2^9 (mulhi24 of two such gradients then yields g*g >> 14), or
@@ -712,10 +721,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     step(OKVFE_PH(2), T(), F(), F());  // score row ys_own - 1: NMS state only
     step(OKVFE_PH(3), T(), T(), F());  // score row ys_own: stored, nothing to test yet
     for (int g = 0; g < kMain / 6; ++g) {
-      if (n_a != 0 && g == kSplitTests / 6) {
+      if (kSets > 1 && g > 0 && g % (kSplitTests / 6) == 0 && g / (kSplitTests / 6) < kSets) {
+        const int set_done = g / (kSplitTests / 6) - 1;  // scalar
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          hitsA[i] = hits[i];
+          hit_sets[((wave * (kSets - 1) + set_done) * 4 + i) * 64 + lane] = hits[i];
           hits[i] = 0u;
         }
       }
@@ -763,23 +773,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       }
       return m;
     };
-    const uint32_t valid[2] = {n_a ? bits_of(t_lo, t_hi, 0, n_a) : 0u,
-                               bits_of(t_lo, t_hi, n_a, kTHF - n_a)};
+    // test t of set s = kSplitTests * s + (n_s - 1 - bit): n_s tests per set
     const int x0 = dcl * 4;
-    uint32_t rows_adj[2] = {0u, 0u};
-    int cnt = 0;
+    uint32_t M[kSets][4], R[kSets][4];  // masked / raw hit bits
+    uint32_t rows_adj[kSets];
+    int pushed_before[kSets];
+    int cnt = 0, pushed = 0;
     // every hit was pushed, the ones masked below included: slot indices count the unmasked bits
-    const uint32_t rawA[4] = {hitsA[0], hitsA[1], hitsA[2], hitsA[3]};
-    const uint32_t rawB[4] = {hits[0], hits[1], hits[2], hits[3]};
-    const int pushed_a = __popc(rawA[0]) + __popc(rawA[1]) + __popc(rawA[2]) + __popc(rawA[3]);
 #pragma unroll
-    for (int set = 0; set < 2; ++set) {
-      uint32_t* m = set == 0 ? hitsA : hits;
+    for (int set = 0; set < kSets; ++set) {
+      const int n_s = set == kSets - 1 ? kLastTests : kSplitTests;
+      const uint32_t valid = bits_of(t_lo, t_hi, kSplitTests * set, n_s);
+      rows_adj[set] = 0u;
+      pushed_before[set] = pushed;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {  // columns 0, 1, w-2, w-1 are never maxima
-        m[i] &= valid[set];
-        if (x0 + i < 2 || x0 + i >= w - 2) m[i] = 0u;
+      for (int i = 0; i < 4; ++i) {
+        R[set][i] = set == kSets - 1 ? hits[i] : hit_sets[((wave * (kSets - 1) + set) * 4 + i) * 64 + lane];
+        pushed += __popc(R[set][i]);
+        M[set][i] = R[set][i] & valid;
+        if (x0 + i < 2 || x0 + i >= w - 2) M[set][i] = 0u;  // columns 0, 1, w-2, w-1 are never maxima
       }
+      uint32_t* m = M[set];
       const uint32_t adj = (m[0] & m[1]) | (m[1] & m[2]) | (m[2] & m[3]) |
                            (m[3] & (uint32_t)from_right((int)m[0]));
       if (__builtin_expect(__any(adj != 0u), 0)) {
@@ -831,13 +845,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     }
     Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
     __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
-    const bool staged = !packed_block && wave_total <= kCandStage;  // wave-uniform
-    Candidate* stage = cand_stage[wave];
+    const bool staged = !packed_block && wave_total <= kStageCap;  // wave-uniform
+    __builtin_amdgcn_wave_barrier();  // all parked mask sets are in registers: their LDS may be reused
+    Candidate* stage = kSets > 2 ? reinterpret_cast<Candidate*>(&hit_sets[wave * (kSets - 1) * 4 * 64])
+                                 : cand_stage[kSets > 2 ? 0 : wave];
     int flagged = 0;
+    uint32_t any_adj = 0u;
 #pragma unroll
-    for (int set = 0; set < 2; ++set) {
-      const uint32_t* m = set == 0 ? hitsA : hits;
-      const int row_hi = ys_own + (set == 0 ? n_a : kTHF) - 1;  // row of bit 0
+    for (int set = 0; set < kSets; ++set) {
+      const uint32_t* m = M[set];
+      const int n_s = set == kSets - 1 ? kLastTests : kSplitTests;
+      const int row_hi = ys_own + kSplitTests * set + n_s - 1;  // row of bit 0
+      any_adj |= rows_adj[set];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint32_t mm = m[i];
@@ -854,17 +873,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
           }
           // slot = pushes of earlier tests (higher bits; all of set A for set B) + pushes of the
           // same test in the columns before i
-          const uint32_t* raw = set == 0 ? rawA : rawB;
-          int e = set == 0 ? 0 : pushed_a;
+          const uint32_t* raw = R[set];
+          int e = pushed_before[set];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             e += __popc((raw[c] >> b) >> 1);
             if (c < i) e += (int)((raw[c] >> b) & 1u);
           }
 #ifdef OKVFE_K1_NOLDSPUSH
-          e = kScoreSlots;
+          e = kSlots;
 #endif
-          if (e < kScoreSlots)
+          if (e < kSlots)
             cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
           else
             cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * pitch * 4, 1);
@@ -881,7 +900,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       for (int r = lane; r < wave_total; r += 64)
         if (wave_base + r < nms.cand_cap) outc[wave_base + r] = stage[r];
     }
-    if ((rows_adj[0] | rows_adj[1]) != 0u && __any(flagged != 0)) {
+    if (any_adj != 0u && __any(flagged != 0)) {
       if (flagged) atomicAdd(&nms.fix_count[image_l], flagged);
     }
   }
@@ -955,6 +974,8 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
         case 43: OKVFE_K1_NMS_LAUNCH(43); break;
         case 49: OKVFE_K1_NMS_LAUNCH(49); break;
         case 55: OKVFE_K1_NMS_LAUNCH(55); break;
+        case 91: OKVFE_K1_NMS_LAUNCH(91); break;
+        case 121: OKVFE_K1_NMS_LAUNCH(121); break;
         default: OKVFE_K1_NMS_LAUNCH(61); break;
       }
     } else {
