@@ -321,7 +321,7 @@ __device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& s
 }
 
 constexpr int kSplitTests = 30;  // tiles of more than 32 rows: a set of hit masks per 30 tested rows (the last takes the rest)
-constexpr int kCandStage = 128;  // candidate records staged per wave (1536 B) when the mask sets leave no room to reuse
+constexpr int kCandStage = 248;  // candidate records staged per wave (2976 B; 5 workgroups per CU leave 32 KB each)
 
 // One wave = one strip x kTHF rows, ONE branch-free code path for every tile: a prologue,
 // kMain / 6 groups of six identical steps (the rolling buffers have periods 2 and 3, so after six
@@ -845,7 +845,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     }
     Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
     __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
-    const bool staged = !packed_block && wave_total <= kStageCap;  // wave-uniform
+#ifdef OKVFE_K1_NOCANDSTAGE  // A/B: the direct 12-byte stores of round 2
+    const bool staged = false;
+#else
+    const bool staged = !packed_block;  // wave-uniform; records past the stage's capacity are stored directly
+#endif
     __builtin_amdgcn_wave_barrier();  // all parked mask sets are in registers: their LDS may be reused
     Candidate* stage = kSets > 2 ? reinterpret_cast<Candidate*>(&hit_sets[wave * (kSets - 1) * 4 * 64])
                                  : cand_stage[kSets > 2 ? 0 : wave];
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
             cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
           else
             cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * pitch * 4, 1);
-          if (staged)
+          if (staged && pos - wave_base < kStageCap)
             stage[pos - wave_base] = cd;
           else if (pos < nms.cand_cap)
             outc[pos] = cd;
@@ -897,7 +901,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     }
     if (staged) {  // the wave's records as one contiguous run: lane = record, 12 bytes each
       __builtin_amdgcn_wave_barrier();
-      for (int r = lane; r < wave_total; r += 64)
+      const int n_staged = wave_total < kStageCap ? wave_total : kStageCap;
+      for (int r = lane; r < n_staged; r += 64)
         if (wave_base + r < nms.cand_cap) outc[wave_base + r] = stage[r];
     }
     if (any_adj != 0u && __any(flagged != 0)) {
