@@ -321,7 +321,10 @@ __device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& s
 }
 
 constexpr int kSplitTests = 30;  // tiles of more than 32 rows: a set of hit masks per 30 tested rows (the last takes the rest)
-constexpr int kCandStage = 248;  // candidate records staged per wave (2976 B; 5 workgroups per CU leave 32 KB each)
+#ifndef OKVFE_K1_STAGE
+#define OKVFE_K1_STAGE 248
+#endif
+constexpr int kCandStage = OKVFE_K1_STAGE;  // candidate records staged per wave (2976 B; 5 workgroups per CU leave 32 KB each)
 
 // One wave = one strip x kTHF rows, ONE branch-free code path for every tile: a prologue,
 // kMain / 6 groups of six identical steps (the rolling buffers have periods 2 and 3, so after six
@@ -844,7 +847,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       reserve(true, image);
     }
     Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
-    __builtin_amdgcn_s_waitcnt(0);  // this wave's own score stores have reached L2
+    // a lane whose LDS stack overflowed re-reads scores from the map: only then must this wave's own
+    // score stores have reached L2 (the unconditional wait kept every wave's slot busy until its last
+    // store was acknowledged)
+    if (__any(pushed > kSlots)) __builtin_amdgcn_s_waitcnt(0);
 #ifdef OKVFE_K1_NOCANDSTAGE  // A/B: the direct 12-byte stores of round 2
     const bool staged = false;
 #else

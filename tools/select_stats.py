@@ -20,5 +20,9 @@ for it in range(2):
     torch.cuda.synchronize()
     L.okvfe_debug_select_stats(out, 0)
 n = out[0]
-names = ["blocks", "rounds", "windows", "kept", "cyc_decide", "cyc_stamp", "cyc_init", "cyc_subpix"]
+# the grid kernels (OKVFE_SELECT_GRID=1) report rounds / decide / stamp / init / sub-pixel cycles; the lazy kernel
+# (default) reports, from wave 0's view: slot 1 = (passing lanes << 20 | linked lanes), walk, accept, barrier
+# waits, and (neighbour test + sub-pixel) cycles -- see the OKVFE_SELECT_STATS blocks in k_select.hip
+names = ["blocks", "rounds|pass<<20+linked", "windows", "kept", "cyc_decide|walk", "cyc_stamp|accept",
+         "cyc_init|sync", "cyc_subpix(+neighbour test)"]
 print({k: round(out[i] / n, 1) for i, k in enumerate(names)})
