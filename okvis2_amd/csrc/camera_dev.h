@@ -16,6 +16,7 @@
 #pragma once
 
 #include "atan_fixed.h"
+#include "equidistant_jacobian.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -55,30 +56,7 @@ __device__ inline void distort(const DeviceCamera& c, double u0, double u1, doub
   out[0] = scaling * u0;
   out[1] = scaling * u1;
   if (r > 1e-8) {
-    double t2, t3, t4, t6, t7, t8, t9, t11, t17, t18, t19, t20, t25;
-    t2 = u0 * u0;
-    t3 = u1 * u1;
-    t4 = t2 + t3;
-    t6 = atan_fixed(sqrt(t4));
-    t7 = t6 * t6;
-    t8 = 1.0 / sqrt(t4);
-    t9 = t7 * t7;
-    t11 = 1.0 / ((t2 + t3) + 1.0);
-    t17 = (((k1 * t7 + k2 * t9) + k3 * t7 * t9) + k4 * (t9 * t9)) + 1.0;
-    t18 = 1.0 / t4;
-    t19 = 1.0 / sqrt(t4 * t4 * t4);
-    t20 = t6 * t8 * t17;
-    t25 = ((k2 * t6 * t7 * t8 * t11 * u1 * 4.0 + k3 * t6 * t8 * t9 * t11 * u1 * 6.0) +
-           k4 * t6 * t7 * t8 * t9 * t11 * u1 * 8.0) +
-          k1 * t6 * t8 * t11 * u1 * 2.0;
-    t4 = ((k2 * t6 * t7 * t8 * t11 * u0 * 4.0 + k3 * t6 * t8 * t9 * t11 * u0 * 6.0) +
-          k4 * t6 * t7 * t8 * t9 * t11 * u0 * 8.0) +
-         k1 * t6 * t8 * t11 * u0 * 2.0;
-    t7 = t11 * t17 * t18 * u0 * u1;
-    J[1] = (t7 + t6 * t8 * t25 * u0) - t6 * t17 * t19 * u0 * u1;
-    J[3] = ((t20 - t3 * t6 * t17 * t19) + t3 * t11 * t17 * t18) + t6 * t8 * t25 * u1;
-    J[0] = ((t20 - t2 * t6 * t17 * t19) + t2 * t11 * t17 * t18) + t6 * t8 * t4 * u0;
-    J[2] = (t7 + t6 * t8 * t4 * u1) - t6 * t17 * t19 * u0 * u1;
+    equidistant_jacobian(u0, u1, k1, k2, k3, k4, [](double v) { return sqrt(v); }, J);  // equidistant_jacobian.h
   } else {
     J[0] = 1.0; J[1] = 0.0; J[2] = 0.0; J[3] = 1.0;
   }

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "atan_fixed.h"
+#include "equidistant_jacobian.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -158,31 +159,13 @@ void distort(const okvfe_camera& cam, Vec2 u, Vec2* out, Mat2* J) {
   out->y = scaling * u1;
   if (!J) return;
   if (r > 1e-8) {
-    // generated expression of the reference (EquidistantDistortion.hpp:128-171); the operation
-    // order is kept because it fixes the rounding
-    const double t2 = u0 * u0;
-    const double t3 = u1 * u1;
-    double t4 = t2 + t3;
-    const double t6 = atan_fixed(std::sqrt(t4));
-    double t7 = t6 * t6;
-    const double t8 = 1.0 / std::sqrt(t4);
-    const double t9 = t7 * t7;
-    const double t11 = 1.0 / ((t2 + t3) + 1.0);
-    const double t17 = (((k1 * t7 + k2 * t9) + k3 * t7 * t9) + k4 * (t9 * t9)) + 1.0;
-    const double t18 = 1.0 / t4;
-    const double t19 = 1.0 / std::sqrt(t4 * t4 * t4);
-    const double t20 = t6 * t8 * t17;
-    const double t25 = ((k2 * t6 * t7 * t8 * t11 * u1 * 4.0 + k3 * t6 * t8 * t9 * t11 * u1 * 6.0) +
-                        k4 * t6 * t7 * t8 * t9 * t11 * u1 * 8.0) +
-                       k1 * t6 * t8 * t11 * u1 * 2.0;
-    t4 = ((k2 * t6 * t7 * t8 * t11 * u0 * 4.0 + k3 * t6 * t8 * t9 * t11 * u0 * 6.0) +
-          k4 * t6 * t7 * t8 * t9 * t11 * u0 * 8.0) +
-         k1 * t6 * t8 * t11 * u0 * 2.0;
-    t7 = t11 * t17 * t18 * u0 * u1;
-    J->b = (t7 + t6 * t8 * t25 * u0) - t6 * t17 * t19 * u0 * u1;
-    J->d = ((t20 - t3 * t6 * t17 * t19) + t3 * t11 * t17 * t18) + t6 * t8 * t25 * u1;
-    J->a = ((t20 - t2 * t6 * t17 * t19) + t2 * t11 * t17 * t18) + t6 * t8 * t4 * u0;
-    J->c = (t7 + t6 * t8 * t4 * u1) - t6 * t17 * t19 * u0 * u1;
+    // generated expression of the reference (EquidistantDistortion.hpp:128-171): equidistant_jacobian.h
+    double j4[4];
+    equidistant_jacobian(u0, u1, k1, k2, k3, k4, [](double v) { return std::sqrt(v); }, j4);
+    J->a = j4[0];
+    J->b = j4[1];
+    J->c = j4[2];
+    J->d = j4[3];
   } else {
     *J = {1.0, 0.0, 0.0, 1.0};
   }
