@@ -21,7 +21,8 @@ namespace okvfe {
 namespace {
 
 constexpr int kTileW = 64, kTileH = 16, kApron = 3;
-constexpr int kLdsPitch = 72;  // >= kTileW + 2 * kApron
+constexpr int kLdsPitch = 72;  // 18 dwords: columns x0 - 4 .. x0 + 67 (>= kTileW + 2 * kApron)
+constexpr int kLdsX = 4;       // LDS column of image column x0: the row starts one aligned dword to the left
 
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i_(int a, int b, int c) { return max(max(a, b), c); }
@@ -29,7 +30,7 @@ __device__ __forceinline__ int max3i_(int a, int b, int c) { return max(max(a, b
 __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restrict__ images, int w, int h,
                                                           int32_t* __restrict__ scores, int tiles_x,
                                                           int tiles_y, int n_images) {
-  __shared__ uint8_t tile[kTileH + 2 * kApron][kLdsPitch];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kTileH + 2 * kApron][kLdsPitch];
   int image, t;
   xcd_tile(tiles_x * tiles_y, n_images, &image, &t);
   const int ty0 = t / tiles_x, tx0 = t - ty0 * tiles_x;
@@ -38,13 +39,25 @@ __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restr
   int32_t* out = scores + (size_t)image * w * h;
   const int tid = threadIdx.x;
   // stage the tile; coordinates outside the image are clamped (those values only reach pixels
-  // whose score is 0 by the border rule)
-  for (int i = tid; i < (kTileH + 2 * kApron) * (kTileW + 2 * kApron); i += 256) {
-    const int r = i / (kTileW + 2 * kApron), c = i - r * (kTileW + 2 * kApron);
-    int yy = y0 - kApron + r, xx = x0 - kApron + c;
-    yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
-    xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
-    tile[r][c] = img[(size_t)yy * w + xx];
+  // whose score is 0 by the border rule).  Rows of 4-aligned widths move as 18 aligned dwords (the
+  // byte-wise loop below was the kernel's actual bound: 6 byte loads + LDS byte stores per thread)
+  if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0) {
+    const int ndw = w >> 2;
+    for (int i = tid; i < (kTileH + 2 * kApron) * (kLdsPitch / 4); i += 256) {
+      const int r = i / (kLdsPitch / 4), c = i - r * (kLdsPitch / 4);
+      int yy = y0 - kApron + r, dq = (x0 >> 2) - 1 + c;
+      yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      dq = dq < 0 ? 0 : (dq > ndw - 1 ? ndw - 1 : dq);
+      reinterpret_cast<uint32_t*>(&tile[r][0])[c] = reinterpret_cast<const uint32_t*>(img + (size_t)yy * w)[dq];
+    }
+  } else {
+    for (int i = tid; i < (kTileH + 2 * kApron) * (kTileW + 2 * kApron); i += 256) {
+      const int r = i / (kTileW + 2 * kApron), c = i - r * (kTileW + 2 * kApron);
+      int yy = y0 - kApron + r, xx = x0 - kApron + c;
+      yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+      xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+      tile[r][c + kLdsX - kApron] = img[(size_t)yy * w + xx];
+    }
   }
   __syncthreads();
   const int tx = tid & 63, tyy = tid >> 6;
@@ -56,7 +69,7 @@ __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restr
     if (y >= h) break;
     int s = 0;
     if (x >= 3 && y >= 3 && x < w - 3 && y < h - 3) {
-      const uint8_t* c = &tile[ly + kApron][tx + kApron];
+      const uint8_t* c = &tile[ly + kApron][tx + kLdsX];
       const int p = c[0];
       // circle in the order of the oracle's table: (0,3) (1,3) (2,2) (3,1) (3,0) (3,-1) (2,-2) (1,-3)
       // (0,-3) (-1,-3) (-2,-2) (-3,-1) (-3,0) (-3,1) (-2,2) (-1,3)
