@@ -433,14 +433,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // rewritten into a v_cndmask_b32_e64 on a re-materialised compare
   asm volatile("" : "+v"(m0), "+v"(m3));
 
+#if !defined(OKVFE_K1_MFMA) || defined(OKVFE_K1_MEMONLY)
   auto unpack4 = [](uint32_t c, int p[4]) {
     p[0] = c & 255;
     p[1] = (c >> 8) & 255;
     p[2] = (c >> 16) & 255;
     p[3] = c >> 24;
   };
-
+#endif
+#ifndef OKVFE_K1_MFMA
   int pr[3][4];      // rolling pixel rows (own 4 columns)
+#endif
 #ifdef OKVFE_K1_MFMA
   // Gradients on the matrix pipe (default; -DOKVFE_K1_VALU_GRAD builds the vector-ALU form).  v_mfma_i32_4x4x4i8 runs one 4x4x4 product per group of 4 lanes:
   // D[i] of a lane = sum_k A[i][k] * B_lane[k], with row i of A supplied by lane 4b + i -- i.e. FOUR
