@@ -762,6 +762,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     if (ye_own == h) store_row(zero, h - 1);
   }
 
+#ifdef OKVFE_K1_NOEPILOGUE  // A/B: the row loop alone (no candidate records are produced)
+  if (NMS) return;
+#endif
   if (NMS) {
     // hit bits -> candidate records.  Test t = centre row ys_own + t, t in [0, kTHF).  Set A: tests
     // [0, n_a), bit b <-> t = n_a - 1 - b; set B: tests [n_a, kTHF), bit b <-> t = kTHF - 1 - b.
