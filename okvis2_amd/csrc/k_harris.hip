@@ -261,12 +261,12 @@ constexpr int kStripLanes = 62;
 // computes the score rows ys-1 and ye (not stored), keeps the previous score row and the horizontal
 // 3-maxima of the last two rows in registers, and tests every centre row against
 // max(8 neighbours, thr) while it is still in registers -- the score map is then never read back
-// from HBM by the detector (a pure-read pass over it costs as much as this whole kernel).  Hits are
-// shifted into 32-bit masks, one per column (v_cmp + v_addc_co); a tile of more than 32 rows uses
-// two mask sets (the first 30 tested rows, then the rest).  The masks are written out after the row
-// loop through one slot reservation per wave.  Where two horizontally adjacent pixels both pass
-// (equal scores) the raster-scan rule of the reference needs the finished score row of the
-// neighbouring strips, so those candidates are flagged and settled by nms_fixup_kernel (k_nms.hip).
+// from HBM by the detector (a pure-read pass over it costs as much as this whole kernel).  A lane
+// that owns a hit pushes {score, row << 2 | column} on its LDS stack right at the test; after the row
+// loop the stacks are copied out as candidate records through one slot reservation per wave.  Where
+// two horizontally adjacent pixels both pass (equal scores) the raster-scan rule of the reference
+// needs the finished score row of the neighbouring strips, so the candidates of such a row are
+// flagged and settled by nms_fixup_kernel (k_nms.hip).
 struct NmsOut {
   int thr;
   Candidate* cand;
@@ -276,51 +276,45 @@ struct NmsOut {
 };
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-// Candidate scores ride from the test to the epilogue in LDS: re-reading them from the score map
-// after the row loop missed the L2 (the tile's own stores had pushed them out) and cost one 64-128 B
-// HBM fetch per candidate -- 0.44 GB per 1536 images, as much as 80 % of the image bytes themselves.
-// Layout: entry e of lane l of wave v at byte e * (256 * waves per block) + v * 256 + l * 4 (bank-conflict-free); a
-// lane pushes in test order.  A lane with more than kScoreSlots hits (flat or noisy content) stops
-// writing (its address is compared with the end of its slice) and the epilogue reads the scores
-// of those candidates from the score map.
+// Hit stacks.  Re-reading candidate scores from the score map after the row loop missed the L2 (the
+// tile's own stores had pushed them out) and cost one 64-128 B HBM fetch per candidate; hit BITS
+// collected per column (v_addc_co into 32-bit masks, the round-2 form) cost four vector instructions
+// per step plus an epilogue that walked eight masks per lane with a popcount chain per record -- 6 %
+// of the kernel.  Now the hit itself carries everything: entry e of lane l of wave v = two dwords,
+// the score at byte v * kSlots * 512 + e * 512 + l * 4 and the tag (row << 2 | column) 256 bytes
+// behind it (one ds_write2_b32, bank-conflict-free).  A lane whose stack is full (flat or noisy
+// content) hands the hit to emit_overflow() instead, which appends the record to the image's list
+// directly (one atomic per record, flagged for the fix-up pass, which re-evaluates it exactly).
 #ifndef OKVFE_K1_SLOTS
-#define OKVFE_K1_SLOTS 16
+#define OKVFE_K1_SLOTS 8
 #endif
 constexpr int kScoreSlots = OKVFE_K1_SLOTS;
-// m = (m << 1) | (c >= nb); lanes that hit push c
-__device__ __forceinline__ void push_hit(uint32_t& m, int c, int nb, uint32_t& sp, uint32_t sp_end) {
-  uint64_t mask, sav;
-#ifndef OKVFE_K1_NOLDSPUSH
-  // about half of the (row, column) tests of a wave have no hit at all: the push is branched over.
-  // Lanes whose stack is full (sp >= sp_end) skip the write but still advance sp, so that slot
-  // indices stay equal to push counts.
+// mask = lanes with c >= nb (every lane: the adjacency test needs the halo lanes' hits too); the
+// lanes of `own` among them push {c, tag}; ovf = owners that hit with a full stack
+__device__ __forceinline__ void push_hit(uint64_t& mask, uint64_t& ovf, int c, int nb, uint64_t own, uint32_t tag,
+                                         uint32_t& sp, uint32_t sp_end) {
+  uint64_t sav, pm;
+  uint32_t vtag;
+  // about half of the (row, column) tests of a wave have no hit at all: the push is branched over
   asm volatile(
       "v_cmp_ge_i32_e64 %[mask], %[c], %[nb]\n\t"
-      "v_addc_co_u32_e64 %[m], vcc, %[m], %[m], %[mask]\n\t"
-      "s_and_saveexec_b64 %[sav], %[mask]\n\t"
-      "s_cbranch_execz .Lokvfe_nopush%=\n\t"
+      "s_mov_b64 %[ovf], 0\n\t"
+      "s_and_b64 %[pm], %[mask], %[own]\n\t"
+      "s_cbranch_scc0 .Lokvfe_nopush%=\n\t"
+      "s_and_saveexec_b64 %[sav], %[pm]\n\t"
       "v_cmp_gt_u32_e32 vcc, %[end], %[sp]\n\t"
+      "s_andn2_b64 %[ovf], exec, vcc\n\t"
       "s_and_b64 exec, exec, vcc\n\t"
-      "ds_write_b32 %[sp], %[c]\n\t"
-      "s_and_b64 exec, %[sav], %[mask]\n\t"
-      "v_add_u32 %[sp], %[stride], %[sp]\n"
-      ".Lokvfe_nopush%=:\n\t"
-      "s_mov_b64 exec, %[sav]"
-      : [m] "+v"(m), [sp] "+v"(sp), [mask] "=&s"(mask), [sav] "=&s"(sav)
-      : [c] "v"(c), [nb] "v"(nb), [end] "s"(sp_end), [stride] "i"(kWavesPerBlock * 256)
+      "v_mov_b32 %[vtag], %[tag]\n\t"
+      "ds_write2_b32 %[sp], %[c], %[vtag] offset1:64\n\t"
+      "v_add_u32 %[sp], %[stride], %[sp]\n\t"
+      "s_mov_b64 exec, %[sav]\n"
+      ".Lokvfe_nopush%=:"
+      : [sp] "+v"(sp), [mask] "=&s"(mask), [ovf] "=&s"(ovf), [sav] "=&s"(sav), [pm] "=&s"(pm), [vtag] "=&v"(vtag)
+      : [c] "v"(c), [nb] "v"(nb), [own] "s"(own), [tag] "s"(tag), [end] "s"(sp_end), [stride] "i"(512)
       : "vcc", "scc", "memory");
-#else
-  (void)sav;
-  (void)sp;
-  (void)sp_end;
-  asm volatile("v_cmp_ge_i32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, vcc, %0, %0, %1"
-               : "+v"(m), "=&s"(mask)
-               : "v"(c), "v"(nb)
-               : "vcc");
-#endif
 }
 
-constexpr int kSplitTests = 30;  // tiles of more than 32 rows: a set of hit masks per 30 tested rows (the last takes the rest)
 #ifndef OKVFE_K1_STAGE
 #define OKVFE_K1_STAGE 248
 #endif
@@ -336,20 +330,14 @@ constexpr int kCandStage = OKVFE_K1_STAGE;  // candidate records staged per wave
 //   * score rows 0 and h-1: computed like any other row (they are never an NMS centre and never the
 //     neighbour of a tested row) and overwritten with zeros after the loop by the two waves that
 //     own them; rows past the image (partial last tile) are not stored;
-//   * hit bits of rows that may not be maxima (y < 2, y >= h-2) are masked in the epilogue.
+//   * rows that may not carry maxima (y < 2, y >= h-2) skip their test on a scalar branch.
 template <int kTHF, bool NMS, bool PACK = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
     int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
   constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
   static_assert(kMain % 6 == 0 && kTHF <= 121, "rows per wave: 6k (+1 with the fused NMS), <= 121");
-  // hit masks: one set of four 32-bit masks per kSplitTests tested rows; finished sets are parked in
-  // LDS (4 dwords per lane each), so only ONE set lives in registers whatever the tile height
-  constexpr int kSets = (NMS && kTHF > 32) ? (kTHF - 32 + kSplitTests - 1) / kSplitTests + 1 : 1;
-  constexpr int kLastTests = kTHF - kSplitTests * (kSets - 1);  // tests of the last set (<= 32)
-  static_assert(kLastTests >= 1 && kLastTests <= 32, "last mask set");
-  // stack depth per lane: fewer slots for the tall tiles (their three parked sets take the LDS)
-  constexpr int kSlots = kSets > 2 ? 12 : kScoreSlots;
+  constexpr int kSlots = kTHF > 64 ? kScoreSlots + kScoreSlots / 2 : kScoreSlots;  // stack depth per lane
   const int lane = threadIdx.x;
   const int nd = w >> 2;
   // PACK (narrow last strip, e.g. 7 dwords of a 1024-px row): `strips` counts the full strips
@@ -488,22 +476,45 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
 
   // NMS state: scores + edge neighbours of the previous row, horizontal 3-max of the last two
   int nc[4] = {0, 0, 0, 0}, nh[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, nl = 0, nr = 0;
-  uint32_t hits[4] = {0u, 0u, 0u, 0u};
-  __shared__ uint32_t hit_sets[NMS && kSets > 1 ? kWavesPerBlock * (kSets - 1) * 4 * 64 : 1];  // [wave][set][column][lane]
-  __shared__ int32_t score_stack[NMS ? kSlots * kWavesPerBlock * 64 : 1];
+  __shared__ int32_t hit_stack[NMS ? kWavesPerBlock * kSlots * 128 : 1];  // [wave][slot][score | tag][lane]
   // candidate records of a wave are collected here and written out as ONE contiguous run: 12-byte
   // records stored straight from the lanes land in scattered 32-byte sectors (the WRITE_SIZE counter
   // showed ~110 KB per image of extra write traffic, 7 % of the score map) -- the common case (a
   // wave's candidates fit) goes through LDS, larger sets keep the direct stores
-  // (tiles with three parked mask sets reuse that LDS for the records once the sets are back in registers)
-  constexpr int kStageCap = kSets > 2 ? (kSets - 1) * 4 * 64 * 4 / 12 : kCandStage;
-  __shared__ Candidate cand_stage[NMS && kSets <= 2 ? kWavesPerBlock : 1][NMS && kSets <= 2 ? kCandStage : 1];
-  const uint32_t sp0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
-                       (uint32_t)(wave * 256 + lane * 4);
-  uint32_t sp = sp0;  // LDS byte address of this lane's next score slot
-  // end of the stack as ONE scalar: slot e of any lane lies below base + (e + 1) * stride
-  const uint32_t sp_end = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)score_stack +
-                          (uint32_t)(kSlots * kWavesPerBlock * 256);
+  constexpr int kStageCap = kCandStage;
+  __shared__ Candidate cand_stage[NMS ? kWavesPerBlock : 1][NMS ? kCandStage : 1];
+  const uint32_t sp0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)hit_stack +
+                       (uint32_t)(wave * (kSlots * 512) + lane * 4);
+  uint32_t sp = sp0;  // LDS byte address of this lane's next slot
+  // end of the wave's stack as ONE scalar: slot e < kSlots of any lane lies below it
+  const uint32_t sp_end = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int32_t*)hit_stack +
+                          (uint32_t)((wave + 1) * (kSlots * 512));
+  // lanes that own column i of their quad as a possible maximum: store lanes, columns 2 .. w-3
+  const uint64_t own_lo = __ballot(store && d != 0);       // columns 0, 1 of the quad
+  const uint64_t own_hi = __ballot(store && d != nd - 1);  // columns 2, 3
+  const int r_lo = ys_own > 2 ? ys_own : 2;                       // rows that may carry maxima:
+  const int r_hi = ye_own < h - 2 ? ye_own : h - 2;               // [r_lo, r_hi) (scalars)
+  uint64_t rows_adj[2] = {0ull, 0ull};  // bit t: tested row ys_own + t holds two adjacent hits
+  // a hit of a lane whose stack is full: straight into the image's list (rare)
+  auto emit_overflow = [&](uint64_t ovf, int c, int i, int r, bool flag) {
+    if ((ovf >> lane) & 1ull) {
+      int sub_o = 0;
+      if (packed_block) {
+        sub_o = lane / pack_u;
+        if (sub_o >= group_images) sub_o = 0;
+      }
+      const int img = image + sub_o;
+      const int p = atomicAdd(&nms.cand_count[img], 1);
+      if (p < nms.cand_cap) {
+        Candidate cd;
+        cd.x = dcl * 4 + i;
+        cd.y = flag ? r | kCandidateFixupFlag : r;
+        cd.score = c;
+        nms.cand[(size_t)img * nms.cand_cap + p] = cd;
+      }
+      if (flag) atomicAdd(&nms.fix_count[img], 1);
+    }
+  };
 
   // covariance row g from pixel rows a (g-1), b (g), c (g+1) -> H (horizontally smoothed); k3, k10 =
   // the (3, 10, 3) filter taps times 2^9 (mulhi24 of two such gradients then yields g*g >> 14), or
@@ -626,19 +637,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   };
   // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc): optionally test centre row y-1, then
   // roll the state
-  auto nms_row = [&](const int sc[4], int q, bool test) {
+  auto nms_row = [&](const int sc[4], int q, bool test, int r) {  // r = the centre row (scalar)
     const int l = from_left(sc[3]), r2 = from_right(sc[0]);
     const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
                        max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
 #ifdef OKVFE_K1_NONMS
     test = false;
 #endif
-    if (test) {
+    if (test && r >= r_lo && r < r_hi) {
       const int lft[4] = {nl, nc[0], nc[1], nc[2]};
       const int rgt[4] = {nc[1], nc[2], nc[3], nr};
+      uint64_t mk[4], ovf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        push_hit(hits[i], nc[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr), sp, sp_end);
+        push_hit(mk[i], ovf[i], nc[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr), i < 2 ? own_lo : own_hi,
+                 (uint32_t)(r << 2 | i), sp, sp_end);
+      // two horizontally adjacent hits anywhere in the row (lane l column 3 | lane l + 1 column 0)
+      const uint64_t adj = (mk[0] & mk[1]) | (mk[1] & mk[2]) | (mk[2] & mk[3]) | (mk[3] & (mk[0] >> 1));
+      if (adj != 0ull) {
+        const int t = r - ys_own;
+        if (kTHF <= 64 || t < 64)
+          rows_adj[0] |= 1ull << t;
+        else
+          rows_adj[1] |= 1ull << (t - 64);
+      }
+      if (__builtin_expect((ovf[0] | ovf[1] | ovf[2] | ovf[3]) != 0ull, 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) emit_overflow(ovf[i], nc[i], i, r, adj != 0ull);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -714,7 +740,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       if (decltype(want_store)::value) {
         if (y < h) store_row(sc, y);  // scalar branch around one instruction (partial last tile)
       }
-      if (NMS) nms_row(sc, q, decltype(want_test)::value);
+      if (NMS) nms_row(sc, q, decltype(want_test)::value, y - 1);
     }
     ++y;
   };
@@ -727,14 +753,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     step(OKVFE_PH(2), T(), F(), F());  // score row ys_own - 1: NMS state only
     step(OKVFE_PH(3), T(), T(), F());  // score row ys_own: stored, nothing to test yet
     for (int g = 0; g < kMain / 6; ++g) {
-      if (kSets > 1 && g > 0 && g % (kSplitTests / 6) == 0 && g / (kSplitTests / 6) < kSets) {
-        const int set_done = g / (kSplitTests / 6) - 1;  // scalar
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          hit_sets[((wave * (kSets - 1) + set_done) * 4 + i) * 64 + lane] = hits[i];
-          hits[i] = 0u;
-        }
-      }
       step(OKVFE_PH(4), T(), T(), T());
       step(OKVFE_PH(5), T(), T(), T());
       step(OKVFE_PH(6), T(), T(), T());
@@ -766,58 +784,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   if (NMS) return;
 #endif
   if (NMS) {
-    // hit bits -> candidate records.  Test t = centre row ys_own + t, t in [0, kTHF).  Set A: tests
-    // [0, n_a), bit b <-> t = n_a - 1 - b; set B: tests [n_a, kTHF), bit b <-> t = kTHF - 1 - b.
-    // Rows that may carry maxima: 2 <= y < h - 2 (and inside the tile).
-    const int t_lo = 2 - ys_own > 0 ? 2 - ys_own : 0;
-    const int t_hi = (ye_own < h - 2 ? ye_own : h - 2) - ys_own;  // valid tests [t_lo, t_hi)
-    if (t_hi <= t_lo) return;
-    auto bits_of = [](int t0, int t1, int base, int n) -> uint32_t {
-      // mask of the bits whose test index base + (n - 1 - b) lies in [t0, t1)
-      uint32_t m = 0u;
-      const int lo = t0 - base > 0 ? t0 - base : 0, hi = t1 - base < n ? t1 - base : n;  // local tests
-      if (hi > lo) {
-        const int b_lo = n - hi, cnt = hi - lo;
-        m = (cnt >= 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << b_lo;
-      }
-      return m;
-    };
-    // test t of set s = kSplitTests * s + (n_s - 1 - bit): n_s tests per set
-    const int x0 = dcl * 4;
-    uint32_t M[kSets][4], R[kSets][4];  // masked / raw hit bits
-    uint32_t rows_adj[kSets];
-    int pushed_before[kSets];
-    int cnt = 0, pushed = 0;
-    // every hit was pushed, the ones masked below included: slot indices count the unmasked bits
-#pragma unroll
-    for (int set = 0; set < kSets; ++set) {
-      const int n_s = set == kSets - 1 ? kLastTests : kSplitTests;
-      const uint32_t valid = bits_of(t_lo, t_hi, kSplitTests * set, n_s);
-      rows_adj[set] = 0u;
-      pushed_before[set] = pushed;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        R[set][i] = set == kSets - 1 ? hits[i] : hit_sets[((wave * (kSets - 1) + set) * 4 + i) * 64 + lane];
-        pushed += __popc(R[set][i]);
-        M[set][i] = R[set][i] & valid;
-        if (x0 + i < 2 || x0 + i >= w - 2) M[set][i] = 0u;  // columns 0, 1, w-2, w-1 are never maxima
-      }
-      uint32_t* m = M[set];
-      const uint32_t adj = (m[0] & m[1]) | (m[1] & m[2]) | (m[2] & m[3]) |
-                           (m[3] & (uint32_t)from_right((int)m[0]));
-      if (__builtin_expect(__any(adj != 0u), 0)) {
-        uint32_t ra = adj;
-#pragma unroll
-        for (int dd = 32; dd > 0; dd >>= 1) ra |= (uint32_t)__shfl_xor((int)ra, dd);
-        rows_adj[set] = ra;
-      }
-      if (!store) m[0] = m[1] = m[2] = m[3] = 0u;  // halo lanes only fed the neighbours
-      cnt += __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
-    }
+    // hit stacks -> candidate records
+    const int cnt = (int)((sp - sp0) >> 9);
     if (!__any(cnt != 0)) return;
-    // one reservation in the image's candidate list per wave (PACK: per image of the wave)
     // (the sub-strip index is recomputed here instead of being kept in a register across the
-    // row loop: the PACK variant has to stay within 80 VGPRs as well)
+    // row loop: the PACK variant has to stay within the same register budget)
     int sub_e = 0;
     if (packed_block) {
       int l2 = lane;
@@ -826,100 +797,84 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       if (sub_e >= group_images) sub_e = 0;
     }
     const int image_l = image + sub_e;
-    int pos = 0;
-    int wave_base = 0, wave_total = 0;  // the wave's run in the image's list (unpacked waves)
-    auto reserve = [&](bool mine, int img) {
-      const int c = mine ? cnt : 0;
+    const int x0 = dcl * 4;
+    Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
+    const int32_t* mine = hit_stack + wave * (kSlots * 128) + lane;
+    int flagged = 0;
+    auto record = [&](int e) {
+      Candidate cd;
+      const int tag = mine[e * 128 + 64];
+      cd.score = mine[e * 128];
+      cd.x = x0 + (tag & 3);
+      cd.y = tag >> 2;
+      const int t = cd.y - ys_own;
+      const uint64_t bit = (kTHF <= 64 || t < 64) ? rows_adj[0] >> t : rows_adj[1] >> (t - 64);
+      if (bit & 1ull) {  // to be settled by nms_fixup_kernel
+        cd.y |= kCandidateFixupFlag;
+        ++flagged;
+      }
+      return cd;
+    };
+    // one reservation in the image's candidate list per wave (PACK: per image of the wave)
+    auto scan = [&](int c, int* total) {
       int incl = c;
 #pragma unroll
       for (int dd = 1; dd < 64; dd <<= 1) {
         const int t = __shfl_up(incl, dd);
         if (lane >= dd) incl += t;
       }
-      const int total = __shfl(incl, 63);
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&nms.cand_count[img], total);
-      base = __shfl(base, 0);  // by all lanes: a cross-lane read of an inactive lane returns 0
-      if (mine) pos = base + incl - c;
-      wave_base = base;
-      wave_total = total;
+      *total = __builtin_amdgcn_readlane(incl, 63);
+      return incl - c;
     };
     if (packed_block) {
+      int pos = 0;
       for (int g = 0; g < group_images; ++g) {  // wave-uniform
-        const bool mine = sub_e == g;
-        if (__any(mine && cnt != 0)) reserve(mine, image + g);
+        const bool in_g = sub_e == g;
+        if (!__any(in_g && cnt != 0)) continue;
+        int total;
+        const int first = scan(in_g ? cnt : 0, &total);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&nms.cand_count[image + g], total);
+        base = __builtin_amdgcn_readlane(base, 0);
+        if (in_g) pos = base + first;
       }
-    } else {
-      reserve(true, image);
-    }
-    Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
-    // a lane whose LDS stack overflowed re-reads scores from the map: only then must this wave's own
-    // score stores have reached L2 (the unconditional wait kept every wave's slot busy until its last
-    // store was acknowledged)
-    if (__any(pushed > kSlots)) __builtin_amdgcn_s_waitcnt(0);
-#ifdef OKVFE_K1_NOCANDSTAGE  // A/B: the direct 12-byte stores of round 2
-    const bool staged = false;
-#else
-    const bool staged = !packed_block;  // wave-uniform; records past the stage's capacity are stored directly
-#endif
-    __builtin_amdgcn_wave_barrier();  // all parked mask sets are in registers: their LDS may be reused
-    Candidate* stage = kSets > 2 ? reinterpret_cast<Candidate*>(&hit_sets[wave * (kSets - 1) * 4 * 64])
-                                 : cand_stage[kSets > 2 ? 0 : wave];
-    int flagged = 0;
-    uint32_t any_adj = 0u;
-#pragma unroll
-    for (int set = 0; set < kSets; ++set) {
-      const uint32_t* m = M[set];
-      const int n_s = set == kSets - 1 ? kLastTests : kSplitTests;
-      const int row_hi = ys_own + kSplitTests * set + n_s - 1;  // row of bit 0
-      any_adj |= rows_adj[set];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t mm = m[i];
-        while (mm) {
-          const int b = __ffs((int)mm) - 1;
-          mm &= mm - 1;
-          const int yy = row_hi - b;
-          Candidate cd;
-          cd.x = x0 + i;
-          cd.y = yy;
-          if ((rows_adj[set] >> b) & 1u) {  // to be settled by nms_fixup_kernel
-            cd.y |= kCandidateFixupFlag;
-            ++flagged;
-          }
-          // slot = pushes of earlier tests (higher bits; all of set A for set B) + pushes of the
-          // same test in the columns before i
-          const uint32_t* raw = R[set];
-          int e = pushed_before[set];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            e += __popc((raw[c] >> b) >> 1);
-            if (c < i) e += (int)((raw[c] >> b) & 1u);
-          }
-#ifdef OKVFE_K1_NOLDSPUSH
-          e = kSlots;
-#endif
-          if (e < kSlots)
-            cd.score = score_stack[e * (kWavesPerBlock * 64) + wave * 64 + lane];
-          else
-            cd.score = __builtin_amdgcn_raw_buffer_load_b32(out_rsrc, st_off + 4 * i, yy * pitch * 4, 1);
-          if (staged && pos - wave_base < kStageCap)
-            stage[pos - wave_base] = cd;
-          else if (pos < nms.cand_cap)
-            outc[pos] = cd;
-          ++pos;
+      for (int e = 0; __any(e < cnt); ++e)
+        if (e < cnt) {
+          const Candidate cd = record(e);
+          if (pos + e < nms.cand_cap) outc[pos + e] = cd;
         }
-      }
-    }
-    if (staged) {  // the wave's records as one contiguous run: lane = record, 12 bytes each
+    } else {
+      // the reservation's round trip overlaps the record loop: the records go to LDS by their index
+      // within the wave, the list position is only needed for the copy-out
+      int total;
+      const int first = scan(cnt, &total);
+      int base_l0 = 0;
+      if (lane == 0) base_l0 = atomicAdd(&nms.cand_count[image], total);
+#ifdef OKVFE_K1_NOCANDSTAGE  // A/B: the direct 12-byte stores of round 2
+      constexpr int cap_stage = 0;
+#else
+      constexpr int cap_stage = kStageCap;  // records past the stage's capacity are stored directly
+#endif
+      Candidate* stage = cand_stage[wave];
+      for (int e = 0; __any(e < cnt); ++e)
+        if (e < cnt) {
+          const Candidate cd = record(e);
+          const int idx = first + e;
+          if (idx < cap_stage) {
+            stage[idx] = cd;
+          } else {
+            const int at = __builtin_amdgcn_readlane(base_l0, 0) + idx;
+            if (at < nms.cand_cap) outc[at] = cd;
+          }
+        }
+      // the wave's records as one contiguous run: lane = record, 12 bytes each
       __builtin_amdgcn_wave_barrier();
-      const int n_staged = wave_total < kStageCap ? wave_total : kStageCap;
+      const int base = __builtin_amdgcn_readlane(base_l0, 0);
+      const int n_staged = total < cap_stage ? total : cap_stage;
       for (int r = lane; r < n_staged; r += 64)
-        if (wave_base + r < nms.cand_cap) outc[wave_base + r] = stage[r];
+        if (base + r < nms.cand_cap) outc[base + r] = stage[r];
     }
-    if (any_adj != 0u && __any(flagged != 0)) {
-      if (flagged) atomicAdd(&nms.fix_count[image_l], flagged);
-    }
+    if ((rows_adj[0] | rows_adj[1]) != 0ull && flagged) atomicAdd(&nms.fix_count[image_l], flagged);
   }
 }
 
