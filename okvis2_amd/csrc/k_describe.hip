@@ -45,9 +45,16 @@ constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B sl
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
 // intensity): float reciprocal estimate (off by at most 1) + exact integer correction, instead of
 // the ~40-instruction generic 32-bit division
+// (q < 2^22 and den = Pattern::box_scaling2 ~ 4096: the 24-bit multiply is exact and full rate;
+// v_mul_lo_u32 is a quarter-rate instruction)
+__device__ __forceinline__ int mul24i(int a, int b) {  // (__mul24 sign-extends both operands first)
+  int d;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ int div_nonneg(int num, int den) {
   int q = (int)((float)num * __builtin_amdgcn_rcpf((float)den));
-  int r = num - q * den;
+  int r = num - mul24i(q, den);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (r < 0) {
@@ -93,13 +100,11 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
   t = r_x_1 * r_y1;  const int D = (int)(t * fs);
   const int r_x_1_i = (int)(r_x_1 * fs), r_y_1_i = (int)(r_y_1 * fs);
   const int r_x1_i = (int)(r_x1 * fs), r_y1_i = (int)(r_y1 * fs);
-  int ret = A * px(y_top, x_left);
-  ret += B * px(y_top, x_right);
-  ret += C * px(y_bottom, x_right);
-  ret += D * px(y_bottom, x_left);
+  int ret;
   int upper = 0, middle = 0, left = 0, right = 0, bottom = 0;
   const int bw = x_right - x_left, bh = y_bottom - y_top;  // >= 1 for sigma_half >= 0.5
-  if (PX::kFixedTrip && __all(bw <= kMaxBox && bh <= kMaxBox)) {
+  if constexpr (PX::kFixedTrip) {
+  if (__all(bw <= kMaxBox && bh <= kMaxBox)) {
     // Fixed trip counts, no data-dependent selects: the top and the bottom row are read once each,
     // then kMaxBox - 1 interior slots, where a slot past the box (dy >= bh) reads the all-zero
     // row of the patch instead, so every accumulation is unconditional.  Interior columns
@@ -118,31 +123,44 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
       const int nb = eb - sb;
       m[j] = nb > 0 ? ((0xFFFFFFFFu >> (8 * (4 - nb))) << (8 * sb)) : 0u;
     }
-    const uint8_t* top = px.row8(y_top);
-    const uint8_t* zero = px.zero_row8();
+    // Rows are addressed by 32-bit byte offsets from the first patch row (the zero row lies
+    // kZeroRowBytes before it); every product below has both factors under 2^23 (weights <= 2^22,
+    // pixel sums <= 81 * 255), so the full-rate 24-bit multiplies give the same low 32 bits as the
+    // quarter-rate v_mul_lo_u32 / v_mad_u64_u32 the plain expressions compile to.
+    const int pitch = px.pitch;
+    int run = mul24i(y_top - px.y0, pitch);
     int pl, pr;
-    auto read_row = [&](const uint8_t* rp, uint32_t acc) -> uint32_t {
-      pl = rp[cl];
-      pr = rp[cr];
-      const uint32_t* d = reinterpret_cast<const uint32_t*>(rp) + q0;
+    auto read_row = [&](int off, uint32_t acc) -> uint32_t {
+      pl = px.patch[off + cl];
+      pr = px.patch[off + cr];
+      const uint32_t* d = reinterpret_cast<const uint32_t*>(px.patch + off) + q0;
       acc = __builtin_amdgcn_sad_u8(d[0] & m[0], 0u, acc);
       acc = __builtin_amdgcn_sad_u8(d[1] & m[1], 0u, acc);
       return __builtin_amdgcn_sad_u8(d[2] & m[2], 0u, acc);
     };
-    upper = (int)read_row(top, 0u);
-    ret = A * pl + B * pr;
-    const int pitch = px.pitch;
-    bottom = (int)read_row(top + bh * pitch, 0u);
-    ret += D * pl + C * pr;
+    upper = (int)read_row(run, 0u);
+    ret = mul24i(A, pl) + mul24i(B, pr);
+    bottom = (int)read_row(run + mul24i(bh, pitch), 0u);
+    ret += mul24i(D, pl) + mul24i(C, pr);
     uint32_t mid = 0u;
 #pragma unroll
     for (int dy = 1; dy < kMaxBox; ++dy) {
-      mid = read_row(dy < bh ? top + dy * pitch : zero, mid);
+      run += pitch;
+      mid = read_row(dy < bh ? run : -kZeroRowBytes, mid);
       left += pl;
       right += pr;
     }
     middle = (int)mid;
-  } else {
+    ret += mul24i(upper, r_y_1_i) + mul24i(middle, scaling) + mul24i(left, r_x_1_i) + mul24i(right, r_x1_i) +
+           mul24i(bottom, r_y1_i);
+    return div_nonneg(ret + scaling2 / 2, scaling2);
+  }
+  }
+  {
+    ret = A * px(y_top, x_left);
+    ret += B * px(y_top, x_right);
+    ret += C * px(y_bottom, x_right);
+    ret += D * px(y_bottom, x_left);
     for (int x = x_left + 1; x < x_right; ++x) {
       upper += px(y_top, x);
       bottom += px(y_bottom, x);
@@ -279,7 +297,11 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
 
 // One wave per keypoint, lane i = pattern point i.  The pixels under the keypoint's pattern
 // (<= 80 x 96) are staged once in LDS with coalesced dword loads; all box sums then read LDS.
-__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(6, 8))) void describe_kernel(
+// kWavesPerSimd = 6 (80 VGPRs) is the fastest form when nearly every patch fits the LDS buffer; the
+// banded path of the wide-angle cameras spills at 80 registers and runs 26 % faster with 96 (five
+// waves per SIMD): launch_describe picks the instantiation from the cameras' patch statistics.
+template <int kWavesPerSimd>
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(kWavesPerSimd, 8))) void describe_kernel(
     const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
     const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
@@ -656,8 +678,10 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     hipStream_t stream) {
+                     bool wide_patches, hipStream_t stream) {
   if (n_images <= 0) return;
+  static const char* force = getenv("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
+  if (force) wide_patches = force[0] == '5';
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
                      valid_tmp);
@@ -666,9 +690,27 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
   if (tiles > kDescBlocksPerImage) tiles = kDescBlocksPerImage;
   const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
-  hipLaunchKernelGGL(describe_kernel, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
-                     w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                     valid_tmp, n_images, tiles, inv_tiles);
+  if (wide_patches)
+    hipLaunchKernelGGL(describe_kernel<5>, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
+                       w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
+                       valid_tmp, n_images, tiles, inv_tiles);
+  else
+    hipLaunchKernelGGL(describe_kernel<6>, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
+                       w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
+                       valid_tmp, n_images, tiles, inv_tiles);
+}
+
+// Does the camera-aware patch of a keypoint with the row norms (nx, ny) of M fit the wave's LDS
+// buffer in one piece?  (the same arithmetic as sample_all / stage_patch, on the host: used by
+// okvfe_set_camera_maps to find out which describe_kernel instantiation suits a camera)
+bool describe_patch_fits(float nx, float ny, int border) {
+  const float ex = fmaxf(nx * 1.001f, 1.0f) * (float)(border - 1) + 1.5f;
+  const float ey = fmaxf(ny * 1.001f, 1.0f) * (float)(border - 1) + 1.5f;
+  const int pw = 2 * (int)ceilf(ex) + 2 + 3, ph = 2 * (int)ceilf(ey) + 2;  // + 3: the row start is aligned down to a dword
+  const int nq = (pw + 15) >> 4;
+  if (nq * 16 > kZeroRowBytes - 8) return false;
+  const int R = 64 / nq, trips = (ph + R - 1) / R;
+  return trips * R * nq * 16 <= kPatchDataBytes;
 }
 
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,

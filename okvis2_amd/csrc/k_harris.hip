@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
   constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
   static_assert(kMain % 6 == 0 && kTHF <= 121, "rows per wave: 6k (+1 with the fused NMS), <= 121");
-  constexpr int kSlots = kTHF > 64 ? kScoreSlots + kScoreSlots / 2 : kScoreSlots;  // stack depth per lane
+  constexpr int kSlots = kTHF > 64 ? kScoreSlots + 2 : kScoreSlots;  // stack depth per lane
   const int lane = threadIdx.x;
   const int nd = w >> 2;
   // PACK (narrow last strip, e.g. 7 dwords of a 1024-px row): `strips` counts the full strips
@@ -629,7 +629,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   auto store_row = [&](const int sc[4], int y) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = {sc[0], sc[1], sc[2], sc[3]};
-#if !defined(OKVFE_K1_NOSTORE)
+#if defined(OKVFE_K1_STRIPMAJOR_TEST)  // timing experiment only (wrong layout): a wave's rows contiguous in memory
+    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_on ? lane * 16 : 0x7FFFFFF0, (strip * h + y) * 1024, OKVFE_K1_STORE_AUX);
+#elif !defined(OKVFE_K1_NOSTORE)
     __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, OKVFE_K1_STORE_AUX);
 #else
     if (v.x == 0x12345678 && v.y == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, 0);

@@ -94,6 +94,8 @@ struct okvfe_ctx {
   unsigned feed_next = 0;
   std::vector<float*> cam_rays, cam_jac;  // device maps per camera slot (nullptr = not set)
   std::vector<float> cam_fu;
+  std::vector<uint8_t> cam_wide;  // camera-aware patches of this camera often exceed the LDS buffer (describe_kernel<5>)
+  bool wide_patches = false;      // of the images of the current batch
   std::vector<DeviceCamera> h_cams;
   std::vector<bool> cam_has_intrinsics;
   int last_n_images = 0;
@@ -537,6 +539,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     c->cam_rays.assign(cfg->num_cameras, nullptr);
     c->cam_jac.assign(cfg->num_cameras, nullptr);
     c->cam_fu.assign(cfg->num_cameras, 0.0f);
+    c->cam_wide.assign(cfg->num_cameras, 0);
     c->h_cams.assign(cfg->num_cameras, DeviceCamera{});
     c->cam_has_intrinsics.assign(cfg->num_cameras, false);
     if (n_layers > 1) {
@@ -651,6 +654,19 @@ okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* ray
   HIP_TRY(ctx, hipMemcpy(ctx->d_rays_ptrs + cam, &ctx->cam_rays[cam], sizeof(float*), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMemcpy(ctx->d_jac_ptrs + cam, &ctx->cam_jac[cam], sizeof(float*), hipMemcpyHostToDevice));
   ctx->cam_fu[cam] = fu;
+  // how often does a keypoint's warped pattern exceed the one-piece LDS patch?  (row norms of the
+  // image Jacobian bound the row norms of M = J [e_x e_y] / fu; every 8th pixel)
+  size_t seen = 0, large = 0;
+  for (int y = 0; y < ctx->h; y += 8)
+    for (int x = 0; x < ctx->w; x += 8) {
+      const float* J = jacobians_hw6 + ((size_t)y * ctx->w + x) * 6;
+      const float nx = std::sqrt(J[0] * J[0] + J[1] * J[1] + J[2] * J[2]) / fu;
+      const float ny = std::sqrt(J[3] * J[3] + J[4] * J[4] + J[5] * J[5]) / fu;
+      if (!(nx == nx) || !(ny == ny)) continue;  // pixels without a ray
+      ++seen;
+      if (!describe_patch_fits(nx, ny, ctx->host_pattern.border)) ++large;
+    }
+  ctx->cam_wide[cam] = seen > 0 && large * 20 > seen;  // more than 5 %
   return OKVFE_OK;
 }
 
@@ -692,6 +708,7 @@ okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev
 static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int32_t* cam_ids,
                                         const float* gravity, hipStream_t s) {
   std::vector<ImageParams> prm(n_images);
+  ctx->wide_patches = false;
   for (int i = 0; i < n_images; ++i) {
     ImageParams& p = prm[i];
     p.cam = cam_ids ? cam_ids[i] : -1;
@@ -707,6 +724,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
       p.dir[1] = gravity[3 * i + 1];
       p.dir[2] = gravity[3 * i + 2];
       p.fu = ctx->cam_fu[p.cam];
+      if (ctx->cam_wide[p.cam]) ctx->wide_patches = true;
     } else {
       p.mode = ctx->mode_default;
       p.dir[0] = 0.0f; p.dir[1] = 1.0f; p.dir[2] = 0.0f;
@@ -957,7 +975,7 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
-                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, s);
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->wide_patches, s);
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -1222,7 +1240,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
-                  ctx->d_desc_tmp, ctx->d_valid_tmp, s);
+                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->wide_patches, s);
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

@@ -175,7 +175,8 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     hipStream_t stream);
+                     bool wide_patches, hipStream_t stream);
+bool describe_patch_fits(float nx, float ny, int border);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
                     const uint8_t* valid_tmp, const int32_t* kp_count_in, int kp_cap,
