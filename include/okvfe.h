@@ -58,7 +58,7 @@ typedef enum okvfe_status {
   OKVFE_ERR_INVALID_ARGUMENT = 1,
   OKVFE_ERR_NO_DEVICE = 2,
   OKVFE_ERR_OUT_OF_MEMORY = 3,
-  OKVFE_ERR_UNSUPPORTED = 4, /* e.g. scale_invariant extraction, octaves > 4 */
+  OKVFE_ERR_UNSUPPORTED = 4, /* e.g. octaves > 4 */
   OKVFE_ERR_CAPACITY = 5,    /* a caller- or context-sized buffer was too small */
   OKVFE_ERR_DEVICE = 6,      /* HIP runtime error; see okvfe_last_error */
   OKVFE_ERR_NOT_READY = 7    /* e.g. camera-aware extraction without okvfe_set_camera */
@@ -112,7 +112,10 @@ typedef struct okvfe_config {
   int32_t absolute_threshold; /* Harris noise floor, >= 1 */
   int32_t max_keypoints;      /* max_num_keypoints */
   int32_t rotation_invariant; /* Frontend.cpp:142 default true */
-  int32_t scale_invariant;    /* Frontend.cpp:143 default false; true is unsupported */
+  int32_t scale_invariant;    /* Frontend.cpp:143 default false.  true: the published BRISK scale
+                               * ladder -- the pattern of keypoint k is the base pattern scaled to
+                               * index okvfe_scale_index(k.size) of 64 (the fixed-scale extractor is
+                               * index 17 of the same ladder) */
   int32_t match_threshold;    /* matching_threshold (Hamming bits, strict <) */
   int32_t max_candidates;     /* per-image NMS candidate capacity; 0 = worst case */
   int32_t score_type;         /* OKVFE_SCORE_HARRIS (0): brisk::HarrisScoreCalculator, the x86
@@ -228,6 +231,11 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
 /* Column of pixel x within a row of okvfe_device_outputs.scores (x itself for dense maps).  For a
  * dense copy of the score map use okvfe_harris_score_device. */
 int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x);
+
+/* Scale index of the scale-invariant extractor (brisk::BriskDescriptorExtractor(rotInv, scaleInv =
+ * true), Frontend.cpp:2410-2412) for a keypoint of diameter `size`, published BRISK:
+ * max(int(64 / lb(30) * lb(size / (0.6 * 12)) + 0.5), 0), at most 63.  Host-only, no context. */
+int32_t okvfe_scale_index(float keypoint_size);
 
 /* NMS candidate capacity check of the last batch (synchronises; one small copy): an image whose
  * score map had more maxima than the context's candidate capacity (okvfe_config.max_candidates)

@@ -82,7 +82,7 @@ EXPORTS = [
     "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
     "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
     "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_describe_batch_device",
-    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_download_image_result", "okvfe_harris_score_device",
+    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device",
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
@@ -273,6 +273,13 @@ def popcnt_xor(a, b, n128=3) -> int:
     a = np.ascontiguousarray(a, dtype=np.uint8)
     b = np.ascontiguousarray(b, dtype=np.uint8)
     return int(lib().okvfe_popcnt_xor(_p(a), _p(b), int(n128)))
+
+
+def scale_index(size) -> int:
+    """Scale index (0..63) of the scale-invariant extractor for a keypoint diameter (host only)."""
+    f = lib().okvfe_scale_index
+    f.restype, f.argtypes = C.c_int32, [C.c_float]
+    return int(f(float(size)))
 
 
 def build_awareness_maps(cam):

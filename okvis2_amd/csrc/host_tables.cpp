@@ -91,6 +91,54 @@ void build_pattern(Pattern* p) {
   }
 }
 
+int pattern_scale_index(float size) {
+  const double lb_range = std::log(30.0) / std::log(2.0);
+  if (!(size > 0.0f)) return 0;
+  const double v = 64.0 / lb_range * (std::log(static_cast<double>(size) / (0.6 * 12.0)) / std::log(2.0)) + 0.5;
+  if (!(v > 0.0)) return 0;
+  if (v >= static_cast<double>(kPatternScales)) return kPatternScales - 1;
+  return static_cast<int>(v);
+}
+
+void build_pattern_scales(const Pattern& base, PatternScales* out) {
+  const double lb_range = std::log(30.0) / std::log(2.0);
+  std::memset(out, 0, sizeof(*out));
+  for (int s = 0; s < kPatternScales; ++s) {
+    const double rel = std::pow(2.0, static_cast<double>(s - kBasicScale) * (lb_range / 64.0));
+    for (int i = 0; i < kPatternPoints; ++i) {
+      const bool on = i < base.n_points;
+      if (s == kBasicScale) {
+        out->px[s][i] = base.px[i];
+        out->py[s][i] = base.py[i];
+        out->sigma_half[s][i] = base.sigma_half[i];
+      } else {
+        out->px[s][i] = static_cast<float>(static_cast<double>(base.px[i]) * rel);
+        out->py[s][i] = static_cast<float>(static_cast<double>(base.py[i]) * rel);
+        out->sigma_half[s][i] = static_cast<float>(static_cast<double>(base.sigma_half[i]) * rel);
+      }
+      const float sg = on ? out->sigma_half[s][i] : 1.0f;  // same float sequence as build_pattern
+      float area = 4.0f * sg;
+      area = area * sg;
+      const int scaling = static_cast<int>(4194304.0f / area);
+      const float s2 = static_cast<float>(scaling) * area;
+      out->box_scaling[s][i] = scaling;
+      out->box_scaling2[s][i] = static_cast<int>(s2 / 1024.0f);
+    }
+    out->border[s] = s == kBasicScale ? base.border
+                                      : static_cast<int>(std::ceil(rel * static_cast<double>(base.border - 1))) + 1;
+    // smallest float size whose index reaches s: start at the analytic boundary, then step
+    // float by float on the formula itself (it is what the oracle evaluates per keypoint)
+    if (s == 0) {
+      out->size_from[0] = 0.0f;
+      continue;
+    }
+    float b = static_cast<float>(7.2 * std::pow(2.0, (static_cast<double>(s) - 0.5) * (lb_range / 64.0)));
+    while (pattern_scale_index(b) >= s) b = std::nextafterf(b, 0.0f);
+    while (pattern_scale_index(b) < s) b = std::nextafterf(b, INFINITY);
+    out->size_from[s] = b;
+  }
+}
+
 void build_uniformity_lut(float lut[kLutFloats]) {
   std::memset(lut, 0, sizeof(float) * kLutFloats);
   for (int y = 0; y < 31; ++y)

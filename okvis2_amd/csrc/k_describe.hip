@@ -275,14 +275,21 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
     int w, int h, const Pattern* __restrict__ pat, const ImageParams* __restrict__ prm,
     const float* const* __restrict__ rays, const float* const* __restrict__ jac,
     const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
-    okvfe_keypoint* __restrict__ kps_tmp, uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
+    okvfe_keypoint* __restrict__ kps_tmp, uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp,
+    const PatternScales* __restrict__ scales) {
   const int img = blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= kp_count_in[img]) return;
   const size_t slot = (size_t)img * kp_cap + k;
   const okvfe_keypoint kp = kps_in[slot];
   const ImageParams ip = prm[img];
-  const int border = pat->border;
+  // scale-invariant extraction: the pattern's scale index from the keypoint's diameter (it rides to
+  // describe_kernel in bits 1..6 of the valid byte)
+  int scale = 0;
+  if (scales) {
+    for (int i = 1; i < kPatternScales; ++i) scale += kp.size >= scales->size_from[i] ? 1 : 0;
+  }
+  const int border = scales ? scales->border[scale] : pat->border;
   bool valid = !(kp.x < (float)border || kp.x >= (float)(w - border) || kp.y < (float)border ||
                  kp.y >= (float)(h - border));
   float M[4] = {1.0f, 0.0f, 0.0f, 1.0f};
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
     valid = camera_aware_matrix(rays[ip.cam], jac[ip.cam], w, ip.fu, dir, kp.x, kp.y, M);
   }
   *reinterpret_cast<float4*>(desc_tmp + slot * OKVFE_DESC_BYTES) = make_float4(M[0], M[1], M[2], M[3]);
-  valid_tmp[slot] = valid ? 1 : 0;
+  valid_tmp[slot] = (uint8_t)((valid ? 1 : 0) | (scale << 1));
   kps_tmp[slot] = kp;  // the record travels on from here; describe_kernel only rewrites the angle
 }
 
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     const float* const* __restrict__ jac, const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
     const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
     uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images, int tiles,
-    uint32_t inv_tiles) {
+    uint32_t inv_tiles, const PatternScales* __restrict__ scales) {
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchBufBytes];
   __shared__ int values[kDescWaves][64];
   // the 383 short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   if (tile * kDescWaves + wv >= n) return;  // whole wave exits; no block-wide barriers below
   const uint8_t* im = images + (size_t)img * w * h;
   const ImageParams ip = prm[img];
-  const int border = pat->border;
+  int border = pat->border;  // (per keypoint with scale-invariant extraction)
   const bool active = lane < pat->n_points;  // <= kPatternPoints (okvfe_set_pattern may install fewer samples)
   const int li = active ? lane : 0;
   float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
@@ -550,7 +557,17 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   kp.x = uni(nxt_xy.x);
   kp.y = uni(nxt_xy.y);
   // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
-  bool valid = __builtin_amdgcn_readfirstlane(nxt_valid) != 0;
+  const int vbyte = __builtin_amdgcn_readfirstlane(nxt_valid);  // valid | scale index << 1
+  bool valid = (vbyte & 1) != 0;
+  if (scales) {  // wave-uniform: this keypoint's pattern scale
+    const int sc = vbyte >> 1;
+    px = scales->px[sc][li];
+    py = scales->py[sc][li];
+    sg = scales->sigma_half[sc][li];
+    bsc = scales->box_scaling[sc][li];
+    bsc2 = scales->box_scaling2[sc][li];
+    border = scales->border[sc];
+  }
   M[0] = uni(nxt_M.x); M[1] = uni(nxt_M.y); M[2] = uni(nxt_M.z); M[3] = uni(nxt_M.w);
   if (k + k_step < n) fetch(k + k_step);  // scalar branch
   bool new_angle = false;
@@ -678,13 +695,13 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     bool wide_patches, hipStream_t stream) {
+                     const PatternScales* scales, bool wide_patches, hipStream_t stream) {
   if (n_images <= 0) return;
   static const char* force = getenv("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                     valid_tmp);
+                     valid_tmp, scales);
   // blocks per image: enough waves to fill the machine with one image's ~300 keypoints spread
   // over them (a wave then describes ~9 keypoints of its image in a row)
   int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
@@ -693,11 +710,11 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   if (wide_patches)
     hipLaunchKernelGGL(describe_kernel<5>, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
                        w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                       valid_tmp, n_images, tiles, inv_tiles);
+                       valid_tmp, n_images, tiles, inv_tiles, scales);
   else
     hipLaunchKernelGGL(describe_kernel<6>, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
                        w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                       valid_tmp, n_images, tiles, inv_tiles);
+                       valid_tmp, n_images, tiles, inv_tiles, scales);
 }
 
 // Does the camera-aware patch of a keypoint with the row norms (nx, ny) of M fit the wave's LDS

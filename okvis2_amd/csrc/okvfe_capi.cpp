@@ -43,6 +43,7 @@ struct okvfe_ctx {
   uint8_t* d_occ = nullptr;
   float* d_lut = nullptr;
   Pattern* d_pattern = nullptr;
+  PatternScales* d_scales = nullptr;  // scale_invariant extraction: the pattern at 64 scales
   okvfe_keypoint* d_kps_det = nullptr;
   int32_t* d_det_count = nullptr;
   okvfe_keypoint* d_kps_tmp = nullptr;
@@ -445,8 +446,6 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
       return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: %dx%d is too small for %d octaves (top layer %dx%d)",
                   cfg->width, cfg->height, cfg->octaves, lw, lh);
   }
-  if (cfg->scale_invariant)
-    return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: scale_invariant extraction unsupported");
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -506,6 +505,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     }
     A(d_lut, kLutFloats);
     A(d_pattern, 1);
+    if (cfg->scale_invariant && describes) A(d_scales, 1);
     A(d_kps_det, K * B);
     A(d_det_count, B);
     const size_t Kd = describes ? K : 1, Bd = describes ? B : 1;
@@ -530,6 +530,11 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     build_pattern(&c->host_pattern);
     HIP_TRY(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_pattern, &c->host_pattern, sizeof(Pattern), hipMemcpyHostToDevice));
+    if (c->d_scales) {
+      std::unique_ptr<PatternScales> ps(new PatternScales);
+      build_pattern_scales(c->host_pattern, ps.get());
+      HIP_TRY(c, hipMemcpy(c->d_scales, ps.get(), sizeof(PatternScales), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMemset(c->d_count, 0, Bd * sizeof(int32_t)));
     HIP_TRY(c, hipMemset(c->d_det_count, 0, B * sizeof(int32_t)));
     if (detects) HIP_TRY(c, hipMemset(c->d_cand_count, 0, 2 * B * sizeof(int32_t)));
@@ -975,7 +980,7 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
-                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->wide_patches, s);
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s);
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -1105,6 +1110,8 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
   out->score_strips = ctx->score_layout.strips;
   return OKVFE_OK;
 }
+
+int32_t okvfe_scale_index(float keypoint_size) { return pattern_scale_index(keypoint_size); }
 
 int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x) {
   return ctx ? score_col(ctx->score_layout, x) : x;
@@ -1240,7 +1247,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
-                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->wide_patches, s);
+                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s);
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());
@@ -2098,6 +2105,11 @@ okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* p) {
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipMemcpy(ctx->d_pattern, &P, sizeof(Pattern), hipMemcpyHostToDevice));
+  if (ctx->d_scales) {  // the installed pattern is the base (index 17) of the scale ladder
+    std::unique_ptr<PatternScales> ps(new PatternScales);
+    build_pattern_scales(P, ps.get());
+    HIP_TRY(ctx, hipMemcpy(ctx->d_scales, ps.get(), sizeof(PatternScales), hipMemcpyHostToDevice));
+  }
   return OKVFE_OK;
 }
 

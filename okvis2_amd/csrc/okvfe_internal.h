@@ -36,6 +36,21 @@ struct Pattern {
   int32_t box_scaling[kPatternPoints], box_scaling2[kPatternPoints];
 };
 void build_pattern(Pattern* p);
+// scale_invariant = true (Frontend.hpp:235-237): the published BRISK extractor keeps the pattern at 64
+// scales spanning a factor of 30 and picks index max(int(64 / lb(30) * lb(size / 7.2) + 0.5), 0)
+// (<= 63) from the keypoint's diameter; the fixed-scale extractor is index 17 of the same ladder.
+// Scale i = the base pattern with offsets, box half-sides and reach times 2^((i - 17) lb(30) / 64).
+constexpr int kPatternScales = 64;
+constexpr int kBasicScale = 17;
+struct PatternScales {
+  float px[kPatternScales][kPatternPoints], py[kPatternScales][kPatternPoints];
+  float sigma_half[kPatternScales][kPatternPoints];
+  int32_t box_scaling[kPatternScales][kPatternPoints], box_scaling2[kPatternScales][kPatternPoints];
+  int32_t border[kPatternScales];
+  float size_from[kPatternScales];  // index(size) = #{i >= 1 : size >= size_from[i]} (bisected on the host formula)
+};
+int pattern_scale_index(float size);
+void build_pattern_scales(const Pattern& base, PatternScales* out);
 // d_lut layout: [0, 961) the 31x31 weights; from kStampTableOffset the compacted stamp, one
 // {(ry << 8) | rx, weight} pair per non-zero cell (697 of them), padded to kStampSlots.
 constexpr int kStampSlots = 704;
@@ -175,7 +190,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     bool wide_patches, hipStream_t stream);
+                     const PatternScales* scales, bool wide_patches, hipStream_t stream);
 bool describe_patch_fits(float nx, float ny, int border);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,

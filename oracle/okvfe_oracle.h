@@ -121,6 +121,13 @@ int orc_describe(const uint8_t* img, int w, int h, int stride, const orc_pattern
                  const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
                  orc_keypoint* kps, int n, uint8_t* desc);
 
+/* scaleInvariant = true: per keypoint the pattern at scale index orc_scale_index(kp.size) */
+int orc_scale_index(float size);
+void orc_pattern_scaled(const orc_pattern* base, int index, orc_pattern* out);
+int orc_describe_scaled(const uint8_t* img, int w, int h, int stride, const orc_pattern* pat, int mode,
+                        const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
+                        orc_keypoint* kps, int n, uint8_t* desc);
+
 /* ---- Hamming (A3) -------------------------------------------------------- */
 uint32_t orc_popcnt_xor(const uint8_t* a, const uint8_t* b, int n128);
 

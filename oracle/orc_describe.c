@@ -100,6 +100,37 @@ void orc_pattern_build(orc_pattern* p) {
   }
 }
 
+/* ---- scale invariance (scaleInvariant = true, Frontend.hpp:235-237 / Frontend.cpp:2410-2412) ----
+ * Published BRISK: the pattern exists at 64 scales spanning a factor of 30, scale step
+ * 2^(lb(30)/64); a keypoint of diameter `size` uses index
+ *   max(int(64 / lb(30) * lb(size / (0.6 * 12)) + 0.5), 0), at most 63
+ * (the non-scale-invariant extractor is the same formula at size = 1.45 * 12: index 17).  The
+ * pattern at index i is the base pattern (index 17: orc_pattern_build, or any pattern installed as
+ * data) with offsets, box half-sides and reach multiplied by 2^((i - 17) * lb(30) / 64); pair
+ * tables and gradient weights are defined on the unit pattern and do not change. */
+#define ORC_SCALES 64
+#define ORC_BASIC_SCALE 17
+int orc_scale_index(float size) {
+  const double lb_scalerange = log(30.0) / log(2.0);
+  if (!(size > 0.0f)) return 0;
+  const double v = 64.0 / lb_scalerange * (log((double)size / (0.6 * 12.0)) / log(2.0)) + 0.5;
+  if (!(v > 0.0)) return 0;
+  if (v >= (double)ORC_SCALES) return ORC_SCALES - 1;
+  return (int)v;
+}
+void orc_pattern_scaled(const orc_pattern* base, int index, orc_pattern* out) {
+  const double lb_scalerange = log(30.0) / log(2.0);
+  const double rel = pow(2.0, (double)(index - ORC_BASIC_SCALE) * (lb_scalerange / 64.0));
+  *out = *base;
+  if (index == ORC_BASIC_SCALE) return;
+  for (int i = 0; i < base->n_points; ++i) {
+    out->px[i] = (float)((double)base->px[i] * rel);
+    out->py[i] = (float)((double)base->py[i] * rel);
+    out->sigma_half[i] = (float)((double)base->sigma_half[i] * rel);
+  }
+  out->border = (int)ceil(rel * (double)(base->border - 1)) + 1;
+}
+
 /* ---- integral image (exclusive: I[y][x] = sum of rows < y, cols < x) ----------------------- */
 void orc_integral(const uint8_t* img, int w, int h, int stride, int32_t* integral) {
   const int iw = w + 1;
@@ -254,17 +285,29 @@ static int camera_aware_matrix(const float* rays, const float* jac, int w, float
   return 1;
 }
 
-int orc_describe(const uint8_t* img, int w, int h, int stride, const orc_pattern* pat, int mode,
-                 const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
-                 orc_keypoint* kps, int n, uint8_t* desc) {
+static int describe_impl(const uint8_t* img, int w, int h, int stride, const orc_pattern* base, int mode,
+                         const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
+                         orc_keypoint* kps, int n, uint8_t* desc, int scale_invariant) {
   int32_t* integral = (int32_t*)malloc((size_t)(w + 1) * (h + 1) * sizeof(int32_t));
   orc_integral(img, w, h, stride, integral);
-  const int border = pat->border;
+  orc_pattern* scaled = NULL;       /* patterns per scale index, built on first use */
+  uint8_t have[ORC_SCALES] = {0};
+  if (scale_invariant) scaled = (orc_pattern*)malloc(sizeof(orc_pattern) * ORC_SCALES);
   int kept = 0;
   float xs[ORC_PATTERN_POINTS], ys[ORC_PATTERN_POINTS];
   int values[ORC_PATTERN_POINTS];
   for (int k = 0; k < n; ++k) {
     orc_keypoint kp = kps[k];
+    const orc_pattern* pat = base;
+    if (scale_invariant) {
+      const int idx = orc_scale_index(kp.size);
+      if (!have[idx]) {
+        orc_pattern_scaled(base, idx, &scaled[idx]);
+        have[idx] = 1;
+      }
+      pat = &scaled[idx];
+    }
+    const int border = pat->border;
     /* RoI predicate: pattern circle must fit */
     if (kp.x < (float)border || kp.x >= (float)(w - border) || kp.y < (float)border ||
         kp.y >= (float)(h - border))
@@ -312,7 +355,19 @@ int orc_describe(const uint8_t* img, int w, int h, int stride, const orc_pattern
     kps[kept++] = kp;
   }
   free(integral);
+  free(scaled);
   return kept;
+}
+
+int orc_describe(const uint8_t* img, int w, int h, int stride, const orc_pattern* pat, int mode,
+                 const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
+                 orc_keypoint* kps, int n, uint8_t* desc) {
+  return describe_impl(img, w, h, stride, pat, mode, rays_hw3, jac_hw6, fu, dir, kps, n, desc, 0);
+}
+int orc_describe_scaled(const uint8_t* img, int w, int h, int stride, const orc_pattern* pat, int mode,
+                        const float* rays_hw3, const float* jac_hw6, float fu, const float dir[3],
+                        orc_keypoint* kps, int n, uint8_t* desc) {
+  return describe_impl(img, w, h, stride, pat, mode, rays_hw3, jac_hw6, fu, dir, kps, n, desc, 1);
 }
 
 int orc_detect_describe(const uint8_t* img, int w, int h, int stride,

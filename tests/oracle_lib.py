@@ -187,21 +187,34 @@ def integral(img):
     return out
 
 
-def describe(img, kps, mode, rays=None, jac=None, fu=1.0, direction=(0.0, 1.0, 0.0)):
+def describe(img, kps, mode, rays=None, jac=None, fu=1.0, direction=(0.0, 1.0, 0.0), scale_invariant=False):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape
     kps = kps.copy()
     desc = np.zeros((max(len(kps), 1), 48), dtype=np.uint8)
     d = (C.c_float * 3)(*[float(v) for v in direction])
-    n = lib().orc_describe(_p(img), w, h, w, C.byref(pattern()), int(mode), _p(rays), _p(jac),
-                           C.c_float(fu), d, _p(kps), len(kps), _p(desc))
+    fn = lib().orc_describe_scaled if scale_invariant else lib().orc_describe
+    n = fn(_p(img), w, h, w, C.byref(pattern()), int(mode), _p(rays), _p(jac),
+           C.c_float(fu), d, _p(kps), len(kps), _p(desc))
     return kps[:n].copy(), desc[:n].copy()
 
 
 def detect_describe(img, radius, octaves, thr, max_kpts, mode, rays=None, jac=None, fu=1.0,
-                    direction=(0.0, 1.0, 0.0), score_type=SCORE_HARRIS):
+                    direction=(0.0, 1.0, 0.0), score_type=SCORE_HARRIS, scale_invariant=False):
     kps = detect(img, radius, octaves, thr, max_kpts, score_type=score_type)
-    return describe(img, kps, mode, rays, jac, fu, direction)
+    return describe(img, kps, mode, rays, jac, fu, direction, scale_invariant)
+
+
+def scale_index(size) -> int:
+    f = lib().orc_scale_index
+    f.restype, f.argtypes = C.c_int, [C.c_float]
+    return int(f(float(size)))
+
+
+def pattern_scaled(index):
+    out = type(pattern())()
+    lib().orc_pattern_scaled(C.byref(pattern()), int(index), C.byref(out))
+    return out
 
 
 def popcnt_xor(a, b, n128=3) -> int:

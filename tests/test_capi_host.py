@@ -57,7 +57,6 @@ def test_no_silent_cpu_fallback():
 
 def test_argument_validation_precedes_device_probe():
     for kw, status in ((dict(octaves=5), capi.ERR_UNSUPPORTED),
-                       (dict(scale_invariant=True), capi.ERR_UNSUPPORTED),
                        (dict(absolute_threshold=0), capi.ERR_INVALID_ARGUMENT),
                        (dict(max_keypoints=5000), capi.ERR_INVALID_ARGUMENT),
                        (dict(width=32), capi.ERR_INVALID_ARGUMENT)):
