@@ -687,6 +687,17 @@ def main():
         lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav_v[0], lanes[0][1])
         torch.cuda.synchronize()
     iso = lanes[0][0].profile_read()["harris"]
+    # ... and its byte mover: the same loads and stores on the same layout without the arithmetic
+    # (okvfe_harris_byte_mover_device) -- the kernel's own memory floor, same box, same minute
+    mover = None
+    try:
+        lanes[0][0].profile_enable(True, stages=("harris",))
+        for _ in range(5):
+            lanes[0][0].harris_byte_mover_device(lanes[0][2], n_lane_img, lanes[0][1])
+            torch.cuda.synchronize()
+        mover = lanes[0][0].profile_read()["harris"]
+    except capi.OkvfeError:
+        mover = None
     # the score kernel WITHOUT the fused NMS (okvfe_harris_score_device), same images, for reference
     d_sc = torch.empty((n_lane_img, cfg.h, cfg.w), dtype=torch.int32, device=dev)
     lanes[0][0].profile_enable(True, stages=("harris",))
@@ -796,6 +807,12 @@ def main():
             "roofline": roofline_block(P, n_lane_img, harris_ms, {
                 "isolated_launch_ms": iso[0] / iso[1],
                 "isolated_frac": 5.0 * P * n_lane_img / (iso[0] / iso[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "byte_mover_ms": (mover[0] / mover[1]) if mover and mover[1] else None,
+                "frac_of_byte_mover": (mover[0] / mover[1]) / (iso[0] / iso[1]) if mover and mover[1] else None,
+                "byte_mover_note": "harris_kernel<61, true, PACK, MEMONLY>: the kernel's own loads and stores "
+                                   "(same tiles, same slotted layout, same launch geometry) with the arithmetic, "
+                                   "the NMS and the candidate records removed; frac_of_byte_mover = byte mover / "
+                                   "isolated kernel duration",
                 "copy_kernel_GBps": copy_gbps, "fill_kernel_GBps": fill_gbps,
                 "frac_of_copy_kernel": 5.0 * P * n_lane_img / (harris_ms * 1e-3) / 1e9 / copy_gbps,
                 "widen_kernel_ms": widen_ms,

@@ -271,6 +271,13 @@ okvfe_status okvfe_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_d
  * OKVFE_SCORE_AGAST_9_16), n_images * H * W int32. */
 okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev,
                                        int32_t n_images, int32_t* scores_dev, void* stream);
+/* Diagnostic: the byte mover of the fused score + NMS kernel -- the same loads and the same stores
+ * on the context's score-map layout with no arithmetic in between (the score maps receive pixel
+ * bytes; no candidates are produced).  Its duration is that kernel's own memory floor; bench.py
+ * times it beside the kernel (roofline.byte_mover_ms).  OKVFE_ERR_UNSUPPORTED where the fused kernel
+ * does not apply (AGAST score types, widths that are no multiple of 4, octaves > 0). */
+okvfe_status okvfe_harris_byte_mover_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                            int32_t n_images, void* stream);
 
 /* ---- stage profiling ----------------------------------------------------- */
 /* When enabled, every stage launch of the batch entry points is bracketed by a

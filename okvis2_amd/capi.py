@@ -82,7 +82,7 @@ EXPORTS = [
     "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
     "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
     "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_describe_batch_device",
-    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device",
+    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device", "okvfe_harris_byte_mover_device",
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
@@ -402,6 +402,10 @@ class Frontend:
         self._check(lib().okvfe_detect(self._h, _p(image), C.c_size_t(image.strides[0]), _p(kps),
                                        cap, C.byref(n)))
         return kps[:n.value].copy()
+
+    def harris_byte_mover_device(self, images_ptr, n_images, stream=None):
+        """Diagnostic: the fused score kernel's loads and stores without its arithmetic."""
+        self._check(lib().okvfe_harris_byte_mover_device(self._h, _p(images_ptr), int(n_images), _s(stream)))
 
     def detect_describe(self, image, cam=-1, gravity=None):
         image = np.ascontiguousarray(image, dtype=np.uint8)

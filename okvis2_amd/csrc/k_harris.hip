@@ -331,7 +331,15 @@ constexpr int kCandStage = OKVFE_K1_STAGE;  // candidate records staged per wave
 //     neighbour of a tested row) and overwritten with zeros after the loop by the two waves that
 //     own them; rows past the image (partial last tile) are not stored;
 //   * rows that may not carry maxima (y < 2, y >= h-2) skip their test on a scalar branch.
-template <int kTHF, bool NMS, bool PACK = false>
+// MEMONLY: the byte mover of this kernel -- the same loads, the same stores on the same layout, no
+// arithmetic (a stored row = the unpacked pixel row three steps ahead).  Its duration is the
+// kernel's own memory floor (okvfe_harris_byte_mover_device; bench.py reports both).
+#ifdef OKVFE_K1_MEMONLY
+constexpr bool kForceMemOnly = true;   // A/B build: every launch is the byte mover
+#else
+constexpr bool kForceMemOnly = false;
+#endif
+template <int kTHF, bool NMS, bool PACK = false, bool MEMONLY = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
     int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
@@ -421,14 +429,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // rewritten into a v_cndmask_b32_e64 on a re-materialised compare
   asm volatile("" : "+v"(m0), "+v"(m3));
 
-#if !defined(OKVFE_K1_MFMA) || defined(OKVFE_K1_MEMONLY)
   auto unpack4 = [](uint32_t c, int p[4]) {
     p[0] = c & 255;
     p[1] = (c >> 8) & 255;
     p[2] = (c >> 16) & 255;
     p[3] = c >> 24;
   };
-#endif
+  (void)unpack4;
 #ifndef OKVFE_K1_MFMA
   int pr[3][4];      // rolling pixel rows (own 4 columns)
 #endif
@@ -711,8 +718,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     ring[(PH + kAhead) % 6] = load_next();
     const int g = y + 1;
     const bool inner = g >= 1 && g <= h - 2;  // scalar
-#ifdef OKVFE_K1_MEMONLY  // A/B: the kernel's loads and stores with no arithmetic (its own memory floor)
-    {
+    if constexpr (MEMONLY || kForceMemOnly) {  // the byte mover: loads and stores, no arithmetic
       int sc[4];
 #ifdef OKVFE_K1_MEMONLY_NOLOADUSE  // stores of a constant: the loads are dead (and removed by the compiler)
       sc[0] = sc[1] = sc[2] = sc[3] = y;
@@ -724,7 +730,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       (void)inner;
       return;
     }
-#endif
 #ifdef OKVFE_K1_MFMA
     make_windows(ring[PH], win[s_new]);
     cov_row(win[s_a], win[s_b], win[s_new], hs[q], inner);
@@ -901,7 +906,7 @@ ScoreLayout harris_nms_layout(int w, int h) {
 }
 
 static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, int32_t* score,
-                               ScoreLayout layout, const NmsOut* nms, hipStream_t stream) {
+                               ScoreLayout layout, const NmsOut* nms, hipStream_t stream, bool byte_mover = false) {
   if (n_images <= 0) return true;
   const dim3 block(64, kWavesPerBlock, 1);
   const bool aligned = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) &&
@@ -923,22 +928,25 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
   const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                      \
   const int ytiles_blk = ytiles;
 #define OKVFE_K1_SGROUPS(n) (n)
-#define OKVFE_K1_NMS_LAUNCH(TH)                                                                 \
+#define OKVFE_K1_NMS_LAUNCH_M(TH, MEM)                                                          \
   {                                                                                              \
     OKVFE_K1_TILING(TH)                                                                          \
     if (pack_g >= 2 && !no_pack) {                                                               \
       const int main_blocks = ytiles * n_images * OKVFE_K1_SGROUPS(strips - 1);                  \
       const int groups = (n_images + pack_g - 1) / pack_g;                                       \
-      hipLaunchKernelGGL((harris_kernel<TH, true, true>), dim3(main_blocks + groups * ytiles_blk), \
+      hipLaunchKernelGGL((harris_kernel<TH, true, true, MEM>), dim3(main_blocks + groups * ytiles_blk), \
                          block, 0, stream, img, w, h, score, layout.pitch, strips - 1, ytiles, n_images, *nms, \
                          pack_g, pack_u, main_blocks);                                           \
     } else {                                                                                     \
-      hipLaunchKernelGGL((harris_kernel<TH, true>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0,  \
+      hipLaunchKernelGGL((harris_kernel<TH, true, false, MEM>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0,  \
                          stream, img, w, h, score, layout.pitch, strips, ytiles, n_images, *nms, 1, 64, 0);    \
     }                                                                                            \
   }
+#define OKVFE_K1_NMS_LAUNCH(TH) OKVFE_K1_NMS_LAUNCH_M(TH, false)
     static const bool no_pack = getenv("OKVFE_K1_NOPACK") != nullptr;  // A/B knob
-    if (nms) {
+    if (nms && byte_mover) {
+      OKVFE_K1_NMS_LAUNCH_M(61, true);
+    } else if (nms) {
       // rows per wave (6k + 1): more rows = fewer halo rows per tile (6 per tile), but longer waves
       // (tail) and a later epilogue
       switch (th_env) {
@@ -959,6 +967,7 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
                          img, w, h, score, w, strips, ytiles, n_images, NmsOut{}, 1, 64, 0);
     }
 #undef OKVFE_K1_NMS_LAUNCH
+#undef OKVFE_K1_NMS_LAUNCH_M
 #undef OKVFE_K1_TILING
 #undef OKVFE_K1_SGROUPS
   } else {
@@ -981,6 +990,14 @@ bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* 
   if (layout.strips < 1) return false;
   const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count};
   return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream);
+}
+
+// the fused kernel's byte mover on the same layout (diagnostic: the score map receives pixel bytes)
+bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, int32_t* score,
+                              ScoreLayout layout, hipStream_t stream) {
+  if (layout.strips < 1) return false;
+  const NmsOut nms{1, nullptr, 0, nullptr, nullptr};
+  return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream, true);
 }
 
 }  // namespace okvfe

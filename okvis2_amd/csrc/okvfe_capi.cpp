@@ -710,6 +710,25 @@ okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_harris_byte_mover_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                            void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 0 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_harris_byte_mover_device: bad argument");
+  if (ctx->cfg.score_type != OKVFE_SCORE_HARRIS || !ctx->d_scores || ctx->score_layout.strips < 1)
+    return fail(ctx, OKVFE_ERR_UNSUPPORTED, "okvfe_harris_byte_mover_device: the fused score kernel does not apply to this context");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  bool ok;
+  {
+    StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+    ok = launch_harris_byte_mover(images_dev, ctx->w, ctx->h, n_images, ctx->d_scores, ctx->score_layout, s);
+  }
+  if (!ok) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "okvfe_harris_byte_mover_device: image base or width not dword aligned");
+  HIP_TRY(ctx, hipGetLastError());
+  return OKVFE_OK;
+}
+
 static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int32_t* cam_ids,
                                         const float* gravity, hipStream_t s) {
   std::vector<ImageParams> prm(n_images);

@@ -439,3 +439,28 @@ def test_host_fed_batches_equal_device_fed(oracle):
     for i in range(B):
         for a, b in zip(fe.download(i), got[-1][i]):
             assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
+def test_byte_mover_diagnostic(oracle):
+    """okvfe_harris_byte_mover_device moves the fused kernel's bytes (score maps receive pixel
+    bytes, no candidates); a detection afterwards recomputes everything."""
+    import ctypes as C
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg, max_batch=2)
+    imgs = np.stack([G.image_for(cfg, 31), G.image_for(cfg, 32)])
+    d_img = torch.from_numpy(imgs).cuda()
+    fe.harris_byte_mover_device(d_img.data_ptr(), 2)
+    torch.cuda.synchronize()
+    out = fe.device_outputs()
+    host = np.empty((2, cfg.h, out.score_pitch), dtype=np.int32)
+    st = capi.lib().okvfe_copy_to_host(C.c_void_p(host.ctypes.data), C.c_void_p(out.scores),
+                                       C.c_size_t(host.nbytes), None)
+    assert st == capi.OK
+    inner = host[:, 1:-1, :]  # rows 0 and h-1 are the zero rim rows
+    assert inner.min() >= 0 and inner.max() <= 255 and inner.max() > 0  # every stored int is a pixel byte
+    for i in range(2):
+        got = fe.detect(imgs[i])
+        ref = oracle.detect(imgs[i], cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts)
+        G.assert_keypoints_equal(got, ref)
+    with pytest.raises(capi.OkvfeError):
+        G.make_frontend(cfg, score_type=capi.SCORE_AGAST_9_16).harris_byte_mover_device(d_img.data_ptr(), 1)
