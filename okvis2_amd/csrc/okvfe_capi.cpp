@@ -97,6 +97,7 @@ struct okvfe_ctx {
   std::vector<float> cam_fu;
   std::vector<uint8_t> cam_wide;  // camera-aware patches of this camera often exceed the LDS buffer (describe_kernel<5>)
   bool wide_patches = false;      // of the images of the current batch
+  bool counters_cleared = false;  // upload_image_params zeroed d_cand_count on the call's stream
   std::vector<DeviceCamera> h_cams;
   std::vector<bool> cam_has_intrinsics;
   int last_n_images = 0;
@@ -224,7 +225,8 @@ okvfe_status ring_reserve(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, size_t slot_b
 // takes the next slot, copies `bytes` from src through the pinned half to the device half on
 // stream s (asynchronous: returns at once) and hands back the device address
 okvfe_status ring_upload(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, const void* src, size_t bytes,
-                         hipStream_t s, void** d_out, int* slot_out) {
+                         hipStream_t s, void** d_out, int* slot_out, int32_t* zero_dev = nullptr, int n_zero = 0,
+                         bool* zeroed = nullptr) {
   okvfe_status st = ring_reserve(ctx, r, bytes);
   if (st != OKVFE_OK) return st;
   const int slot = (int)(r->next++ % okvfe_ctx::ParamRing::kRingSlots);
@@ -235,7 +237,18 @@ okvfe_status ring_upload(okvfe_ctx* ctx, okvfe_ctx::ParamRing* r, const void* sr
   uint8_t* h = r->h + (size_t)slot * r->slot_bytes;
   uint8_t* d = r->d + (size_t)slot * r->slot_bytes;
   std::memcpy(h, src, bytes);
-  HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+  // a copy KERNEL reading the pinned slot keeps the hand-over inside the compute queue (k_util.hip);
+  // OKVFE_PARAM_MEMCPY=1 restores the DMA-engine copy for A/B
+  static const bool dma = getenv("OKVFE_PARAM_MEMCPY") != nullptr;
+  void* h_dev = nullptr;
+  if (!dma && hipHostGetDevicePointer(&h_dev, h, 0) == hipSuccess && h_dev) {
+    launch_param_copy(d, h_dev, bytes, zero_dev, n_zero, s);
+    HIP_TRY(ctx, hipGetLastError());
+    if (zeroed) *zeroed = n_zero > 0;
+  } else {
+    (void)hipGetLastError();
+    HIP_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+  }
   // guarded from here on: an early return between upload and ring_release still leaves an event
   // behind the copy (ring_release moves it behind the slot's last reader)
   HIP_TRY(ctx, hipEventRecord(r->done[slot], s));
@@ -730,7 +743,7 @@ okvfe_status okvfe_harris_byte_mover_device(okvfe_ctx* ctx, const uint8_t* image
 }
 
 static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int32_t* cam_ids,
-                                        const float* gravity, hipStream_t s) {
+                                        const float* gravity, hipStream_t s, bool before_detect = false) {
   std::vector<ImageParams> prm(n_images);
   ctx->wide_patches = false;
   for (int i = 0; i < n_images; ++i) {
@@ -759,8 +772,12 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
   // intrinsics are needed for back-projection; a slot with maps only (set_camera_maps) keeps its
   // cam id for the maps and gets invalid back-projections (DeviceCamera zeroed -> fu = 0)
   void* d = nullptr;
+  // (single-scale detector: its candidate / fix-up counters are cleared by the same launch)
+  ctx->counters_cleared = false;
   okvfe_status st = ring_upload(ctx, &ctx->prm_ring, prm.data(), n_images * sizeof(ImageParams), s, &d,
-                                &ctx->prm_slot);
+                                &ctx->prm_slot, before_detect && ctx->n_layers == 1 ? ctx->d_cand_count : nullptr,
+                                before_detect && ctx->n_layers == 1 && ctx->d_cand_count ? 2 * ctx->B : 0,
+                                &ctx->counters_cleared);
   if (st != OKVFE_OK) return st;
   ctx->d_prm = static_cast<ImageParams*>(d);
   return OKVFE_OK;
@@ -832,7 +849,9 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
   TokenScope token;
   okvfe_status st;
   if (ctx->n_layers == 1) {
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+    if (!ctx->counters_cleared)  // (cleared together with the parameter upload of the same call otherwise)
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+    ctx->counters_cleared = false;
     if ((st = heavy_begin(ctx, s, 0, &token)) != OKVFE_OK) return st;
     bool fused;
     {
@@ -1052,7 +1071,7 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
                 n_images, ctx->B);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   hipStream_t s = pick_stream(ctx, stream);
-  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
   if (st != OKVFE_OK) return st;
   if ((st = detect_stage(ctx, images_dev, n_images, s)) != OKVFE_OK) return st;
   ctx->detected_images = n_images;
@@ -1104,7 +1123,7 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
                               ctx->feed_stream));
   HIP_TRY(ctx, hipEventRecord(ctx->feed_copied[slot], ctx->feed_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->feed_copied[slot], 0));
-  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
   if (st != OKVFE_OK) return st;
   if ((st = detect_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
   ctx->detected_images = n_images;

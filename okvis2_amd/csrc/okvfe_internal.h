@@ -172,6 +172,8 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                        ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
                        int32_t* cand_count, int32_t* fix_count, hipStream_t stream);
+void launch_param_copy(void* dst_dev, const void* src_host_mapped, size_t bytes, int32_t* zero_dev, int n_zero,
+                       hipStream_t stream);
 bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                               ScoreLayout layout, hipStream_t stream);
 // the layout launch_harris_nms writes for w x h images (dense when the fused kernel does not apply)
