@@ -28,6 +28,7 @@
 #include <limits.h>
 
 #include "camera_dev.h"
+#include "describe_setup_dev.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -190,54 +191,6 @@ __device__ __forceinline__ bool sample_pos(const float M[4], float kx, float ky,
   return (x_1 >= 0.0f && y_1 >= 0.0f && x1 < (float)(w - 1) && y1 < (float)(h - 1));
 }
 
-// M = J * [e_x e_y] / fu on the tangent plane of the keypoint's ray, e_y along `dir`
-__device__ __forceinline__ bool camera_aware_matrix(const float* __restrict__ rays,
-                                                    const float* __restrict__ jac, int w, float fu,
-                                                    const float dir[3], float kx, float ky,
-                                                    float M[4]) {
-  const int u = (int)(kx + 0.5f), v = (int)(ky + 0.5f);
-  const float* r = rays + ((size_t)v * w + u) * 3;
-  const float* J = jac + ((size_t)v * w + u) * 6;
-  const float r0 = r[0], r1 = r[1], r2 = r[2];
-  if (r0 == 0.0f && r1 == 0.0f && r2 == 0.0f) return false;
-  float ey0 = 0.f, ey1 = 0.f, ey2 = 0.f, n2 = 0.0f;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float g0 = c == 0 ? dir[0] : (c == 1 ? 0.0f : 1.0f);
-    const float g1 = c == 0 ? dir[1] : (c == 1 ? 1.0f : 0.0f);
-    const float g2 = c == 0 ? dir[2] : 0.0f;
-    if (c > 0 && n2 >= 1.0e-12f) break;
-    float gr = g0 * r0;
-    float t = g1 * r1;
-    gr = gr + t;
-    t = g2 * r2;
-    gr = gr + t;
-    t = gr * r0; ey0 = g0 - t;
-    t = gr * r1; ey1 = g1 - t;
-    t = gr * r2; ey2 = g2 - t;
-    n2 = ey0 * ey0;
-    t = ey1 * ey1;
-    n2 = n2 + t;
-    t = ey2 * ey2;
-    n2 = n2 + t;
-  }
-  if (!(n2 >= 1.0e-12f)) return false;
-  const float n = sqrtf(n2);
-  ey0 = ey0 / n;
-  ey1 = ey1 / n;
-  ey2 = ey2 / n;
-  float t1, t2;
-  t1 = ey1 * r2; t2 = ey2 * r1; const float ex0 = t1 - t2;
-  t1 = ey2 * r0; t2 = ey0 * r2; const float ex1 = t1 - t2;
-  t1 = ey0 * r1; t2 = ey1 * r0; const float ex2 = t1 - t2;
-  float s;
-  s = J[0] * ex0; t1 = J[1] * ex1; s = s + t1; t1 = J[2] * ex2; s = s + t1; M[0] = s / fu;
-  s = J[0] * ey0; t1 = J[1] * ey1; s = s + t1; t1 = J[2] * ey2; s = s + t1; M[1] = s / fu;
-  s = J[3] * ex0; t1 = J[4] * ex1; s = s + t1; t1 = J[5] * ex2; s = s + t1; M[2] = s / fu;
-  s = J[3] * ey0; t1 = J[4] * ey1; s = s + t1; t1 = J[5] * ey2; s = s + t1; M[3] = s / fu;
-  return true;
-}
-
 constexpr int kDescWaves = 4;
 #ifndef OKVFE_DESC_BLOCKS
 #define OKVFE_DESC_BLOCKS 16
@@ -281,25 +234,8 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= kp_count_in[img]) return;
   const size_t slot = (size_t)img * kp_cap + k;
-  const okvfe_keypoint kp = kps_in[slot];
-  const ImageParams ip = prm[img];
-  // scale-invariant extraction: the pattern's scale index from the keypoint's diameter (it rides to
-  // describe_kernel in bits 1..6 of the valid byte)
-  int scale = 0;
-  if (scales) {
-    for (int i = 1; i < kPatternScales; ++i) scale += kp.size >= scales->size_from[i] ? 1 : 0;
-  }
-  const int border = scales ? scales->border[scale] : pat->border;
-  bool valid = !(kp.x < (float)border || kp.x >= (float)(w - border) || kp.y < (float)border ||
-                 kp.y >= (float)(h - border));
-  float M[4] = {1.0f, 0.0f, 0.0f, 1.0f};
-  if (valid && ip.mode == kCameraAware) {
-    const float dir[3] = {ip.dir[0], ip.dir[1], ip.dir[2]};
-    valid = camera_aware_matrix(rays[ip.cam], jac[ip.cam], w, ip.fu, dir, kp.x, kp.y, M);
-  }
-  *reinterpret_cast<float4*>(desc_tmp + slot * OKVFE_DESC_BYTES) = make_float4(M[0], M[1], M[2], M[3]);
-  valid_tmp[slot] = (uint8_t)((valid ? 1 : 0) | (scale << 1));
-  kps_tmp[slot] = kp;  // the record travels on from here; describe_kernel only rewrites the angle
+  const DescribeSetup ds{pat, prm, rays, jac, kps_tmp, desc_tmp, valid_tmp, scales};
+  describe_setup_one(ds, w, h, img, slot, kps_in[slot]);
 }
 
 // One wave per keypoint, lane i = pattern point i.  The pixels under the keypoint's pattern
@@ -695,10 +631,11 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     const PatternScales* scales, bool wide_patches, hipStream_t stream) {
+                     const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done) {
   if (n_images <= 0) return;
   static const char* force = getenv("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
+  if (!setup_done)  // (done by select_lazy_kernel when detection and description were one call)
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
                      valid_tmp, scales);

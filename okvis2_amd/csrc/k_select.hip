@@ -20,6 +20,7 @@
 //                         large images): 1024 threads test 1024 candidates per round, the first
 //                         that passes is accepted, 961 threads add its 31x31 stamp.
 // Bound: latency / LDS (no HBM roofline); batches keep all CUs busy with independent images.
+#include "describe_setup_dev.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
-    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
+    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, DescribeSetup setup) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_kept;
   const int bpitch = bins_x + 2;  // bordered bin grid: the border bins stay empty, so no range checks
@@ -1172,6 +1173,9 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     kp.response = (float)kp.class_id;
     kp.class_id = -1;
     out[i] = kp;
+    // detection and description in one call: the extractor's per-keypoint preparation right here
+    // (describe_setup_dev.h) instead of a launch of its own
+    if (setup.pat) describe_setup_one(setup, w, h, img, (size_t)img * kp_cap + i, kp);
   }
   if (tid == 0) kp_count[img] = kept;
 #ifdef OKVFE_SELECT_STATS
@@ -1229,12 +1233,12 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
                        2 * kLdsSortKeys);
 }
 
-void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
+bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_image_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
-                   uint64_t* sort_ws, hipStream_t stream) {
-  if (n_images <= 0) return;
+                   uint64_t* sort_ws, hipStream_t stream, const DescribeSetup* setup) {
+  if (n_images <= 0) return false;
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
@@ -1263,8 +1267,8 @@ void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
       }
       hipLaunchKernelGGL(select_lazy_kernel, dim3(n_images), dim3(kLazyThreads), lds, stream, score, layout, w, h,
                          cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, bins_x, bins_y, cap, kps,
-                         kp_cap, kp_count);
-      return;
+                         kp_cap, kp_count, setup ? *setup : DescribeSetup{});
+      return setup != nullptr;  // the extractor's setup ran with the emission
     }
   }
   if (occ_lds && !legacy) {
@@ -1285,7 +1289,7 @@ void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
         OKVFE_SELECT_LAUNCH(true, uint32_t, lds, (uint8_t*)nullptr, (size_t)0);
       else
         OKVFE_SELECT_LAUNCH(true, uint16_t, lds, (uint8_t*)nullptr, (size_t)0);
-      return;
+      return false;
     }
   }
   if (radius > 0.0f && occupancy != nullptr && !legacy && acc_bytes + 128 * 8 <= 24 * 1024) {
@@ -1298,7 +1302,7 @@ void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
       OKVFE_SELECT_LAUNCH(false, uint32_t, acc_bytes + chunk * 8, occupancy, occ_image_bytes);
     else
       OKVFE_SELECT_LAUNCH(false, uint16_t, acc_bytes + chunk * 8, occupancy, occ_image_bytes);
-    return;
+    return false;
   }
 #undef OKVFE_SELECT_LAUNCH
   if (occ_lds) {
@@ -1313,6 +1317,7 @@ void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
                        h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
                        occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap, kp_count);
   }
+  return false;
 }
 
 }  // namespace okvfe

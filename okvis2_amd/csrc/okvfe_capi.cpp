@@ -98,6 +98,8 @@ struct okvfe_ctx {
   std::vector<uint8_t> cam_wide;  // camera-aware patches of this camera often exceed the LDS buffer (describe_kernel<5>)
   bool wide_patches = false;      // of the images of the current batch
   bool counters_cleared = false;  // upload_image_params zeroed d_cand_count on the call's stream
+  bool fuse_setup = false;        // the current call describes what it detects: setup rides in the selection kernel
+  bool setup_done = false;        // ... and did
   std::vector<DeviceCamera> h_cams;
   std::vector<bool> cam_has_intrinsics;
   int last_n_images = 0;
@@ -837,9 +839,15 @@ void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
   launch_sort(L->d_cand, L->cand_cap, L->d_cand_count, n_images, L->cfg.uniformity_radius, L->d_sort_ws, s);
 }
 void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
-  launch_select(L->d_scores, L->score_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap, L->d_cand_count,
-                L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ, L->occ_image_bytes,
-                L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count, L->d_sort_ws, s);
+  // detection + description in one call (single scale): the selection kernel also prepares the
+  // extractor's per-keypoint inputs (describe_setup_dev.h)
+  const DescribeSetup setup{L->d_pattern, L->d_prm, L->d_rays_ptrs, L->d_jac_ptrs, L->d_kps_tmp, L->d_desc_tmp,
+                            L->d_valid_tmp, L->d_scales};
+  const bool fuse = L->fuse_setup && L->n_layers == 1 && L->d_pattern && L->d_kps_tmp && L->d_prm;
+  L->setup_done = launch_select(L->d_scores, L->score_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
+                                L->d_cand_count, L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ,
+                                L->occ_image_bytes, L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count,
+                                L->d_sort_ws, s, fuse ? &setup : nullptr);
 }
 
 // K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count.
@@ -1018,7 +1026,8 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
-                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s);
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, ctx->setup_done);
+    ctx->setup_done = false;
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -1073,7 +1082,11 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
   hipStream_t s = pick_stream(ctx, stream);
   okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
   if (st != OKVFE_OK) return st;
-  if ((st = detect_stage(ctx, images_dev, n_images, s)) != OKVFE_OK) return st;
+  static const bool no_fuse = getenv("OKVFE_NO_FUSED_SETUP") != nullptr;  // A/B knob
+  ctx->fuse_setup = !no_fuse;
+  st = detect_stage(ctx, images_dev, n_images, s);
+  ctx->fuse_setup = false;
+  if (st != OKVFE_OK) return st;
   ctx->detected_images = n_images;
   return describe_stage(ctx, images_dev, n_images, s);
 }
@@ -1125,7 +1138,10 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
   HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->feed_copied[slot], 0));
   okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
   if (st != OKVFE_OK) return st;
-  if ((st = detect_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
+  ctx->fuse_setup = getenv("OKVFE_NO_FUSED_SETUP") == nullptr;
+  st = detect_stage(ctx, ctx->d_feed[slot], n_images, s);
+  ctx->fuse_setup = false;
+  if (st != OKVFE_OK) return st;
   ctx->detected_images = n_images;
   if ((st = describe_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
   HIP_TRY(ctx, hipEventRecord(ctx->feed_consumed[slot], s));

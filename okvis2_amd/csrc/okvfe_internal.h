@@ -185,16 +185,27 @@ void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_thresh
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
                  float radius, uint64_t* sort_ws, hipStream_t stream);
-void launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
+// per-keypoint preparation of the extractor (describe_setup_dev.h), optionally run by the selection kernel
+struct DescribeSetup {  // pat == nullptr: not requested
+  const Pattern* pat;
+  const ImageParams* prm;
+  const float* const* rays;
+  const float* const* jac;
+  okvfe_keypoint* kps_tmp;
+  uint8_t* desc_tmp;
+  uint8_t* valid_tmp;
+  const PatternScales* scales;
+};
+bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
-                   uint64_t* sort_ws, hipStream_t stream);
+                   uint64_t* sort_ws, hipStream_t stream, const DescribeSetup* setup = nullptr);
 void launch_describe(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     const PatternScales* scales, bool wide_patches, hipStream_t stream);
+                     const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done = false);
 bool describe_patch_fits(float nx, float ny, int border);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
