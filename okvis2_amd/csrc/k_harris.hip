@@ -499,6 +499,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // lanes that own column i of their quad as a possible maximum: store lanes, columns 2 .. w-3
   const uint64_t own_lo = __ballot(store && d != 0);       // columns 0, 1 of the quad
   const uint64_t own_hi = __ballot(store && d != nd - 1);  // columns 2, 3
+  // lanes past the row end (and idle lanes of a packed wave) repeat the last dword: their hits are
+  // no neighbours of anything (they used to flag whole rows for the fix-up pass on every width
+  // whose last strip is not full: 640, 720, 1024 px)
+  const uint64_t real_lanes = __ballot(d < nd);
   const int r_lo = ys_own > 2 ? ys_own : 2;                       // rows that may carry maxima:
   const int r_hi = ye_own < h - 2 ? ye_own : h - 2;               // [r_lo, r_hi) (scalars)
   uint64_t rows_adj[2] = {0ull, 0ull};  // bit t: tested row ys_own + t holds two adjacent hits
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
         push_hit(mk[i], ovf[i], nc[i], max3i(max3i(nh[q][i], hn[i], lft[i]), rgt[i], nms.thr), i < 2 ? own_lo : own_hi,
                  (uint32_t)(r << 2 | i), sp, sp_end);
       // two horizontally adjacent hits anywhere in the row (lane l column 3 | lane l + 1 column 0)
-      const uint64_t adj = (mk[0] & mk[1]) | (mk[1] & mk[2]) | (mk[2] & mk[3]) | (mk[3] & (mk[0] >> 1));
+      const uint64_t adj = ((mk[0] & mk[1]) | (mk[1] & mk[2]) | (mk[2] & mk[3]) | (mk[3] & (mk[0] >> 1))) & real_lanes;
       if (adj != 0ull) {
         const int t = r - ys_own;
         if (kTHF <= 64 || t < 64)

@@ -41,7 +41,7 @@ done
 unset OKVFE_PMC_CALIB
 # K1 against its own byte-mover floor on the same (slotted) score layout, and the A/B knobs
 if [ -f $R/okvis2_amd/libokvfe_memonly.so ]; then
-  ( cd $R && ROUNDS=2 bash tools/k1ab_env.sh - -:OKVFE_K1_DENSE=1 memonly memonly:OKVFE_K1_DENSE=1 valu 2>&1 | sort ) > $OUT/${TAG}_k1_floor.txt
+  ( cd $R && ROUNDS=2 bash tools/k1ab_env.sh - -:OKVFE_K1_DENSE=1 memonly memonly:OKVFE_K1_DENSE=1 valu noepi 2>&1 | sort ) > $OUT/${TAG}_k1_floor.txt
 fi
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -o p -- $BENCH --steps 3 > /tmp/prof_sq.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/prof_sq -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_sq.json > /dev/null
