@@ -273,6 +273,7 @@ struct NmsOut {
   int cand_cap;
   int32_t* cand_count;
   int32_t* fix_count;
+  int32_t* fix_list;  // [image][kFixListCap] list positions of the flagged records (fix_count = how many)
 };
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -523,7 +524,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
         cd.score = c;
         nms.cand[(size_t)img * nms.cand_cap + p] = cd;
       }
-      if (flag) atomicAdd(&nms.fix_count[img], 1);
+      if (flag) {
+        const int k = atomicAdd(&nms.fix_count[img], 1);
+        if (k < kFixListCap) nms.fix_list[(size_t)img * kFixListCap + k] = p;
+      }
     }
   };
 
@@ -811,8 +815,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     const int x0 = dcl * 4;
     Candidate* outc = nms.cand + (size_t)image_l * nms.cand_cap;
     const int32_t* mine = hit_stack + wave * (kSlots * 128) + lane;
-    int flagged = 0;
-    auto record = [&](int e) {
+    // a flagged record registers its list position for nms_fixup_kernel (rare)
+    auto flag_record = [&](int at) {
+      const int k = atomicAdd(&nms.fix_count[image_l], 1);
+      if (k < kFixListCap) nms.fix_list[(size_t)image_l * kFixListCap + k] = at;
+    };
+    auto record = [&](int e, bool* flagged) {
       Candidate cd;
       const int tag = mine[e * 128 + 64];
       cd.score = mine[e * 128];
@@ -820,10 +828,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       cd.y = tag >> 2;
       const int t = cd.y - ys_own;
       const uint64_t bit = (kTHF <= 64 || t < 64) ? rows_adj[0] >> t : rows_adj[1] >> (t - 64);
-      if (bit & 1ull) {  // to be settled by nms_fixup_kernel
-        cd.y |= kCandidateFixupFlag;
-        ++flagged;
-      }
+      *flagged = (bit & 1ull) != 0ull;
+      if (*flagged) cd.y |= kCandidateFixupFlag;  // to be settled by nms_fixup_kernel
       return cd;
     };
     // one reservation in the image's candidate list per wave (PACK: per image of the wave)
@@ -851,8 +857,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       }
       for (int e = 0; __any(e < cnt); ++e)
         if (e < cnt) {
-          const Candidate cd = record(e);
+          bool fl;
+          const Candidate cd = record(e, &fl);
           if (pos + e < nms.cand_cap) outc[pos + e] = cd;
+          if (fl) flag_record(pos + e);
         }
     } else {
       // the reservation's round trip overlaps the record loop: the records go to LDS by their index
@@ -869,7 +877,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       Candidate* stage = cand_stage[wave];
       for (int e = 0; __any(e < cnt); ++e)
         if (e < cnt) {
-          const Candidate cd = record(e);
+          bool fl;
+          const Candidate cd = record(e, &fl);
           const int idx = first + e;
           if (idx < cap_stage) {
             stage[idx] = cd;
@@ -877,6 +886,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
             const int at = __builtin_amdgcn_readlane(base_l0, 0) + idx;
             if (at < nms.cand_cap) outc[at] = cd;
           }
+          if (fl) flag_record(__builtin_amdgcn_readlane(base_l0, 0) + idx);
         }
       // the wave's records as one contiguous run: lane = record, 12 bytes each
       __builtin_amdgcn_wave_barrier();
@@ -885,7 +895,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       for (int r = lane; r < n_staged; r += 64)
         if (base + r < nms.cand_cap) outc[base + r] = stage[r];
     }
-    if ((rows_adj[0] | rows_adj[1]) != 0ull && flagged) atomicAdd(&nms.fix_count[image_l], flagged);
   }
 }
 
@@ -990,9 +999,9 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                        ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
-                       int32_t* cand_count, int32_t* fix_count, hipStream_t stream) {
+                       int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream) {
   if (layout.strips < 1) return false;
-  const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count};
+  const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list};
   return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream);
 }
 
@@ -1000,7 +1009,7 @@ bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* 
 bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                               ScoreLayout layout, hipStream_t stream) {
   if (layout.strips < 1) return false;
-  const NmsOut nms{1, nullptr, 0, nullptr, nullptr};
+  const NmsOut nms{1, nullptr, 0, nullptr, nullptr, nullptr};
   return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream, true);
 }
 

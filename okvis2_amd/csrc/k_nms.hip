@@ -257,14 +257,15 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
 // into the holes -- the list is unordered -- instead of compacting the whole list chunk by chunk
 // (0.09 ms per 1024 TUM-VI images, where nearly every image has one flagged row).
 constexpr int kFixupHoles = 128;
-constexpr int kFixupThreads = 1024;  // a 13 k-record list (1024 x 1024 px) is two batches of loads per thread
+constexpr int kFixupThreads = 256;  // (eight workgroups per CU: the few images with flagged records overlap)
 constexpr int kFixupBatch = 8;
 __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t* __restrict__ scores,
                                                         ScoreLayout layout, int w,
                                                         int h, int thr, Candidate* __restrict__ cand,
                                                         int cand_cap,
                                                         int32_t* __restrict__ cand_count,
-                                                        const int32_t* __restrict__ fix_count) {
+                                                        const int32_t* __restrict__ fix_count,
+                                                        const int32_t* __restrict__ fix_list) {
   __shared__ int wave_cnt[kFixupThreads / 64];
   __shared__ int s_base;
   __shared__ int n_rej;
@@ -281,6 +282,23 @@ __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t*
     n_rej = 0;
   }
   __syncthreads();
+  auto settle = [&](int i, int y) {
+    if (accepted_slow(s, w, c[i].x, y & ~kCandidateFixupFlag, thr)) {
+      c[i].y = y & ~kCandidateFixupFlag;
+    } else {  // stays flagged = to be removed
+      const int k = atomicAdd(&n_rej, 1);
+      if (k < kFixupHoles) holes[k] = i;
+    }
+  };
+  const int n_flagged = fix_count[img];
+  if (fix_list && n_flagged <= kFixListCap) {
+    // the fused kernel listed where its flagged records are: no pass over the whole list (reading
+    // 13 k records per 1024 x 1024 image cost 0.04 ms per launch for a handful of ties)
+    for (int t = tid; t < n_flagged; t += kFixupThreads) {
+      const int i = fix_list[(size_t)img * kFixListCap + t];
+      if (i < n) settle(i, c[i].y);
+    }
+  } else
   // (the y fields of a batch are requested before any of them is looked at: one memory round trip
   // per batch instead of one per record)
   for (int i0 = tid; i0 < n; i0 += kFixupThreads * kFixupBatch) {
@@ -293,14 +311,7 @@ __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t*
 #pragma unroll
     for (int u = 0; u < kFixupBatch; ++u) {
       const int i = i0 + u * kFixupThreads, y = ys[u];
-      if (y & kCandidateFixupFlag) {
-        if (accepted_slow(s, w, c[i].x, y & ~kCandidateFixupFlag, thr)) {
-          c[i].y = y & ~kCandidateFixupFlag;
-        } else {  // stays flagged = to be removed
-          const int k = atomicAdd(&n_rej, 1);
-          if (k < kFixupHoles) holes[k] = i;
-        }
-      }
+      if (y & kCandidateFixupFlag) settle(i, y);
     }
   }
   // (workgroup scope: an agent-scope fence writes the XCD's L2 back -- 0.1 ms per launch right after
@@ -361,10 +372,10 @@ __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t*
 
 void launch_nms_fixup(const int32_t* score, ScoreLayout layout, int w, int h, int n_images,
                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
-                      const int32_t* fix_count, hipStream_t stream) {
+                      const int32_t* fix_count, const int32_t* fix_list, hipStream_t stream) {
   if (n_images <= 0) return;
   hipLaunchKernelGGL(nms_fixup_kernel, dim3(n_images), dim3(kFixupThreads), 0, stream, score, layout, w, h,
-                     abs_threshold, cand, cand_cap, cand_count, fix_count);
+                     abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list);
 }
 
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,

@@ -514,7 +514,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
       c->score_layout = cfg->score_type == OKVFE_SCORE_HARRIS ? harris_nms_layout(c->w, c->h) : ScoreLayout{c->w, 0};
       A(d_scores, (size_t)c->score_layout.pitch * c->h * B);
       A(d_cand, (size_t)c->cand_cap * B);
-      A(d_cand_count, 2 * B);
+      A(d_cand_count, 2 * B + (size_t)kFixListCap * B);  // candidate counts, fix-up counts, fix-up lists
       A(d_sort_ws, (size_t)c->ws_stride * B);
       A(d_occ, c->occ_image_bytes * B);
     }
@@ -823,14 +823,15 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
   // a slotted score layout exists only where the fused kernel applies (decided at creation)
   *fused = L->score_layout.strips >= 1 &&
            launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->score_layout,
-                             L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count, s);
+                             L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count,
+                             L->d_cand_count + 2 * (size_t)L->B, s);
   if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
 }
 void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
   int32_t* d_fix_count = L->d_cand_count + L->B;
   if (fused)
     launch_nms_fixup(L->d_scores, L->score_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
-                     L->d_cand_count, d_fix_count, s);
+                     L->d_cand_count, d_fix_count, L->d_cand_count + 2 * (size_t)L->B, s);
   else
     launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
                L->d_cand_count, s);

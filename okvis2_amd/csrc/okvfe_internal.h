@@ -69,6 +69,9 @@ struct Candidate {  // NMS maximum
 // set in Candidate::y by the fused score+NMS kernel: acceptance still depends on the raster-scan
 // rule over a run of equal maxima, settled by nms_fixup_kernel
 constexpr int32_t kCandidateFixupFlag = 0x40000000;
+// the fused kernel also lists the positions of the flagged records, up to this many per image (more:
+// nms_fixup_kernel scans the whole list)
+constexpr int kFixListCap = 1024;
 
 struct DeviceCamera {  // intrinsics for on-device back-projection
   double fu, fv, cu, cv;
@@ -171,7 +174,7 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 // launch_nms_fixup.
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                        ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
-                       int32_t* cand_count, int32_t* fix_count, hipStream_t stream);
+                       int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream);
 void launch_param_copy(void* dst_dev, const void* src_host_mapped, size_t bytes, int32_t* zero_dev, int n_zero,
                        hipStream_t stream);
 bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, int32_t* score,
@@ -180,7 +183,7 @@ bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, in
 ScoreLayout harris_nms_layout(int w, int h);
 void launch_nms_fixup(const int32_t* score, ScoreLayout layout, int w, int h, int n_images,
                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
-                      const int32_t* fix_count, hipStream_t stream);
+                      const int32_t* fix_count, const int32_t* fix_list, hipStream_t stream);
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,

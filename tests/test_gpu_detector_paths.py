@@ -170,6 +170,39 @@ def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     assert out.returncode == 0 and "KNOB-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+_KNOB_DESC_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from okvis2_amd import capi, synth
+import oracle_lib as O, gpu_common as G
+cfg = synth.euroc_config()
+fe = G.make_frontend(cfg)
+cam = cfg.cams[0]
+fe.set_camera(0, cam)
+rays, jac = O.awareness_maps(cam)
+for seed, grav in ((4, (0.0, 1.0, 0.0)), (5, (0.3, 0.9, -0.2))):
+    img = G.image_for(cfg, seed)
+    rk, rd = O.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                               O.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), grav)
+    kps, desc, bp, bpv = fe.detect_describe(img, cam=0, gravity=grav)
+    G.assert_keypoints_equal(kps, rk)
+    assert np.array_equal(desc, rd) and len(kps) > 50
+print("KNOB-OK")
+"""
+
+
+@pytest.mark.parametrize("knob", ["OKVFE_PARAM_MEMCPY", "OKVFE_NO_FUSED_SETUP", "OKVFE_DESC_WAVES=5"])
+def test_ab_knobs_of_the_describe_path(oracle, knob):
+    """Parameter upload through the DMA engine instead of the copy kernel, the extractor's setup as
+    its own launch instead of inside the selection kernel, the 5-wave describe instantiation."""
+    env = dict(os.environ)
+    k, _, v = knob.partition("=")
+    env[k] = v or "1"
+    out = subprocess.run([sys.executable, "-c", _KNOB_DESC_CHILD, ROOT], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "KNOB-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_profile_stage_mask():
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg, max_batch=2)
