@@ -46,8 +46,7 @@ constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B sl
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
 // intensity): float reciprocal estimate (off by at most 1) + exact integer correction, instead of
 // the ~40-instruction generic 32-bit division
-// (q < 2^22 and den = Pattern::box_scaling2 ~ 4096: the 24-bit multiply is exact and full rate;
-// v_mul_lo_u32 is a quarter-rate instruction)
+// (q < 2^22 and den = Pattern::box_scaling2 ~ 4096: the 24-bit multiply is exact)
 __device__ __forceinline__ int mul24i(int a, int b) {  // (__mul24 sign-extends both operands first)
   int d;
   asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
@@ -126,8 +125,10 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     }
     // Rows are addressed by 32-bit byte offsets from the first patch row (the zero row lies
     // kZeroRowBytes before it); every product below has both factors under 2^23 (weights <= 2^22,
-    // pixel sums <= 81 * 255), so the full-rate 24-bit multiplies give the same low 32 bits as the
-    // quarter-rate v_mul_lo_u32 / v_mad_u64_u32 the plain expressions compile to.
+    // pixel sums <= 81 * 255), so the 24-bit multiplies give the same low 32 bits as the
+    // v_mul_lo_u32 / 64-bit v_mad_u64_u32 chains (pointer arithmetic included) the plain expressions
+    // compile to.  (Measured: no change of the kernel's time -- it is latency-bound, and
+    // v_mul_lo_u32 issues at the same rate as the 24-bit forms on this part.)
     const int pitch = px.pitch;
     int run = mul24i(y_top - px.y0, pitch);
     int pl, pr;

@@ -13,9 +13,10 @@
 // horizontally smoothed covariance entries in registers, so every pixel is fetched once per
 // strip (+4 halo rows per kTH) and nothing is staged through LDS.  The inner loop is branch-free:
 // rim handling is an AND with per-lane column masks and a wave-uniform row mask.  All products
-// fit 24 bits (|g| <= 4080, entries <= 16256), so the multiplies are the full-rate
-// v_mul_i32_i24 / v_mad_i32_i24 (emitted explicitly: the compiler otherwise falls back to the
-// quarter-rate v_mul_lo_u32 for loop-carried values whose range it cannot prove).
+// fit 24 bits (|g| <= 4080, entries <= 16256), so the multiplies are v_mul_i32_i24 /
+// v_mad_i32_i24 (emitted explicitly: a fused multiply-add is one issue slot where the compiler's
+// v_mul_lo_u32 + add is two; the plain multiply itself issues at the same 4.4 cycles on this part,
+// profiles/round2_valu_rate_ubench.txt).
 #include <cstdlib>
 #include <type_traits>
 
