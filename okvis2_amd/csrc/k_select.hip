@@ -40,12 +40,12 @@ __device__ __forceinline__ uint64_t make_key(const Candidate& c) {
 // 128 KiB for the few that need up to 16384 keys; lds_lo_keys / lds_keys bound the range a launch
 // handles, every other image is left to the other launch.  Above 16384 keys the network runs in
 // the HBM workspace.
-__global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restrict__ cand,
-                                                        int cand_cap,
-                                                        const int32_t* __restrict__ cand_count,
-                                                        uint64_t* __restrict__ sort_ws,
-                                                        int ws_stride, int lds_lo_keys,
-                                                        int lds_keys) {
+__device__ __forceinline__ void sort_classic_body(const Candidate* __restrict__ cand,
+                                                  int cand_cap,
+                                                  const int32_t* __restrict__ cand_count,
+                                                  uint64_t* __restrict__ sort_ws,
+                                                  int ws_stride, int lds_lo_keys,
+                                                  int lds_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
   const int img = blockIdx.x;
@@ -182,11 +182,11 @@ __device__ __forceinline__ void rb_network(RbKey (&key)[kRbKeys]) {
   }
 }
 // one LDS pass: strides 2^(q+R-1) .. 2^q of the network on np keys
-template <int R, bool MIRROR>
+template <int R, bool MIRROR, int THREADS>
 __device__ __forceinline__ void rb_pass(RbKey* lds, int np, int n, int q, int tid) {
   constexpr int N = 1 << R;
   const int low_mask = (1 << q) - 1;
-  for (int g = tid; g < (np >> R); g += kRbThreads) {
+  for (int g = tid; g < (np >> R); g += THREADS) {
     const int low = g & low_mask;
     const int base = ((g >> q) << (q + R)) | low;
     if (base >= n) continue;  // smallest index of the group: all of its keys are padding
@@ -202,26 +202,14 @@ __device__ __forceinline__ void rb_pass(RbKey* lds, int np, int n, int q, int ti
   }
 }
 
-__global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __restrict__ cand,
-                                                             int cand_cap,
-                                                             const int32_t* __restrict__ cand_count,
-                                                             uint64_t* __restrict__ sort_ws,
-                                                             int ws_stride, int max_keys) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  RbKey* lds = reinterpret_cast<RbKey*>(smem_raw);
-  const int img = blockIdx.x;
-  int n = cand_count[img];
-  n = n > cand_cap ? 0 : n;  // overflowed list: no keypoints (see sort_kernel)
-  if (n == 0) return;
-  int lnp = 4;
-  while ((1 << lnp) < n) ++lnp;
+// the network on one image's list of n <= 2^lnp keys, THREADS threads, 2^lnp + 2^(lnp-4) LDS slots
+template <int THREADS>
+__device__ __forceinline__ void sort_rb_body(RbKey* lds, const Candidate* __restrict__ c, int n, int lnp,
+                                             uint64_t* __restrict__ ws) {
   const int np = 1 << lnp;
-  if (np > max_keys) return;  // left to sort_kernel (second launch)
-  const Candidate* c = cand + (size_t)img * cand_cap;
-  uint64_t* ws = sort_ws + (size_t)img * ws_stride;
   const int tid = threadIdx.x;
   // phases 1..4 on 16 consecutive keys straight from the candidate list
-  for (int g = tid; g < (np >> 4); g += kRbThreads) {
+  for (int g = tid; g < (np >> 4); g += THREADS) {
     RbKey key[kRbKeys];
 #pragma unroll
     for (int m = 0; m < kRbKeys; ++m) {
@@ -254,13 +242,13 @@ __global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __
       const int r = top + 1 < 4 ? top + 1 : 4;
       const int q = top - r + 1;
       if (mirror) {
-        rb_pass<4, true>(lds, np, n, q, tid);  // lk >= 5: the first pass always has 4 strides
+        rb_pass<4, true, THREADS>(lds, np, n, q, tid);  // lk >= 5: the first pass always has 4 strides
       } else {
         switch (r) {
-          case 4: rb_pass<4, false>(lds, np, n, q, tid); break;
-          case 3: rb_pass<3, false>(lds, np, n, q, tid); break;
-          case 2: rb_pass<2, false>(lds, np, n, q, tid); break;
-          default: rb_pass<1, false>(lds, np, n, q, tid); break;
+          case 4: rb_pass<4, false, THREADS>(lds, np, n, q, tid); break;
+          case 3: rb_pass<3, false, THREADS>(lds, np, n, q, tid); break;
+          case 2: rb_pass<2, false, THREADS>(lds, np, n, q, tid); break;
+          default: rb_pass<1, false, THREADS>(lds, np, n, q, tid); break;
         }
       }
       __syncthreads();
@@ -268,7 +256,49 @@ __global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __
       mirror = false;
     }
   }
-  for (int i = tid; i < n; i += kRbThreads) ws[i] = rb_decode(lds[rb_slot(i)]);
+  for (int i = tid; i < n; i += THREADS) ws[i] = rb_decode(lds[rb_slot(i)]);
+}
+
+__global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __restrict__ cand,
+                                                             int cand_cap,
+                                                             const int32_t* __restrict__ cand_count,
+                                                             uint64_t* __restrict__ sort_ws,
+                                                             int ws_stride, int max_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int img = blockIdx.x;
+  int n = cand_count[img];
+  n = n > cand_cap ? 0 : n;  // overflowed list: no keypoints (see sort_kernel)
+  if (n == 0) return;
+  int lnp = 4;
+  while ((1 << lnp) < n) ++lnp;
+  if ((1 << lnp) > max_keys) return;  // left to sort_kernel (second launch)
+  sort_rb_body<kRbThreads>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
+                           sort_ws + (size_t)img * ws_stride);
+}
+
+// The large-list launch (and the legacy path): lists of 8193 .. 16384 keys run the register-blocked
+// network with 1024 threads in 136 KiB of LDS (13.5 k maxima per 1024 x 1024 image: 0.28 -> 0.17 ms per
+// 1024 images with the two-stride network before), everything else the classic bodies above.
+__global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restrict__ cand,
+                                                        int cand_cap,
+                                                        const int32_t* __restrict__ cand_count,
+                                                        uint64_t* __restrict__ sort_ws,
+                                                        int ws_stride, int lds_lo_keys,
+                                                        int lds_keys, int rb_mid) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (rb_mid) {
+    const int img = blockIdx.x;
+    int n = cand_count[img];
+    n = n > cand_cap ? 0 : n;
+    int lnp = 4;
+    while ((1 << lnp) < n) ++lnp;
+    if ((1 << lnp) > lds_lo_keys && (1 << lnp) <= 2 * kLdsSortKeys) {  // block-uniform
+      sort_rb_body<kThreads>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
+                             sort_ws + (size_t)img * ws_stride);
+      return;
+    }
+  }
+  sort_classic_body(cand, cand_cap, cand_count, sort_ws, ws_stride, lds_lo_keys, lds_keys);
 }
 
 // 2-D quadratic sub-pixel refinement; mirrors the published BRISK Subpixel2D with 64-bit
@@ -1220,17 +1250,25 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
     // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
     hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
                        cand, cand_cap, cand_count, sort_ws, ws_stride, 0,
-                       two ? sort_keys : 2 * kLdsSortKeys);
+                       two ? sort_keys : 2 * kLdsSortKeys, 0);
   } else {
     // up to 8192 keys: register-blocked network in 68 KiB (16 keys minimum: one thread's share)
     const int keys = sort_keys < kRbKeys ? kRbKeys : sort_keys;
     hipLaunchKernelGGL(sort_rb_kernel, dim3(n_images), dim3(kRbThreads), (size_t)rb_slot(keys) * 8, stream,
                        cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
   }
-  if (two)  // second launch: 8193..16384 keys in 128 KiB, larger sets in the HBM workspace
-    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)2 * kLdsSortKeys * 8,
-                       stream, cand, cand_cap, cand_count, sort_ws, ws_stride, kLdsSortKeys,
-                       2 * kLdsSortKeys);
+  if (two) {  // second launch: 8193..16384 keys in 136 KiB, larger sets in the HBM workspace
+    const size_t big_lds = (size_t)rb_slot(2 * kLdsSortKeys) * 8;  // >= the classic 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)big_lds) != hipSuccess)
+        (void)hipGetLastError();
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), big_lds, stream, cand, cand_cap, cand_count,
+                       sort_ws, ws_stride, kLdsSortKeys, 2 * kLdsSortKeys, legacy ? 0 : 1);
+  }
 }
 
 bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
