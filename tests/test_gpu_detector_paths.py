@@ -203,6 +203,54 @@ def test_ab_knobs_of_the_describe_path(oracle, knob):
     assert out.returncode == 0 and "KNOB-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+_RING_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from okvis2_amd import capi, synth
+import oracle_lib as O, gpu_common as G
+cfg = synth.euroc_config()
+fe = G.make_frontend(cfg, max_batch=2)
+cam = cfg.cams[0]
+fe.set_camera(0, cam)
+rays, jac = O.awareness_maps(cam)
+img = G.image_for(cfg, 21)
+d_img = torch.from_numpy(np.stack([img, img])).cuda()
+ids = np.zeros(2, dtype=np.int32)
+s = torch.cuda.current_stream().cuda_stream
+refs = {}
+# 20 calls = 2.5 laps of the 8-slot parameter ring, a different gravity pair each time, no
+# synchronisation in between; every call's descriptors must be those of ITS parameters
+gs = [np.array([[np.sin(0.3 * i), np.cos(0.3 * i), 0.1 * (i % 3)], [0.0, 1.0, 0.02 * i]], dtype=np.float32) for i in range(20)]
+outs = []
+for i, g in enumerate(gs):
+    fe.detect_describe_batch_device(d_img.data_ptr(), 2, ids, g, s)
+    torch.cuda.synchronize() if i % 7 == 6 else None
+    if i in (0, 9, 19):
+        torch.cuda.synchronize()
+        outs.append((i, [fe.download(j) for j in range(2)]))
+for i, res in outs:
+    for j in range(2):
+        rk, rd = O.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                   O.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), tuple(float(v) for v in gs[i][j]))
+        G.assert_keypoints_equal(res[j][0], rk)
+        assert np.array_equal(res[j][1], rd), (i, j)
+print("RING-OK")
+"""
+
+
+@pytest.mark.parametrize("knob", ["", "OKVFE_TEST_SKIP_RING_RELEASE"])
+def test_parameter_ring_laps(oracle, knob):
+    """The per-call parameter blocks travel through an 8-slot pinned ring: slots are reused after the
+    event behind their last reader -- or, for a call that never released its slot (forced here by the
+    test knob), after a wait on that call's stream."""
+    env = dict(os.environ)
+    if knob:
+        env[knob] = "1"
+    out = subprocess.run([sys.executable, "-c", _RING_CHILD, ROOT], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "RING-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_profile_stage_mask():
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg, max_batch=2)
