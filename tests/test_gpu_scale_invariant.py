@@ -77,3 +77,29 @@ def test_basic_size_equals_fixed_scale(oracle):
     kps17["size"] = np.float32(1.45 * 12.0)
     k1, d1, _, _ = si.compute(img, kps17)
     assert len(k0) == len(k1) and np.array_equal(d0, d1)
+
+
+def test_installed_pattern_is_the_base_of_the_scale_ladder(oracle, monkeypatch):
+    """okvfe_set_pattern on a scale-invariant context: the installed pattern is index 17 of the ladder,
+    the other 63 scales are rebuilt from it (PatternScales), exactly as orc_pattern_scaled does."""
+    import ctypes as C
+    from test_gpu_pattern import _to_orc
+    cfg = synth.euroc_config()
+    cfg.octaves = 2
+    fe = G.make_frontend(cfg, rotation_invariant=True, scale_invariant=True)
+    base = fe.get_pattern()
+    p = capi.PatternData()
+    C.memmove(C.byref(p), C.byref(base), C.sizeof(p))
+    for i in range(p.n_points):
+        p.px[i] = np.float32(base.px[i] * 0.9)
+        p.py[i] = np.float32(base.py[i] * 0.9)
+        p.sigma_half[i] = np.float32(base.sigma_half[i] * (1.1 if i % 2 else 0.95))
+    fe.set_pattern(p)
+    q = _to_orc(oracle, p)
+    monkeypatch.setattr(oracle, "pattern", lambda: q)
+    img = G.image_for(cfg, 14)
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 2, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_GRADIENT, scale_invariant=True)
+    kps, desc, _, _ = fe.detect_describe(img)
+    G.assert_keypoints_equal(kps, rk)
+    assert np.array_equal(desc, rd) and len(kps) > 50 and len(np.unique(kps["size"])) > 1
