@@ -17,6 +17,13 @@
 // v_mad_i32_i24 (emitted explicitly: a fused multiply-add is one issue slot where the compiler's
 // v_mul_lo_u32 + add is two; the plain multiply itself issues at the same 4.4 cycles on this part,
 // profiles/round2_valu_rate_ubench.txt).
+//
+// The production kernel is harris_kernel<61, true[, PACK]> further down: the same walk with the
+// gradients on the matrix pipe (v_mfma_i32_4x4x4i8), the detector's non-maximum suppression fused in
+// (hits pushed as {score, position} on per-lane LDS stacks, candidate records written through an LDS
+// stage), whole-line stores through the slotted score layout, and its MEMONLY instantiation -- the
+// byte mover that bench.py times next to it.  harris_generic_kernel / harris_kernel<30, false> are the
+// plain score-map forms (unaligned widths, okvfe_harris_score_device).
 #include <cstdlib>
 #include <type_traits>
 
