@@ -209,13 +209,15 @@ __device__ __forceinline__ void load_scan_chunk(const ScanChunk& C, const uint8_
     for (int i = threadIdx.x; i < cnt; i += 64) C.skip[i] = skip1[c0 + i];
   __builtin_amdgcn_wave_barrier();
 }
-template <bool HAS_SKIP>
-__device__ __forceinline__ void scan_top2(const Desc12& d0, const ScanChunk& C,
-                                          const uint8_t* __restrict__ desc1,
-                                          const uint8_t* __restrict__ skip1, int k1_lo, int k1_hi,
-                                          bool resident, uint32_t floor_key, uint32_t threshold,
-                                          uint32_t* c1_out, uint32_t* c2_out) {
-  uint32_t c1 = kNoKey, c2 = kNoKey;
+// K smallest admissible keys, ascending in c[0 .. K)
+template <int K, bool HAS_SKIP>
+__device__ __forceinline__ void scan_top(const Desc12& d0, const ScanChunk& C,
+                                         const uint8_t* __restrict__ desc1,
+                                         const uint8_t* __restrict__ skip1, int k1_lo, int k1_hi,
+                                         bool resident, uint32_t floor_key, uint32_t threshold,
+                                         uint32_t (&c)[K]) {
+#pragma unroll
+  for (int t = 0; t < K; ++t) c[t] = kNoKey;
   for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
     const int cnt = min(kStereoChunk, k1_hi - c0);
     if (!resident) load_scan_chunk(C, desc1, HAS_SKIP ? skip1 : nullptr, c0, cnt);
@@ -226,12 +228,22 @@ __device__ __forceinline__ void scan_top2(const Desc12& d0, const ScanChunk& C,
       bool ok = key > floor_key && dist < threshold;
       if (HAS_SKIP) ok = ok && C.skip[j] == 0;
       key = ok ? key : kNoKey;
-      c2 = min(c2, max(c1, key));
-      c1 = min(c1, key);
+#pragma unroll
+      for (int t = K - 1; t > 0; --t) c[t] = min(c[t], max(c[t - 1], key));  // insertion into the sorted K
+      c[0] = min(c[0], key);
     }
   }
-  *c1_out = c1;
-  *c2_out = c2;
+}
+template <bool HAS_SKIP>
+__device__ __forceinline__ void scan_top2(const Desc12& d0, const ScanChunk& C,
+                                          const uint8_t* __restrict__ desc1,
+                                          const uint8_t* __restrict__ skip1, int k1_lo, int k1_hi,
+                                          bool resident, uint32_t floor_key, uint32_t threshold,
+                                          uint32_t* c1_out, uint32_t* c2_out) {
+  uint32_t c[2];
+  scan_top<2, HAS_SKIP>(d0, C, desc1, skip1, k1_lo, k1_hi, resident, floor_key, threshold, c);
+  *c1_out = c[0];
+  *c2_out = c[1];
 }
 
 __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
@@ -267,15 +279,33 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   const ScanChunk chunk{seg_desc[seg], nullptr};
   const bool resident = k1_hi - k1_lo <= kStereoChunk;
   if (resident) load_scan_chunk(chunk, I1.desc, nullptr, k1_lo, k1_hi - k1_lo);
+  int n_scans = 0;
   while (__any(!done)) {
     // the two smallest admissible keys of the segment in one scan: a rejected best candidate
-    // usually has its successor at hand, so the tail of the kernel is not set by re-scans
-    uint32_t c1, c2;
-    scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
-                     (uint32_t)threshold, &c1, &c2);
+    // usually has its successor at hand, so the tail of the kernel is not set by re-scans.  A lane
+    // that is still undecided after them sits in look-alike content (repetitive texture: dozens of
+    // candidates below the threshold, most of them rejected by the gate): every further scan then
+    // brings SIX keys (insertion costs 5 min/max pairs more per descriptor, a re-scan 24 + 7)
+    constexpr int kMore = 6;
+#ifndef OKVFE_MATCH_NARROW_SCANS
+#define OKVFE_MATCH_NARROW_SCANS 1
+#endif
+    constexpr int kNarrowScans = OKVFE_MATCH_NARROW_SCANS;
+    uint32_t cs[kMore] = {kNoKey, kNoKey, kNoKey, kNoKey, kNoKey, kNoKey};
+    int n_c = 2;
+    if (n_scans < kNarrowScans) {
+      scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
+                       (uint32_t)threshold, &cs[0], &cs[1]);
+    } else {
+      scan_top<kMore, false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key, (uint32_t)threshold, cs);
+      n_c = kMore;
+    }
+    ++n_scans;
 #pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-      const uint32_t cand = t == 0 ? c1 : c2;
+    for (int t = 0; t < n_c; ++t) {
+      uint32_t cand = cs[0];  // cs[t] without a dynamically indexed register array
+#pragma unroll
+      for (int u = 1; u < kMore; ++u) cand = t == u ? cs[u] : cand;
       bool pending = !done;
       if (pending && cand == kNoKey) {  // nothing (more) above the floor in this segment
         done = true;
@@ -342,7 +372,7 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   }
 }
 
-__global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_kernel(
+__global__ __launch_bounds__(64 * kStereoSegs) __attribute__((amdgpu_waves_per_eu(4, 8))) void match_stereo_kernel(
     const PairParams* __restrict__ pairs, const okvfe_keypoint* __restrict__ kps,
     const uint8_t* __restrict__ desc, const double* __restrict__ bp,
     const uint8_t* __restrict__ bpv, const int32_t* __restrict__ counts, int kp_cap,
@@ -358,7 +388,7 @@ __global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_kernel(
 }
 
 // explicit arrays (host-buffer API and gathered blocks)
-__global__ __launch_bounds__(64 * kStereoSegs) void match_stereo_arrays_kernel(
+__global__ __launch_bounds__(64 * kStereoSegs) __attribute__((amdgpu_waves_per_eu(4, 8))) void match_stereo_arrays_kernel(
     const PairParams* __restrict__ pair, const uint8_t* __restrict__ desc0,
     const double* __restrict__ bp0, const uint8_t* __restrict__ bpv0, const int32_t* n0p, int n0,
     const uint8_t* __restrict__ desc1, const double* __restrict__ bp1,
