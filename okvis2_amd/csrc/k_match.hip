@@ -623,17 +623,32 @@ __device__ void match_motion_rows(const PairParams& P, const DeviceCamera& camer
   const bool resident = k1_hi - k1_lo <= kStereoChunk;
   const bool has_skip = I1.flag != nullptr;  // kernel-uniform
   if (resident) load_scan_chunk(chunk, I1.desc, I1.flag, k1_lo, k1_hi - k1_lo);
+  int n_scans = 0;
   while (__any(!done)) {
-    uint32_t c1, c2;
-    if (has_skip)
-      scan_top2<true>(d0, chunk, I1.desc, I1.flag, k1_lo, k1_hi, resident, floor_key,
-                      (uint32_t)threshold, &c1, &c2);
-    else
-      scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
-                       (uint32_t)threshold, &c1, &c2);
+    // two keys from the first scan, six from every re-scan (see match_stereo_rows)
+    constexpr int kMore = 6;
+    uint32_t cs[kMore] = {kNoKey, kNoKey, kNoKey, kNoKey, kNoKey, kNoKey};
+    int n_c = 2;
+    if (n_scans < 1) {
+      if (has_skip)
+        scan_top2<true>(d0, chunk, I1.desc, I1.flag, k1_lo, k1_hi, resident, floor_key,
+                        (uint32_t)threshold, &cs[0], &cs[1]);
+      else
+        scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
+                         (uint32_t)threshold, &cs[0], &cs[1]);
+    } else {
+      if (has_skip)
+        scan_top<kMore, true>(d0, chunk, I1.desc, I1.flag, k1_lo, k1_hi, resident, floor_key, (uint32_t)threshold, cs);
+      else
+        scan_top<kMore, false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key, (uint32_t)threshold, cs);
+      n_c = kMore;
+    }
+    ++n_scans;
 #pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-      const uint32_t cand = t == 0 ? c1 : c2;
+    for (int t = 0; t < n_c; ++t) {
+      uint32_t cand = cs[0];
+#pragma unroll
+      for (int u = 1; u < kMore; ++u) cand = t == u ? cs[u] : cand;
       bool pending = !done;
       if (pending && cand == kNoKey) {
         done = true;
