@@ -190,6 +190,9 @@ struct SegBest {
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+#ifndef OKVFE_MATCH_MORE
+#define OKVFE_MATCH_MORE 6  // keys per re-scan of the gated matchers (the first scan keeps two)
+#endif
 
 // One scan of segment [k1_lo, k1_hi) of the other side's descriptors: the two smallest keys
 // ((dist << 22) | k1) + 1 that exceed floor_key, have dist < threshold and are not flagged in
@@ -286,12 +289,14 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
     // that is still undecided after them sits in look-alike content (repetitive texture: dozens of
     // candidates below the threshold, most of them rejected by the gate): every further scan then
     // brings SIX keys (insertion costs 5 min/max pairs more per descriptor, a re-scan 24 + 7)
-    constexpr int kMore = 6;
+    constexpr int kMore = OKVFE_MATCH_MORE;
 #ifndef OKVFE_MATCH_NARROW_SCANS
 #define OKVFE_MATCH_NARROW_SCANS 1
 #endif
     constexpr int kNarrowScans = OKVFE_MATCH_NARROW_SCANS;
-    uint32_t cs[kMore] = {kNoKey, kNoKey, kNoKey, kNoKey, kNoKey, kNoKey};
+    uint32_t cs[kMore];
+#pragma unroll
+    for (int u = 0; u < kMore; ++u) cs[u] = kNoKey;
     int n_c = 2;
     if (n_scans < kNarrowScans) {
       scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
@@ -626,8 +631,10 @@ __device__ void match_motion_rows(const PairParams& P, const DeviceCamera& camer
   int n_scans = 0;
   while (__any(!done)) {
     // two keys from the first scan, six from every re-scan (see match_stereo_rows)
-    constexpr int kMore = 6;
-    uint32_t cs[kMore] = {kNoKey, kNoKey, kNoKey, kNoKey, kNoKey, kNoKey};
+    constexpr int kMore = OKVFE_MATCH_MORE;
+    uint32_t cs[kMore];
+#pragma unroll
+    for (int u = 0; u < kMore; ++u) cs[u] = kNoKey;
     int n_c = 2;
     if (n_scans < 1) {
       if (has_skip)
