@@ -172,6 +172,37 @@ def test_match_stereo_host_buffers(oracle):
     assert nmatch > 20
 
 
+def test_match_stereo_lookalike_content(oracle):
+    """Exact two-level checker cells: hundreds of near-identical descriptors, half a dozen
+    candidates below the threshold per keypoint (up to 15), most of them rejected by the geometric gate -- the regime of
+    the matcher's re-scans (six keys each after the first scan's two), also for matchMotionStereo's
+    twin loop through the same arrays."""
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg)
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    L, R, _ = synth.stereo_pair(cfg.w, cfg.h, 77, cell=12, levels=(0, 255), noise=0, jitter=0)
+    sides = []
+    for ci, img in enumerate((L, R)):
+        cam = cfg.cams[ci]
+        rays, jac = oracle.awareness_maps(cam)
+        k, d = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                      oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.0, 1.0, 0.0))
+        bp, bv = oracle.backproject_keypoints(cam, k)
+        sides.append((k, d, bp, bv))
+    (k0, d0, b0, v0), (k1, d1, b1, v1) = sides
+    assert len(k0) > 400 and len(k1) > 400
+    # candidates below the threshold per keypoint: the re-scan regime is really entered
+    dist = np.unpackbits(d0[:64, None, :] ^ d1[None, :, :], axis=2).sum(axis=2)
+    assert np.median((dist < cfg.match_threshold).sum(axis=1)) >= 5
+    ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1, cfg.match_threshold)
+    got = fe.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1)
+    for f in ("k1", "dist", "initialisable"):
+        assert np.array_equal(got[f], ref[f]), f
+    assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
+
+
 def test_stereo_pipeline_device_resident(oracle):
     """detect+describe of a stereo batch and matchStereo, all outputs resident in HBM."""
     cfg = synth.euroc_config()
