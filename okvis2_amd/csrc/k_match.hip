@@ -286,7 +286,7 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   while (__any(!done)) {
     // the two smallest admissible keys of the segment in one scan: a rejected best candidate
     // usually has its successor at hand, so the tail of the kernel is not set by re-scans.  A lane
-    // that is still undecided after them sits in look-alike content (repetitive texture: dozens of
+    // that is still undecided after them sits in look-alike content (repetitive texture: 5-15
     // candidates below the threshold, most of them rejected by the gate): every further scan then
     // brings SIX keys (insertion costs 5 min/max pairs more per descriptor, a re-scan 24 + 7)
     constexpr int kMore = OKVFE_MATCH_MORE;
