@@ -37,6 +37,7 @@ struct okvfe_ctx {
   int32_t* d_map_perm = nullptr;  // okvfe_match_to_map_blocks_device: keypoint order per frame [frames][kp_cap]
   size_t map_perm_frames = 0;  // scale-space parent, OKVFE_SCORE_BRISK_SCALESPACE: FAST 5-8 map of layer 0
   ScoreLayout score_layout{0, 0};  // of d_scores: slotted where the fused score+NMS kernel applies
+  ScoreLayout live_layout{0, 0};   // the layout the LAST score launch actually wrote (dense when the fused kernel refused the call)
   Candidate* d_cand = nullptr;
   int32_t* d_cand_count = nullptr;
   uint64_t* d_sort_ws = nullptr;
@@ -534,6 +535,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
       // AGAST score maps and maps of the unfused fall-back are dense; the fused Harris kernel
       // writes its slotted layout (okvfe_internal.h)
       c->score_layout = cfg->score_type == OKVFE_SCORE_HARRIS ? harris_nms_layout(c->w, c->h) : ScoreLayout{c->w, 0};
+      c->live_layout = c->score_layout;
       A(d_scores, (size_t)c->score_layout.pitch * c->h * B);
       A(d_cand, (size_t)c->cand_cap * B);
       A(d_cand_count, 2 * B + (size_t)kFixListCap * B);  // candidate counts, fix-up counts, fix-up lists
@@ -840,6 +842,7 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
   if (L->cfg.score_type != OKVFE_SCORE_HARRIS) {  // AGAST score map only; the stand-alone NMS follows
     launch_agast_score(images_dev, L->w, L->h, n_images, L->d_scores, s);
     *fused = false;
+    L->live_layout = L->score_layout;
     return;
   }
   // a slotted score layout exists only where the fused kernel applies (decided at creation)
@@ -848,11 +851,14 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
                              L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count,
                              L->d_cand_count + 2 * (size_t)L->B, s);
   if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
+  // the unfused pair writes and reads a dense map (pitch w) into the same buffer: every later
+  // reader of this call (selection, scale filter, okvfe_get_device_outputs) must follow it
+  L->live_layout = *fused ? L->score_layout : ScoreLayout{L->w, 0};
 }
 void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
   int32_t* d_fix_count = L->d_cand_count + L->B;
   if (fused)
-    launch_nms_fixup(L->d_scores, L->score_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
+    launch_nms_fixup(L->d_scores, L->live_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
                      L->d_cand_count, d_fix_count, L->d_cand_count + 2 * (size_t)L->B, s);
   else
     launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
@@ -867,7 +873,7 @@ void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
   const DescribeSetup setup{L->d_pattern, L->d_prm, L->d_rays_ptrs, L->d_jac_ptrs, L->d_kps_tmp, L->d_desc_tmp,
                             L->d_valid_tmp, L->d_scales};
   const bool fuse = L->fuse_setup && L->n_layers == 1 && L->d_pattern && L->d_kps_tmp && L->d_prm;
-  L->setup_done = launch_select(L->d_scores, L->score_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
+  L->setup_done = launch_select(L->d_scores, L->live_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
                                 L->d_cand_count, L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ,
                                 L->occ_image_bytes, L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count,
                                 L->d_sort_ws, s, fuse ? &setup : nullptr);
@@ -879,6 +885,7 @@ void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
 okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
   TokenScope token;
   okvfe_status st;
+  ctx->setup_done = false;  // set by this call's selection launch only (a failed earlier call must not leak it)
   if (ctx->n_layers == 1) {
     if (!ctx->counters_cleared)  // (cleared together with the parameter upload of the same call otherwise)
       HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
@@ -946,9 +953,9 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
             while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
           out[0] = rn; out[1] = rd;
         };
-        if (l > 0) { below = ctx->layers[l - 1]->d_scores; lb = ctx->layers[l - 1]->score_layout; ratio(l - 1, rb); }
+        if (l > 0) { below = ctx->layers[l - 1]->d_scores; lb = ctx->layers[l - 1]->live_layout; ratio(l - 1, rb); }
         if (l == 0 && ctx->d_virtual) { below = ctx->d_virtual; lb = ScoreLayout{ctx->layer_w[0], 0}; }  // same grid: ratio 1
-        if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; la = ctx->layers[l + 1]->score_layout; ratio(l + 1, ra); }
+        if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; la = ctx->layers[l + 1]->live_layout; ratio(l + 1, ra); }
         launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below, lb,
                             l > 0 ? ctx->layer_w[l - 1] : (below ? ctx->layer_w[0] : 0),
                             l > 0 ? ctx->layer_h[l - 1] : (below ? ctx->layer_h[0] : 0), rb[0], rb[1], above, la,
@@ -1043,14 +1050,15 @@ okvfe_status find_overflow(okvfe_ctx* ctx, int first, int n_images, int* bad, in
 okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
   const int w = ctx->w, h = ctx->h;
   TokenScope token;
+  const bool setup_done = ctx->setup_done;  // consumed here, whatever happens below
+  ctx->setup_done = false;
   okvfe_status st = heavy_begin(ctx, s, 1, &token);
   if (st != OKVFE_OK) return st;
   {
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
-                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, ctx->setup_done);
-    ctx->setup_done = false;
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done);
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -1109,7 +1117,11 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
   ctx->fuse_setup = !no_fuse;
   st = detect_stage(ctx, images_dev, n_images, s);
   ctx->fuse_setup = false;
-  if (st != OKVFE_OK) return st;
+  if (st != OKVFE_OK) {
+    ctx->setup_done = false;
+    ctx->detected_images = 0;
+    return st;
+  }
   ctx->detected_images = n_images;
   return describe_stage(ctx, images_dev, n_images, s);
 }
@@ -1164,7 +1176,11 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
   ctx->fuse_setup = getenv("OKVFE_NO_FUSED_SETUP") == nullptr;
   st = detect_stage(ctx, ctx->d_feed[slot], n_images, s);
   ctx->fuse_setup = false;
-  if (st != OKVFE_OK) return st;
+  if (st != OKVFE_OK) {
+    ctx->setup_done = false;
+    ctx->detected_images = 0;
+    return st;
+  }
   ctx->detected_images = n_images;
   if ((st = describe_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
   HIP_TRY(ctx, hipEventRecord(ctx->feed_consumed[slot], s));
@@ -1183,15 +1199,17 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
   out->scores = ctx->d_scores;
   out->detect_counts = ctx->d_det_count;
   out->candidate_counts = ctx->d_cand_count;
-  out->score_pitch = ctx->score_layout.pitch;
-  out->score_strips = ctx->score_layout.strips;
+  // the layout of the LAST batch's map (dense if that call took the unfused score + NMS kernels)
+  const ScoreLayout& sl = ctx->n_layers > 1 ? ctx->layers[0]->live_layout : ctx->live_layout;
+  out->score_pitch = sl.pitch;
+  out->score_strips = sl.strips;
   return OKVFE_OK;
 }
 
 int32_t okvfe_scale_index(float keypoint_size) { return pattern_scale_index(keypoint_size); }
 
 int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x) {
-  return ctx ? score_col(ctx->score_layout, x) : x;
+  return ctx ? score_col(ctx->n_layers > 1 ? ctx->layers[0]->live_layout : ctx->live_layout, x) : x;
 }
 
 okvfe_status okvfe_check_capacity(okvfe_ctx* ctx, int32_t n_images, int32_t* first_overflowed) {

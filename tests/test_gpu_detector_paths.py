@@ -545,3 +545,51 @@ def test_byte_mover_diagnostic(oracle):
         G.assert_keypoints_equal(got, ref)
     with pytest.raises(capi.OkvfeError):
         G.make_frontend(cfg, score_type=capi.SCORE_AGAST_9_16).harris_byte_mover_device(d_img.data_ptr(), 1)
+
+
+def test_unaligned_image_pointer_takes_the_dense_fallback(oracle):
+    """a batch whose device pointer is not dword aligned is refused by the fused
+    score+NMS kernel at RUN time; the unfused pair then writes a dense map into the buffer whose
+    layout was chosen slotted at creation.  Selection / sub-pixel / okvfe_get_device_outputs must
+    follow the layout that was actually written -- and switch back on the next aligned call."""
+    cfg = synth.euroc_config()
+    fe = G.make_frontend(cfg, max_batch=2)
+    fe.set_camera(0, cfg.cams[0])
+    fe.set_camera(1, cfg.cams[1])
+    imgs = np.stack([G.image_for(cfg, 61), G.image_for(cfg, 62)])
+    P = cfg.w * cfg.h
+    buf = torch.zeros(2 * P + 8, dtype=torch.uint8, device="cuda")
+    grav = np.tile(np.array([0.0, 1.0, 0.0], np.float32), (2, 1))
+    cams = np.array([0, 1], np.int32)
+    stream = torch.cuda.current_stream().cuda_stream
+    want = []
+    for ci in range(2):
+        rays, jac = oracle.awareness_maps(cfg.cams[ci])
+        want.append(oracle.detect_describe(imgs[ci], cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                           oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cfg.cams[ci].fu),
+                                           (0.0, 1.0, 0.0)))
+    for off, strips_expected in ((1, 0), (0, None), (3, 0), (4, None)):
+        buf[off:off + 2 * P] = torch.from_numpy(imgs.reshape(-1)).cuda()
+        fe.detect_describe_batch_device(buf.data_ptr() + off, 2, cams, grav, stream)
+        torch.cuda.synchronize()
+        out = fe.device_outputs()
+        if strips_expected is not None:
+            assert out.score_strips == strips_expected and out.score_pitch == cfg.w
+        else:
+            assert out.score_strips >= 1 and out.score_pitch > cfg.w
+        for ci in range(2):
+            k, d, _, _ = fe.download(ci)
+            G.assert_keypoints_equal(k, want[ci][0])
+            assert np.array_equal(d, want[ci][1])
+        # the score map read through the reported layout equals the oracle's
+        sc = oracle.harris_score(imgs[1])
+        pitch = out.score_pitch
+        import ctypes
+        host = np.empty(2 * cfg.h * pitch, dtype=np.int32)
+        st = capi.lib().okvfe_copy_to_host(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(out.scores),
+                                           ctypes.c_size_t(host.nbytes), None)
+        assert st == 0
+        m = host.reshape(2, cfg.h, pitch)[1]
+        cols = np.array([capi.lib().okvfe_score_column(fe._h, int(x)) for x in range(cfg.w)])
+        inner = np.s_[3:cfg.h - 3, 3:cfg.w - 3]
+        assert np.array_equal(m[:, cols][inner], sc[inner])
