@@ -273,17 +273,11 @@ def run_map_workload(args, torch, capi, synth, dev):
     st.synchronize()
     torch.cuda.synchronize()
     steps = args.steps
-    while True:
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        st.synchronize()
-        elapsed = time.perf_counter() - t0
-        if elapsed >= MIN_TIMED_S or args.exact_steps:
-            break
-        steps *= int(math.ceil(MIN_TIMED_S / max(elapsed, 1e-6))) + 1
-        fe.profile_enable(False)
-        fe.profile_enable(True, stages=("map",))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    st.synchronize()
+    elapsed = time.perf_counter() - t0
     ms, cnt = fe.profile_read()["map"]
     launch_ms = ms / cnt
     lm = d_lm.cpu().numpy()
@@ -295,7 +289,7 @@ def run_map_workload(args, torch, capi, synth, dev):
     res = {
         "metric": "map-matcher frames/s (matchToMapByThread, 5000 pooled landmarks x 700 keypoints)",
         "value": B * steps / elapsed, "unit": "frames/s", "n_gpus": 1, "steps": steps,
-        "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8 (Hamming) + f64 (reprojection gate)", "data": "synthetic",
         "config": {"workload": "Frontend::matchToMapByThread (Frontend.cpp:1552-1589) on device-resident data: "
@@ -318,6 +312,133 @@ def run_map_workload(args, torch, capi, synth, dev):
                              "wave is near, so most of its time is the FP64 radius test over K x L, not popcounts; "
                              "peak = 12 x (v_xor + v_bcnt) per pair at the measured VALU issue rates"},
     }
+    return res
+
+
+
+def batch_sweep(cfg, capi, torch, dev, local_rank, base, max_candidates, budget_s=0.35):
+    """the hot path at B in {1, 16, 256} stereo frames per call.  The reference's
+    seams are B = 1 calls; the batch entry points amortise launches over B frames.  Per B, device-
+    and host-fed: `pipelined` = calls enqueued back to back on one stream (throughput), `latency_ms`
+    = one call with a host synchronisation after it (what a caller waiting for the result sees)."""
+    C = len(cfg.cams)
+    out = {}
+    n_distinct = len(base) // C
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[min(1, C - 1)].fu + cfg.cams[min(1, C - 1)].fv)
+    for B in (1, 16, 256):
+        fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold, cfg.max_kpts,
+                           match_threshold=cfg.match_threshold, max_batch=C * B, num_cameras=C,
+                           device=local_rank, max_candidates=max_candidates)
+        for ci, cam in enumerate(cfg.cams):
+            fe.set_camera(ci, cam)
+        imgs = np.concatenate([base] * ((B + n_distinct - 1) // n_distinct))[:C * B]
+        d_img = torch.from_numpy(imgs).to(dev)
+        h_img = torch.from_numpy(imgs).pin_memory()
+        d_match = torch.zeros((B, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        cam_ids = np.array(list(range(C)) * B, dtype=np.int32)
+        grav = gravity_variant(0, C * B)
+        T0, T1 = pose_variant(cfg, 0)
+        pairs = []
+        for i in range(B):
+            sp = capi.StereoPair()
+            sp.image0, sp.image1 = C * i, C * i + (1 if C > 1 else 0)
+            sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
+            sp.f0, sp.f1 = f0, f1
+            pairs.append(sp)
+        pairs = (capi.StereoPair * B)(*pairs)
+        st = torch.cuda.Stream(device=dev)
+
+        def call(feed):
+            if feed == "host":
+                fe.detect_describe_batch_host(h_img.data_ptr(), C * B, cam_ids, grav, st)
+            else:
+                fe.detect_describe_batch_device(d_img.data_ptr(), C * B, cam_ids, grav, st)
+            if C > 1:
+                fe.match_stereo_batch_device(pairs, d_match.data_ptr(), st)
+
+        row = {}
+        for feed in ("device", "host"):
+            for _ in range(3):
+                call(feed)
+            st.synchronize()
+            # pipelined
+            n = 4
+            while True:
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    call(feed)
+                st.synchronize()
+                el = time.perf_counter() - t0
+                if el >= budget_s or n >= 1 << 14:
+                    break
+                n *= 4
+            # one call at a time
+            lat = []
+            t_end = time.perf_counter() + budget_s
+            while time.perf_counter() < t_end or len(lat) < 5:
+                t0 = time.perf_counter()
+                call(feed)
+                st.synchronize()
+                lat.append(time.perf_counter() - t0)
+            lat.sort()
+            row[feed] = {"pipelined_frames_per_s": B * n / el, "pipelined_ms_per_call": 1e3 * el / n,
+                         "latency_ms_median": 1e3 * lat[len(lat) // 2], "latency_ms_p90": 1e3 * lat[(len(lat) * 9) // 10],
+                         "calls_timed": n, "latency_calls": len(lat)}
+        fe.check_capacity(C * B)
+        out[str(B)] = row
+        fe.close()
+        del d_img, h_img, d_match
+    out["note"] = ("B = stereo frames per okvfe_detect_describe_batch_* + okvfe_match_stereo_batch_device call pair; "
+                   "pipelined = calls back to back on one stream, latency = host waits for every call; host = images "
+                   "cross PCIe from pinned memory in the call")
+    return out
+
+
+def latency_b1(cfg, base, n_frames=8, iters=300, warmup=30):
+    """B = 1 latency through the C++ seams (tests/cpp/latency_cli.cpp): okvfe::HipViFrontend::
+    detectAndDescribe with one thread per camera as ThreadedSlam.cpp:434-448 runs it, then matchStereo;
+    the cv::Feature2D adapters (Frame::detect + Frame::describe); HipFrontend over the C ABI."""
+    import struct
+    import subprocess
+    import tempfile
+    from okvis2_amd import synth
+    exe = os.path.join(ROOT, "tests", "cpp", "latency_cli")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "tests", "mock"),
+                               "-o", exe, exe + ".cpp", "-L" + os.path.join(ROOT, "okvis2_amd"), "-lokvfe",
+                               "-Wl,-rpath," + os.path.join(ROOT, "okvis2_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    C = len(cfg.cams)
+    n_frames = min(n_frames, len(base) // C)
+    T = synth.stereo_poses(cfg.baseline)
+    # camera y axis = world -z: the extraction direction T_WC^-1 (0,0,-1) is (0, 1, 0)
+    Cm = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]])
+    with tempfile.NamedTemporaryFile(suffix=".req", delete=False) as f:
+        f.write(struct.pack("<5i", cfg.w, cfg.h, n_frames, iters, warmup))
+        f.write(struct.pack("<f3i", cfg.uniformity_radius, cfg.abs_threshold, cfg.match_threshold, cfg.max_kpts))
+        for c in range(2):
+            cam = cfg.cams[c]
+            f.write(struct.pack("<4d", cam.fu, cam.fv, cam.cu, cam.cv))
+            f.write(struct.pack("<i", cam.dist_type))
+            f.write(struct.pack("<4d", *cam.d))
+            f.write(struct.pack("<9d", *Cm.reshape(-1)))
+            f.write(struct.pack("<3d", *T[c][1]))
+        for i in range(n_frames):
+            for c in range(2):
+                f.write(np.ascontiguousarray(base[C * i + c]).tobytes())
+        path = f.name
+    try:
+        p = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+        if p.returncode != 0:
+            return {"error": f"latency_cli rc {p.returncode}: {p.stderr[-300:]}"}
+        res = json.loads(p.stdout.strip().splitlines()[-1])
+    finally:
+        os.unlink(path)
+    res["note"] = ("one stereo frame per iteration, wall clock on the host: vi = HipViFrontend::detectAndDescribe "
+                   "(std::thread per camera >= 1 as ThreadedSlam.cpp:434-448, mock OKVIS2/OpenCV containers) + "
+                   "HipFrontend::matchStereo on the GPU's outputs; cv = cv::FeatureDetector::detect + "
+                   "cv::DescriptorExtractor::compute per camera (Frame.hpp:152,167); hipfrontend = detect+describe "
+                   "of both cameras through the C ABI")
     return res
 
 
@@ -443,7 +564,8 @@ def run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="steps of the timed region, timed EXACTLY; without the flag: 340 (about 0.5 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=768, help="stereo frames per step per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
@@ -454,8 +576,8 @@ def main():
                          "latency-bound kernels of one lane hide behind the score kernel of "
                          "another, but the score kernel then shares the GPU while it is being timed")
     ap.add_argument("--stagger", type=int, default=1,
-                    help="with --lanes > 1: serialise the score kernels of the lanes (library env "
-                         "OKVFE_SCORE_TOKEN) so that the lanes run out of phase")
+                    help="with --lanes > 1: serialise the score kernels of the lanes (okvfe_set_heavy_kernel_chaining "
+                         "mode 1) so that the lanes run out of phase")
     ap.add_argument("--map-radius", type=float, default=20.0,
                     help="--workload map: reprojection threshold in px (20 with IMU, 150 without; Frontend.cpp:1530)")
     ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640", "map"), default="euroc",
@@ -475,8 +597,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed / dense-content legs")
     ap.add_argument("--exact-steps", action="store_true",
-                    help="time exactly --steps steps (default: repeat them until the region lasts 0.5 s)")
+                    help="skip the informational `long_region` leg (the timed region is always exactly --steps)")
     args = ap.parse_args()
+    steps_flag = args.steps is not None
+    if args.steps is None:
+        args.steps = 340 if args.workload == "euroc" else 100
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
@@ -485,10 +610,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...)")
-    if args.lanes > 1 and args.stagger:
-        os.environ["OKVFE_SCORE_TOKEN"] = "1"  # read by libokvfe.so at its first batch call
     import torch
     from okvis2_amd import capi, synth
+    if args.lanes > 1 and args.stagger:
+        capi.set_heavy_kernel_chaining(1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -619,6 +744,12 @@ def main():
     if args.feed == "host":
         ensure_pinned()
     torch.cuda.synchronize()  # allocations / fills above ran on torch's default stream
+    # clock ramp: a box that sat idle while the inputs were generated runs its first tens of
+    # milliseconds below its sustained clocks; untimed, before the W warm-up steps of the contract
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.3:
+        step(args.feed)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(args.feed)
     torch.cuda.synchronize()
@@ -634,18 +765,19 @@ def main():
     # the full per-stage breakdown is taken in a short extra pass after the timed region
     for lane in lanes:
         lane[0].profile_enable(True, stages=("harris",))
-    # the timed region is args.steps steps, repeated in ONE barrier-bracketed region until it lasts at
-    # least MIN_TIMED_S (a 34 ms region cannot resolve a 2 % change): `steps` of the JSON line = the
-    # steps actually timed, `steps_requested` = the command line's
+    # the timed region is EXACTLY args.steps steps (the contract).  A region shorter than
+    # MIN_TIMED_S cannot resolve a 2 % change, so a second, longer region is timed as well and
+    # reported beside it as `long_region` -- `value` always comes from the requested steps.
     elapsed, last_v = timed(args.steps, args.feed)
     steps_timed = args.steps
-    if elapsed < MIN_TIMED_S and not args.exact_steps:
+    long_region = None
+    if elapsed < MIN_TIMED_S and not args.exact_steps and steps_flag:
         reps = int(math.ceil(MIN_TIMED_S / max(elapsed, 1e-6)))
-        for lane in lanes:  # restart the stage events: the roofline averages the region that counts
-            lane[0].profile_enable(False)
-            lane[0].profile_enable(True, stages=("harris",))
-        steps_timed = args.steps * reps
-        elapsed, last_v = timed(steps_timed, args.feed)
+        el_long, last_v = timed(args.steps * reps, args.feed)
+        long_region = {"steps": args.steps * reps, "ms_per_step": 1e3 * el_long / (args.steps * reps),
+                       "value": world * B * args.steps * reps / el_long,
+                       "note": "the same step repeated until the region lasts >= 0.5 s (a %.0f ms region is "
+                               "noisier); informational, `value` is the requested region" % (1e3 * elapsed)}
     # capacity check of EVERY image of every lane (outside the timed region): an overflowed NMS
     # candidate list would have left that image without keypoints
     for lane in lanes:
@@ -772,6 +904,12 @@ def main():
                 "mean_keypoints_per_image": kp_d / max(1, min(n_img, C * distinct)),
                 "note": "exact two-level checker cells: tied maxima all pass the uniformity stage, "
                         "the stereo matcher works on ~700 x 700 descriptors per frame"}
+        # (3) SURVEY.md 8 D2: B in {1, 16, 256} through the batch entry points, and the B = 1 latency of
+        # the C++ seams (rank 0 of a single-GPU run only: other ranks would share the host)
+        if rank == 0 and world == 1 and C == 2:
+            torch.cuda.synchronize()
+            extras["batch_sweep"] = batch_sweep(cfg, capi, torch, dev, local_rank, base, args.max_candidates)
+            extras["latency_b1"] = latency_b1(cfg, base)
 
     if rank == 0:
         P = cfg.w * cfg.h
@@ -787,7 +925,6 @@ def main():
             "unit": unit,
             "n_gpus": world,
             "steps": steps_timed,
-            "steps_requested": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps_timed,
             "higher_is_better": True,
@@ -839,6 +976,8 @@ def main():
                              "the roofline comes from the timed region itself",
         }
         result.update(extras)
+        if long_region is not None:
+            result["long_region"] = long_region
         # the less favourable legs next to `value`, at the top level
         result["value_dense"] = extras.get("dense_content", {}).get("value")
         result["value_host_fed"] = extras.get("host_fed", {}).get("value")

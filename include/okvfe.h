@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define OKVFE_ABI_VERSION 3
+#define OKVFE_ABI_VERSION 4
 #define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
@@ -231,6 +231,15 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
 /* Column of pixel x within a row of okvfe_device_outputs.scores (x itself for dense maps).  For a
  * dense copy of the score map use okvfe_harris_score_device. */
 int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x);
+
+/* Several contexts fed in turn from several host threads / streams on ONE GPU (a camera per context,
+ * ThreadedSlam.cpp:434-448): mode 1 runs the score kernels of all contexts of the process on a device
+ * one after the other in enqueue order while everything downstream of them overlaps freely, so the
+ * VALU-bound score kernel of one context runs beside the latency-bound selection / matching of
+ * another instead of beside another score kernel; mode 2 also chains the descriptor kernels; 0 (the
+ * default) = off.  Process-wide, takes effect for calls enqueued afterwards.  (The library reads no
+ * environment variable.) */
+okvfe_status okvfe_set_heavy_kernel_chaining(int32_t mode);
 
 /* Scale index of the scale-invariant extractor (brisk::BriskDescriptorExtractor(rotInv, scaleInv =
  * true), Frontend.cpp:2410-2412) for a keypoint of diameter `size`, published BRISK:

@@ -1,0 +1,636 @@
+// capi_detect.cpp -- detector / extractor pipeline behind the C ABI: score map + NMS, sort,
+// uniformity selection, sub-pixel, descriptors, compaction + FP64 back-projection; the batch entry
+// points (device- and host-fed) and the single-image host-buffer calls that stand behind
+// cv::FeatureDetector::detect / cv::DescriptorExtractor::compute (Frame.hpp:152,167) and
+// Frontend::detectAndDescribe (Frontend.cpp:221-269).
+#include "okvfe_ctx.h"
+
+using namespace okvfe;
+
+extern "C" {
+
+okvfe_status okvfe_harris_score_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                       int32_t* scores_dev, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || !scores_dev || n_images < 0)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_harris_score_device: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  {
+    hipStream_t s = pick_stream(ctx, stream);
+    StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+    if (ctx->cfg.score_type != OKVFE_SCORE_HARRIS)
+      launch_agast_score(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
+    else
+      launch_harris(images_dev, ctx->w, ctx->h, n_images, scores_dev, s);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_harris_byte_mover_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                            void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 0 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_harris_byte_mover_device: bad argument");
+  if (ctx->cfg.score_type != OKVFE_SCORE_HARRIS || !ctx->d_scores || ctx->score_layout.strips < 1)
+    return fail(ctx, OKVFE_ERR_UNSUPPORTED, "okvfe_harris_byte_mover_device: the fused score kernel does not apply to this context");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  bool ok;
+  {
+    StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+    ok = launch_harris_byte_mover(images_dev, ctx->w, ctx->h, n_images, ctx->d_scores, ctx->score_layout, s);
+  }
+  if (!ok) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "okvfe_harris_byte_mover_device: image base or width not dword aligned");
+  HIP_TRY(ctx, hipGetLastError());
+  return OKVFE_OK;
+}
+
+static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int32_t* cam_ids,
+                                        const float* gravity, hipStream_t s, bool before_detect = false) {
+  std::vector<ImageParams> prm(n_images);
+  ctx->wide_patches = false;
+  for (int i = 0; i < n_images; ++i) {
+    ImageParams& p = prm[i];
+    p.cam = cam_ids ? cam_ids[i] : -1;
+    if (p.cam >= ctx->cfg.num_cameras)
+      return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "camera id %d out of range", p.cam);
+    const bool aware = gravity != nullptr && p.cam >= 0;
+    if (aware) {
+      if (!ctx->cam_rays[p.cam])
+        return fail(ctx, OKVFE_ERR_NOT_READY,
+                    "camera-aware extraction requested for camera %d before okvfe_set_camera[_maps]", p.cam);
+      p.mode = kCameraAware;
+      p.dir[0] = gravity[3 * i];
+      p.dir[1] = gravity[3 * i + 1];
+      p.dir[2] = gravity[3 * i + 2];
+      p.fu = ctx->cam_fu[p.cam];
+      if (ctx->cam_wide[p.cam]) ctx->wide_patches = true;
+    } else {
+      p.mode = ctx->mode_default;
+      p.dir[0] = 0.0f; p.dir[1] = 1.0f; p.dir[2] = 0.0f;
+      p.fu = 1.0f;
+    }
+    if (p.cam >= 0 && !ctx->cam_has_intrinsics[p.cam]) p.cam = aware ? p.cam : -1;
+  }
+  // intrinsics are needed for back-projection; a slot with maps only (set_camera_maps) keeps its
+  // cam id for the maps and gets invalid back-projections (DeviceCamera zeroed -> fu = 0)
+  void* d = nullptr;
+  // (single-scale detector: its candidate / fix-up counters are cleared by the same launch)
+  ctx->counters_cleared = false;
+  okvfe_status st = ring_upload(ctx, &ctx->prm_ring, prm.data(), n_images * sizeof(ImageParams), s, &d,
+                                &ctx->prm_slot, before_detect && ctx->n_layers == 1 ? ctx->d_cand_count : nullptr,
+                                before_detect && ctx->n_layers == 1 && ctx->d_cand_count ? 2 * ctx->B : 0,
+                                &ctx->counters_cleared);
+  if (st != OKVFE_OK) return st;
+  ctx->d_prm = static_cast<ImageParams*>(d);
+  return OKVFE_OK;
+}
+
+// ---- batch pipeline ----------------------------------------------------------------------------
+// OKVFE_SCORE_TOKEN: see g_score_token.
+namespace {
+// The token mutex is held from the wait on the previous holder's event to the record of this
+// launch's event, so two host threads can never chain on the same predecessor.
+struct TokenScope {
+  std::unique_lock<std::mutex> lock;
+  bool on = false;
+};
+okvfe_status heavy_begin(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) {
+  t->on = score_token_mode() > which && ctx->cfg.device >= 0 && ctx->cfg.device < kMaxTokenDevices;
+  if (!t->on) return OKVFE_OK;
+  t->lock = std::unique_lock<std::mutex>(g_token_mutex);
+  hipEvent_t prev = g_score_token[ctx->cfg.device];
+  if (prev) HIP_TRY(ctx, hipStreamWaitEvent(s, prev, 0));
+  return OKVFE_OK;
+}
+okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) {
+  if (!t->on) return OKVFE_OK;
+  hipEvent_t& ev = ctx->heavy_done[which];
+  if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventRecord(ev, s));
+  g_score_token[ctx->cfg.device] = ev;
+  t->lock.unlock();
+  return OKVFE_OK;
+}
+
+// K1 + K2 of one layer context `L` (score map + NMS candidates), launched for `owner`
+void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipStream_t s, bool* fused) {
+  int32_t* d_fix_count = L->d_cand_count + L->B;  // [0, B) candidate counts, [B, 2B) flagged counts
+  if (L->cfg.score_type != OKVFE_SCORE_HARRIS) {  // AGAST score map only; the stand-alone NMS follows
+    launch_agast_score(images_dev, L->w, L->h, n_images, L->d_scores, s);
+    *fused = false;
+    L->live_layout = L->score_layout;
+    return;
+  }
+  // a slotted score layout exists only where the fused kernel applies (decided at creation)
+  *fused = L->score_layout.strips >= 1 &&
+           launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->score_layout,
+                             L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count,
+                             L->d_cand_count + 2 * (size_t)L->B, s);
+  if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
+  // the unfused pair writes and reads a dense map (pitch w) into the same buffer: every later
+  // reader of this call (selection, scale filter, okvfe_get_device_outputs) must follow it
+  L->live_layout = *fused ? L->score_layout : ScoreLayout{L->w, 0};
+}
+void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
+  int32_t* d_fix_count = L->d_cand_count + L->B;
+  if (fused)
+    launch_nms_fixup(L->d_scores, L->live_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
+                     L->d_cand_count, d_fix_count, L->d_cand_count + 2 * (size_t)L->B, s);
+  else
+    launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
+               L->d_cand_count, s);
+}
+void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
+  launch_sort(L->d_cand, L->cand_cap, L->d_cand_count, n_images, L->cfg.uniformity_radius, L->d_sort_ws, s);
+}
+void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
+  // detection + description in one call (single scale): the selection kernel also prepares the
+  // extractor's per-keypoint inputs (describe_setup_dev.h)
+  const DescribeSetup setup{L->d_pattern, L->d_prm, L->d_rays_ptrs, L->d_jac_ptrs, L->d_kps_tmp, L->d_desc_tmp,
+                            L->d_valid_tmp, L->d_scales};
+  const bool fuse = L->fuse_setup && L->n_layers == 1 && L->d_pattern && L->d_kps_tmp && L->d_prm;
+  L->setup_done = launch_select(L->d_scores, L->live_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
+                                L->d_cand_count, L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ,
+                                L->occ_image_bytes, L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count,
+                                L->d_sort_ws, s, fuse ? &setup : nullptr);
+}
+
+// K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count.
+// octaves > 0: the same per layer of the scale space (k_pyramid.hip), with the cross-layer maximum
+// test between NMS and selection and the merge into image coordinates at the end.
+okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
+  TokenScope token;
+  okvfe_status st;
+  ctx->setup_done = false;  // set by this call's selection launch only (a failed earlier call must not leak it)
+  if (ctx->n_layers == 1) {
+    if (!ctx->counters_cleared)  // (cleared together with the parameter upload of the same call otherwise)
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+    ctx->counters_cleared = false;
+    if ((st = heavy_begin(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    bool fused;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+      layer_score_nms(ctx, images_dev, n_images, s, &fused);
+    }
+    if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_NMS, s);
+      layer_nms_finish(ctx, n_images, s, fused);
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SORT, s);
+      layer_sort(ctx, n_images, s);
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
+      layer_select(ctx, n_images, s);
+    }
+  } else {
+    const int L = ctx->n_layers;
+    std::vector<const uint8_t*> img(L);
+    std::vector<bool> fused(L);
+    img[0] = images_dev;
+    if ((st = heavy_begin(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
+      for (int l = 1; l < L; ++l) {
+        if (l == 1)
+          launch_twothird(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_layer_img[1], s);
+        else
+          launch_halfsample(img[l - 2], ctx->layer_w[l - 2], ctx->layer_h[l - 2], n_images, ctx->d_layer_img[l], s);
+        img[l] = ctx->d_layer_img[l];
+      }
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        HIP_TRY(ctx, hipMemsetAsync(ch->d_cand_count, 0, 2 * (size_t)ch->B * sizeof(int32_t), s));
+        bool f;
+        layer_score_nms(ch, img[l], n_images, s, &f);
+        fused[l] = f;
+      }
+      if (ctx->d_virtual) launch_fast58_score(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_virtual, s);
+    }
+    if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_NMS, s);
+      for (int l = 0; l < L; ++l) layer_nms_finish(ctx->layers[l], n_images, s, fused[l]);
+      // scale-space maxima: every layer against the finished score maps below and above
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        int sn, sd;
+        layer_scale(l, &sn, &sd);
+        const int32_t *below = nullptr, *above = nullptr;
+        ScoreLayout lb{0, 0}, la{0, 0};
+        int rb[2] = {1, 1}, ra[2] = {1, 1};
+        auto ratio = [&](int m, int out[2]) {  // scale_l / scale_m, reduced
+          int mn, md;
+          layer_scale(m, &mn, &md);
+          int rn = sn * md, rd = sd * mn;
+          for (int g = 2; g <= 3; ++g)
+            while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+          out[0] = rn; out[1] = rd;
+        };
+        if (l > 0) { below = ctx->layers[l - 1]->d_scores; lb = ctx->layers[l - 1]->live_layout; ratio(l - 1, rb); }
+        if (l == 0 && ctx->d_virtual) { below = ctx->d_virtual; lb = ScoreLayout{ctx->layer_w[0], 0}; }  // same grid: ratio 1
+        if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; la = ctx->layers[l + 1]->live_layout; ratio(l + 1, ra); }
+        launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below, lb,
+                            l > 0 ? ctx->layer_w[l - 1] : (below ? ctx->layer_w[0] : 0),
+                            l > 0 ? ctx->layer_h[l - 1] : (below ? ctx->layer_h[0] : 0), rb[0], rb[1], above, la,
+                            l + 1 < L ? ctx->layer_w[l + 1] : 0, l + 1 < L ? ctx->layer_h[l + 1] : 0, ra[0], ra[1], s);
+      }
+    }
+    const bool brisk_ss = ctx->cfg.score_type == OKVFE_SCORE_BRISK_SCALESPACE;
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SORT, s);
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        if (brisk_ss)  // always ordered (score desc, y, x): there is no uniformity radius to switch the sort on
+          launch_sort(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, 1.0f, ch->d_sort_ws, s);
+        else
+          layer_sort(ch, n_images, s);
+      }
+    }
+    {
+      StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
+      for (int l = 0; l < L; ++l) {
+        okvfe_ctx* ch = ctx->layers[l];
+        if (!brisk_ss) {
+          layer_select(ch, n_images, s);
+          continue;
+        }
+        // strongest maxima + continuous scale from the scores of the layers below and above
+        int sn, sd;
+        layer_scale(l, &sn, &sd);
+        auto ratio2 = [&](int m, int out[2]) {
+          int mn, md;
+          layer_scale(m, &mn, &md);
+          int rn = sn * md, rd = sd * mn;
+          for (int g = 2; g <= 3; ++g)
+            while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+          out[0] = rn; out[1] = rd;
+        };
+        int rb2[2] = {1, 1}, ra2[2] = {1, 1};
+        const int32_t* below = l == 0 ? ctx->d_virtual : ctx->layers[l - 1]->d_scores;
+        const int wb = l == 0 ? ctx->layer_w[0] : ctx->layer_w[l - 1], hb = l == 0 ? ctx->layer_h[0] : ctx->layer_h[l - 1];
+        if (l > 0) ratio2(l - 1, rb2);
+        const int32_t* above = l + 1 < L ? ctx->layers[l + 1]->d_scores : nullptr;
+        if (above) ratio2(l + 1, ra2);
+        const double rel_b = (l & 1) ? 2.0 / 3.0 : 0.75, rel_a = (l & 1) ? 4.0 / 3.0 : 1.5;
+        launch_brisk_refine(ch->d_scores, ch->w, ch->h, n_images, ch->cand_cap, ch->d_cand_count, ch->d_sort_ws,
+                            ch->cfg.max_keypoints, below, wb, hb, rb2[0], rb2[1], above,
+                            above ? ctx->layer_w[l + 1] : 0, above ? ctx->layer_h[l + 1] : 0, ra2[0], ra2[1], rel_b,
+                            rel_a, ch->d_kps_det, ch->kp_cap, ch->d_det_count, s);
+      }
+      const okvfe_keypoint* kps[8];
+      const int32_t* counts[8];
+      float scale[8];
+      for (int l = 0; l < L; ++l) {
+        kps[l] = ctx->layers[l]->d_kps_det;
+        counts[l] = ctx->layers[l]->d_det_count;
+        int sn, sd;
+        layer_scale(l, &sn, &sd);
+        scale[l] = (float)sn / (float)sd;
+      }
+      launch_merge_layers(kps, counts, scale, L, ctx->cfg.max_keypoints, n_images, ctx->d_kps_det, ctx->kp_cap,
+                          ctx->d_det_count, s);
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_n_images = n_images;
+  ctx->last_stream = s;
+  return OKVFE_OK;
+}
+
+// first image of the last batch whose NMS candidate list overflowed in any layer (-1 = none);
+// synchronises the last stream
+okvfe_status find_overflow(okvfe_ctx* ctx, int first, int n_images, int* bad, int* count, int* cap) {
+  *bad = -1;
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  std::vector<int32_t> counts(n_images);
+  const int L = ctx->n_layers;
+  for (int l = 0; l < L && *bad < 0; ++l) {
+    okvfe_ctx* lc = L == 1 ? ctx : ctx->layers[l];
+    HIP_TRY(ctx, hipMemcpy(counts.data(), lc->d_cand_count + first, (size_t)n_images * sizeof(int32_t),
+                           hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_images; ++i)
+      if (counts[i] > lc->cand_cap) {
+        *bad = first + i;
+        *count = counts[i];
+        *cap = lc->cand_cap;
+        break;
+      }
+  }
+  return OKVFE_OK;
+}
+
+// K6 + compaction + back-projection of the keypoints detect_stage left in d_kps_det
+okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
+  const int w = ctx->w, h = ctx->h;
+  TokenScope token;
+  const bool setup_done = ctx->setup_done;  // consumed here, whatever happens below
+  ctx->setup_done = false;
+  okvfe_status st = heavy_begin(ctx, s, 1, &token);
+  if (st != OKVFE_OK) return st;
+  {
+    StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
+    launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
+                    ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done);
+  }
+  if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
+  {
+    StageTimer t(ctx, OKVFE_STAGE_COMPACT, s);
+    launch_compact(n_images, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp,
+                   ctx->d_det_count, ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv,
+                   ctx->d_count, s);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_stream = s;
+  const int slot = ctx->prm_slot;
+  ctx->prm_slot = -1;
+  return ring_release(ctx, &ctx->prm_ring, slot, s);  // the ImageParams slot has no reader after this
+}
+}  // namespace
+
+okvfe_status okvfe_detect_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                       void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_batch_device: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  ctx->detected_images = 0;
+  okvfe_status st = detect_stage(ctx, images_dev, n_images, pick_stream(ctx, stream));
+  if (st == OKVFE_OK) ctx->detected_images = n_images;
+  return st;
+}
+
+okvfe_status okvfe_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev, int32_t n_images,
+                                         const int32_t* cam_ids, const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images != ctx->detected_images)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT,
+                "okvfe_describe_batch_device: n_images=%d, but the last okvfe_detect_batch_device "
+                "covered %d", n_images, ctx->detected_images);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s);
+  if (st != OKVFE_OK) return st;
+  return describe_stage(ctx, images_dev, n_images, s);
+}
+
+okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,
+                                                int32_t n_images, const int32_t* cam_ids,
+                                                const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_dev || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_device: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
+  if (st != OKVFE_OK) return st;
+  static const bool no_fuse = lab_env("OKVFE_NO_FUSED_SETUP") != nullptr;  // A/B knob
+  ctx->fuse_setup = !no_fuse;
+  st = detect_stage(ctx, images_dev, n_images, s);
+  ctx->fuse_setup = false;
+  if (st != OKVFE_OK) {
+    ctx->setup_done = false;
+    ctx->detected_images = 0;
+    return st;
+  }
+  ctx->detected_images = n_images;
+  return describe_stage(ctx, images_dev, n_images, s);
+}
+
+okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* images_host, int32_t n_images,
+                                              const int32_t* cam_ids, const float* gravity_C, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!images_host || n_images < 1 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_host: n_images=%d (max_batch %d)",
+                n_images, ctx->B);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  hipStream_t s = pick_stream(ctx, stream);
+  const size_t P = (size_t)ctx->w * ctx->h;
+  if (!ctx->feed_stream) {
+    // the feed state becomes visible only when ALL of it exists: a failed allocation leaves the
+    // context as it was (the next call tries again) instead of a stream without buffers
+    hipStream_t fs = nullptr;
+    uint8_t* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      void* q = nullptr;
+      e = hipMalloc(&q, P * (size_t)ctx->B);
+      buf[i] = static_cast<uint8_t*>(q);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[2 * i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[2 * i + 1], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+      for (hipEvent_t v : ev)
+        if (v) (void)hipEventDestroy(v);
+      for (uint8_t* b : buf)
+        if (b) (void)hipFree(b);
+      if (fs) (void)hipStreamDestroy(fs);
+      HIP_TRY(ctx, e);
+    }
+    for (int i = 0; i < 2; ++i) {
+      ctx->d_feed[i] = buf[i];
+      ctx->feed_copied[i] = ev[2 * i];
+      ctx->feed_consumed[i] = ev[2 * i + 1];
+    }
+    ctx->feed_stream = fs;
+  }
+  const int slot = (int)(ctx->feed_next++ & 1u);
+  // the buffer is rewritten only after the kernels of the batch that used it two calls ago
+  if (ctx->feed_busy[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->feed_stream, ctx->feed_consumed[slot], 0));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_feed[slot], images_host, P * (size_t)n_images, hipMemcpyHostToDevice,
+                              ctx->feed_stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->feed_copied[slot], ctx->feed_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->feed_copied[slot], 0));
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
+  if (st != OKVFE_OK) return st;
+  ctx->fuse_setup = lab_env("OKVFE_NO_FUSED_SETUP") == nullptr;
+  st = detect_stage(ctx, ctx->d_feed[slot], n_images, s);
+  ctx->fuse_setup = false;
+  if (st != OKVFE_OK) {
+    ctx->setup_done = false;
+    ctx->detected_images = 0;
+    return st;
+  }
+  ctx->detected_images = n_images;
+  if ((st = describe_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
+  HIP_TRY(ctx, hipEventRecord(ctx->feed_consumed[slot], s));
+  ctx->feed_busy[slot] = true;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out) {
+  if (!ctx || !out) return OKVFE_ERR_INVALID_ARGUMENT;
+  out->max_keypoints = ctx->kp_cap;
+  out->counts = ctx->d_count;
+  out->keypoints = ctx->d_kps;
+  out->descriptors = ctx->d_desc;
+  out->backproj = ctx->d_bp;
+  out->backproj_valid = ctx->d_bpv;
+  out->scores = ctx->d_scores;
+  out->detect_counts = ctx->d_det_count;
+  out->candidate_counts = ctx->d_cand_count;
+  // the layout of the LAST batch's map (dense if that call took the unfused score + NMS kernels)
+  const ScoreLayout& sl = ctx->n_layers > 1 ? ctx->layers[0]->live_layout : ctx->live_layout;
+  out->score_pitch = sl.pitch;
+  out->score_strips = sl.strips;
+  return OKVFE_OK;
+}
+
+int32_t okvfe_scale_index(float keypoint_size) { return pattern_scale_index(keypoint_size); }
+
+int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x) {
+  return ctx ? score_col(ctx->n_layers > 1 ? ctx->layers[0]->live_layout : ctx->live_layout, x) : x;
+}
+
+okvfe_status okvfe_check_capacity(okvfe_ctx* ctx, int32_t n_images, int32_t* first_overflowed) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (n_images < 0 || n_images > ctx->B)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_check_capacity: n_images=%d (max_batch %d)", n_images, ctx->B);
+  if (first_overflowed) *first_overflowed = -1;
+  if (n_images == 0) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  int bad = -1, count = 0, cap = 0;
+  okvfe_status st = find_overflow(ctx, 0, n_images, &bad, &count, &cap);
+  if (st != OKVFE_OK) return st;
+  if (bad >= 0) {
+    if (first_overflowed) *first_overflowed = bad;
+    return fail(ctx, OKVFE_ERR_CAPACITY,
+                "image %d produced %d NMS maxima, candidate capacity is %d (its keypoint list was left empty)", bad,
+                count, cap);
+  }
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_keypoint* keypoints,
+                                         uint8_t* descriptors, double* backproj,
+                                         uint8_t* backproj_valid, int32_t cap, int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (index < 0 || index >= ctx->last_n_images || !n_out || cap < 0)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_download_image_result: index %d of %d", index,
+                ctx->last_n_images);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
+  int32_t counts[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpy(&counts[0], ctx->d_count + index, sizeof(int32_t), hipMemcpyDeviceToHost));
+  {
+    int bad = -1, cnt = 0, cap_c = 0;
+    okvfe_status st = find_overflow(ctx, index, 1, &bad, &cnt, &cap_c);
+    if (st != OKVFE_OK) return st;
+    if (bad >= 0)
+      return fail(ctx, OKVFE_ERR_CAPACITY, "image %d produced %d NMS maxima, candidate capacity is %d", index, cnt,
+                  cap_c);
+  }
+  const int n = counts[0];
+  *n_out = n;
+  if (n > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+  const size_t off = (size_t)index * ctx->kp_cap;
+  if (n > 0) {
+    if (keypoints)
+      HIP_TRY(ctx, hipMemcpy(keypoints, ctx->d_kps + off, n * sizeof(okvfe_keypoint), hipMemcpyDeviceToHost));
+    if (descriptors)
+      HIP_TRY(ctx, hipMemcpy(descriptors, ctx->d_desc + off * OKVFE_DESC_BYTES, (size_t)n * OKVFE_DESC_BYTES,
+                             hipMemcpyDeviceToHost));
+    if (backproj)
+      HIP_TRY(ctx, hipMemcpy(backproj, ctx->d_bp + off * 3, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (backproj_valid)
+      HIP_TRY(ctx, hipMemcpy(backproj_valid, ctx->d_bpv + off, n, hipMemcpyDeviceToHost));
+  }
+  return OKVFE_OK;
+}
+
+static okvfe_status stage_image(okvfe_ctx* ctx, const uint8_t* image, size_t stride) {
+  const size_t P = (size_t)ctx->w * ctx->h;
+  if (stride < (size_t)ctx->w) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "stride %zu < width %d", stride, ctx->w);
+  okvfe_status st = ensure_pinned(ctx, P);
+  if (st != OKVFE_OK) return st;
+  for (int y = 0; y < ctx->h; ++y) std::memcpy(ctx->h_pinned + (size_t)y * ctx->w, image + (size_t)y * stride, ctx->w);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_img_stage, ctx->h_pinned, P, hipMemcpyHostToDevice, ctx->stream));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_detect_describe(okvfe_ctx* ctx, const uint8_t* image, size_t stride, int32_t cam,
+                                   const float gravity_C[3], okvfe_keypoint* keypoints,
+                                   uint8_t* descriptors, double* backproj, uint8_t* backproj_valid,
+                                   int32_t cap, int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!image || !n_out) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  okvfe_status st = stage_image(ctx, image, stride);
+  if (st != OKVFE_OK) return st;
+  const int32_t cam_id = cam;
+  st = okvfe_detect_describe_batch_device(ctx, ctx->d_img_stage, 1, &cam_id, (cam >= 0) ? gravity_C : nullptr,
+                                          ctx->stream);
+  if (st != OKVFE_OK) return st;
+  return okvfe_download_image_result(ctx, 0, keypoints, descriptors, backproj, backproj_valid, cap, n_out);
+}
+
+okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride, okvfe_keypoint* keypoints,
+                          int32_t cap, int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!image || !n_out) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect: null argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  okvfe_status st = stage_image(ctx, image, stride);
+  if (st != OKVFE_OK) return st;
+  hipStream_t s = ctx->stream;
+  if ((st = detect_stage(ctx, ctx->d_img_stage, 1, s)) != OKVFE_OK) return st;
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  int32_t n = 0;
+  HIP_TRY(ctx, hipMemcpy(&n, ctx->d_det_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  {
+    int bad = -1, cnt = 0, cap_c = 0;
+    if ((st = find_overflow(ctx, 0, 1, &bad, &cnt, &cap_c)) != OKVFE_OK) return st;
+    if (bad >= 0) return fail(ctx, OKVFE_ERR_CAPACITY, "%d NMS maxima, candidate capacity is %d", cnt, cap_c);
+  }
+  *n_out = n;
+  if (n > cap) return fail(ctx, OKVFE_ERR_CAPACITY, "%d keypoints, caller capacity %d", n, cap);
+  if (n > 0 && keypoints)
+    HIP_TRY(ctx, hipMemcpy(keypoints, ctx->d_kps_det, n * sizeof(okvfe_keypoint), hipMemcpyDeviceToHost));
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, int32_t cam,
+                           const float gravity_C[3], okvfe_keypoint* keypoints, int32_t n_in,
+                           uint8_t* descriptors, double* backproj, uint8_t* backproj_valid,
+                           int32_t* n_out) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (!image || !n_out || n_in < 0 || (n_in > 0 && !keypoints))
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_compute: bad argument");
+  if (n_in > ctx->kp_cap)
+    return fail(ctx, OKVFE_ERR_CAPACITY, "okvfe_compute: %d keypoints exceed max_keypoints %d", n_in, ctx->kp_cap);
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  okvfe_status st = stage_image(ctx, image, stride);
+  if (st != OKVFE_OK) return st;
+  hipStream_t s = ctx->stream;
+  const int32_t cam_id = cam;
+  st = upload_image_params(ctx, 1, &cam_id, (cam >= 0) ? gravity_C : nullptr, s);
+  if (st != OKVFE_OK) return st;
+  const int w = ctx->w, h = ctx->h;
+  if (n_in > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_kps_det, keypoints, n_in * sizeof(okvfe_keypoint), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_det_count, &n_in, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, sizeof(int32_t), s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));  // pageable sources
+  launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
+                  ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
+                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s);
+  launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
+                 ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->last_n_images = 1;
+  ctx->last_stream = s;
+  {
+    const int slot = ctx->prm_slot;
+    ctx->prm_slot = -1;
+    if ((st = ring_release(ctx, &ctx->prm_ring, slot, s)) != OKVFE_OK) return st;
+  }
+  return okvfe_download_image_result(ctx, 0, keypoints, descriptors, backproj, backproj_valid, n_in, n_out);
+}
+}  // extern "C"

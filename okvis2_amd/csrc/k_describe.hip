@@ -306,7 +306,6 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     by1 = __builtin_amdgcn_readfirstlane(by1);
     const int px0 = bx0 & ~3;
     const int pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
-#ifndef OKVFE_DESC_NO_X4
     // 16 bytes per lane (buffer_load_dwordx4 ... lds, new on gfx950): a quarter of the load
     // instructions for the same pixels.  The staging is bound by the number of vector-memory
     // requests in flight at L2 latency, not by bytes (stage-only 0.43 ms of the kernel's 0.51 with
@@ -323,14 +322,12 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         const uint32_t c = (uint32_t)lane - rr * (uint32_t)nq;
         const uint32_t src_lane = rr * (uint32_t)w + c * 16u;
         const int src0 = by0 * w + px0;
-#ifndef OKVFE_DESC_NOSTAGE
         if ((int)rr < R) {
           for (int it = 0; it < trips; ++it)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * R * pitch), 16,
                 (int)src_lane, src0 + it * R * w, 0, 0);
         }
-#endif
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         ppx->patch = patch;
@@ -340,7 +337,6 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         return true;
       }
     }
-#endif
     const int ndw = (pw + 3) >> 2;  // dwords per patch row
     const int pitch = ndw * 4;
     if (pitch > kZeroRowBytes - 8 || ndw < 1) return false;  // wave-uniform
@@ -359,14 +355,12 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       const uint32_t c = (uint32_t)lane - rr * (uint32_t)ndw;
       const uint32_t src_lane = rr * (uint32_t)w + c * 4u;
       const int src0 = by0 * w + px0;
-#ifndef OKVFE_DESC_NOSTAGE  // A/B: box sums on whatever the LDS holds (no image traffic)
       if ((int)rr < R) {
         for (int it = 0; it < trips; ++it)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(
               img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * R * pitch), 4,
               (int)src_lane, src0 + it * R * w, 0, 0);
       }
-#endif
       __builtin_amdgcn_s_waitcnt(0);
     } else {
       if (ph * pitch > kPatchDataBytes) return false;
@@ -409,11 +403,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     PatchPx ppx;
     int v = 0;
     if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
-#ifdef OKVFE_DESC_STAGEONLY  // A/B: patch staging without the box sums
-      v = ppx.patch[lane];
-#else
       if (active) v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
-#endif
     } else {
       // The patch does not fit in the wave's LDS buffer (wide-angle cameras stretch the camera-aware
       // pattern towards the image rim: fu = 350 on 640 px gives |M| up to ~1.6).  It is staged in
@@ -634,7 +624,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done) {
   if (n_images <= 0) return;
-  static const char* force = getenv("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
+  static const char* force = lab_env("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
   if (!setup_done)  // (done by select_lazy_kernel when detection and description were one call)
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,

@@ -256,11 +256,8 @@ __device__ __forceinline__ int from_right(int v) {  // value of lane+1
 }
 
 constexpr int kStripLanes = 62;
-// Gradients on the matrix pipe (v_mfma_i32_4x4x4i8) unless built with -DOKVFE_K1_VALU_GRAD (A/B):
-// bit-exact, and with the slotted score layout 0.658 -> 0.635 ms per 1536 EuRoC images.
-#if !defined(OKVFE_K1_VALU_GRAD) && !defined(OKVFE_K1_MFMA)
-#define OKVFE_K1_MFMA 1
-#endif
+// Gradients run on the matrix pipe (v_mfma_i32_4x4x4i8): bit-exact, and with the slotted score layout
+// 0.658 -> 0.635 ms per 1536 EuRoC images against the vector-ALU form (LAB_NOTES.md).
 #ifndef OKVFE_K1_WAVES
 #define OKVFE_K1_WAVES __attribute__((amdgpu_waves_per_eu(5, 8)))
 #endif
@@ -343,11 +340,6 @@ constexpr int kCandStage = OKVFE_K1_STAGE;  // candidate records staged per wave
 // MEMONLY: the byte mover of this kernel -- the same loads, the same stores on the same layout, no
 // arithmetic (a stored row = the unpacked pixel row three steps ahead).  Its duration is the
 // kernel's own memory floor (okvfe_harris_byte_mover_device; bench.py reports both).
-#ifdef OKVFE_K1_MEMONLY
-constexpr bool kForceMemOnly = true;   // A/B build: every launch is the byte mover
-#else
-constexpr bool kForceMemOnly = false;
-#endif
 template <int kTHF, bool NMS, bool PACK = false, bool MEMONLY = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
@@ -385,22 +377,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     if (!lane_on) sub = 0;
     d = lane_on ? strip * kStripLanes + j : nd;  // idle lanes behave like lanes past the row end
   } else {
-#if defined(OKVFE_K1_MAP) && OKVFE_K1_MAP == 1   // A/B: plain image-major order (an image's blocks spread over all XCDs)
-    image = (int)blockIdx.x / (strips * ytiles);
-    tile = (int)blockIdx.x - image * (strips * ytiles);
-#elif defined(OKVFE_K1_MAP) && OKVFE_K1_MAP == 2  // A/B: tile-major order (the same tile of consecutive images back to back)
-    tile = (int)blockIdx.x / n_images;
-    image = (int)blockIdx.x - tile * n_images;
-#else
     xcd_tile(strips * ytiles, n_images, &image, &tile);
-#endif
-#if defined(OKVFE_K1_MAP) && OKVFE_K1_MAP == 3  // A/B: strip-major tile order inside an image
-    strip = tile / ytiles;
-    ytile = tile - strip * ytiles;
-#else
     ytile = tile / strips;
     strip = tile - ytile * strips;
-#endif
     row_tile = ytile * kWavesPerBlock + wave;
     d = strip * kStripLanes + lane;
   }
@@ -445,11 +424,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     p[3] = c >> 24;
   };
   (void)unpack4;
-#ifndef OKVFE_K1_MFMA
-  int pr[3][4];      // rolling pixel rows (own 4 columns)
-#endif
-#ifdef OKVFE_K1_MFMA
-  // Gradients on the matrix pipe (default; -DOKVFE_K1_VALU_GRAD builds the vector-ALU form).  v_mfma_i32_4x4x4i8 runs one 4x4x4 product per group of 4 lanes:
+  // Gradients on the matrix pipe.  v_mfma_i32_4x4x4i8 runs one 4x4x4 product per group of 4 lanes:
   // D[i] of a lane = sum_k A[i][k] * B_lane[k], with row i of A supplied by lane 4b + i -- i.e. FOUR
   // different 4-tap dot products of the lane's own B dword in one issue slot (4.2 cycles beside the
   // vector ALU, tools/ubench/mfma4_test.hip).  B = a 4-pixel window of one pixel row (bytes - 128:
@@ -478,7 +453,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     wn[0] = (int)__builtin_amdgcn_alignbyte((uint32_t)x, (uint32_t)l, 3);  // l.b3 x.b0 x.b1 x.b2
     wn[1] = (int)__builtin_amdgcn_alignbyte((uint32_t)r, (uint32_t)x, 1);  // x.b1 x.b2 x.b3 r.b0
   };
-#endif
   // stream 0 carries the xx and yy entries PACKED (xx | yy << 16: both are non-negative and every
   // partial sum stays below 2^16, so one 32-bit add smooths two channels); stream 1 carries xy
   int hs[2][2][4];   // horizontally smoothed entries: current / previous row
@@ -542,7 +516,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // covariance row g from pixel rows a (g-1), b (g), c (g+1) -> H (horizontally smoothed); k3, k10 =
   // the (3, 10, 3) filter taps times 2^9 (mulhi24 of two such gradients then yields g*g >> 14), or
   // 0, 0 for a rim row
-#ifdef OKVFE_K1_MFMA
   auto cov_row = [&](const int* wa, const int* wb, const int* wc, int (*H)[4], bool inner) {
     v4i_t acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
     acc1 = __builtin_amdgcn_mfma_i32_4x4x4i8(A_above, wa[0], acc1, 0, 0, 0);
@@ -571,47 +544,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     gy[1] = acc1[3] << 6;
     gy[2] = acc2[2] << 6;
     gy[3] = (acc2[3] << 6) & m3;
-#else
-  auto cov_row = [&](const int* a, const int* b, const int* c, int (*H)[4], int k3, int k10) {
-    int vs[4], vd[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vs[i] = __mul24(b[i], k10) + __mul24(a[i] + c[i], k3);
-      vd[i] = c[i] - a[i];
-    }
-    // NOTE: the subtrahend of gx[0] is shifted in NEGATED form and added: hipcc folds
-    // "x - dpp(y)" into v_subrev_u32_dpp wave_shr:1, which does not shift on gfx950
-    // (tools/ubench/dpp_test.hip); v_add_u32_dpp / v_sub_u32_dpp(dpp - x) are fine.
-    const int vs_l_neg = from_left(-vs[3]), vs_r = from_right(vs[0]);
-    const int vd_l = from_left(vd[3]), vd_r = from_right(vd[0]);
-    int gx[4], gy[4];
-    gx[0] = (vs[1] + vs_l_neg) & m0;
-    gx[1] = vs[2] - vs[0];
-    gx[2] = vs[3] - vs[1];
-    gx[3] = (vs_r - vs[2]) & m3;
-    // __mul24: 24-bit multiplies (v_mul_i32_i24 / v_mad_i32_i24); a plain int expression here is
-    // lowered to v_mad_u64_u32, which is several times slower
-    gy[0] = (__mul24(vd[0], k10) + __mul24(vd_l + vd[1], k3)) & m0;
-    gy[1] = __mul24(vd[1], k10) + __mul24(vd[0] + vd[2], k3);
-    gy[2] = __mul24(vd[2], k10) + __mul24(vd[1] + vd[3], k3);
-    gy[3] = (__mul24(vd[3], k10) + __mul24(vd[2] + vd_r, k3)) & m3;
-#endif
     int G[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       // xx | yy << 16 without a separate pack: the second product is written into the upper half
       // of the register that already holds the first one (SDWA destination select; both products
       // are < 2^10)
-#ifndef OKVFE_K1_NOPACKMERGE
       int g0 = mulhi24(gx[i], gx[i]);
       asm("v_mul_hi_i32_i24_sdwa %0, %1, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE "
           "src0_sel:DWORD src1_sel:DWORD"
           : "+v"(g0)
           : "v"(gy[i]));
       G[0][i] = g0;
-#else
-      G[0][i] = mulhi24(gx[i], gx[i]) | (mulhi24(gy[i], gy[i]) << 16);
-#endif
       G[1][i] = mulhi24(gx[i], gy[i]);
     }
     dpp_fence4(G[0][0], G[0][3], G[1][0], G[1][3]);
@@ -646,19 +590,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     sc[0] &= m0;
     sc[3] &= m3;
   };
-#ifndef OKVFE_K1_STORE_AUX
-#define OKVFE_K1_STORE_AUX 0
-#endif
   auto store_row = [&](const int sc[4], int y) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = {sc[0], sc[1], sc[2], sc[3]};
-#if defined(OKVFE_K1_STRIPMAJOR_TEST)  // timing experiment only (wrong layout): a wave's rows contiguous in memory
-    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_on ? lane * 16 : 0x7FFFFFF0, (strip * h + y) * 1024, OKVFE_K1_STORE_AUX);
-#elif !defined(OKVFE_K1_NOSTORE)
-    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, OKVFE_K1_STORE_AUX);
-#else
-    if (v.x == 0x12345678 && v.y == 0x7654321) __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, 0);
-#endif
+    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, 0);
   };
   // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc): optionally test centre row y-1, then
   // roll the state
@@ -666,9 +601,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     const int l = from_left(sc[3]), r2 = from_right(sc[0]);
     const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
                        max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
-#ifdef OKVFE_K1_NONMS
-    test = false;
-#endif
     if (test && r >= r_lo && r < r_hi) {
       const int lft[4] = {nl, nc[0], nc[1], nc[2]};
       const int rgt[4] = {nc[1], nc[2], nc[3], nr};
@@ -717,13 +649,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     const uint32_t t0 = load_next(), t1 = load_next();
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) ring[i] = load_next();
-#ifdef OKVFE_K1_MFMA
     make_windows(t0, win[0]);
     make_windows(t1, win[1]);
-#else
-    unpack4(t0, pr[0]);
-    unpack4(t1, pr[1]);
-#endif
   }
   int y = ys - 2;  // score row completed by the current step (meaningful from step 2 on)
   // step j (compile-time phase PH = j % 6): pixel row ys+j, covariance row g = ys+j-1, score row
@@ -734,25 +661,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     ring[(PH + kAhead) % 6] = load_next();
     const int g = y + 1;
     const bool inner = g >= 1 && g <= h - 2;  // scalar
-    if constexpr (MEMONLY || kForceMemOnly) {  // the byte mover: loads and stores, no arithmetic
+    if constexpr (MEMONLY) {  // the byte mover: loads and stores, no arithmetic
       int sc[4];
-#ifdef OKVFE_K1_MEMONLY_NOLOADUSE  // stores of a constant: the loads are dead (and removed by the compiler)
-      sc[0] = sc[1] = sc[2] = sc[3] = y;
-#else
       unpack4(ring[PH], sc);
-#endif
       if (decltype(want_store)::value && y < h) store_row(sc, y);
       ++y;
       (void)inner;
       return;
     }
-#ifdef OKVFE_K1_MFMA
     make_windows(ring[PH], win[s_new]);
     cov_row(win[s_a], win[s_b], win[s_new], hs[q], inner);
-#else
-    unpack4(ring[PH], pr[s_new]);
-    cov_row(pr[s_a], pr[s_b], pr[s_new], hs[q], inner ? 3 << 9 : 0, inner ? 10 << 9 : 0);
-#endif
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -803,9 +721,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     if (ye_own == h) store_row(zero, h - 1);
   }
 
-#ifdef OKVFE_K1_NOEPILOGUE  // A/B: the row loop alone (no candidate records are produced)
-  if (NMS) return;
-#endif
   if (NMS) {
     // hit stacks -> candidate records
     const int cnt = (int)((sp - sp0) >> 9);
@@ -877,11 +792,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
       const int first = scan(cnt, &total);
       int base_l0 = 0;
       if (lane == 0) base_l0 = atomicAdd(&nms.cand_count[image], total);
-#ifdef OKVFE_K1_NOCANDSTAGE  // A/B: the direct 12-byte stores of round 2
-      constexpr int cap_stage = 0;
-#else
       constexpr int cap_stage = kStageCap;  // records past the stage's capacity are stored directly
-#endif
       Candidate* stage = cand_stage[wave];
       for (int e = 0; __any(e < cnt); ++e)
         if (e < cnt) {
@@ -917,10 +828,10 @@ static int harris_strips(int w) {  // strips of 62 quads (+ halo lanes) covering
 
 ScoreLayout harris_nms_layout(int w, int h) {
   (void)h;
-  static const bool off = getenv("OKVFE_NO_FUSED_NMS") != nullptr;  // A/B knob for profiling
+  static const bool off = lab_env("OKVFE_NO_FUSED_NMS") != nullptr;  // A/B knob for profiling
   if (off || w % 4 != 0) return ScoreLayout{w, 0};
   const int strips = harris_strips(w);
-  static const bool dense = getenv("OKVFE_K1_DENSE") != nullptr;  // A/B knob: fused kernel, dense map
+  static const bool dense = lab_env("OKVFE_K1_DENSE") != nullptr;  // A/B knob: fused kernel, dense map
   if (strips == 1 || dense) return ScoreLayout{w, 1};
   const int pitch = ((w + 8 * (strips - 1)) + 31) & ~31;
   return ScoreLayout{pitch, strips};
@@ -938,7 +849,7 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     // the caller's map must be the fused kernel's layout (or dense: strips == 1, pitch == w)
     if (nms && !(layout.strips == strips || (layout.strips == 1 && layout.pitch == w))) return false;
     static const int th_env = [] {
-      const char* e = getenv("OKVFE_K1_TH");  // A/B knob: rows per wave of the fused kernel (25..61)
+      const char* e = lab_env("OKVFE_K1_TH");  // A/B knob: rows per wave of the fused kernel (25..61)
       return e ? atoi(e) : 0;
     }();
     // narrow last strip (1024-px rows: 7 of 64 lanes): the last strips of pack_g images share a wave
@@ -964,7 +875,7 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     }                                                                                            \
   }
 #define OKVFE_K1_NMS_LAUNCH(TH) OKVFE_K1_NMS_LAUNCH_M(TH, false)
-    static const bool no_pack = getenv("OKVFE_K1_NOPACK") != nullptr;  // A/B knob
+    static const bool no_pack = lab_env("OKVFE_K1_NOPACK") != nullptr;  // A/B knob
     if (nms && byte_mover) {
       OKVFE_K1_NMS_LAUNCH_M(61, true);
     } else if (nms) {

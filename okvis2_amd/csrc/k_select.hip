@@ -543,10 +543,6 @@ __global__ __launch_bounds__(kThreads) void select_kernel(
 //     ordering between them is needed.
 // Two workgroup barriers per round; sub-pixel refinement of the accepted points runs at the end.
 constexpr int kSelThreads = 256;
-#ifdef OKVFE_SELECT_STATS  // profiling build only (tools/select_stats.py): where do the cycles of a block go?
-__device__ unsigned long long g_sel_stats[8];
-#define OKVFE_SEL_CLOCK() (unsigned long long)__builtin_readcyclecounter()
-#endif
 constexpr int kStampIts = (kStampCells + kSelThreads - 1) / kSelThreads;
 constexpr int kRoundCap = 64;
 
@@ -583,9 +579,6 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
   const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
-#ifdef OKVFE_SELECT_STATS
-  unsigned long long st_rounds = 0, st_windows = 0, st_decide = 0, st_stamp = 0, st_t0 = OKVFE_SEL_CLOCK(), st_loop0 = 0, st_loop1 = 0;
-#endif
   if (n > 0) {  // block-uniform
     if (OCC_LDS) {
       uint4* z = reinterpret_cast<uint4*>(smem_raw);
@@ -628,13 +621,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
     int pos = 0;
     __syncthreads();
-#ifdef OKVFE_SELECT_STATS
-    st_loop0 = OKVFE_SEL_CLOCK();
-#endif
     while (true) {
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long st_a = OKVFE_SEL_CLOCK();
-#endif
       // the 64-candidate window would run past the resident chunk: slide it (block-uniform)
       if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
         chunk_base = pos;
@@ -649,9 +636,6 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
             refill = true;  // skipped past the chunk through windows without a passing candidate
             break;
           }
-#ifdef OKVFE_SELECT_STATS
-          ++st_windows;
-#endif
           const int idx = pos + lane;
           uint2 rec = make_uint2(0, 0);
           if (idx < n) rec = recs[idx - chunk_base];
@@ -704,11 +688,6 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
         }
       }
       __syncthreads();
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long st_b = OKVFE_SEL_CLOCK();
-      st_decide += st_b - st_a;
-      ++st_rounds;
-#endif
       const int nacc = s_round;
       pos = s_pos;
       kept = s_kept;
@@ -739,13 +718,7 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
         }
       }
       __syncthreads();
-#ifdef OKVFE_SELECT_STATS
-      st_stamp += OKVFE_SEL_CLOCK() - st_b;
-#endif
     }
-#ifdef OKVFE_SELECT_STATS
-    st_loop1 = OKVFE_SEL_CLOCK();
-#endif
   }
   for (int i = tid; i < kept; i += kSelThreads) {
     const uint64_t k = keys[acc_idx[i]];
@@ -770,18 +743,6 @@ __global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
     out[i] = kp;
   }
   if (tid == 0) kp_count[img] = kept;
-#ifdef OKVFE_SELECT_STATS
-  if (tid == 0) {
-    atomicAdd(&g_sel_stats[0], 1ull);
-    atomicAdd(&g_sel_stats[1], st_rounds);
-    atomicAdd(&g_sel_stats[2], st_windows);
-    atomicAdd(&g_sel_stats[3], (unsigned long long)kept);
-    atomicAdd(&g_sel_stats[4], st_decide);
-    atomicAdd(&g_sel_stats[5], st_stamp);
-    atomicAdd(&g_sel_stats[6], st_loop0 - st_t0);
-    atomicAdd(&g_sel_stats[7], OKVFE_SEL_CLOCK() - st_loop1);
-  }
-#endif
 }
 
 
@@ -1016,15 +977,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     }
     const int limit = min(min(max_kpts, kp_cap), cap);
     __syncthreads();
-#ifdef OKVFE_SELECT_STATS
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define ST_T() OKVFE_SEL_CLOCK()
-#endif
     for (int pos = 0; pos < n; pos += 64) {  // block-uniform
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long t0 = ST_T();
-      ++st[2];
-#endif
       const int idx = pos + lane;
       const bool valid = idx < n;
       uint4 rec = recs[idx & (kLazyChunk - 1)];
@@ -1064,13 +1017,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         }
       }
       part[wave * 64 + lane] = occf;
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long t1 = ST_T();
-#endif
       __syncthreads();
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long t2 = ST_T();
-#endif
       if (wave == 0) {
         int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
         bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
@@ -1102,11 +1049,6 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           __builtin_amdgcn_wave_barrier();
           if (pass) atomicSub(&head[bin], 1u << 24);
           const unsigned long long seq = __ballot(linked && pass);
-#ifdef OKVFE_SELECT_STATS
-          st[0] += __popcll(rem);
-          st[1] += __popcll(seq);
-          st[3] += ST_T() - t2;
-#endif
           const int room = limit - kept;
           if (__popcll(rem) <= room) {
             // the unlinked ones neither change nor are changed by anything in this window: accepted
@@ -1158,34 +1100,12 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         convert();
         request(pos + 64 + kLazyChunk);
       }
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long t3 = ST_T();
-#endif
       __syncthreads();
-#ifdef OKVFE_SELECT_STATS
-      const unsigned long long t4 = ST_T();
-      st[4] += t1 - t0; st[5] += t3 - t2; st[6] += (t2 - t1) + (t4 - t3);
-#endif
       kept = s_kept;
       if (kept >= limit) break;  // block-uniform
     }
-#ifdef OKVFE_SELECT_STATS
-    if (tid == 0) {
-      atomicAdd(&g_sel_stats[0], 1ull);
-      atomicAdd(&g_sel_stats[2], st[2]);
-      atomicAdd(&g_sel_stats[1], (st[0] << 20) | st[1]);
-      atomicAdd(&g_sel_stats[7], st[3]);
-      atomicAdd(&g_sel_stats[3], (unsigned long long)kept);
-      atomicAdd(&g_sel_stats[4], st[4]);
-      atomicAdd(&g_sel_stats[5], st[5]);
-      atomicAdd(&g_sel_stats[6], st[6]);
-    }
-#endif
   }
   // ---- K4: sub-pixel refinement and keypoint emission (all four waves)
-#ifdef OKVFE_SELECT_STATS
-  const unsigned long long ts0 = OKVFE_SEL_CLOCK();
-#endif
   __syncthreads();
   for (int i = tid; i < kept; i += kLazyThreads) {
     okvfe_keypoint kp = out[i];
@@ -1208,23 +1128,10 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     if (setup.pat) describe_setup_one(setup, w, h, img, (size_t)img * kp_cap + i, kp);
   }
   if (tid == 0) kp_count[img] = kept;
-#ifdef OKVFE_SELECT_STATS
-  __syncthreads();
-  if (tid == 0) atomicAdd(&g_sel_stats[7], OKVFE_SEL_CLOCK() - ts0);
-#endif
 }
 
 }  // namespace
 
-#ifdef OKVFE_SELECT_STATS
-extern "C" __attribute__((visibility("default"))) void okvfe_debug_select_stats(unsigned long long* out8, int reset) {
-  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sel_stats), sizeof(g_sel_stats));
-  if (reset) {
-    unsigned long long z[8] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stats), z, sizeof(z));
-  }
-}
-#endif
 
 void launch_brisk_refine(const int32_t* score, int w, int h, int n_images, int cand_cap, const int32_t* cand_count,
                          const uint64_t* sort_ws, int max_kpts, const int32_t* below, int wb, int hb, int rn_b,
@@ -1245,7 +1152,7 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
   const bool two = ws_stride > kLdsSortKeys;
-  static const bool legacy = getenv("OKVFE_LEGACY_SORT") != nullptr;  // A/B knob
+  static const bool legacy = lab_env("OKVFE_LEGACY_SORT") != nullptr;  // A/B knob
   if (legacy) {
     // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
     hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
@@ -1280,15 +1187,15 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
-  static const bool force_hbm = getenv("OKVFE_SELECT_OCC_HBM") != nullptr;  // A/B knob
+  static const bool force_hbm = lab_env("OKVFE_SELECT_OCC_HBM") != nullptr;  // A/B knob
   const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024 && !force_hbm;
   // greedy kernel: occupancy + accepted indices (u16, u32 for capacities above 65536) + a sliding
   // chunk of candidate records.  Half a CU's LDS (two images per CU) when at least 128 records
   // fit, else the whole CU; grids that do not fit at all stay in the HBM workspace.
   const bool wide = cand_cap > 65536;
   const size_t acc_bytes = ((size_t)kp_cap * (wide ? 4 : 2) + 15) & ~(size_t)15;
-  static const bool legacy = getenv("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
-  static const bool grid = getenv("OKVFE_SELECT_GRID") != nullptr;      // A/B knob: the occupancy-grid kernels
+  static const bool legacy = lab_env("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
+  static const bool grid = lab_env("OKVFE_SELECT_GRID") != nullptr;      // A/B knob: the occupancy-grid kernels
   if (radius > 0.0f && !legacy && !grid) {
     // lazy occupancy (no grid): any image size / radius whose bin heads and keypoint slots fit in LDS
     const int bins_x = (occ_cols + 15) >> 4, bins_y = (occ_rows + 15) >> 4;

@@ -1,6 +1,7 @@
 // okvfe_internal.h -- shared declarations of the libokvfe.so runtime (host + HIP kernels).
 // Product code; never includes or links anything under oracle/.
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,6 +12,17 @@
 #include "../../include/okvfe.h"
 
 namespace okvfe {
+
+// Lab switches = the A/B knobs of the experiments recorded in LAB_NOTES.md.  The product library
+// reads NO environment variable: lab_env() is a constant nullptr there, so every knob folds away at
+// compile time.  `make lab` builds libokvfe_lab.so with -DOKVFE_LAB, where the knobs are live
+// (tests/test_gpu_detector_paths.py loads that build for the tests that flip them).
+#ifdef OKVFE_LAB
+inline const char* lab_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
+
 
 constexpr int kPatternPoints = 60;
 constexpr int kMaxLongPairs = 1100;

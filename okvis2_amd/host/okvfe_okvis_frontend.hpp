@@ -46,7 +46,7 @@ class HipViFrontend : public okvis::ViFrontendInterface {
   // rest: the reference front-end that keeps serving the estimator-side virtuals
   HipViFrontend(std::unique_ptr<okvis::ViFrontendInterface> rest, const std::vector<okvfe_camera>& cameras,
                 const FrontendParameters& p, int device = 0)
-      : rest_(std::move(rest)), gpu_(cameras, p, device) {}
+      : rest_(std::move(rest)), gpu_(cameras, p, device), last_(cameras.size()) {}
 
   bool detectAndDescribe(size_t cameraIndex, std::shared_ptr<okvis::MultiFrame> frameOut,
                          const okvis::kinematics::Transformation& T_WC,
@@ -57,7 +57,10 @@ class HipViFrontend : public okvis::ViFrontendInterface {
     const auto C = T_WC.C();
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) pose.C[3 * r + c] = C(r, c);
-    FrameData fd;
+    if (cameraIndex >= last_.size()) throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "Camera index exceeds number of cameras.");
+    // kept per camera: the GPU's back-projections and descriptors are what an AssociationHook
+    // hands to HipFrontend::matchStereo / matchMotionStereo / matchToMap (lastFrameData)
+    FrameData& fd = last_[cameraIndex];
     gpu_.detectAndDescribe(cameraIndex, cv_adapters::view(frameOut->image(cameraIndex)), pose, fd);
     static_assert(sizeof(cv::KeyPoint) == sizeof(KeyPoint), "cv::KeyPoint layout");
     std::vector<cv::KeyPoint> kps(fd.keypoints.size());
@@ -90,10 +93,14 @@ class HipViFrontend : public okvis::ViFrontendInterface {
   }
 
   HipFrontend& gpu() { return gpu_; }
+  // keypoints, descriptors and FP64 back-projections of the camera's last detectAndDescribe, as the
+  // GPU produced them (valid until that camera's next call; one thread per camera, Frontend.hpp:87)
+  const FrameData& lastFrameData(size_t cameraIndex) const { return last_.at(cameraIndex); }
 
  private:
   std::unique_ptr<okvis::ViFrontendInterface> rest_;
   HipFrontend gpu_;
+  std::vector<FrameData> last_;
   std::shared_ptr<AssociationHook> hook_;
 };
 

@@ -51,6 +51,8 @@ class HipExtractor : public cv::DescriptorExtractor {
     CV_Assert(rays.isContinuous() && imageJacobians.isContinuous());
     impl_.setCameraProperties(rays.ptr<float>(), imageJacobians.ptr<float>(), fu);
   }
+  // full intrinsics instead of caller-built maps: also enables the GPU's FP64 back-projection
+  void setCamera(const okvfe_camera& camera) { impl_.setCamera(camera); }
   void setExtractionDirection(const cv::Vec3f& d) { impl_.setExtractionDirection({d[0], d[1], d[2]}); }
   void compute(cv::InputArray image, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors) override {
     std::vector<KeyPoint> k(keypoints.size());

@@ -143,3 +143,17 @@ def test_bow_vector_host_helper_against_the_oracle_and_a_plain_restatement(oracl
                 assert 5 not in got[0]
     with pytest.raises(capi.OkvfeError):
         capi.bow_vector([n_words], ww)
+
+
+def test_product_library_reads_no_environment():
+    """the shipping library decides no code path from the environment -- it does
+    not even import getenv; the lab build (A/B knobs of LAB_NOTES.md) does."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    und = subprocess.run(["nm", "-D", "--undefined-only", os.path.join(root, "okvis2_amd", "libokvfe.so")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    lab = os.path.join(root, "okvis2_amd", "libokvfe_lab.so")
+    if os.path.exists(lab):
+        und = subprocess.run(["nm", "-D", "--undefined-only", lab], capture_output=True, text=True, check=True).stdout
+        assert "getenv" in und

@@ -23,6 +23,14 @@ import gpu_common as G
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the A/B knobs exist in the LAB build only (make -C okvis2_amd/csrc lab); the product library reads
+# no environment variable (tests/test_capi_host.py::test_product_library_reads_no_environment)
+LAB_LIB = os.path.join(ROOT, "okvis2_amd", "libokvfe_lab.so")
+
+
+def _lab_environ(**knobs):
+    assert os.path.exists(LAB_LIB), "libokvfe_lab.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+    return dict(os.environ, OKVFE_LIB=LAB_LIB, **knobs)
 
 
 def _plateau_image(w, h, seed, bx, by):
@@ -111,7 +119,7 @@ print("UNFUSED-OK")
 
 
 def test_standalone_score_and_nms_kernels(oracle):
-    env = dict(os.environ, OKVFE_NO_FUSED_NMS="1")
+    env = _lab_environ(OKVFE_NO_FUSED_NMS="1")
     out = subprocess.run([sys.executable, "-c", _CHILD, ROOT], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "UNFUSED-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
@@ -135,7 +143,7 @@ def test_legacy_select_kernel_for_grids_outside_lds(oracle):
     """Occupancy grids that do not fit in LDS normally take select_greedy_kernel<false> (grid in
     HBM; covered by the small-radius cases above); OKVFE_LEGACY_SELECT keeps the older
     one-accept-per-round kernel reachable, which is also the path for > 65536 candidates."""
-    env = dict(os.environ, OKVFE_LEGACY_SELECT="1")
+    env = _lab_environ(OKVFE_LEGACY_SELECT="1")
     out = subprocess.run([sys.executable, "-c", _LEGACY_CHILD, ROOT], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "LEGACY-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
@@ -163,7 +171,7 @@ def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     """The A/B switches the profiling notes refer to (read once per process, hence a child process
     each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
     grid in HBM, one-accept-per-round selection.  Each must stay bit-exact."""
-    env = dict(os.environ)
+    env = _lab_environ()
     env[knob] = "1"
     out = subprocess.run([sys.executable, "-c", _KNOB_CHILD, ROOT], env=env, capture_output=True,
                          text=True, timeout=600)
@@ -195,7 +203,7 @@ print("KNOB-OK")
 def test_ab_knobs_of_the_describe_path(oracle, knob):
     """Parameter upload through the DMA engine instead of the copy kernel, the extractor's setup as
     its own launch instead of inside the selection kernel, the 5-wave describe instantiation."""
-    env = dict(os.environ)
+    env = _lab_environ()
     k, _, v = knob.partition("=")
     env[k] = v or "1"
     out = subprocess.run([sys.executable, "-c", _KNOB_DESC_CHILD, ROOT], env=env, capture_output=True,
@@ -243,7 +251,7 @@ def test_parameter_ring_laps(oracle, knob):
     """The per-call parameter blocks travel through an 8-slot pinned ring: slots are reused after the
     event behind their last reader -- or, for a call that never released its slot (forced here by the
     test knob), after a wait on that call's stream."""
-    env = dict(os.environ)
+    env = _lab_environ() if knob else dict(os.environ)
     if knob:
         env[knob] = "1"
     out = subprocess.run([sys.executable, "-c", _RING_CHILD, ROOT], env=env, capture_output=True,
@@ -408,6 +416,7 @@ import torch
 from okvis2_amd import capi, synth
 import oracle_lib as O, gpu_common as G
 cfg = synth.mono640_config()
+capi.set_heavy_kernel_chaining(int(sys.argv[2]))
 lanes = []
 for l in range(3):
     fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
@@ -435,9 +444,9 @@ print("TOKEN-OK")
 
 @pytest.mark.parametrize("mode", [1, 2])
 def test_score_token_across_contexts(oracle, mode):
-    """OKVFE_SCORE_TOKEN chains the heavy kernels of three contexts on three streams through
-    events: same results, no deadlock, in both enqueue orders."""
-    env = dict(os.environ, OKVFE_SCORE_TOKEN=str(mode))
+    """okvfe_set_heavy_kernel_chaining chains the heavy kernels of three contexts on three streams
+    through events: same results, no deadlock, in both enqueue orders."""
+    env = dict(os.environ)
     out = subprocess.run([sys.executable, "-c", _TOKEN_CHILD, ROOT, str(mode)], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "TOKEN-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
