@@ -427,11 +427,14 @@ def latency_b1(cfg, base, n_frames=8, iters=300, warmup=30):
             for c in range(2):
                 f.write(np.ascontiguousarray(base[C * i + c]).tobytes())
         path = f.name
+    res = {}
     try:
-        p = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
-        if p.returncode != 0:
-            return {"error": f"latency_cli rc {p.returncode}: {p.stderr[-300:]}"}
-        res = json.loads(p.stdout.strip().splitlines()[-1])
+        for route in ("vi", "cv", "c"):  # one process per route: each sees the GPU's hardware queues alone
+            p = subprocess.run([exe, path, route], capture_output=True, text=True, timeout=300)
+            if p.returncode != 0:
+                return {"error": f"latency_cli {route} rc {p.returncode}: {p.stderr[-300:]}"}
+            r = json.loads(p.stdout.strip().splitlines()[-1])
+            res.update({k: v for k, v in r.items() if v is not None and (k not in res or route == "vi")})
     finally:
         os.unlink(path)
     res["note"] = ("one stereo frame per iteration, wall clock on the host: vi = HipViFrontend::detectAndDescribe "

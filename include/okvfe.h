@@ -183,6 +183,17 @@ okvfe_status okvfe_detect_describe(okvfe_ctx* ctx, const uint8_t* image, size_t 
 okvfe_status okvfe_detect(okvfe_ctx* ctx, const uint8_t* image, size_t stride,
                           okvfe_keypoint* keypoints, int32_t cap, int32_t* n_out);
 
+/* cv::FeatureDetector::detect when the SAME image goes to cv::DescriptorExtractor::compute right after
+ * it, as okvis::Frame::detect() / Frame::describe() do (okvis_cv/include/okvis/implementation/
+ * Frame.hpp:152,167; the extraction direction is set before both, Frontend.cpp:246-251): returns what
+ * okvfe_detect returns, but runs the whole detect + describe chain for (cam, gravity_C) on the one
+ * upload and keeps the result.  An okvfe_compute that then asks for exactly this -- same image pointer,
+ * stride and pixel content, same cam / gravity_C, the keypoints unchanged -- is answered from the kept
+ * result without touching the GPU; any other okvfe_compute runs as usual.  One image upload and one
+ * synchronisation per frame instead of two. */
+okvfe_status okvfe_detect_ahead(okvfe_ctx* ctx, const uint8_t* image, size_t stride, int32_t cam,
+                                const float gravity_C[3], okvfe_keypoint* keypoints, int32_t cap, int32_t* n_out);
+
 /* compute() only = cv::DescriptorExtractor::compute(image, keypoints, descriptors)
  * (Frame.hpp:167): describes the n_in caller keypoints (in/out: the extractor
  * removes keypoints too close to the rim, order preserved) and back-projects

@@ -81,7 +81,7 @@ class DeviceOutputs(C.Structure):
 EXPORTS = [
     "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
     "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
-    "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_describe_batch_device",
+    "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_ahead", "okvfe_detect_describe_batch_device",
     "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_set_heavy_kernel_chaining", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device", "okvfe_harris_byte_mover_device",
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
@@ -408,6 +408,18 @@ class Frontend:
         n = C.c_int32()
         self._check(lib().okvfe_detect(self._h, _p(image), C.c_size_t(image.strides[0]), _p(kps),
                                        cap, C.byref(n)))
+        return kps[:n.value].copy()
+
+    def detect_ahead(self, image, cam=-1, gravity=None):
+        """okvfe_detect_ahead: detect() whose compute() on the same image is answered from the kept result."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        self._ahead_image = image  # the pairing is by pointer: keep the buffer alive for compute()
+        cap = self.max_keypoints
+        kps = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        n = C.c_int32()
+        g = None if gravity is None else (C.c_float * 3)(*[float(v) for v in gravity])
+        self._check(lib().okvfe_detect_ahead(self._h, _p(image), C.c_size_t(image.strides[0]), int(cam), g,
+                                             _p(kps), cap, C.byref(n)))
         return kps[:n.value].copy()
 
     def harris_byte_mover_device(self, images_ptr, n_images, stream=None):

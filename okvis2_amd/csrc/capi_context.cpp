@@ -63,6 +63,11 @@ okvfe_status ensure_pinned(okvfe_ctx* ctx, size_t bytes) {
   HIP_TRY(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault));
   ctx->h_pinned = static_cast<uint8_t*>(p);
   ctx->h_pinned_bytes = bytes;
+  ctx->h_pinned_dev = nullptr;
+  if (hipHostGetDevicePointer(&ctx->h_pinned_dev, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->h_pinned_dev = nullptr;  // copies then go through hipMemcpyAsync
+  }
   return OKVFE_OK;
 }
 
@@ -508,6 +513,7 @@ void okvfe_destroy(okvfe_ctx* ctx) {
     if (p) (void)hipFree(p);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->h_result) (void)hipHostFree(ctx->h_result);
   ring_destroy(&ctx->prm_ring);
   ring_destroy(&ctx->pair_ring);
   ring_destroy(&ctx->cls_ring);

@@ -853,59 +853,83 @@ __global__ __launch_bounds__(256) void brisk_refine_kernel(
 // min(255, sum over the points accepted so far within 15 cells of ceil(weight(offset) * 0.99 *
 // level(point))) -- every stamp adds a non-negative integer with u8 saturation, so the saturating
 // adds collapse into one clamp of the plain sum, in any order.  This kernel therefore keeps no grid:
-// accepted points go into spatial bins of 16 x 16 cells (singly linked lists in LDS, heads swapped in
-// with one LDS atomic), and a candidate's occupancy is evaluated on demand from the 3 x 3 bins
-// around its cell.  Per window of 64 candidates (lane = candidate):
-//   walk (4 waves): the nine bin lists of a candidate are split over the waves (2 + 2 + 2 + 3),
-//     all of a wave's lists in flight per lane, ONE 4-byte link word per step; the weight comes
-//     from a 64 x 64 table indexed by the biased offset (zero outside the stamp: no range test),
-//     the level from an array with a zero sentinel (finished walks read it: no branch).  Partial
-//     sums go to LDS.
-//   accept (wave 0): passing candidates without another passing candidate of the window within 15
-//     cells are accepted in one step, the others in order (a newly accepted point adds its weight
-//     to the later lanes within reach, which re-evaluate their test) -- a window never restarts.
-//     Meanwhile waves 1-2 convert the next chunk of sorted keys into candidate records.
-// Two workgroup barriers per window.  LDS per image: table 16 KB + bin heads + 8 B per keypoint slot
-// + 128 candidate records ~ 25 KB for EuRoC: six images per CU (the grid kernel: two), and the
-// serial chain per image is ~3x shorter (the grid kernel paid ~3.4 k cycles per accepted point in
-// LDS round trips and barriers).
-// Slot layout: link = 4 * ((cy & 15) << 6 | (cx & 15)) in bits 0..11, (LDS address of the next
-// slot's link word) >> 2 in bits 16..31 (bits 12..15 zero, so link >> 14 IS that address); the
-// level array sits at a fixed distance; slot `cap` is the terminator (level 0, linked to itself).
-constexpr int kLazyChunk = 128;
-constexpr int kLazyLutBytes = 64 * 64 * 4;
+// accepted points go into spatial bins of 16 x 16 cells and a candidate's occupancy is evaluated on
+// demand from the 3 x 3 bins around its cell.
+//
+// Bins are ARRAYS (round 4): kLazyBinCap slots of {cell code, level} per bin plus a count; a
+// candidate reads all slots of a bin with two 16-byte loads that depend on nothing but its own cell,
+// so an evaluation is two LDS round trips (slots, then weights) whatever the bins hold -- the
+// round-3 form chased linked lists, one dependent round trip per point, and was bound by exactly that
+// latency (profiles/round3_select_stats.txt: 1.5 k cycles per window in the walk).  Empty slots hold
+// level 0 and contribute ceil(w * 0) = 0.  The uniformity rule itself keeps bins sparse (a point
+// needs the summed weights of its accepted neighbours below ~1, which spaces equal-level points ~13
+// cells apart); a bin that does fill up spills into a per-image list in the HBM workspace that every
+// evaluation then scans as well (exact, practically never taken).
+//
+// Prefilter (round 4).  The greedy pass walks the candidates in rank order, but a candidate's test
+// only ever gets HARDER (occupancy grows): one that already fails against the points accepted before
+// a block of candidates started fails when its turn comes as well.  So the sorted list is cut into
+// blocks of 64, 128, 256, ... kLazyBlockMax candidates; all of a block's candidates are first
+// evaluated IN PARALLEL (lane = candidate, every lane reads its own nine bins, no barrier between
+// them) against the points accepted before the block, and only the survivors -- in rank order, a
+// compaction of a sorted list stays sorted -- go through the ordered windows of 64: EuRoC-like
+// content, 4.4 k candidates, ~500 survivors: 11 ordered windows instead of 70; TUM-VI 17 instead of
+// 119 (the blocks grow geometrically because early blocks reject little: nothing is accepted yet).
+//
+// Ordered window of 64 survivors (lane = candidate): the nine bins are split over the four waves
+// (2 + 2 + 2 + 3), partial sums go to LDS; wave 0 accepts: passing candidates without another
+// passing candidate of the window within 15 cells are accepted in one step, the others in order (a
+// newly accepted point adds its weight to the later lanes within reach, which re-evaluate their
+// test) -- a window never restarts.  Two workgroup barriers per window.
+constexpr int kLazyTabBytes = 32 * 32 * 4;  // weight(|dx|, |dy|), zero beyond 15
 constexpr int kLazyThreads = 256;
-__device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
-  return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>((uintptr_t)addr);
-}
-__device__ __forceinline__ float lds_f32(uint32_t addr) {
-  return *reinterpret_cast<__attribute__((address_space(3))) const float*>((uintptr_t)addr);
-}
+constexpr int kLazyBinCap = 4;
+constexpr int kLazyBlockMax = 1024;
+constexpr int kLazySurvPerWave = kLazyBlockMax / 4;  // surviving KEYS, one list per wave (the ordered windows read no HBM)
 __host__ __device__ inline size_t lazy_align16(size_t v) { return (v + 15) & ~(size_t)15; }
-// table | heads of the bordered bin grid | link, level (cap + 1 slots each) | record chunk | partial sums
-__host__ __device__ inline size_t lazy_lds_bytes(int bins_x, int bins_y, int cap) {
-  return (size_t)kLazyLutBytes + lazy_align16((size_t)(bins_x + 2) * (bins_y + 2) * 4) +
-         2 * lazy_align16((size_t)(cap + 1) * 4) + (size_t)kLazyChunk * 16 + 4 * 64 * 4;
+// table | counts of the bordered bin grid | bin slots | survivor lists | partial sums
+__host__ __device__ inline size_t lazy_lds_bytes(int bins_x, int bins_y) {
+  const size_t nbins = (size_t)(bins_x + 2) * (bins_y + 2);
+  return (size_t)kLazyTabBytes + lazy_align16(nbins * 4) + nbins * kLazyBinCap * 8 + (size_t)kLazyBlockMax * 8 +
+         4 * 64 * 4;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's global
+// stores (s_waitcnt vmcnt(0)), and the acceptance writes a keypoint record per accepted point -- an
+// HBM round trip per window on the critical path of the selection (4.2 us per window measured; the
+// records are only read again after the loop, behind a full barrier).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef OKVFE_LAB
+// lab build: where does an image's time go?  [0] launches, [1..4] 10-ns ticks (s_memrealtime) of image 0's
+// phases init / blocks / tail / total, [5] prefilter ticks, [6] survivors, [7] candidates
+__device__ unsigned long long g_lazy_prof[8];
+#define OKVFE_LAZY_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define OKVFE_LAZY_TICK(var)
+#endif
 __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void select_lazy_kernel(
     const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
-    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, DescribeSetup setup) {
+    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, uint2* __restrict__ spill_ws,
+    size_t spill_stride, int bin_cap, DescribeSetup setup) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_kept;
+  __shared__ int s_spill;       // points that did not fit their bin (HBM list)
+  __shared__ int s_surv[2][4];  // survivor counts per wave, double-buffered by block parity
   const int bpitch = bins_x + 2;  // bordered bin grid: the border bins stay empty, so no range checks
   const int nbins = bpitch * (bins_y + 2);
-  const size_t cap4 = lazy_align16((size_t)(cap + 1) * 4);
-  float* lut_s = reinterpret_cast<float*>(smem_raw);
-  unsigned char* q0 = smem_raw + kLazyLutBytes;
-  uint32_t* head = reinterpret_cast<uint32_t*>(q0);
+  float* tab = reinterpret_cast<float*>(smem_raw);
+  unsigned char* q0 = smem_raw + kLazyTabBytes;
+  uint32_t* head = reinterpret_cast<uint32_t*>(q0);  // bits 0..7: points in the bin; top byte: scratch of the acceptance
   q0 += lazy_align16((size_t)nbins * 4);
-  uint32_t* link = reinterpret_cast<uint32_t*>(q0);
-  float* pnsc = reinterpret_cast<float*>(q0 + cap4);
-  uint4* recs = reinterpret_cast<uint4*>(q0 + 2 * cap4);
-  float* part = reinterpret_cast<float*>(q0 + 2 * cap4 + (size_t)kLazyChunk * 16);  // [4][64]
+  uint4* slot4 = reinterpret_cast<uint4*>(q0);  // [nbins][2]: {code, level, code, level}
+  q0 += (size_t)nbins * kLazyBinCap * 8;
+  uint64_t* surv = reinterpret_cast<uint64_t*>(q0);  // [4][kLazySurvPerWave]
+  float* part = reinterpret_cast<float*>(q0 + (size_t)kLazyBlockMax * 8);  // [4][64]
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -917,196 +941,318 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
   const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
+  uint2* spill = spill_ws + (size_t)img * spill_stride;  // {cy << 16 | cx, level}
   int kept = 0;
+  OKVFE_LAZY_TICK(t_start);
+#ifdef OKVFE_LAB
+  unsigned long long t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0;
+  int n_windows = 0, n_surv = 0;
+#endif
   if (n > 0) {  // block-uniform
-    // weight(dx, dy) at [(dy + 32) << 6 | (dx + 32)], zero outside the 31 x 31 stamp
-    for (int i = tid; i < 64 * 64; i += kLazyThreads) {
-      const int dx = (i & 63) - 32, dy = (i >> 6) - 32;
-      const bool in = dx >= -15 && dx <= 15 && dy >= -15 && dy <= 15;
-      lut_s[i] = in ? lut[(dy + 15) * 31 + (dx + 15)] : 0.0f;
+    // weight(|dx|, |dy|) at [|dy| << 5 | |dx|], zero outside the 31 x 31 stamp
+    for (int i = tid; i < 32 * 32; i += kLazyThreads) {
+      const int dx = i & 31, dy = i >> 5;
+      tab[i] = (dx <= 15 && dy <= 15) ? lut[(dy + 15) * 31 + (dx + 15)] : 0.0f;
     }
-    const uint32_t link_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)link;
-    const uint32_t end_addr = link_addr + 4u * (uint32_t)cap;
-    const uint32_t nsc_delta = (uint32_t)cap4;
-    const uint32_t lut_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lut_s;
-    for (int i = tid; i < nbins; i += kLazyThreads) head[i] = end_addr;
+    for (int i = tid; i < nbins; i += kLazyThreads) head[i] = 0u;
+    // empty slot: level 0 (contributes nothing) at a VALID cell code, so its table index stays in range
+    for (int i = tid; i < nbins * 2; i += kLazyThreads)
+      slot4[i] = make_uint4((16u << 23) | (16u << 2), 0u, (16u << 23) | (16u << 2), 0u);
     if (tid == 0) {
-      pnsc[cap] = 0.0f;
-      link[cap] = (end_addr >> 2) << 16;
       s_kept = 0;
+      s_spill = 0;
     }
     const float scaling = (float)(15.0 / (double)radius);
     const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-    // candidates [base, base + kLazyChunk): keys are requested one chunk ahead (threads 64..191, one
-    // key each), converted into records {cell, level, pixel, score} when their chunk is next
-    uint64_t kq = 0;
-    const bool converter = tid >= 64 && tid < 64 + kLazyChunk;
-    auto request = [&](int base) {
-      const int i = base + tid - 64;
-      kq = (converter && i < n) ? keys[i] : 0ull;
+    // sorted key -> candidate record {cell, level, pixel, score}
+    auto make_rec = [&](uint64_t k) {
+      const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+      const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
+      const float fy = (float)y * scaling;
+      const float fx = (float)x * scaling;
+      const int cy = (int)(fy + 16.0f);
+      const int cx = (int)(fx + 16.0f);
+      const float q = (float)score / max_score;
+      const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+      return make_uint4(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1), (uint32_t)(k & 0xFFFFFFFFu),
+                        (uint32_t)score);
     };
-    auto convert = [&]() {
-      if (converter) {
-        const uint64_t k = kq;
-        const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-        const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
-        const float fy = (float)y * scaling;
-        const float fx = (float)x * scaling;
-        const int cy = (int)(fy + 16.0f);
-        const int cx = (int)(fx + 16.0f);
-        const float q = (float)score / max_score;
-        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
-        recs[tid - 64] = make_uint4(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1),
-                                    (uint32_t)(k & 0xFFFFFFFFu), (uint32_t)score);
+    // One slot = {code, level}: code = (128 * (16 + y in bin)) << 16 | 4 * (16 + x in bin).  A candidate
+    // at (lx, ly) of its bin looks at the bin at offset (ox, oy) with A = (128 * (ly + 16 (1 - oy))) << 16
+    // | 4 * (lx + 16 (1 - ox)): v_sad_u16 adds the absolute differences of both halves, so
+    // sad(A, code) + table address = the ADDRESS of weight(|dx|, |dy|) in one instruction.
+    const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)tab;
+    auto term = [&](uint32_t waddr, uint32_t levbits) {
+      return ceilf(*reinterpret_cast<__attribute__((address_space(3))) const float*>((uintptr_t)waddr) *
+                   __uint_as_float(levbits));  // 0 for an empty slot (level 0)
+    };
+    // three bins at once (all slot loads, then all weight loads, then the arithmetic: two LDS round
+    // trips for the group); half = 0: slots 0, 1 of every bin, half = 1: slots 2, 3
+    auto bins3 = [&](const int b[3], const uint32_t A[3], int half) {
+      uint4 s3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s3[k] = slot4[2 * b[k] + half];
+      uint32_t wa[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        wa[2 * k] = __builtin_amdgcn_sad_u16(A[k], s3[k].x, tab_addr);
+        wa[2 * k + 1] = __builtin_amdgcn_sad_u16(A[k], s3[k].z, tab_addr);
       }
+      float f = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) f += term(wa[2 * k], s3[k].y) + term(wa[2 * k + 1], s3[k].w);
+      return f;
     };
-    request(0);
-    convert();
-    request(kLazyChunk);
-    // this wave's share of the nine bin lists: chains c = first, first + 4 (, first + 8)
-    const int first = (wave + 1) & 3;  // wave 0 (which also runs the acceptance) and waves 1, 2 walk two lists
+    // points that overflowed their bins (rare): every lane scans the whole list
+    auto spill_terms = [&](int cx, int cy) {
+      float f = 0.0f;
+      const int ns = s_spill;
+      for (int i = 0; i < ns; ++i) {  // block-uniform trip count
+        const uint2 p = spill[i];
+        const int dx = cx - (int)(p.x & 0xFFFF), dy = cy - (int)(p.x >> 16);
+        const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+        if (adx <= 15 && ady <= 15) f += ceilf(tab[(ady << 5) | adx] * __uint_as_float(p.y));
+      }
+      return f;
+    };
+    // the ordered windows split the nine bins of a candidate over the waves: bins c = first,
+    // first + 4 (, first + 8) in row-major order of the 3 x 3 block
+    const int first = (wave + 1) & 3;  // wave 0 (which also runs the acceptance) and waves 1, 2 take two bins
     const int nch = first == 0 ? 3 : 2;
-    int hoff[3];       // offset of the chain's bin from the candidate's bin in the bordered grid
-    uint32_t boff4[3];  // table offset of the chain's bin: 4 * ((16 oy) << 6 + 16 ox)
+    int hoff[3];          // offset of the bin from the candidate's bin in the bordered grid
+    uint32_t aoff[3];     // what the bin's offset adds to the candidate's slot-address operand
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int c = first + 4 * k < 9 ? first + 4 * k : first;
       const int ox = (c % 3) - 1, oy = (c / 3) - 1;
       hoff[k] = oy * bpitch + ox;
-      boff4[k] = (uint32_t)(((16 * oy) << 6) + 16 * ox) << 2;
+      aoff[k] = ((uint32_t)(-16 * oy) << 23) + ((uint32_t)(-16 * ox) << 2);  // (wraps: the fields stay in range)
     }
     const int limit = min(min(max_kpts, kp_cap), cap);
+    uint64_t* my_surv = surv + wave * kLazySurvPerWave;
     __syncthreads();
-    for (int pos = 0; pos < n; pos += 64) {  // block-uniform
-      const int idx = pos + lane;
-      const bool valid = idx < n;
-      uint4 rec = recs[idx & (kLazyChunk - 1)];
-      if (!valid) rec.x = 0u;  // a cell inside the grid; the lane never passes
-      const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
-      const float level = __uint_as_float(rec.y);
-      const int bx = cx >> 4, by = cy >> 4;
-      const int bin = (by + 1) * bpitch + (bx + 1);
-      // The weight table is indexed by (dy + 32) << 6 | (dx + 32): for the bin at offset (ox, oy)
-      // that is cc - (link & 0xFFC) / 4 with cc = (cy & 15 + 32 - 16 oy) << 6 | (cx & 15 + 32 - 16 ox)
-      // -- both fields stay in [1, 63], so there is no borrow between them.
-      const uint32_t lcode = ((uint32_t)(cy & 15) << 6) | (uint32_t)(cx & 15);
-      const uint32_t cc4 = lut_addr + ((lcode + ((32u << 6) | 32u)) << 2);
-      uint32_t hp[3], lk[3];
+#ifdef OKVFE_LAB
+    t_init = __builtin_amdgcn_s_memrealtime();
+#endif
+    // this wave's quarter of a block: keys [lo, hi), up to kLazySurvPerWave = 4 x 64 of them, held in
+    // registers; the NEXT block's are requested before the current block is worked on, so their HBM /
+    // L2 round trip hides behind it
+    auto load_quarter = [&](int a_, int blen_, uint64_t kr[4]) {
+      const int q = blen_ >> 2;
+      const int lo = a_ + wave * q, hi = min(lo + q, min(a_ + blen_, n));
 #pragma unroll
-      for (int k = 0; k < 3; ++k) hp[k] = (k < nch) ? head[bin + hoff[k]] : end_addr;
+      for (int t = 0; t < 4; ++t) {
+        const int i = lo + 64 * t + lane;
+        kr[t] = i < hi ? keys[i] : 0ull;
+      }
+    };
+    uint64_t kcur[4] = {0ull, 0ull, 0ull, 0ull}, knxt[4];
+    int blen = 64, par = 0;
+    for (int a = 0; a < n; a += blen, blen = min(2 * blen, kLazyBlockMax), par ^= 1) {  // block-uniform
+      const int e = min(a + blen, n);
+      load_quarter(a + blen, min(2 * blen, kLazyBlockMax), knxt);
+#ifdef OKVFE_LAB
+      t_mark = __builtin_amdgcn_s_memrealtime();
+#endif
+      // ---- prefilter: this wave's quarter of the block, against the points accepted before the block
+      int my_cnt = 0;
+      if (a == 0) {
+        // nothing is accepted yet: every candidate of the first block survives
+        const int q = (e - a + 3) >> 2;
+        const int lo = wave * q, hi = min(lo + q, e - a);
+        for (int c = lo + lane; c < hi; c += 64) my_surv[c - lo] = keys[c];
+        my_cnt = hi > lo ? hi - lo : 0;
+      } else {
+        const int q = blen >> 2;  // multiple of 16
+        const int lo = a + wave * q, hi = min(lo + q, e);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) lk[k] = lds_u32(hp[k]);
-      float occf = 0.0f;  // sums of small integers: exact in float
-      while (true) {
-        const bool alive = hp[0] != end_addr || hp[1] != end_addr || hp[2] != end_addr;
-        if (!__any(alive)) break;
-        float wgt[3], lev[3];
-        uint32_t nlk[3], nhp[3];
+        for (int t = 0; t < 4; ++t) {
+          const int c0 = lo + 64 * t;
+          if (c0 >= hi) break;  // wave-uniform
+          const int i = c0 + lane;
+          const bool valid = i < hi;
+          const uint64_t kthis = kcur[t];
+          uint4 rec = make_rec(kthis);
+          if (!valid) rec.x = 0u;
+          const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
+          const float level = __uint_as_float(rec.y);
+          const int bin = ((cy >> 4) + 1) * bpitch + ((cx >> 4) + 1);
+          const uint32_t lx = (uint32_t)(cx & 15), ly = (uint32_t)(cy & 15);
+          const uint32_t A0 = ((ly + 16u) << 23) | ((lx + 16u) << 2);  // the candidate's own bin
+          float occf = 0.0f;  // sums of small integers: exact in float
+          uint32_t any_cnt = 0u;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          wgt[k] = lds_f32(cc4 - boff4[k] - (lk[k] & 0xFFCu));
-          lev[k] = lds_f32(hp[k] + nsc_delta);
-          nhp[k] = lk[k] >> 14;
-          nlk[k] = lds_u32(nhp[k]);
-        }
+          for (int g = 0; g < 3; ++g) {  // bin rows oy = g - 1, three bins each
+            const int b0 = bin + (g - 1) * bpitch;
+            const int b[3] = {b0 - 1, b0, b0 + 1};
+            const uint32_t Ag = A0 + ((uint32_t)(16 * (1 - g)) << 23);
+            const uint32_t A[3] = {Ag + (16u << 2), Ag, Ag - (16u << 2)};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          occf += ceilf(wgt[k] * lev[k]);  // 0 for finished walks (level 0) and points out of reach (weight 0)
-          hp[k] = nhp[k];
-          lk[k] = nlk[k];
+            for (int k = 0; k < 3; ++k) any_cnt |= ((head[b[k]] & 0xFFu) > 2u) ? 1u : 0u;
+            occf += bins3(b, A, 0);
+          }
+          if (__any(any_cnt != 0u)) {  // some bin of some lane holds more than two points
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+              const int b0 = bin + (g - 1) * bpitch;
+              const int b[3] = {b0 - 1, b0, b0 + 1};
+              const uint32_t Ag = A0 + ((uint32_t)(16 * (1 - g)) << 23);
+              const uint32_t A[3] = {Ag + (16u << 2), Ag, Ag - (16u << 2)};
+              occf += bins3(b, A, 1);
+            }
+          }
+          if (s_spill != 0) occf += spill_terms(cx, cy);
+          const int occ = (int)occf;
+          const bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
+          const unsigned long long m = __ballot(pass);
+          if (pass) my_surv[my_cnt + __popcll(m & ((1ull << lane) - 1ull))] = kthis;
+          my_cnt += __popcll(m);
         }
       }
-      part[wave * 64 + lane] = occf;
-      __syncthreads();
-      if (wave == 0) {
-        int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
-        bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
-        const float nsc = (float)(0.99 * (double)level);
-        unsigned long long rem = __ballot(pass), accm = 0;
-        int nacc = 0;
-        if (rem != 0) {
-          // Which passing candidates may have another passing candidate of the window within 15
-          // cells?  Two such candidates sit in the same or in adjacent bins (a bin is 16 cells wide):
-          // every passing lane counts itself into the top byte of its bin's head word (the address
-          // below it needs 18 bits; the walks of the other waves never overlap with this phase), reads
-          // the nine counts around it and removes itself again -- two LDS round trips whatever the
-          // number of passing lanes.  Conservative (adjacent bins may be farther apart than 15 cells):
-          // the ordered loop below treats the flagged lanes exactly.
-          bool linked = false;
-          if (pass) {
-            atomicAdd(&head[bin], 1u << 24);
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (pass) {
-            uint32_t cnt = 0;
+      // (a wave may run ahead into the next block's prefilter while another still reads these counts:
+      // the buffer written two blocks later is safe, that wave has passed the barrier in between)
+      if (lane == 0) s_surv[par][wave] = my_cnt;
+      lds_barrier();
+      const int c0n = s_surv[par][0], c1n = c0n + s_surv[par][1], c2n = c1n + s_surv[par][2],
+                total = c2n + s_surv[par][3];
+#ifdef OKVFE_LAB
+      n_surv += total;
+      n_windows += (total + 63) >> 6;
+      t_pref += __builtin_amdgcn_s_memrealtime() - t_mark;
+#endif
+      // ---- ordered windows over the block's survivors (rank order: wave lists in turn)
+      for (int pos = 0; pos < total; pos += 64) {  // block-uniform
+        const int g = pos + lane;
+        const bool valid = g < total;
+        int li = 0, lo = g;
+        if (g >= c2n) { li = 3; lo = g - c2n; }
+        else if (g >= c1n) { li = 2; lo = g - c1n; }
+        else if (g >= c0n) { li = 1; lo = g - c0n; }
+        uint4 rec = make_rec(valid ? surv[li * kLazySurvPerWave + lo] : 0ull);
+        if (!valid) rec.x = 0u;  // a cell inside the grid; the lane never passes
+        const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
+        const float level = __uint_as_float(rec.y);
+        const int bx = cx >> 4, by = cy >> 4;
+        const int bin = (by + 1) * bpitch + (bx + 1);
+        const uint32_t lx = (uint32_t)(cx & 15), ly = (uint32_t)(cy & 15);
+        {
+          const uint32_t A0 = ((ly + 16u) << 23) | ((lx + 16u) << 2);
+          int b[3];
+          uint32_t A[3];
+          bool more = false;
 #pragma unroll
-            for (int b = 0; b < 9; ++b) {
-              const uint32_t c = head[bin + ((b / 3) - 1) * bpitch + (b % 3) - 1] >> 24;
-              cnt += b == 4 ? c - 1u : c;  // own bin: the others in it
-            }
-            linked = cnt != 0;
+          for (int k = 0; k < 3; ++k) {
+            // a wave with two bins looks at bin 0 as its third: a border bin, always empty
+            b[k] = k < nch ? bin + hoff[k] : 0;
+            A[k] = A0 + aoff[k];
+            more = more || (head[b[k]] & 0xFFu) > 2u;
           }
-          __builtin_amdgcn_wave_barrier();
-          if (pass) atomicSub(&head[bin], 1u << 24);
-          const unsigned long long seq = __ballot(linked && pass);
-          const int room = limit - kept;
-          if (__popcll(rem) <= room) {
-            // the unlinked ones neither change nor are changed by anything in this window: accepted
-            // at once; the linked ones go through the ordered loop below
-            accm = rem & ~seq;
-            nacc = __popcll(accm);
-            rem = seq;
-          }  // else: the cap falls inside this window -- everything in order
-          while (rem != 0 && kept + nacc < limit) {  // one iteration per accepted point
-            const int f = (int)__ffsll((long long)rem) - 1;
-            accm |= 1ull << f;
-            ++nacc;
-            const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
-            const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
-            const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
-            const bool near = pass && lane > f && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
-            if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
-              if (near) {
-                occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * wnsc);
-                pass = !(level < (float)(occ > 255 ? 255 : occ));
+          float f = bins3(b, A, 0);
+          if (__any(more)) f += bins3(b, A, 1);
+          if (wave == 3 && s_spill != 0) f += spill_terms(cx, cy);
+          part[wave * 64 + lane] = f;
+        }
+        lds_barrier();
+        if (wave == 0) {
+          int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
+          bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
+          const float nsc = (float)(0.99 * (double)level);
+          unsigned long long rem = __ballot(pass), accm = 0;
+          int nacc = 0;
+          if (rem != 0) {
+            // Which passing candidates may have another passing candidate of the window within 15
+            // cells?  Two such candidates sit in the same or in adjacent bins (a bin is 16 cells wide):
+            // every passing lane counts itself into the top byte of its bin's count word (the walks of
+            // the other waves never overlap with this phase), reads the nine counts around it and
+            // removes itself again -- two LDS round trips whatever the number of passing lanes.
+            // Conservative (adjacent bins may be farther apart than 15 cells): the ordered loop below
+            // treats the flagged lanes exactly.
+            bool linked = false;
+            if (pass) {
+              atomicAdd(&head[bin], 1u << 24);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (pass) {
+              uint32_t cnt = 0;
+#pragma unroll
+              for (int b = 0; b < 9; ++b) {
+                const uint32_t c = head[bin + ((b / 3) - 1) * bpitch + (b % 3) - 1] >> 24;
+                cnt += b == 4 ? c - 1u : c;  // own bin: the others in it
               }
-              rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
-            } else {
-              rem &= rem - 1;
+              linked = cnt != 0;
             }
+            __builtin_amdgcn_wave_barrier();
+            if (pass) atomicSub(&head[bin], 1u << 24);
+            const unsigned long long seq = __ballot(linked && pass);
+            const int room = limit - kept;
+            if (__popcll(rem) <= room) {
+              // the unlinked ones neither change nor are changed by anything in this window: accepted
+              // at once; the linked ones go through the ordered loop below
+              accm = rem & ~seq;
+              nacc = __popcll(accm);
+              rem = seq;
+            }  // else: the cap falls inside this window -- everything in order
+            while (rem != 0 && kept + nacc < limit) {  // one iteration per accepted point
+              const int f = (int)__ffsll((long long)rem) - 1;
+              accm |= 1ull << f;
+              ++nacc;
+              const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
+              const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
+              const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
+              const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+              const bool near = pass && lane > f && adx <= 15 && ady <= 15;
+              if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
+                if (near) {
+                  occ += (int)ceilf(tab[(ady << 5) | adx] * wnsc);
+                  pass = !(level < (float)(occ > 255 ? 255 : occ));
+                }
+                rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
+              } else {
+                rem &= rem - 1;
+              }
+            }
+            if ((accm >> lane) & 1) {
+              const int slot = kept + __popcll(accm & ((1ull << lane) - 1ull));
+              // into the bin: slot j of its array, or the spill list when the array is full
+              const uint32_t j = atomicAdd(&head[bin], 1u) & 0xFFu;
+              const uint32_t code = ((ly + 16u) << 23) | ((lx + 16u) << 2);
+              if (j < (uint32_t)bin_cap) {  // (kLazyBinCap; the lab build can shrink it to exercise the spill list)
+                reinterpret_cast<uint2*>(slot4)[bin * kLazyBinCap + (int)j] = make_uint2(code, __float_as_uint(nsc));
+              } else {
+                atomicSub(&head[bin], 1u);  // the count stays at the capacity
+                const int at = atomicAdd(&s_spill, 1);
+                spill[at] = make_uint2(rec.x, __float_as_uint(nsc));
+                __threadfence_block();  // the other waves read the list right after the window's barrier
+              }
+              // pixel position and score wait in the output record for the sub-pixel pass
+              okvfe_keypoint kp;
+              kp.x = (float)(int)(rec.z & 0xFFFF);
+              kp.y = (float)(int)(rec.z >> 16);
+              kp.size = 12.0f;
+              kp.angle = -1.0f;
+              kp.response = (float)(int32_t)rec.w;
+              kp.octave = 0;
+              kp.class_id = (int32_t)rec.w;  // the exact score (response is its float image)
+              out[slot] = kp;
+            }
+            kept += nacc;
+            if (lane == 0) s_kept = kept;
           }
-          if ((accm >> lane) & 1) {
-            const int slot = kept + __popcll(accm & ((1ull << lane) - 1ull));
-            const uint32_t addr = link_addr + 4u * (uint32_t)slot;
-            const uint32_t prev = atomicExch(&head[bin], addr);
-            link[slot] = (lcode << 2) | ((prev >> 2) << 16);
-            pnsc[slot] = nsc;
-            // pixel position and score wait in the output record for the sub-pixel pass
-            okvfe_keypoint kp;
-            kp.x = (float)(int)(rec.z & 0xFFFF);
-            kp.y = (float)(int)(rec.z >> 16);
-            kp.size = 12.0f;
-            kp.angle = -1.0f;
-            kp.response = (float)(int32_t)rec.w;
-            kp.octave = 0;
-            kp.class_id = (int32_t)rec.w;  // the exact score (response is its float image)
-            out[slot] = kp;
-          }
-          kept += nacc;
-          if (lane == 0) s_kept = kept;
         }
-      } else if (((pos + 64) & (kLazyChunk - 1)) == 0) {
-        // the next window starts a new chunk: every wave holds this window's records in registers
-        convert();
-        request(pos + 64 + kLazyChunk);
+        lds_barrier();
+        kept = s_kept;
+        if (kept >= limit) break;  // block-uniform
       }
-      __syncthreads();
-      kept = s_kept;
       if (kept >= limit) break;  // block-uniform
+#pragma unroll
+      for (int t = 0; t < 4; ++t) kcur[t] = knxt[t];
     }
   }
   // ---- K4: sub-pixel refinement and keypoint emission (all four waves)
   __syncthreads();
+#ifdef OKVFE_LAB
+  t_blocks = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int i = tid; i < kept; i += kLazyThreads) {
     okvfe_keypoint kp = out[i];
     const int u = (int)kp.x, v = (int)kp.y;
@@ -1128,6 +1274,20 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     if (setup.pat) describe_setup_one(setup, w, h, img, (size_t)img * kp_cap + i, kp);
   }
   if (tid == 0) kp_count[img] = kept;
+#ifdef OKVFE_LAB
+  __syncthreads();
+  if (tid == 0 && img == 0) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+    atomicAdd(&g_lazy_prof[0], 1ull);
+    atomicAdd(&g_lazy_prof[1], t_init - t_start);
+    atomicAdd(&g_lazy_prof[2], t_blocks - t_init);
+    atomicAdd(&g_lazy_prof[3], t_end - t_blocks);
+    atomicAdd(&g_lazy_prof[4], t_end - t_start);
+    atomicAdd(&g_lazy_prof[5], t_pref);
+    atomicAdd(&g_lazy_prof[6], (unsigned long long)n_surv);
+    atomicAdd(&g_lazy_prof[7], (unsigned long long)n);
+  }
+#endif
 }
 
 }  // namespace
@@ -1200,9 +1360,16 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
     // lazy occupancy (no grid): any image size / radius whose bin heads and keypoint slots fit in LDS
     const int bins_x = (occ_cols + 15) >> 4, bins_y = (occ_rows + 15) >> 4;
     const int cap = max_kpts < kp_cap ? max_kpts : kp_cap;
-    const size_t lds = lazy_lds_bytes(bins_x, bins_y, cap);
+    const size_t lds = lazy_lds_bytes(bins_x, bins_y);
     constexpr size_t kLazyMaxLds = 159 * 1024;  // the kernel also has a few bytes of static LDS
-    if (lds <= kLazyMaxLds && occ_cols <= 65535 && occ_rows <= 65535) {
+    // the occupancy workspace doubles as the spill list of full bins: 8 bytes per point at worst
+    if (lds <= kLazyMaxLds && occ_cols <= 65535 && occ_rows <= 65535 && occupancy != nullptr &&
+        occ_image_bytes >= (size_t)cap * 8) {
+      static const int bin_cap = [] {  // lab knob: 1..kLazyBinCap slots per bin (fewer = more spills)
+        const char* e = lab_env("OKVFE_LAZY_BINCAP");
+        const int v = e ? atoi(e) : kLazyBinCap;
+        return v < 1 ? 1 : (v > kLazyBinCap ? kLazyBinCap : v);
+      }();
       static bool attr_set = false;
       if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel),
@@ -1212,7 +1379,8 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
       }
       hipLaunchKernelGGL(select_lazy_kernel, dim3(n_images), dim3(kLazyThreads), lds, stream, score, layout, w, h,
                          cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, bins_x, bins_y, cap, kps,
-                         kp_cap, kp_count, setup ? *setup : DescribeSetup{});
+                         kp_cap, kp_count, reinterpret_cast<uint2*>(occupancy), occ_image_bytes / 8, bin_cap,
+                         setup ? *setup : DescribeSetup{});
       return setup != nullptr;  // the extractor's setup ran with the emission
     }
   }
@@ -1264,5 +1432,16 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   }
   return false;
 }
+
+#ifdef OKVFE_LAB
+extern "C" int okvfe_lab_lazy_prof(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lazy_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace okvfe

@@ -109,8 +109,24 @@ struct okvfe_ctx {
   // scratch for the explicit-array matchers (grown on demand)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  uint8_t* h_pinned = nullptr;  // pinned staging for the host-buffer API
+  uint8_t* h_pinned = nullptr;  // pinned staging for the host-buffer API: [image][keypoints in]
+  void* h_pinned_dev = nullptr; // its device-visible address (the copy kernels read it in place)
   size_t h_pinned_bytes = 0;
+  // single-image host-buffer API: ONE image's results land in this pinned block (export_result_kernel),
+  // so a caller waiting for a frame pays one stream synchronisation
+  uint8_t* h_result = nullptr;
+  void* h_result_dev = nullptr;
+  // okvfe_detect_ahead: the whole detect + describe chain ran for this image with this extraction
+  // set-up; an okvfe_compute that asks for exactly that is answered from h_result
+  struct Ahead {
+    bool valid = false;
+    const uint8_t* image = nullptr;
+    size_t stride = 0;
+    int32_t cam = -1;
+    bool aware = false;
+    float g[3] = {0.0f, 0.0f, 0.0f};
+  } ahead;
+  std::vector<uint8_t> ahead_shadow;  // the image okvfe_detect_ahead ran on (ordinary memory)
 
   // stage profiling (okvfe_profile_*): event pairs per recorded stage launch
   uint32_t prof_mask = 0;  // bit s = stage s is timed

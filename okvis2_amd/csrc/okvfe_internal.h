@@ -188,7 +188,23 @@ bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* 
                        ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
                        int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream);
 void launch_param_copy(void* dst_dev, const void* src_host_mapped, size_t bytes, int32_t* zero_dev, int n_zero,
-                       hipStream_t stream);
+                       hipStream_t stream, int32_t* poke_dev = nullptr, int32_t poke_value = 0);
+// one image's results -> one block of pinned host memory (k_util.hip); null sources are skipped
+struct ResultSrc {
+  const int32_t* count;          // [B] final keypoint counts
+  const okvfe_keypoint* kps;     // [B][kp_cap]
+  const uint8_t* desc;           // [B][kp_cap][48]
+  const double* bp;              // [B][kp_cap][3]
+  const uint8_t* bpv;            // [B][kp_cap]
+  const int32_t* det_count;      // [B] detector's counts
+  const okvfe_keypoint* det_kps; // [B][kp_cap]
+  const int32_t* cand_count;     // [B] NMS maxima found (may exceed the capacity)
+};
+struct ResultLayout {  // byte offsets inside the host block: header {n, candidates, detected, 0}
+  int32_t o_count, o_kps, o_desc, o_bp, o_bpv, o_det, total;
+};
+void launch_export_result(const ResultSrc& src, int index, int kp_cap, const ResultLayout& layout,
+                          void* dst_host_mapped, hipStream_t stream);
 bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                               ScoreLayout layout, hipStream_t stream);
 // the layout launch_harris_nms writes for w x h images (dense when the fused kernel does not apply)

@@ -67,10 +67,21 @@ class Context {
   void check(okvfe_status st) const {
     if (st != OKVFE_OK) throw Exception(st, okvfe_last_error(ctx_));
   }
+  // The extractor that shares this context announces what its next compute() will ask for
+  // (Frontend.cpp:246-251 sets the direction BEFORE Frame::detect / Frame::describe): the detector
+  // then runs okvfe_detect_ahead, and the compute() that follows on the same image costs no GPU work.
+  struct NextExtraction {
+    bool paired = false;  // an extractor is attached and wants pairing
+    int cam = -1;
+    bool aware = false;
+    std::array<float, 3> dir{{0.0f, 1.0f, 0.0f}};
+  };
+  NextExtraction& nextExtraction() { return next_; }
 
  private:
   okvfe_ctx* ctx_ = nullptr;
   int max_keypoints_ = 0;
+  NextExtraction next_;
 };
 
 // = brisk::ScaleSpaceFeatureDetector<brisk::HarrisScoreCalculator>(uniformityRadius, octaves,
@@ -81,8 +92,13 @@ class HipBriskDetector {
   void detect(const ImageView& image, std::vector<KeyPoint>& keypoints) const {
     keypoints.resize(size_t(ctx_->maxKeypoints()));
     int32_t n = 0;
-    ctx_->check(okvfe_detect(ctx_->get(), image.data, image.stride, keypoints.data(),
-                             int32_t(keypoints.size()), &n));
+    const Context::NextExtraction& nx = ctx_->nextExtraction();
+    if (nx.paired)
+      ctx_->check(okvfe_detect_ahead(ctx_->get(), image.data, image.stride, nx.aware ? nx.cam : -1,
+                                     nx.aware ? nx.dir.data() : nullptr, keypoints.data(), int32_t(keypoints.size()), &n));
+    else
+      ctx_->check(okvfe_detect(ctx_->get(), image.data, image.stride, keypoints.data(),
+                               int32_t(keypoints.size()), &n));
     keypoints.resize(size_t(n));
   }
 
@@ -94,20 +110,30 @@ class HipBriskDetector {
 //   cv::DescriptorExtractor with the camera-aware extras (Frontend.cpp:2410-2412, 232-251)
 class HipBriskExtractor {
  public:
-  HipBriskExtractor(std::shared_ptr<Context> ctx, int cameraSlot)
-      : ctx_(std::move(ctx)), cam_(cameraSlot) {}
+  // pairWithDetector: a HipBriskDetector on the same context answers this extractor's compute()
+  // ahead of time when both see the same image (okvfe_detect_ahead)
+  HipBriskExtractor(std::shared_ptr<Context> ctx, int cameraSlot, bool pairWithDetector = true)
+      : ctx_(std::move(ctx)), cam_(cameraSlot) {
+    ctx_->nextExtraction().paired = pairWithDetector;
+    ctx_->nextExtraction().cam = cam_;
+  }
   bool isCameraAware() const { return aware_; }
   // rays: H*W*3 f32, imageJacobians: H*W*6 f32 (PinholeCamera.hpp:180-208)
   void setCameraProperties(const float* rays, const float* imageJacobians, float fu) {
     ctx_->check(okvfe_set_camera_maps(ctx_->get(), cam_, rays, imageJacobians, fu));
     aware_ = true;
+    ctx_->nextExtraction().aware = true;
   }
   // full intrinsics: also enables back-projection of the kept keypoints on the GPU
   void setCamera(const okvfe_camera& camera) {
     ctx_->check(okvfe_set_camera(ctx_->get(), cam_, &camera));
     aware_ = true;
+    ctx_->nextExtraction().aware = true;
   }
-  void setExtractionDirection(const std::array<float, 3>& dir) { dir_ = dir; }
+  void setExtractionDirection(const std::array<float, 3>& dir) {
+    dir_ = dir;
+    ctx_->nextExtraction().dir = dir;
+  }
   // keypoints in/out: keypoints too close to the rim are removed (Frame.hpp:146)
   void compute(const ImageView& image, std::vector<KeyPoint>& keypoints, Descriptors& descriptors,
                std::vector<std::array<double, 3>>* backProjections = nullptr,
@@ -161,7 +187,7 @@ struct FrontendParameters {  // okvis_common/include/okvis/Parameters.hpp:123-13
 class HipFrontend {
  public:
   HipFrontend(const std::vector<okvfe_camera>& cameras, const FrontendParameters& p, int device = 0)
-      : cameras_(cameras), mutexes_(cameras.size()) {
+      : cameras_(cameras), mutexes_(cameras.size()), bp_scratch_(cameras.size()) {
     if (cameras.empty()) throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "no cameras");
     for (size_t i = 0; i < cameras.size(); ++i) {
       okvfe_config cfg{};
@@ -198,10 +224,26 @@ class HipFrontend {
     std::array<float, 3> dir;
     for (int i = 0; i < 3; ++i) dir[size_t(i)] = float(-T_WC.C[6 + i]);  // C^T * (0,0,-1)
     ex.setExtractionDirection(dir);
-    detectors_[cameraIndex].detect(image, frameOut.keypoints);
-    ex.compute(image, frameOut.keypoints, frameOut.descriptors, &frameOut.backProjections,
-               &frameOut.backProjectionsValid);
-    frameOut.landmarkIds.assign(frameOut.keypoints.size(), 0);
+    // Frame::detect + Frame::describe + computeBackProjections (Frontend.cpp:257-266) as ONE call:
+    // one image upload, one kernel chain, one synchronisation
+    Context& c = *contexts_[cameraIndex];
+    const int cap = c.maxKeypoints();
+    frameOut.keypoints.resize(size_t(cap));
+    frameOut.descriptors.data.resize(size_t(cap) * OKVFE_DESC_BYTES);
+    bp_scratch_[cameraIndex].resize(size_t(cap) * 3);
+    frameOut.backProjectionsValid.resize(size_t(cap));
+    int32_t n = 0;
+    c.check(okvfe_detect_describe(c.get(), image.data, image.stride, 0, dir.data(), frameOut.keypoints.data(),
+                                  frameOut.descriptors.data.data(), bp_scratch_[cameraIndex].data(),
+                                  frameOut.backProjectionsValid.data(), cap, &n));
+    frameOut.keypoints.resize(size_t(n));
+    frameOut.descriptors.rows = n;
+    frameOut.descriptors.data.resize(size_t(n) * OKVFE_DESC_BYTES);
+    frameOut.backProjectionsValid.resize(size_t(n));
+    frameOut.backProjections.resize(size_t(n));
+    const double* bp = bp_scratch_[cameraIndex].data();
+    for (int k = 0; k < n; ++k) frameOut.backProjections[size_t(k)] = {bp[3 * k], bp[3 * k + 1], bp[3 * k + 2]};
+    frameOut.landmarkIds.assign(size_t(n), 0);
     return true;
   }
 
@@ -345,6 +387,7 @@ class HipFrontend {
   std::vector<std::shared_ptr<Context>> contexts_;
   std::vector<HipBriskDetector> detectors_;
   std::vector<HipBriskExtractor> extractors_;
+  std::vector<std::vector<double>> bp_scratch_;  // per camera (one thread per camera)
 };
 
 }  // namespace okvfe

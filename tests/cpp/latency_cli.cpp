@@ -50,6 +50,7 @@ struct Stat {
   std::vector<double> v;
   void add(double x) { v.push_back(x); }
   std::string json() {
+    if (v.empty()) return "null";
     std::sort(v.begin(), v.end());
     double s = 0;
     for (double x : v) s += x;
@@ -64,6 +65,10 @@ struct Stat {
 
 int main(int argc, char** argv) {
   if (argc < 2) return 1;
+  // optional second argument: the route to time ("vi", "cv", "c"; default all three in one process --
+  // bench.py runs one process per route, so that every route sees the GPU's hardware queues alone)
+  const std::string only = argc > 2 ? argv[2] : "";
+  auto runs = [&](const char* r) { return only.empty() || only == r; };
   FILE* f = fopen(argv[1], "rb");
   if (!f) return 1;
   int32_t hdr[5];
@@ -101,14 +106,16 @@ int main(int argc, char** argv) {
   }
   fclose(f);
   try {
-    okvfe::HipViFrontend vi(std::unique_ptr<okvis::ViFrontendInterface>(new RestStub()), cams, prm);
+    // every route builds (and drops) its own contexts: a route sees the GPU's hardware queues alone
     okvis::kinematics::Transformation T[2];
     for (int c = 0; c < 2; ++c)
       for (int r = 0; r < 3; ++r)
         for (int q = 0; q < 3; ++q) T[c].C_(r, q) = poses[c].C[3 * r + q];
-    Stat vi_total, vi_dd, vi_match, cv_total, c_total;
+    Stat vi_total, vi_dd, vi_match, cv_total, cv_det0, cv_cmp0, c_total;
     size_t kp_sum = 0, match_sum = 0;
     // ---- route vi ---------------------------------------------------------------------------
+    if (runs("vi")) {
+    okvfe::HipViFrontend vi(std::unique_ptr<okvis::ViFrontendInterface>(new RestStub()), cams, prm);
     for (int it = -warmup; it < iters; ++it) {
       auto mf = mfs[size_t((it + warmup) % nframes)];
       const double t0 = now_ms();
@@ -126,7 +133,9 @@ int main(int argc, char** argv) {
         for (const auto& r : m) match_sum += r.k1 >= 0;
       }
     }
+    }
     // ---- route cv: Frame::detect() then Frame::describe() on the same cv::Mat ------------------
+    if (runs("cv")) {
     std::shared_ptr<cv::FeatureDetector> det[2];
     std::shared_ptr<cv::DescriptorExtractor> ext[2];
     for (int c = 0; c < 2; ++c) {
@@ -146,9 +155,15 @@ int main(int argc, char** argv) {
         static_cast<okvfe::cv_adapters::HipExtractor*>(ext[c].get())
             ->setExtractionDirection(cv::Vec3f(float(-poses[c].C[6]), float(-poses[c].C[7]), float(-poses[c].C[8])));
         std::vector<cv::KeyPoint> kps;
+        const double ta = now_ms();
         det[c]->detect(mf->images_[c], kps);
+        const double tb = now_ms();
         cv::Mat desc;
         ext[c]->compute(mf->images_[c], kps, desc);
+        if (c == 0 && it >= 0) {
+          cv_det0.add(tb - ta);
+          cv_cmp0.add(now_ms() - tb);
+        }
       };
       const double t0 = now_ms();
       std::thread worker([&] { one(1); });
@@ -156,8 +171,9 @@ int main(int argc, char** argv) {
       worker.join();
       if (it >= 0) cv_total.add(now_ms() - t0);
     }
+    }
     // ---- route c: okvfe_detect_describe straight through the C ABI ------------------------------
-    {
+    if (runs("c")) {
       okvfe::HipFrontend fe(cams, prm);
       std::vector<okvfe::FrameData> fd(2);
       for (int it = -warmup; it < iters; ++it) {
@@ -171,9 +187,11 @@ int main(int argc, char** argv) {
     }
     printf("{\"frames\": %d, \"distinct\": %d, \"mean_keypoints_per_image\": %.1f, \"mean_matches\": %.1f, "
            "\"vi_stereo_frame_ms\": %s, \"vi_detect_describe_ms\": %s, \"vi_match_stereo_ms\": %s, "
-           "\"cv_detect_compute_ms\": %s, \"hipfrontend_detect_describe_ms\": %s}\n",
+           "\"cv_detect_compute_ms\": %s, \"cv_cam0_detect_ms\": %s, \"cv_cam0_compute_ms\": %s, "
+           "\"hipfrontend_detect_describe_ms\": %s}\n",
            iters, nframes, double(kp_sum) / (2.0 * iters), double(match_sum) / iters, vi_total.json().c_str(),
-           vi_dd.json().c_str(), vi_match.json().c_str(), cv_total.json().c_str(), c_total.json().c_str());
+           vi_dd.json().c_str(), vi_match.json().c_str(), cv_total.json().c_str(), cv_det0.json().c_str(),
+           cv_cmp0.json().c_str(), c_total.json().c_str());
   } catch (const okvfe::Exception& e) {
     fprintf(stderr, "%s\n", e.what());
     return 4;

@@ -166,7 +166,7 @@ print("KNOB-OK")
 
 
 @pytest.mark.parametrize("knob", ["OKVFE_LEGACY_SORT", "OKVFE_K1_NOPACK", "OKVFE_SELECT_OCC_HBM",
-                                  "OKVFE_LEGACY_SELECT"])
+                                  "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP"])
 def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     """The A/B switches the profiling notes refer to (read once per process, hence a child process
     each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
