@@ -881,8 +881,17 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     } else if (nms) {
       // rows per wave (6k + 1): more rows = fewer halo rows per tile (6 per tile), but longer waves
       // (tail) and a later epilogue
-      switch (th_env) {
+      // A call that cannot fill the GPU anyway (a frame or two: the B = 1 seams) is latency-bound --
+      // one wave's dependent row steps, pixel loads three rows ahead -- so it takes 25-row tiles:
+      // 2.4 x as many, shorter waves (one 752x480 image: 36 -> ~16 us)
+      int th = th_env;
+      if (th == 0) {
+        const int ytiles61 = (h + 61 * kWavesPerBlock - 1) / (61 * kWavesPerBlock);
+        th = (long long)strips * ytiles61 * n_images <= 128 ? 25 : 61;
+      }
+      switch (th) {
         case 25: OKVFE_K1_NMS_LAUNCH(25); break;
+#ifdef OKVFE_LAB  // tile heights of the experiments in LAB_NOTES.md
         case 31: OKVFE_K1_NMS_LAUNCH(31); break;
         case 37: OKVFE_K1_NMS_LAUNCH(37); break;
         case 43: OKVFE_K1_NMS_LAUNCH(43); break;
@@ -890,6 +899,7 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
         case 55: OKVFE_K1_NMS_LAUNCH(55); break;
         case 91: OKVFE_K1_NMS_LAUNCH(91); break;
         case 121: OKVFE_K1_NMS_LAUNCH(121); break;
+#endif
         default: OKVFE_K1_NMS_LAUNCH(61); break;
       }
     } else {

@@ -166,13 +166,14 @@ print("KNOB-OK")
 
 
 @pytest.mark.parametrize("knob", ["OKVFE_LEGACY_SORT", "OKVFE_K1_NOPACK", "OKVFE_SELECT_OCC_HBM",
-                                  "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP"])
+                                  "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP", "OKVFE_K1_TH=61", "OKVFE_K1_TH=25"])
 def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     """The A/B switches the profiling notes refer to (read once per process, hence a child process
     each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
     grid in HBM, one-accept-per-round selection.  Each must stay bit-exact."""
     env = _lab_environ()
-    env[knob] = "1"
+    k, _, v = knob.partition("=")
+    env[k] = v or "1"
     out = subprocess.run([sys.executable, "-c", _KNOB_CHILD, ROOT], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "KNOB-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
