@@ -738,6 +738,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
+        state["elapsed_local"] = el
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -772,6 +773,7 @@ def main():
     # MIN_TIMED_S cannot resolve a 2 % change, so a second, longer region is timed as well and
     # reported beside it as `long_region` -- `value` always comes from the requested steps.
     elapsed, last_v = timed(args.steps, args.feed)
+    elapsed_local = state["elapsed_local"]
     steps_timed = args.steps
     long_region = None
     if elapsed < MIN_TIMED_S and not args.exact_steps and steps_flag:
@@ -785,6 +787,17 @@ def main():
     # candidate list would have left that image without keypoints
     for lane in lanes:
         lane[0].check_capacity(n_lane_img)
+    # multi-GPU sanity for the driver's scaling runs: every rank reports in (an all-reduce of ones must
+    # give the world size) and its own rate, so a rank that idled or ran elsewhere shows in the line
+    ranks_seen, per_rank = 1, None
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        mine = torch.tensor([B * args.steps / elapsed_local], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = [float(v.item()) for v in allv]
     kp_total = 0
     kp_counts = []
     for i in range(min(n_img, C * distinct)):
@@ -927,6 +940,8 @@ def main():
             "value": world * B * steps_timed / elapsed,
             "unit": unit,
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "per_rank_value": per_rank,
             "steps": steps_timed,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / steps_timed,

@@ -25,3 +25,12 @@ def test_vi_frontend_overrides_every_pure_virtual():
     for name in ("detectAndDescribe", "dataAssociationAndInitialization", "propagation"):
         assert re.search(r"bool " + name + r"\([^{;]*\)\s*(const\s*)?override\s*\{", src), name
     assert "public okvis::ViFrontendInterface" in src
+
+
+def test_fp64_reference_dump_tool_type_checks():
+    """tools/ref_compare/ref_dump_fp64.cpp (triangulateFast / backProject / matchStereo rows out of real
+    Eigen) against declarations of the okvis / Eigen names it uses."""
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "mock", "fp64"),
+           os.path.join(ROOT, "tools", "ref_compare", "ref_dump_fp64.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

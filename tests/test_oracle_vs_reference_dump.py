@@ -229,6 +229,96 @@ def stage_report(oracle, DUMP):
     return rep
 
 
+def _fp64_expected(oracle):
+    """What the oracle computes for the inputs of tools/ref_compare/ref_dump_fp64.cpp, in the dump's layout:
+    (tri [n, 6], bp {'rt': [n, 4], 'eq': [n, 4]}, stereo [n0, 7])."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "ref_compare"))
+    import make_inputs
+    _, P = make_inputs.fp64_inputs(oracle)
+    tri = np.zeros((len(P["tri"]), 6))
+    for i, t in enumerate(P["tri"]):
+        hp, valid, par = oracle.triangulate_fast(t[0:3], t[3:6], t[6:9], t[9:12], t[12])
+        tri[i] = [*hp, float(valid), float(par)]
+    bp = {}
+    for key in ("rt", "eq"):
+        out = np.zeros((len(P["pts"][key]), 4))
+        for i, pt in enumerate(P["pts"][key]):
+            ok, ray = oracle.cam_backproject(P["cams"][key], pt)
+            out[i] = [*(ray if ok else (0.0, 0.0, 0.0)), float(ok)]
+        bp[key] = out
+    cfg = P["cfg"]
+    (k0, d0), (k1, d1) = P["sides"]
+    b0, v0 = oracle.backproject_keypoints(cfg.cams[0], k0)
+    b1, v1 = oracle.backproject_keypoints(cfg.cams[1], k1)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    m = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, P["poses"][0], P["poses"][1], f0, f1, cfg.match_threshold)
+    st = np.zeros((len(k0), 7))
+    for i, r in enumerate(m):
+        if r["k1"] >= 0:
+            st[i] = [float(r["k1"]), float(r["dist"]), float(r["initialisable"]), *r["hp_W"]]
+        else:
+            st[i] = [-1.0, float(cfg.match_threshold), 0.0, 0.0, 0.0, 0.0, 0.0]
+    return tri, bp, st
+
+
+def _fp64_read(DUMP):
+    f = os.path.join(DUMP, "fp64_dump.bin")
+    if not os.path.exists(f):
+        return None
+    raw = open(f, "rb").read()
+    n_tri, n_bp, n0, n1 = np.frombuffer(raw[:16], dtype="<i4")
+    v = np.frombuffer(raw[16:], dtype="<f8")
+    a = 6 * n_tri
+    tri = v[:a].reshape(n_tri, 6)
+    rt = v[a:a + 4 * n_bp].reshape(n_bp, 4)
+    eq = v[a + 4 * n_bp:a + 8 * n_bp].reshape(n_bp, 4)
+    st = v[a + 8 * n_bp:a + 8 * n_bp + 7 * n0].reshape(n0, 7)
+    return tri, {"rt": rt, "eq": eq}, st
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int64) - b.view(np.int64))
+
+
+def fp64_stage_report(oracle, DUMP):
+    """The FP64 chain of the matchers against real Eigen (tools/ref_compare/ref_dump_fp64.cpp): doubles are
+    compared as bit patterns; a difference is reported with its size in ulp and where it first shows."""
+    rep = []
+    got = _fp64_read(DUMP)
+    if got is None:
+        return [("triangulateFast (Eigen)", None, "no fp64_dump.bin"), ("backProject radial-tangential", None, ""),
+                ("backProject equidistant", None, ""), ("matchStereo rows", None, "")]
+    tri_r, bp_r, st_r = got
+    tri, bp, st = _fp64_expected(oracle)
+
+    def cmp(name, mine, ref, flags):
+        mine, ref = np.ascontiguousarray(mine), np.ascontiguousarray(ref)
+        if mine.shape != ref.shape:
+            return rep.append((name, False, f"shape {mine.shape} here, {ref.shape} in the dump"))
+        fl = np.flatnonzero((mine[:, flags] != ref[:, flags]).any(axis=1))
+        if len(fl):
+            i = int(fl[0])
+            return rep.append((name, False, f"{len(fl)} rows with different decisions, first row {i}: "
+                                            f"{mine[i, flags].tolist()} here, {ref[i, flags].tolist()} there"))
+        vals = [c for c in range(mine.shape[1]) if c not in flags]
+        u = _ulps(mine[:, vals], ref[:, vals])
+        if u.max() > 0:
+            i, j = np.unravel_index(int(u.argmax()), u.shape)
+            first = int(np.flatnonzero(u.any(axis=1))[0])
+            return rep.append((name, False, f"{int((u > 0).any(axis=1).sum())} of {len(u)} rows differ in some bit "
+                                            f"(max {int(u.max())} ulp at row {i}, first row {first}): the evaluation "
+                                            "order of a sum / product differs from Eigen's"))
+        rep.append((name, True, ""))
+
+    cmp("triangulateFast (Eigen)", tri, tri_r, [4, 5])
+    cmp("backProject radial-tangential", bp["rt"], bp_r["rt"], [3])
+    cmp("backProject equidistant", bp["eq"], bp_r["eq"], [3])
+    cmp("matchStereo rows", st, st_r, [0, 1, 2])
+    return rep
+
+
 def first_divergence(rep):
     for stage, ok, detail in rep:
         if ok is False:
@@ -240,7 +330,7 @@ def first_divergence(rep):
 def test_stage_by_stage_against_the_reference_dump(oracle):
     """THE pin: every stage of detector and extractor against what the real brisk produced; the
     failure message names the first stage that differs and how."""
-    rep = stage_report(oracle, DUMP)
+    rep = stage_report(oracle, DUMP) + fp64_stage_report(oracle, DUMP)
     for stage, ok, detail in rep:
         print(f"{'ok  ' if ok else ('skip' if ok is None else 'DIFF')} {stage} {detail}")
     msg = first_divergence(rep)
@@ -329,3 +419,44 @@ def test_compare_harness_on_a_self_dump(oracle, tmp_path):
     pb.tofile(os.path.join(d, first_probe))
     msg = first_divergence(stage_report(oracle, d))
     assert msg and msg.startswith("FIRST DIVERGING STAGE: extractor probes") and "[28]" in msg, msg
+
+
+def test_fp64_harness_on_a_self_dump(oracle, tmp_path):
+    """The FP64 stages (triangulateFast, backProject x 2, matchStereo rows) against a dump in the format of
+    tools/ref_compare/ref_dump_fp64.cpp written by the oracle itself: proves the reader and the comparison,
+    not parity -- and that ONE flipped ulp in one triangulated point, or one different match decision, is
+    named with its stage."""
+    import struct
+    d = str(tmp_path)
+    tri, bp, st = _fp64_expected(oracle)
+    assert (tri[:, 4] == 1).sum() > 100 and (tri[:, 5] == 1).sum() > 50 and (tri[:, 4] == 0).sum() > 20
+    assert (bp["rt"][:, 3] == 1).sum() > 400 and (bp["eq"][:, 3] == 1).sum() > 400
+    assert (st[:, 0] >= 0).sum() > 50
+
+    def write(tri_, bp_, st_):
+        with open(os.path.join(d, "fp64_dump.bin"), "wb") as f:
+            f.write(struct.pack("<4i", len(tri_), len(bp_["rt"]), len(st_), 0))
+            for a in (tri_, bp_["rt"], bp_["eq"], st_):
+                f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+
+    write(tri, bp, st)
+    rep = fp64_stage_report(oracle, d)
+    assert [ok for _, ok, _ in rep] == [True] * 4, rep
+    t2 = tri.copy()
+    row = int(np.flatnonzero(t2[:, 4] == 1)[3])
+    t2[row, 1] = np.nextafter(t2[row, 1], np.inf)
+    write(t2, bp, st)
+    msg = first_divergence(fp64_stage_report(oracle, d))
+    assert msg and msg.startswith("FIRST DIVERGING STAGE: triangulateFast") and "max 1 ulp" in msg and f"row {row}" in msg, msg
+    s2 = st.copy()
+    row = int(np.flatnonzero(s2[:, 0] >= 0)[0])
+    s2[row, 0] += 1.0
+    write(tri, bp, s2)
+    msg = first_divergence(fp64_stage_report(oracle, d))
+    assert msg and msg.startswith("FIRST DIVERGING STAGE: matchStereo rows") and "different decisions" in msg, msg
+    b2 = {"rt": bp["rt"], "eq": bp["eq"].copy()}
+    row = int(np.flatnonzero(b2["eq"][:, 3] == 1)[5])
+    b2["eq"][row, 2] = np.nextafter(b2["eq"][row, 2], 0.0)
+    write(tri, b2, st)
+    msg = first_divergence(fp64_stage_report(oracle, d))
+    assert msg and msg.startswith("FIRST DIVERGING STAGE: backProject equidistant"), msg

@@ -78,9 +78,83 @@ def probes():
     return out
 
 
+N_TRI, N_BP = 400, 600
+
+
+def fp64_inputs(oracle=None):
+    """Inputs of tools/ref_compare/ref_dump_fp64.cpp as one byte string (layout: see that file) plus the
+    parsed pieces for the comparison side.  Ray pairs: a 3-D point seen from two centres with angular
+    noise (intersecting), near-parallel pairs (far points), diverging and crossing-behind pairs, exactly
+    parallel rays.  Pixels: a grid + seeded random points incl. the image rim, for the EuRoC
+    (radial-tangential) and TUM-VI (equidistant) intrinsics.  Stereo: the oracle's keypoints / descriptors
+    of a seeded EuRoC pair (inputs only -- the dump recomputes every double with the reference's code)."""
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if oracle is None:
+        import oracle_lib as oracle
+    rng = np.random.default_rng(20260928)
+    tri = np.zeros((N_TRI, 13))
+    for i in range(N_TRI):
+        kind = i % 5
+        p1 = rng.normal(0, 0.3, 3)
+        p2 = p1 + np.array([rng.uniform(0.05, 0.3), rng.normal(0, 0.02), rng.normal(0, 0.02)])
+        X = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(0.3, 60.0) if kind != 1 else rng.uniform(200, 5000)])
+        e1, e2 = X - p1, X - p2
+        if kind == 2:      # diverging: the second ray looks away
+            e2 = e2 * np.array([1, 1, -1.0])
+        if kind == 3:      # noisy: rays miss each other
+            e1 = e1 + rng.normal(0, 0.02, 3)
+            e2 = e2 + rng.normal(0, 0.02, 3)
+        if kind == 4 and i % 10 == 4:  # exactly parallel
+            e2 = e1.copy()
+        e1, e2 = e1 / np.linalg.norm(e1), e2 / np.linalg.norm(e2)
+        tri[i] = np.concatenate([p1, e1, p2, e2, [rng.choice([12.0, 18.0, 24.0]) / 458.0 * 0.125]])
+    blob = struct.pack("<4i", N_TRI, N_BP, 0, 0)  # n0 / n1 patched below
+    blob += tri.tobytes()
+    cams = {"rt": synth.euroc_config().cams[0], "eq": synth.tumvi1024_config().cams[0]}
+    pts = {}
+
+    def intr(c):
+        return struct.pack("<4i", c.w, c.h, c.dist_type, 0) + struct.pack("<8d", c.fu, c.fv, c.cu, c.cv, *c.d)
+
+    for key in ("rt", "eq"):
+        c = cams[key]
+        g = np.stack(np.meshgrid(np.linspace(0, c.w - 1, 20), np.linspace(0, c.h - 1, 15)), -1).reshape(-1, 2)
+        r = np.stack([rng.uniform(-8, c.w + 8, N_BP - len(g)), rng.uniform(-8, c.h + 8, N_BP - len(g))], 1)
+        pts[key] = np.concatenate([g, r])[:N_BP].astype(np.float32).astype(np.float64)  # keypoints are floats
+        blob += intr(c) + pts[key].tobytes()
+    cfg = synth.euroc_config()
+    L, R, _ = synth.stereo_pair(cfg.w, cfg.h, 77)
+    sides = []
+    for ci, img in enumerate((L, R)):
+        cam = cfg.cams[ci]
+        rays, jac = oracle.awareness_maps(cam)
+        k, d = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                      oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.0, 1.0, 0.0))
+        sides.append((k, d))
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    # a rotated, translated rig: the products with C and the subtraction of r are not trivial
+    a = 0.3
+    Rw = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(0.1), -np.sin(0.1)], [0, np.sin(0.1), np.cos(0.1)]])
+    tw = np.array([1.5, -0.25, 0.75])
+    poses = [((Rw @ np.asarray(C).reshape(3, 3)).reshape(-1), Rw @ np.asarray(r) + tw) for C, r in (T0, T1)]
+    blob += intr(cfg.cams[0]) + intr(cfg.cams[1])
+    for C, r in poses:
+        blob += np.asarray(C, np.float64).tobytes() + np.asarray(r, np.float64).tobytes()
+    blob += struct.pack("<d", float(cfg.match_threshold))
+    for k, d in sides:
+        blob += np.stack([k["x"], k["y"], k["size"]], 1).astype(np.float32).tobytes() + d.tobytes()
+    n0, n1 = len(sides[0][0]), len(sides[1][0])
+    blob = blob[:8] + struct.pack("<2i", n0, n1) + blob[16:]
+    return blob, dict(tri=tri, cams=cams, pts=pts, cfg=cfg, sides=sides, poses=poses)
+
+
 def main():
     out_dir = sys.argv[1]
     os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "fp64_inputs.bin"), "wb") as f:
+        f.write(fp64_inputs()[0])
     with open(os.path.join(out_dir, "probes.txt"), "w") as f:
         f.write("# file W H kx ky\n")
         for name, img in probes():
