@@ -343,7 +343,7 @@ constexpr int kCandStage = OKVFE_K1_STAGE;  // candidate records staged per wave
 template <int kTHF, bool NMS, bool PACK = false, bool MEMONLY = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
-    int ytiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
+    int rtiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
   constexpr int kMain = NMS ? kTHF - 1 : kTHF;  // steps of the uniform main loop
   static_assert(kMain % 6 == 0 && kTHF <= 121, "rows per wave: 6k (+1 with the fused NMS), <= 121");
   constexpr int kSlots = kTHF > 64 ? kScoreSlots + 2 : kScoreSlots;  // stack depth per lane
@@ -355,20 +355,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   // differs between the sub-strips is per-lane already (dword index, load / store offsets, store
   // predicate), so the row loop is the same code; only the candidate reservation of the epilogue
   // runs once per image.
-  int image, tile, ytile, strip, d;
+  // Tiles are handed out per WAVE, not per block: wave v of block b takes tile 4 b + v of its stream, so
+  // an image whose row tiles do not fill whole blocks of four (540 rows = 9 tiles of 61, 1024 rows = 17)
+  // leaves no idle wave slots behind (a block with one live wave still held its 28 KB of LDS: Hilti
+  // 720x540 ran 25 % more blocks than it had work for).  Streams keep the images on their XCDs: the
+  // dispatcher places block L on XCD L % 8, stream x = the tiles of images x, x + 8, x + 16, ... in
+  // order (strip-major, rows of a strip consecutive: a block's waves are vertical neighbours and
+  // share their halo rows in that XCD's L2); the last n % 8 images form one stream of their own.
+  int image, tile, strip, d;
   int sub = 0;          // PACK: which of the wave's images this lane works on
   int group_images = 1;  // images addressed through this wave's buffer resources
   bool lane_on = true;  // PACK: lane belongs to an existing image
   const bool packed_block = PACK && (int)blockIdx.x >= main_blocks;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
   int row_tile;  // which kTHF-row tile of the image this wave owns
-  const int ytiles_blk = ytiles;
   if (packed_block) {
-    const int p = (int)blockIdx.x - main_blocks;
-    const int group = p / ytiles_blk;
-    ytile = p - group * ytiles_blk;
-    row_tile = ytile * kWavesPerBlock + wave;
+    const int p = ((int)blockIdx.x - main_blocks) * kWavesPerBlock + wave;
+    const int group = p / rtiles;
+    row_tile = p - group * rtiles;
     image = group * pack_g;  // first image of the group
+    if (image >= n_images) return;  // wave-uniform: past the last group
     group_images = n_images - image < pack_g ? n_images - image : pack_g;
     strip = strips;  // index of the (packed) last strip
     sub = lane / pack_u;
@@ -377,10 +383,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     if (!lane_on) sub = 0;
     d = lane_on ? strip * kStripLanes + j : nd;  // idle lanes behave like lanes past the row end
   } else {
-    xcd_tile(strips * ytiles, n_images, &image, &tile);
-    ytile = tile / strips;
-    strip = tile - ytile * strips;
-    row_tile = ytile * kWavesPerBlock + wave;
+    const int T = strips * rtiles;  // tiles per image
+    const int n8 = n_images & ~7;
+    const int S = (n8 >> 3) * T;    // tiles per XCD stream
+    const int full = 8 * ((S + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int L = (int)blockIdx.x;
+    if (L < full) {
+      const int s = (L >> 3) * kWavesPerBlock + wave;
+      if (s >= S) return;  // wave-uniform
+      const int g = s / T;
+      image = g * 8 + (L & 7);
+      tile = s - g * T;
+    } else {
+      const int r = (L - full) * kWavesPerBlock + wave;
+      const int i = r / T;
+      if (n8 + i >= n_images) return;  // wave-uniform
+      image = n8 + i;
+      tile = r - i * T;
+    }
+    strip = tile / rtiles;
+    row_tile = tile - strip * rtiles;
     d = strip * kStripLanes + lane;
   }
   const int ys_own = row_tile * kTHF;
@@ -857,21 +879,25 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
     const int pack_u = nd - last_first;                     // halo lane + store lanes
     const int pack_g = strips >= 2 ? 64 / pack_u : 1;
 #define OKVFE_K1_TILING(TH)                                                                     \
-  const int ytiles = (h + TH * kWavesPerBlock - 1) / (TH * kWavesPerBlock);                      \
-  const int ytiles_blk = ytiles;
-#define OKVFE_K1_SGROUPS(n) (n)
+  const int rtiles = (h + TH - 1) / TH; /* row tiles per image; waves take tiles one by one */  \
+  auto main_blocks_of = [&](int nstrips) {                                                       \
+    const int T = nstrips * rtiles, n8 = n_images & ~7;                                          \
+    return 8 * (((n8 >> 3) * T + kWavesPerBlock - 1) / kWavesPerBlock) +                         \
+           ((n_images - n8) * T + kWavesPerBlock - 1) / kWavesPerBlock;                          \
+  };
 #define OKVFE_K1_NMS_LAUNCH_M(TH, MEM)                                                          \
   {                                                                                              \
     OKVFE_K1_TILING(TH)                                                                          \
     if (pack_g >= 2 && !no_pack) {                                                               \
-      const int main_blocks = ytiles * n_images * OKVFE_K1_SGROUPS(strips - 1);                  \
+      const int main_blocks = main_blocks_of(strips - 1);                                        \
       const int groups = (n_images + pack_g - 1) / pack_g;                                       \
-      hipLaunchKernelGGL((harris_kernel<TH, true, true, MEM>), dim3(main_blocks + groups * ytiles_blk), \
-                         block, 0, stream, img, w, h, score, layout.pitch, strips - 1, ytiles, n_images, *nms, \
+      const int pblocks = (groups * rtiles + kWavesPerBlock - 1) / kWavesPerBlock;               \
+      hipLaunchKernelGGL((harris_kernel<TH, true, true, MEM>), dim3(main_blocks + pblocks),      \
+                         block, 0, stream, img, w, h, score, layout.pitch, strips - 1, rtiles, n_images, *nms, \
                          pack_g, pack_u, main_blocks);                                           \
     } else {                                                                                     \
-      hipLaunchKernelGGL((harris_kernel<TH, true, false, MEM>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0,  \
-                         stream, img, w, h, score, layout.pitch, strips, ytiles, n_images, *nms, 1, 64, 0);    \
+      hipLaunchKernelGGL((harris_kernel<TH, true, false, MEM>), dim3(main_blocks_of(strips)), block, 0,  \
+                         stream, img, w, h, score, layout.pitch, strips, rtiles, n_images, *nms, 1, 64, 0);    \
     }                                                                                            \
   }
 #define OKVFE_K1_NMS_LAUNCH(TH) OKVFE_K1_NMS_LAUNCH_M(TH, false)
@@ -886,8 +912,8 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
       // 2.4 x as many, shorter waves (one 752x480 image: 36 -> ~16 us)
       int th = th_env;
       if (th == 0) {
-        const int ytiles61 = (h + 61 * kWavesPerBlock - 1) / (61 * kWavesPerBlock);
-        th = (long long)strips * ytiles61 * n_images <= 128 ? 25 : 61;
+        const int blocks61 = (int)(((long long)strips * ((h + 60) / 61) * n_images + kWavesPerBlock - 1) / kWavesPerBlock);
+        th = blocks61 <= 128 ? 25 : 61;
       }
       switch (th) {
         case 25: OKVFE_K1_NMS_LAUNCH(25); break;
@@ -904,14 +930,12 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
       }
     } else {
       OKVFE_K1_TILING(30)
-      (void)ytiles_blk;
-      hipLaunchKernelGGL((harris_kernel<30, false>), dim3(OKVFE_K1_SGROUPS(strips) * ytiles * n_images), block, 0, stream,
-                         img, w, h, score, w, strips, ytiles, n_images, NmsOut{}, 1, 64, 0);
+      hipLaunchKernelGGL((harris_kernel<30, false>), dim3(main_blocks_of(strips)), block, 0, stream,
+                         img, w, h, score, w, strips, rtiles, n_images, NmsOut{}, 1, 64, 0);
     }
 #undef OKVFE_K1_NMS_LAUNCH
 #undef OKVFE_K1_NMS_LAUNCH_M
 #undef OKVFE_K1_TILING
-#undef OKVFE_K1_SGROUPS
   } else {
     if (nms) return false;
     const dim3 grid((w + 255) / 256, (h + kTH * kWavesPerBlock - 1) / (kTH * kWavesPerBlock),

@@ -1293,6 +1293,269 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
 }  // namespace
 
 
+// ---- lazy-occupancy selection over LINKED LISTS (round 3): the form for FINE grids ----------------
+// The array-bin kernel below spends 32 bytes of LDS per bin whatever the bin holds; a small
+// uniformity radius on a large image (640x480 at radius 10: 64 x 49 bins for ~800 keypoints) would
+// need 126 KB per image.  This kernel keeps 4 bytes per bin + 8 per keypoint slot (singly linked
+// lists, heads swapped in with one LDS atomic; one dependent LDS round trip per point walked) and
+// takes such configurations: same results, chosen by launch_select from the LDS each form needs.
+constexpr int kListChunk = 128;
+constexpr int kListLutBytes = 64 * 64 * 4;
+__device__ __forceinline__ uint32_t lds_u32(uint32_t addr) {
+  return *reinterpret_cast<__attribute__((address_space(3))) const uint32_t*>((uintptr_t)addr);
+}
+__device__ __forceinline__ float lds_f32(uint32_t addr) {
+  return *reinterpret_cast<__attribute__((address_space(3))) const float*>((uintptr_t)addr);
+}
+// table | heads of the bordered bin grid | link, level (cap + 1 slots each) | record chunk | partial sums
+__host__ __device__ inline size_t list_lds_bytes(int bins_x, int bins_y, int cap) {
+  return (size_t)kListLutBytes + lazy_align16((size_t)(bins_x + 2) * (bins_y + 2) * 4) +
+         2 * lazy_align16((size_t)(cap + 1) * 4) + (size_t)kListChunk * 16 + 4 * 64 * 4;
+}
+
+__global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void select_list_kernel(
+    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
+    const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
+    float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
+    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, DescribeSetup setup) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int s_kept;
+  const int bpitch = bins_x + 2;  // bordered bin grid: the border bins stay empty, so no range checks
+  const int nbins = bpitch * (bins_y + 2);
+  const size_t cap4 = lazy_align16((size_t)(cap + 1) * 4);
+  float* lut_s = reinterpret_cast<float*>(smem_raw);
+  unsigned char* q0 = smem_raw + kListLutBytes;
+  uint32_t* head = reinterpret_cast<uint32_t*>(q0);
+  q0 += lazy_align16((size_t)nbins * 4);
+  uint32_t* link = reinterpret_cast<uint32_t*>(q0);
+  float* pnsc = reinterpret_cast<float*>(q0 + cap4);
+  uint4* recs = reinterpret_cast<uint4*>(q0 + 2 * cap4);
+  float* part = reinterpret_cast<float*>(q0 + 2 * cap4 + (size_t)kListChunk * 16);  // [4][64]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int img = blockIdx.x;
+  int n = cand_count[img];
+  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
+  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
+  n = n > cand_cap ? 0 : n;
+  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
+  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
+  okvfe_keypoint* out = kps + (size_t)img * kp_cap;
+  int kept = 0;
+  if (n > 0) {  // block-uniform
+    // weight(dx, dy) at [(dy + 32) << 6 | (dx + 32)], zero outside the 31 x 31 stamp
+    for (int i = tid; i < 64 * 64; i += kLazyThreads) {
+      const int dx = (i & 63) - 32, dy = (i >> 6) - 32;
+      const bool in = dx >= -15 && dx <= 15 && dy >= -15 && dy <= 15;
+      lut_s[i] = in ? lut[(dy + 15) * 31 + (dx + 15)] : 0.0f;
+    }
+    const uint32_t link_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)link;
+    const uint32_t end_addr = link_addr + 4u * (uint32_t)cap;
+    const uint32_t nsc_delta = (uint32_t)cap4;
+    const uint32_t lut_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lut_s;
+    for (int i = tid; i < nbins; i += kLazyThreads) head[i] = end_addr;
+    if (tid == 0) {
+      pnsc[cap] = 0.0f;
+      link[cap] = (end_addr >> 2) << 16;
+      s_kept = 0;
+    }
+    const float scaling = (float)(15.0 / (double)radius);
+    const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
+    // candidates [base, base + kListChunk): keys are requested one chunk ahead (threads 64..191, one
+    // key each), converted into records {cell, level, pixel, score} when their chunk is next
+    uint64_t kq = 0;
+    const bool converter = tid >= 64 && tid < 64 + kListChunk;
+    auto request = [&](int base) {
+      const int i = base + tid - 64;
+      kq = (converter && i < n) ? keys[i] : 0ull;
+    };
+    auto convert = [&]() {
+      if (converter) {
+        const uint64_t k = kq;
+        const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
+        const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
+        const float fy = (float)y * scaling;
+        const float fx = (float)x * scaling;
+        const int cy = (int)(fy + 16.0f);
+        const int cx = (int)(fx + 16.0f);
+        const float q = (float)score / max_score;
+        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
+        recs[tid - 64] = make_uint4(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1),
+                                    (uint32_t)(k & 0xFFFFFFFFu), (uint32_t)score);
+      }
+    };
+    request(0);
+    convert();
+    request(kListChunk);
+    // this wave's share of the nine bin lists: chains c = first, first + 4 (, first + 8)
+    const int first = (wave + 1) & 3;  // wave 0 (which also runs the acceptance) and waves 1, 2 walk two lists
+    const int nch = first == 0 ? 3 : 2;
+    int hoff[3];       // offset of the chain's bin from the candidate's bin in the bordered grid
+    uint32_t boff4[3];  // table offset of the chain's bin: 4 * ((16 oy) << 6 + 16 ox)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c = first + 4 * k < 9 ? first + 4 * k : first;
+      const int ox = (c % 3) - 1, oy = (c / 3) - 1;
+      hoff[k] = oy * bpitch + ox;
+      boff4[k] = (uint32_t)(((16 * oy) << 6) + 16 * ox) << 2;
+    }
+    const int limit = min(min(max_kpts, kp_cap), cap);
+    __syncthreads();
+    for (int pos = 0; pos < n; pos += 64) {  // block-uniform
+      const int idx = pos + lane;
+      const bool valid = idx < n;
+      uint4 rec = recs[idx & (kListChunk - 1)];
+      if (!valid) rec.x = 0u;  // a cell inside the grid; the lane never passes
+      const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
+      const float level = __uint_as_float(rec.y);
+      const int bx = cx >> 4, by = cy >> 4;
+      const int bin = (by + 1) * bpitch + (bx + 1);
+      // The weight table is indexed by (dy + 32) << 6 | (dx + 32): for the bin at offset (ox, oy)
+      // that is cc - (link & 0xFFC) / 4 with cc = (cy & 15 + 32 - 16 oy) << 6 | (cx & 15 + 32 - 16 ox)
+      // -- both fields stay in [1, 63], so there is no borrow between them.
+      const uint32_t lcode = ((uint32_t)(cy & 15) << 6) | (uint32_t)(cx & 15);
+      const uint32_t cc4 = lut_addr + ((lcode + ((32u << 6) | 32u)) << 2);
+      uint32_t hp[3], lk[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hp[k] = (k < nch) ? head[bin + hoff[k]] : end_addr;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) lk[k] = lds_u32(hp[k]);
+      float occf = 0.0f;  // sums of small integers: exact in float
+      while (true) {
+        const bool alive = hp[0] != end_addr || hp[1] != end_addr || hp[2] != end_addr;
+        if (!__any(alive)) break;
+        float wgt[3], lev[3];
+        uint32_t nlk[3], nhp[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          wgt[k] = lds_f32(cc4 - boff4[k] - (lk[k] & 0xFFCu));
+          lev[k] = lds_f32(hp[k] + nsc_delta);
+          nhp[k] = lk[k] >> 14;
+          nlk[k] = lds_u32(nhp[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          occf += ceilf(wgt[k] * lev[k]);  // 0 for finished walks (level 0) and points out of reach (weight 0)
+          hp[k] = nhp[k];
+          lk[k] = nlk[k];
+        }
+      }
+      part[wave * 64 + lane] = occf;
+      __syncthreads();
+      if (wave == 0) {
+        int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
+        bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
+        const float nsc = (float)(0.99 * (double)level);
+        unsigned long long rem = __ballot(pass), accm = 0;
+        int nacc = 0;
+        if (rem != 0) {
+          // Which passing candidates may have another passing candidate of the window within 15
+          // cells?  Two such candidates sit in the same or in adjacent bins (a bin is 16 cells wide):
+          // every passing lane counts itself into the top byte of its bin's head word (the address
+          // below it needs 18 bits; the walks of the other waves never overlap with this phase), reads
+          // the nine counts around it and removes itself again -- two LDS round trips whatever the
+          // number of passing lanes.  Conservative (adjacent bins may be farther apart than 15 cells):
+          // the ordered loop below treats the flagged lanes exactly.
+          bool linked = false;
+          if (pass) {
+            atomicAdd(&head[bin], 1u << 24);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (pass) {
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) {
+              const uint32_t c = head[bin + ((b / 3) - 1) * bpitch + (b % 3) - 1] >> 24;
+              cnt += b == 4 ? c - 1u : c;  // own bin: the others in it
+            }
+            linked = cnt != 0;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (pass) atomicSub(&head[bin], 1u << 24);
+          const unsigned long long seq = __ballot(linked && pass);
+          const int room = limit - kept;
+          if (__popcll(rem) <= room) {
+            // the unlinked ones neither change nor are changed by anything in this window: accepted
+            // at once; the linked ones go through the ordered loop below
+            accm = rem & ~seq;
+            nacc = __popcll(accm);
+            rem = seq;
+          }  // else: the cap falls inside this window -- everything in order
+          while (rem != 0 && kept + nacc < limit) {  // one iteration per accepted point
+            const int f = (int)__ffsll((long long)rem) - 1;
+            accm |= 1ull << f;
+            ++nacc;
+            const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
+            const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
+            const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
+            const bool near = pass && lane > f && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
+            if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
+              if (near) {
+                occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * wnsc);
+                pass = !(level < (float)(occ > 255 ? 255 : occ));
+              }
+              rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
+            } else {
+              rem &= rem - 1;
+            }
+          }
+          if ((accm >> lane) & 1) {
+            const int slot = kept + __popcll(accm & ((1ull << lane) - 1ull));
+            const uint32_t addr = link_addr + 4u * (uint32_t)slot;
+            const uint32_t prev = atomicExch(&head[bin], addr);
+            link[slot] = (lcode << 2) | ((prev >> 2) << 16);
+            pnsc[slot] = nsc;
+            // pixel position and score wait in the output record for the sub-pixel pass
+            okvfe_keypoint kp;
+            kp.x = (float)(int)(rec.z & 0xFFFF);
+            kp.y = (float)(int)(rec.z >> 16);
+            kp.size = 12.0f;
+            kp.angle = -1.0f;
+            kp.response = (float)(int32_t)rec.w;
+            kp.octave = 0;
+            kp.class_id = (int32_t)rec.w;  // the exact score (response is its float image)
+            out[slot] = kp;
+          }
+          kept += nacc;
+          if (lane == 0) s_kept = kept;
+        }
+      } else if (((pos + 64) & (kListChunk - 1)) == 0) {
+        // the next window starts a new chunk: every wave holds this window's records in registers
+        convert();
+        request(pos + 64 + kListChunk);
+      }
+      __syncthreads();
+      kept = s_kept;
+      if (kept >= limit) break;  // block-uniform
+    }
+  }
+  // ---- K4: sub-pixel refinement and keypoint emission (all four waves)
+  __syncthreads();
+  for (int i = tid; i < kept; i += kLazyThreads) {
+    okvfe_keypoint kp = out[i];
+    const int u = (int)kp.x, v = (int)kp.y;
+    int32_t patch[9];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
+    float ddx, ddy;
+    subpixel2d(patch, &ddx, &ddy);
+    kp.x = (float)u + ddx;
+    kp.y = (float)v + ddy;
+    kp.response = (float)kp.class_id;
+    kp.class_id = -1;
+    out[i] = kp;
+    // detection and description in one call: the extractor's per-keypoint preparation right here
+    // (describe_setup_dev.h) instead of a launch of its own
+    if (setup.pat) describe_setup_one(setup, w, h, img, (size_t)img * kp_cap + i, kp);
+  }
+  if (tid == 0) kp_count[img] = kept;
+}
+
+
 void launch_brisk_refine(const int32_t* score, int w, int h, int n_images, int cand_cap, const int32_t* cand_count,
                          const uint64_t* sort_ws, int max_kpts, const int32_t* below, int wb, int hb, int rn_b,
                          int rd_b, const int32_t* above, int wa, int ha, int rn_a, int rd_a, double rb, double ra,
@@ -1361,10 +1624,28 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
     const int bins_x = (occ_cols + 15) >> 4, bins_y = (occ_rows + 15) >> 4;
     const int cap = max_kpts < kp_cap ? max_kpts : kp_cap;
     const size_t lds = lazy_lds_bytes(bins_x, bins_y);
+    const size_t lds_list = list_lds_bytes(bins_x, bins_y, cap);
     constexpr size_t kLazyMaxLds = 159 * 1024;  // the kernel also has a few bytes of static LDS
+    // Array bins cost 32 B of LDS per bin, linked lists 4 B per bin + 8 B per keypoint slot: a fine
+    // grid with few keypoints per bin (640x480 at radius 10: 3136 bins, ~800 keypoints) takes the list
+    // form when that keeps at least one more image on a CU
+    const bool array_ok = lds <= kLazyMaxLds && occupancy != nullptr && occ_image_bytes >= (size_t)cap * 8;
+    const bool prefer_list = !array_ok || (lds > 48 * 1024 && kLazyMaxLds / lds_list > kLazyMaxLds / lds);
+    if (prefer_list && lds_list <= kLazyMaxLds && occ_cols <= 65535 && occ_rows <= 65535) {
+      static bool attr_set_l = false;
+      if (!attr_set_l) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_list_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
+          (void)hipGetLastError();
+        attr_set_l = true;
+      }
+      hipLaunchKernelGGL(select_list_kernel, dim3(n_images), dim3(kLazyThreads), lds_list, stream, score, layout, w, h,
+                         cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, bins_x, bins_y, cap, kps,
+                         kp_cap, kp_count, setup ? *setup : DescribeSetup{});
+      return setup != nullptr;
+    }
     // the occupancy workspace doubles as the spill list of full bins: 8 bytes per point at worst
-    if (lds <= kLazyMaxLds && occ_cols <= 65535 && occ_rows <= 65535 && occupancy != nullptr &&
-        occ_image_bytes >= (size_t)cap * 8) {
+    if (array_ok && occ_cols <= 65535 && occ_rows <= 65535) {
       static const int bin_cap = [] {  // lab knob: 1..kLazyBinCap slots per bin (fewer = more spills)
         const char* e = lab_env("OKVFE_LAZY_BINCAP");
         const int v = e ? atoi(e) : kLazyBinCap;
