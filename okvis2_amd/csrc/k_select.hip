@@ -45,10 +45,9 @@ __device__ __forceinline__ void sort_classic_body(const Candidate* __restrict__ 
                                                   const int32_t* __restrict__ cand_count,
                                                   uint64_t* __restrict__ sort_ws,
                                                   int ws_stride, int lds_lo_keys,
-                                                  int lds_keys) {
+                                                  int lds_keys, int img) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
-  const int img = blockIdx.x;
   int n = cand_count[img];
   // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
   // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
@@ -284,21 +283,27 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
                                                         const int32_t* __restrict__ cand_count,
                                                         uint64_t* __restrict__ sort_ws,
                                                         int ws_stride, int lds_lo_keys,
-                                                        int lds_keys, int rb_mid) {
+                                                        int lds_keys, int rb_mid, int n_images) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (rb_mid) {
-    const int img = blockIdx.x;
-    int n = cand_count[img];
-    n = n > cand_cap ? 0 : n;
-    int lnp = 4;
-    while ((1 << lnp) < n) ++lnp;
-    if ((1 << lnp) > lds_lo_keys && (1 << lnp) <= 2 * kLdsSortKeys) {  // block-uniform
-      sort_rb_body<kThreads>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
-                             sort_ws + (size_t)img * ws_stride);
-      return;
+  // The large-list launch allocates 136 KiB of LDS per workgroup: one workgroup per CU, so a grid of
+  // one block per image cost ~2.5 us per 256 images even when no image needs it (the usual case: 16 us
+  // per 1536-image step).  The grid is at most one round of workgroups; each walks its images.
+  for (int img = blockIdx.x; img < n_images; img += gridDim.x) {  // block-uniform
+    bool done = false;
+    if (rb_mid) {
+      int n = cand_count[img];
+      n = n > cand_cap ? 0 : n;
+      int lnp = 4;
+      while ((1 << lnp) < n) ++lnp;
+      if ((1 << lnp) > lds_lo_keys && (1 << lnp) <= 2 * kLdsSortKeys) {  // block-uniform
+        sort_rb_body<kThreads>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
+                               sort_ws + (size_t)img * ws_stride);
+        done = true;
+      }
     }
+    if (!done) sort_classic_body(cand, cand_cap, cand_count, sort_ws, ws_stride, lds_lo_keys, lds_keys, img);
+    __syncthreads();  // the LDS is reused by the next image
   }
-  sort_classic_body(cand, cand_cap, cand_count, sort_ws, ws_stride, lds_lo_keys, lds_keys);
 }
 
 // 2-D quadratic sub-pixel refinement; mirrors the published BRISK Subpixel2D with 64-bit
@@ -1580,7 +1585,7 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
     // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
     hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
                        cand, cand_cap, cand_count, sort_ws, ws_stride, 0,
-                       two ? sort_keys : 2 * kLdsSortKeys, 0);
+                       two ? sort_keys : 2 * kLdsSortKeys, 0, n_images);
   } else {
     // up to 8192 keys: register-blocked network in 68 KiB (16 keys minimum: one thread's share)
     const int keys = sort_keys < kRbKeys ? kRbKeys : sort_keys;
@@ -1596,8 +1601,9 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
         (void)hipGetLastError();
       attr_set = true;
     }
-    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), big_lds, stream, cand, cand_cap, cand_count,
-                       sort_ws, ws_stride, kLdsSortKeys, 2 * kLdsSortKeys, legacy ? 0 : 1);
+    hipLaunchKernelGGL(sort_kernel, dim3(n_images < 256 ? n_images : 256), dim3(kThreads), big_lds, stream, cand,
+                       cand_cap, cand_count, sort_ws, ws_stride, kLdsSortKeys, 2 * kLdsSortKeys, legacy ? 0 : 1,
+                       n_images);
   }
 }
 
