@@ -454,7 +454,8 @@ def roofline_block(P, n_img_launch, harris_ms, extra):
     traffic, traffic_src = None, None
     import glob
     # newest PMC collection (this round's first) taken on THIS image shape; none -> null
-    cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_k1_pmc*.json")), reverse=True) +
+    cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "round4_*_k1_pmc*.json")), reverse=True) +
+             sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_k1_pmc*.json")), reverse=True) +
              sorted(glob.glob(os.path.join(ROOT, "profiles", "round2_*_k1_pmc*.json")), reverse=True))
     for pmc_path in cands:
         pmc = json.load(open(pmc_path))

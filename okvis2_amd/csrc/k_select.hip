@@ -951,7 +951,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   OKVFE_LAZY_TICK(t_start);
 #ifdef OKVFE_LAB
   unsigned long long t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0;
-  int n_windows = 0, n_surv = 0;
+  int n_surv = 0;
 #endif
   if (n > 0) {  // block-uniform
     // weight(|dx|, |dy|) at [|dy| << 5 | |dx|], zero outside the 31 x 31 stamp
@@ -1122,7 +1122,6 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
                 total = c2n + s_surv[par][3];
 #ifdef OKVFE_LAB
       n_surv += total;
-      n_windows += (total + 63) >> 6;
       t_pref += __builtin_amdgcn_s_memrealtime() - t_mark;
 #endif
       // ---- ordered windows over the block's survivors (rank order: wave lists in turn)

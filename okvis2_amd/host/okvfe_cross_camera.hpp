@@ -14,6 +14,7 @@
 // from the C ABI (okvfe_device_alloc, okvfe_stream_create, okvfe_comm_create).
 #pragma once
 
+#include <array>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -63,6 +64,26 @@ class Communicator {  // okvfe_comm with RAII
   okvfe_comm* comm_ = nullptr;
 };
 
+// device buffer / stream of the C ABI with RAII: a constructor that throws half way leaks nothing
+struct DeviceBuffer {
+  void* p = nullptr;
+  DeviceBuffer() = default;
+  ~DeviceBuffer() {
+    if (p) okvfe_device_free(p);
+  }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+};
+struct StreamHandle {
+  void* s = nullptr;
+  StreamHandle() = default;
+  ~StreamHandle() {
+    if (s) okvfe_stream_destroy(s);
+  }
+  StreamHandle(const StreamHandle&) = delete;
+  StreamHandle& operator=(const StreamHandle&) = delete;
+};
+
 class CrossCameraMatcher {
  public:
   // cameras / poses: the whole rig (every rank knows it); params as for HipFrontend; nFrames =
@@ -101,23 +122,22 @@ class CrossCameraMatcher {
     kpCap_ = any.maxKeypoints();
     for (const PairOwner& po : pairSchedule(nCams, overlap, world_))
       if (po.rank == rank_) mine_.push_back({po.i, po.j});
-    check(okvfe_stream_create(device, &stream_));
-    check(okvfe_device_alloc(device, localBytes(), &dLocal_));
-    check(okvfe_device_alloc(device, localBytes() * size_t(world_), &dGathered_));
+    check(okvfe_stream_create(device, &streamH_.s));
+    stream_ = streamH_.s;
+    check(okvfe_device_alloc(device, localBytes(), &dLocalH_.p));
+    dLocal_ = dLocalH_.p;
+    check(okvfe_device_alloc(device, localBytes() * size_t(world_), &dGatheredH_.p));
+    dGathered_ = dGatheredH_.p;
     check(okvfe_device_fill(dLocal_, 0, localBytes(), stream_));
     for (const auto& pr : mine_) {
-      void* d = nullptr;
-      check(okvfe_device_alloc(device, matchBytes(), &d));
-      dMatches_[pr] = d;
+      std::unique_ptr<DeviceBuffer> b(new DeviceBuffer());
+      check(okvfe_device_alloc(device, matchBytes(), &b->p));
+      dMatches_[pr] = b->p;
+      matchBuffers_.push_back(std::move(b));
     }
     check(okvfe_stream_synchronize(stream_));
   }
-  ~CrossCameraMatcher() {
-    for (auto& kv : dMatches_) okvfe_device_free(kv.second);
-    okvfe_device_free(dLocal_);
-    okvfe_device_free(dGathered_);
-    okvfe_stream_destroy(stream_);
-  }
+  ~CrossCameraMatcher() = default;  // the holders below release the buffers, then the stream
   CrossCameraMatcher(const CrossCameraMatcher&) = delete;
   CrossCameraMatcher& operator=(const CrossCameraMatcher&) = delete;
 
@@ -193,6 +213,11 @@ class CrossCameraMatcher {
   size_t blockBytes_ = 0;
   std::map<int, std::shared_ptr<Context>> local_;
   std::vector<std::pair<int, int>> mine_;
+  // owners first (destroyed last to first: match buffers, gathered, local, then the stream) ...
+  StreamHandle streamH_;
+  DeviceBuffer dLocalH_, dGatheredH_;
+  std::vector<std::unique_ptr<DeviceBuffer>> matchBuffers_;
+  // ... and the plain views the methods use
   std::map<std::pair<int, int>, void*> dMatches_;
   void* stream_ = nullptr;
   void* dLocal_ = nullptr;

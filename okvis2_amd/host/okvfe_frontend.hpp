@@ -348,9 +348,17 @@ class HipFrontend {
     u.hpSet.assign(n, 0);
     const std::vector<double> bp = flat(frame.backProjections);
     const double focal = 0.5 * (cameras_[cameraIndex].fu + cameras_[cameraIndex].fv);
+    // empty = "every keypoint" / "no keypoint carries a landmark yet", like the sibling wrappers
+    if (!use.empty() && use.size() != n) throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "use: one entry per keypoint");
+    if (!previousLandmark.empty() && previousLandmark.size() != n)
+      throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "previousLandmark: one entry per keypoint");
+    if (descBegin.empty()) throw Exception(OKVFE_ERR_INVALID_ARGUMENT, "descBegin needs n_landmarks + 1 entries");
+    const std::vector<uint8_t> all(n, 1);
+    const std::vector<int32_t> none(n, -1);
     contexts_[cameraIndex]->check(okvfe_match_to_map_uninitialised(
-        contexts_[cameraIndex]->get(), frame.descriptors.data.data(), bp.data(), use.data(),
-        previousLandmark.data(), int32_t(n), descBegin.data(), int32_t(descBegin.size()) - 1, pool.data(),
+        contexts_[cameraIndex]->get(), frame.descriptors.data.data(), bp.data(), use.empty() ? all.data() : use.data(),
+        previousLandmark.empty() ? none.data() : previousLandmark.data(), int32_t(n), descBegin.data(),
+        int32_t(descBegin.size()) - 1, pool.data(),
         e0_W.data(), r0_W.data(), &T_WC1, focal, u.matches.landmark.data(), u.matches.distance.data(), hp.data(),
         u.hpSet.data(), &u.alreadyMatched));
     u.hp_W.resize(n);

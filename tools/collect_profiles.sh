@@ -32,7 +32,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python $R/tools/pmc_summary.py $(find /tmp/prof_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_$C.json > /dev/null
 done
 # the same two passes on the other image shapes (their own traffic figures instead of EuRoC's)
-for W in tumvi mono640; do
+for W in tumvi mono640 hilti; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_${W}_$C -o p -- $BENCH --steps 3 --workload $W > /tmp/prof_${W}_$C.log 2>&1
     python $R/tools/pmc_summary.py $(find /tmp/prof_${W}_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_${W}_pmc_$C.json > /dev/null
