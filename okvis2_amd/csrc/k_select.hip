@@ -258,7 +258,8 @@ __device__ __forceinline__ void sort_rb_body(RbKey* lds, const Candidate* __rest
   for (int i = tid; i < n; i += THREADS) ws[i] = rb_decode(lds[rb_slot(i)]);
 }
 
-__global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __restrict__ cand,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void sort_rb_kernel(const Candidate* __restrict__ cand,
                                                              int cand_cap,
                                                              const int32_t* __restrict__ cand_count,
                                                              uint64_t* __restrict__ sort_ws,
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(kRbThreads) void sort_rb_kernel(const Candidate* __
   int lnp = 4;
   while ((1 << lnp) < n) ++lnp;
   if ((1 << lnp) > max_keys) return;  // left to sort_kernel (second launch)
-  sort_rb_body<kRbThreads>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
-                           sort_ws + (size_t)img * ws_stride);
+  sort_rb_body<THREADS>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
+                        sort_ws + (size_t)img * ws_stride);
 }
 
 // The large-list launch (and the legacy path): lists of 8193 .. 16384 keys run the register-blocked
@@ -1588,8 +1589,14 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   } else {
     // up to 8192 keys: register-blocked network in 68 KiB (16 keys minimum: one thread's share)
     const int keys = sort_keys < kRbKeys ? kRbKeys : sort_keys;
-    hipLaunchKernelGGL(sort_rb_kernel, dim3(n_images), dim3(kRbThreads), (size_t)rb_slot(keys) * 8, stream,
-                       cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
+    // a handful of images (the B = 1 seams) cannot fill the GPU: twice the threads per list shorten the
+    // one chain there is (28 -> ~18 us per 4.4 k keys); batches keep two 512-thread workgroups per CU
+    if (n_images <= 64)
+      hipLaunchKernelGGL(sort_rb_kernel<2 * kRbThreads>, dim3(n_images), dim3(2 * kRbThreads),
+                         (size_t)rb_slot(keys) * 8, stream, cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
+    else
+      hipLaunchKernelGGL(sort_rb_kernel<kRbThreads>, dim3(n_images), dim3(kRbThreads), (size_t)rb_slot(keys) * 8,
+                         stream, cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
   }
   if (two) {  // second launch: 8193..16384 keys in 136 KiB, larger sets in the HBM workspace
     const size_t big_lds = (size_t)rb_slot(2 * kLdsSortKeys) * 8;  // >= the classic 128 KiB
