@@ -21,6 +21,8 @@
 //                         that passes is accepted, 961 threads add its 31x31 stamp.
 // Bound: latency / LDS (no HBM roofline); batches keep all CUs busy with independent images.
 #include "describe_setup_dev.h"
+#include <type_traits>
+
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -911,7 +913,7 @@ __device__ __forceinline__ void lds_barrier() {
 #ifdef OKVFE_LAB
 // lab build: where does an image's time go?  [0] launches, [1..4] 10-ns ticks (s_memrealtime) of image 0's
 // phases init / blocks / tail / total, [5] prefilter ticks, [6] survivors, [7] candidates
-__device__ unsigned long long g_lazy_prof[8];
+__device__ unsigned long long g_lazy_prof[16];
 #define OKVFE_LAZY_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #else
 #define OKVFE_LAZY_TICK(var)
@@ -951,7 +953,8 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   int kept = 0;
   OKVFE_LAZY_TICK(t_start);
 #ifdef OKVFE_LAB
-  unsigned long long t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0;
+  unsigned long long t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0, t_walk = 0, t_acc = 0, t_ins = 0, t_w0 = 0, t_w1 = 0, t_w2 = 0;
+  const unsigned long long c_start = clock64();
   int n_surv = 0;
 #endif
   if (n > 0) {  // block-uniform
@@ -1056,7 +1059,6 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     int blen = 64, par = 0;
     for (int a = 0; a < n; a += blen, blen = min(2 * blen, kLazyBlockMax), par ^= 1) {  // block-uniform
       const int e = min(a + blen, n);
-      load_quarter(a + blen, min(2 * blen, kLazyBlockMax), knxt);
 #ifdef OKVFE_LAB
       t_mark = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1086,25 +1088,52 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           const uint32_t lx = (uint32_t)(cx & 15), ly = (uint32_t)(cy & 15);
           const uint32_t A0 = ((ly + 16u) << 23) | ((lx + 16u) << 2);  // the candidate's own bin
           float occf = 0.0f;  // sums of small integers: exact in float
-          uint32_t any_cnt = 0u;
+          {
+            // all nine count words and all nine first-half slot pairs are requested before anything is
+            // used: one LDS round trip for them, one for the eighteen weights (the per-group form waited
+            // ~50 times per candidate, alone on its SIMD at B = 1)
+            // (two batches of five and four bins: all nine at once need more registers than six waves
+            // per SIMD leave, and a spilled register costs a scratch round trip per candidate)
+            bool more = false;
+            auto batch = [&](auto first, auto count) {
+              constexpr int B0 = decltype(first)::value, NB = decltype(count)::value;
+              uint32_t hw[NB], A[NB];
+              uint4 sb[NB];
 #pragma unroll
-          for (int g = 0; g < 3; ++g) {  // bin rows oy = g - 1, three bins each
-            const int b0 = bin + (g - 1) * bpitch;
-            const int b[3] = {b0 - 1, b0, b0 + 1};
-            const uint32_t Ag = A0 + ((uint32_t)(16 * (1 - g)) << 23);
-            const uint32_t A[3] = {Ag + (16u << 2), Ag, Ag - (16u << 2)};
+              for (int q = 0; q < NB; ++q) {
+                const int b = B0 + q;
+                const int bi = bin + ((b / 3) - 1) * bpitch + (b % 3) - 1;
+                hw[q] = head[bi];
+                sb[q] = slot4[2 * bi];
+                A[q] = A0 + ((uint32_t)(16 * (1 - b / 3)) << 23) + ((uint32_t)(16 * (1 - b % 3)) << 2);
+              }
+              uint32_t wa[2 * NB];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) any_cnt |= ((head[b[k]] & 0xFFu) > 2u) ? 1u : 0u;
-            occf += bins3(b, A, 0);
-          }
-          if (__any(any_cnt != 0u)) {  // some bin of some lane holds more than two points
+              for (int q = 0; q < NB; ++q) {
+                wa[2 * q] = __builtin_amdgcn_sad_u16(A[q], sb[q].x, tab_addr);
+                wa[2 * q + 1] = __builtin_amdgcn_sad_u16(A[q], sb[q].z, tab_addr);
+              }
+              float wv[2 * NB];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) {
-              const int b0 = bin + (g - 1) * bpitch;
-              const int b[3] = {b0 - 1, b0, b0 + 1};
-              const uint32_t Ag = A0 + ((uint32_t)(16 * (1 - g)) << 23);
-              const uint32_t A[3] = {Ag + (16u << 2), Ag, Ag - (16u << 2)};
-              occf += bins3(b, A, 1);
+              for (int t = 0; t < 2 * NB; ++t)
+                wv[t] = *reinterpret_cast<__attribute__((address_space(3))) const float*>((uintptr_t)wa[t]);
+#pragma unroll
+              for (int q = 0; q < NB; ++q) {
+                occf += ceilf(wv[2 * q] * __uint_as_float(sb[q].y)) + ceilf(wv[2 * q + 1] * __uint_as_float(sb[q].w));
+                more = more || (hw[q] & 0xFFu) > 2u;
+              }
+            };
+            batch(std::integral_constant<int, 0>(), std::integral_constant<int, 5>());
+            batch(std::integral_constant<int, 5>(), std::integral_constant<int, 4>());
+            if (__any(more)) {  // some bin of some lane holds more than two points
+#pragma unroll
+              for (int g = 0; g < 3; ++g) {
+                const int b0 = bin + (g - 1) * bpitch;
+                const int b[3] = {b0 - 1, b0, b0 + 1};
+                const uint32_t Ag = A0 + ((uint32_t)(16 * (1 - g)) << 23);
+                const uint32_t A[3] = {Ag + (16u << 2), Ag, Ag - (16u << 2)};
+                occf += bins3(b, A, 1);
+              }
             }
           }
           if (s_spill != 0) occf += spill_terms(cx, cy);
@@ -1115,6 +1144,8 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           my_cnt += __popcll(m);
         }
       }
+      // the next block's keys: requested now, used after this block's ordered windows
+      load_quarter(a + blen, min(2 * blen, kLazyBlockMax), knxt);
       // (a wave may run ahead into the next block's prefilter while another still reads these counts:
       // the buffer written two blocks later is safe, that wave has passed the barrier in between)
       if (lane == 0) s_surv[par][wave] = my_cnt;
@@ -1127,6 +1158,9 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
 #endif
       // ---- ordered windows over the block's survivors (rank order: wave lists in turn)
       for (int pos = 0; pos < total; pos += 64) {  // block-uniform
+#ifdef OKVFE_LAB
+        t_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const int g = pos + lane;
         const bool valid = g < total;
         int li = 0, lo = g;
@@ -1158,6 +1192,10 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           part[wave * 64 + lane] = f;
         }
         lds_barrier();
+#ifdef OKVFE_LAB
+        t_w1 = __builtin_amdgcn_s_memrealtime();
+        t_walk += t_w1 - t_w0;
+#endif
         if (wave == 0) {
           int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
           bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
@@ -1165,57 +1203,92 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           unsigned long long rem = __ballot(pass), accm = 0;
           int nacc = 0;
           if (rem != 0) {
-            // Which passing candidates may have another passing candidate of the window within 15
-            // cells?  Two such candidates sit in the same or in adjacent bins (a bin is 16 cells wide):
-            // every passing lane counts itself into the top byte of its bin's count word (the walks of
-            // the other waves never overlap with this phase), reads the nine counts around it and
-            // removes itself again -- two LDS round trips whatever the number of passing lanes.
-            // Conservative (adjacent bins may be farther apart than 15 cells): the ordered loop below
-            // treats the flagged lanes exactly.
-            bool linked = false;
-            if (pass) {
-              atomicAdd(&head[bin], 1u << 24);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (pass) {
-              uint32_t cnt = 0;
-#pragma unroll
-              for (int b = 0; b < 9; ++b) {
-                const uint32_t c = head[bin + ((b / 3) - 1) * bpitch + (b % 3) - 1] >> 24;
-                cnt += b == 4 ? c - 1u : c;  // own bin: the others in it
-              }
-              linked = cnt != 0;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (pass) atomicSub(&head[bin], 1u << 24);
-            const unsigned long long seq = __ballot(linked && pass);
             const int room = limit - kept;
             if (__popcll(rem) <= room) {
-              // the unlinked ones neither change nor are changed by anything in this window: accepted
-              // at once; the linked ones go through the ordered loop below
-              accm = rem & ~seq;
-              nacc = __popcll(accm);
-              rem = seq;
-            }  // else: the cap falls inside this window -- everything in order
-            while (rem != 0 && kept + nacc < limit) {  // one iteration per accepted point
-              const int f = (int)__ffsll((long long)rem) - 1;
-              accm |= 1ull << f;
-              ++nacc;
-              const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
-              const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
-              const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
-              const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-              const bool near = pass && lane > f && adx <= 15 && ady <= 15;
-              if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
-                if (near) {
-                  occ += (int)ceilf(tab[(ady << 5) | adx] * wnsc);
-                  pass = !(level < (float)(occ > 255 ? 255 : occ));
+              // Acceptance in ROUNDS (round 4).  A passing lane is decided once every EARLIER passing
+              // lane of the window within reach of it is: its occupancy is final then.  All such lanes
+              // are decided together -- they cannot reach each other -- instead of one per iteration of
+              // a scalar-vector ping-pong (~300 cycles per accepted point, half of the selection's
+              // time): nb = the EARLIER passing lanes within the stamp's square around this lane; a round takes the lanes with no undecided earlier
+              // neighbour, adds the weights of the newly accepted ones to the lanes they reach
+              // (2 lane permutes + 1 table read each) and drops the lanes that now fail (a test only
+              // ever gets harder).  3-5 rounds per window of survivors.
+              // nb: the `part` array (free in this phase) becomes 128 lane masks hashed by bin; a passing
+              // lane ORs its bit into its bin's mask, reads the nine masks around it (a superset: other
+              // bins alias) and checks the few lanes it finds exactly
+              unsigned long long* wm = reinterpret_cast<unsigned long long*>(part);
+              wm[lane] = 0ull;
+              wm[64 + lane] = 0ull;
+              __builtin_amdgcn_wave_barrier();
+              if (pass) atomicOr(&wm[bin & 127], 1ull << lane);
+              __builtin_amdgcn_wave_barrier();
+              const unsigned long long lower_ = (1ull << lane) - 1ull;
+              unsigned long long cm = 0ull;
+#pragma unroll
+              for (int b = 0; b < 9; ++b) cm |= wm[(bin + ((b / 3) - 1) * bpitch + (b % 3) - 1) & 127];
+              cm &= rem & lower_;
+              if (!pass) cm = 0ull;
+              unsigned long long nb = 0ull;
+              while (__any(cm != 0ull)) {
+                const int el = cm != 0ull ? (int)__ffsll((long long)cm) - 1 : lane;
+                const uint32_t exy = (uint32_t)__builtin_amdgcn_ds_bpermute(el << 2, (int)rec.x);
+                if (cm != 0ull) {
+                  cm &= cm - 1ull;
+                  const uint32_t ddx = (uint32_t)(cx - (int)(exy & 0xFFFF) + 15);
+                  const uint32_t ddy = (uint32_t)(cy - (int)(exy >> 16) + 15);
+                  nb |= (ddx <= 30u && ddy <= 30u) ? (1ull << el) : 0ull;
                 }
-                rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
-              } else {
-                rem &= rem - 1;
+              }
+              while (rem != 0ull) {
+                const bool in = ((rem >> lane) & 1ull) != 0ull;
+                const bool ready = in && (nb & rem) == 0ull;  // (the lowest lane of rem always is)
+                const unsigned long long rdy = __ballot(ready);
+                const unsigned long long accn = __ballot(ready && pass);
+                accm |= accn;
+                rem &= ~rdy;
+                // undecided lanes in reach of a point accepted in this round
+                unsigned long long m = (in && !ready) ? (nb & accn) : 0ull;
+                while (__any(m != 0ull)) {
+                  const int jl = m != 0ull ? (int)__ffsll((long long)m) - 1 : lane;
+                  const uint32_t jxy = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)rec.x);
+                  const float jnsc = __int_as_float(__builtin_amdgcn_ds_bpermute(jl << 2, __float_as_int(nsc)));
+                  if (m != 0ull) {
+                    m &= m - 1ull;
+                    const int dx = cx - (int)(jxy & 0xFFFF), dy = cy - (int)(jxy >> 16);
+                    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+                    occ += (int)ceilf(tab[(ady << 5) | adx] * jnsc);
+                  }
+                }
+                if (in && !ready) pass = !(level < (float)(occ > 255 ? 255 : occ));
+                rem &= __ballot(pass);  // lanes that fail now fail at their turn as well: decided
+              }
+              nacc = __popcll(accm);
+            } else {
+              // the cap falls inside this window: one candidate at a time, in order
+              while (rem != 0 && kept + nacc < limit) {
+                const int f = (int)__ffsll((long long)rem) - 1;
+                accm |= 1ull << f;
+                ++nacc;
+                const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
+                const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
+                const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
+                const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+                const bool near = pass && lane > f && adx <= 15 && ady <= 15;
+                if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
+                  if (near) {
+                    occ += (int)ceilf(tab[(ady << 5) | adx] * wnsc);
+                    pass = !(level < (float)(occ > 255 ? 255 : occ));
+                  }
+                  rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
+                } else {
+                  rem &= rem - 1;
+                }
               }
             }
+#ifdef OKVFE_LAB
+            t_w2 = __builtin_amdgcn_s_memrealtime();
+            t_acc += t_w2 - t_w1;
+#endif
             if ((accm >> lane) & 1) {
               const int slot = kept + __popcll(accm & ((1ull << lane) - 1ull));
               // into the bin: slot j of its array, or the spill list when the array is full
@@ -1245,6 +1318,9 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           }
         }
         lds_barrier();
+#ifdef OKVFE_LAB
+        t_ins += __builtin_amdgcn_s_memrealtime() - (t_w2 > t_w1 ? t_w2 : t_w1);
+#endif
         kept = s_kept;
         if (kept >= limit) break;  // block-uniform
       }
@@ -1291,6 +1367,10 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     atomicAdd(&g_lazy_prof[5], t_pref);
     atomicAdd(&g_lazy_prof[6], (unsigned long long)n_surv);
     atomicAdd(&g_lazy_prof[7], (unsigned long long)n);
+    atomicAdd(&g_lazy_prof[8], t_walk);
+    atomicAdd(&g_lazy_prof[9], t_acc);
+    atomicAdd(&g_lazy_prof[10], t_ins);
+    atomicAdd(&g_lazy_prof[11], (unsigned long long)(clock64() - c_start));
   }
 #endif
 }
@@ -1727,10 +1807,10 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
 }
 
 #ifdef OKVFE_LAB
-extern "C" int okvfe_lab_lazy_prof(unsigned long long out[8], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lazy_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+extern "C" int okvfe_lab_lazy_prof(unsigned long long out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lazy_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
-    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long z[16] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_prof), z, sizeof(z)) != hipSuccess) return 1;
   }
   return 0;
