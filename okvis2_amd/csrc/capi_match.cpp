@@ -168,44 +168,54 @@ okvfe_status okvfe_match_motion_stereo(okvfe_ctx* ctx, const okvfe_camera* camer
                o_v1 = take(n1), o_m1 = take(n1);
   const size_t o_out = take((size_t)n0 * sizeof(okvfe_motion_match));
   okvfe_status st = ensure_scratch(ctx, off);
+  if (st == OKVFE_OK) st = ensure_pinned(ctx, off);
   if (st != OKVFE_OK) return st;
   uint8_t* base = static_cast<uint8_t*>(ctx->scratch);
+  uint8_t* hb = ctx->h_pinned;  // the same layout in pinned host memory (see okvfe_match_stereo)
   okvfe_stereo_pair sp{};
   sp.T_WC0 = *T_WC0; sp.T_WC1 = *T_WC1;
   sp.f0 = sp.f1 = 0.5 * (camera->fu + camera->fv);  // sigma = size0 / f0 * 0.125 (Frontend.cpp:1834)
   PairParams pp = to_pair_params(sp);
   const DeviceCamera dc = to_device_camera(*camera);
-  auto up = [&](size_t o, const void* src, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(base + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  auto put = [&](size_t o, const void* src, size_t bytes) {
+    if (bytes) std::memcpy(hb + o, src, bytes);
   };
-  double table[kClassTableDoubles];
   if (multi) {
-    fill_class_table(table, sp.f0, sp.f1, true);
+    fill_class_table(reinterpret_cast<double*>(hb + o_cls), sp.f0, sp.f1, true);
     pp.cls = reinterpret_cast<const double*>(base + o_cls);
-    HIP_TRY(ctx, up(o_cls, table, sizeof(table)));
   }
-  HIP_TRY(ctx, up(o_pair, &pp, sizeof(pp)));
-  HIP_TRY(ctx, up(o_cam, &dc, sizeof(dc)));
-  HIP_TRY(ctx, up(o_d0, desc0, (size_t)n0 * 48));
-  HIP_TRY(ctx, up(o_k0, kp0, (size_t)n0 * sizeof(okvfe_keypoint)));
-  HIP_TRY(ctx, up(o_b0, backproj0, (size_t)n0 * 24));
-  HIP_TRY(ctx, up(o_v0, valid0, n0));
-  if (skip0) HIP_TRY(ctx, up(o_s0, skip0, n0));
-  HIP_TRY(ctx, up(o_d1, desc1, (size_t)n1 * 48));
-  HIP_TRY(ctx, up(o_k1, kp1, (size_t)n1 * sizeof(okvfe_keypoint)));
-  HIP_TRY(ctx, up(o_b1, backproj1, (size_t)n1 * 24));
-  HIP_TRY(ctx, up(o_v1, valid1, n1));
-  if (matched1) HIP_TRY(ctx, up(o_m1, matched1, n1));
-  HIP_TRY(ctx, hipStreamSynchronize(s));
+  put(o_pair, &pp, sizeof(pp));
+  put(o_cam, &dc, sizeof(dc));
+  put(o_d0, desc0, (size_t)n0 * 48);
+  put(o_k0, kp0, (size_t)n0 * sizeof(okvfe_keypoint));
+  put(o_b0, backproj0, (size_t)n0 * 24);
+  put(o_v0, valid0, n0);
+  if (skip0) put(o_s0, skip0, n0);
+  if (n1 > 0) {
+    put(o_d1, desc1, (size_t)n1 * 48);
+    put(o_k1, kp1, (size_t)n1 * sizeof(okvfe_keypoint));
+    put(o_b1, backproj1, (size_t)n1 * 24);
+    put(o_v1, valid1, n1);
+    if (matched1) put(o_m1, matched1, n1);
+  }
+  okvfe_motion_match* out_dev = reinterpret_cast<okvfe_motion_match*>(base + o_out);
+  if (ctx->h_pinned_dev) {
+    launch_param_copy(base, ctx->h_pinned_dev, o_out, nullptr, 0, s);
+    out_dev = reinterpret_cast<okvfe_motion_match*>(static_cast<uint8_t*>(ctx->h_pinned_dev) + o_out);
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(base, hb, o_out, hipMemcpyHostToDevice, s));
+  }
   launch_match_motion(reinterpret_cast<PairParams*>(base + o_pair), reinterpret_cast<DeviceCamera*>(base + o_cam),
                       camera->width, camera->height, base + o_d0, reinterpret_cast<okvfe_keypoint*>(base + o_k0),
                       reinterpret_cast<double*>(base + o_b0), base + o_v0, skip0 ? base + o_s0 : nullptr, n0,
                       base + o_d1, reinterpret_cast<okvfe_keypoint*>(base + o_k1),
                       reinterpret_cast<double*>(base + o_b1), base + o_v1, matched1 ? base + o_m1 : nullptr, n1,
-                      ctx->cfg.match_threshold, reinterpret_cast<okvfe_motion_match*>(base + o_out), s);
+                      ctx->cfg.match_threshold, out_dev, s);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipMemcpyAsync(matches, base + o_out, (size_t)n0 * sizeof(okvfe_motion_match), hipMemcpyDeviceToHost, s));
+  if (!ctx->h_pinned_dev)
+    HIP_TRY(ctx, hipMemcpyAsync(hb + o_out, base + o_out, (size_t)n0 * sizeof(okvfe_motion_match), hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  std::memcpy(matches, hb + o_out, (size_t)n0 * sizeof(okvfe_motion_match));
   return OKVFE_OK;
 }
 okvfe_status okvfe_hamming_candidates(okvfe_ctx* ctx, const uint8_t* A, int32_t nA, const uint8_t* B,
