@@ -991,6 +991,14 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     // | 4 * (lx + 16 (1 - ox)): v_sad_u16 adds the absolute differences of both halves, so
     // sad(A, code) + table address = the ADDRESS of weight(|dx|, |dy|) in one instruction.
     const uint32_t tab_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)tab;
+    // (counters, batch of 1536 images: the LDS was the busiest unit of this kernel, 62 % of its cycles
+    // and 71 % of those bank conflicts -- 64 lanes gathering weights at unrelated table addresses.  An
+    // EMPTY slot, two thirds of them, now reads the table's first word instead: one address for all such
+    // lanes is a broadcast, not a conflict.  Its level is 0, so the term stays 0.)
+    auto waddr_of = [&](uint32_t A, uint32_t code, uint32_t levbits) {
+      const uint32_t a = __builtin_amdgcn_sad_u16(A, code, tab_addr);
+      return levbits != 0u ? a : tab_addr;
+    };
     auto term = [&](uint32_t waddr, uint32_t levbits) {
       return ceilf(*reinterpret_cast<__attribute__((address_space(3))) const float*>((uintptr_t)waddr) *
                    __uint_as_float(levbits));  // 0 for an empty slot (level 0)
@@ -1004,8 +1012,9 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
       uint32_t wa[6];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        wa[2 * k] = __builtin_amdgcn_sad_u16(A[k], s3[k].x, tab_addr);
-        wa[2 * k + 1] = __builtin_amdgcn_sad_u16(A[k], s3[k].z, tab_addr);
+        // (bit 0 of a bin's first code word is its "more than two points" flag, not part of the code)
+        wa[2 * k] = waddr_of(A[k], half == 0 ? s3[k].x & ~1u : s3[k].x, s3[k].y);
+        wa[2 * k + 1] = waddr_of(A[k], s3[k].z, s3[k].w);
       }
       float f = 0.0f;
 #pragma unroll
@@ -1097,21 +1106,20 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
             bool more = false;
             auto batch = [&](auto first, auto count) {
               constexpr int B0 = decltype(first)::value, NB = decltype(count)::value;
-              uint32_t hw[NB], A[NB];
+              uint32_t A[NB];
               uint4 sb[NB];
 #pragma unroll
               for (int q = 0; q < NB; ++q) {
                 const int b = B0 + q;
                 const int bi = bin + ((b / 3) - 1) * bpitch + (b % 3) - 1;
-                hw[q] = head[bi];
                 sb[q] = slot4[2 * bi];
                 A[q] = A0 + ((uint32_t)(16 * (1 - b / 3)) << 23) + ((uint32_t)(16 * (1 - b % 3)) << 2);
               }
               uint32_t wa[2 * NB];
 #pragma unroll
               for (int q = 0; q < NB; ++q) {
-                wa[2 * q] = __builtin_amdgcn_sad_u16(A[q], sb[q].x, tab_addr);
-                wa[2 * q + 1] = __builtin_amdgcn_sad_u16(A[q], sb[q].z, tab_addr);
+                wa[2 * q] = waddr_of(A[q], sb[q].x & ~1u, sb[q].y);
+                wa[2 * q + 1] = waddr_of(A[q], sb[q].z, sb[q].w);
               }
               float wv[2 * NB];
 #pragma unroll
@@ -1120,7 +1128,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
 #pragma unroll
               for (int q = 0; q < NB; ++q) {
                 occf += ceilf(wv[2 * q] * __uint_as_float(sb[q].y)) + ceilf(wv[2 * q + 1] * __uint_as_float(sb[q].w));
-                more = more || (hw[q] & 0xFFu) > 2u;
+                more = more || (sb[q].x & 1u) != 0u;
               }
             };
             batch(std::integral_constant<int, 0>(), std::integral_constant<int, 5>());
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
             // a wave with two bins looks at bin 0 as its third: a border bin, always empty
             b[k] = k < nch ? bin + hoff[k] : 0;
             A[k] = A0 + aoff[k];
-            more = more || (head[b[k]] & 0xFFu) > 2u;
+            more = more || (reinterpret_cast<const uint32_t*>(slot4)[8 * b[k]] & 1u) != 0u;
           }
           float f = bins3(b, A, 0);
           if (__any(more)) f += bins3(b, A, 1);
@@ -1296,6 +1304,8 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
               const uint32_t code = ((ly + 16u) << 23) | ((lx + 16u) << 2);
               if (j < (uint32_t)bin_cap) {  // (kLazyBinCap; the lab build can shrink it to exercise the spill list)
                 reinterpret_cast<uint2*>(slot4)[bin * kLazyBinCap + (int)j] = make_uint2(code, __float_as_uint(nsc));
+                // the bin's third point raises the "second half in use" flag in its first code word
+                if (j == 2u) atomicOr(&reinterpret_cast<uint32_t*>(slot4)[8 * bin], 1u);
               } else {
                 atomicSub(&head[bin], 1u);  // the count stays at the capacity
                 const int at = atomicAdd(&s_spill, 1);
