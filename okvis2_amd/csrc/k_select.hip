@@ -932,7 +932,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   const int nbins = bpitch * (bins_y + 2);
   float* tab = reinterpret_cast<float*>(smem_raw);
   unsigned char* q0 = smem_raw + kLazyTabBytes;
-  uint32_t* head = reinterpret_cast<uint32_t*>(q0);  // bits 0..7: points in the bin; top byte: scratch of the acceptance
+  uint32_t* head = reinterpret_cast<uint32_t*>(q0);  // bits 0..7: points in the bin (the acceptance keeps its lane masks in `part`)
   q0 += lazy_align16((size_t)nbins * 4);
   uint4* slot4 = reinterpret_cast<uint4*>(q0);  // [nbins][2]: {code, level, code, level}
   q0 += (size_t)nbins * kLazyBinCap * 8;
