@@ -143,6 +143,10 @@ void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
                L->d_cand_count, s);
 }
 void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
+  // the array-bin selection kernel buckets and orders its candidates itself (k_select.hip, round 4)
+  if (select_sorts_candidates(L->cfg.uniformity_radius, L->cfg.max_keypoints, L->kp_cap, L->d_occ, L->occ_image_bytes,
+                              L->occ_rows, L->occ_cols))
+    return;
   launch_sort(L->d_cand, L->cand_cap, L->d_cand_count, n_images, L->cfg.uniformity_radius, L->d_sort_ws, s);
 }
 void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {

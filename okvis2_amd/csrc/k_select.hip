@@ -918,16 +918,37 @@ __device__ unsigned long long g_lazy_prof[16];
 #else
 #define OKVFE_LAZY_TICK(var)
 #endif
+// log buckets of the score for the kernel that orders its candidates itself: 16 per octave, bucket 0 = the
+// highest scores (ascending with the sort key)
+constexpr int kFuseBins = 496;
+constexpr int kFuseUnroll = 8;  // candidate records in flight per thread in the scatter pass
+constexpr int kFuseFirst = 20;   // scores per thread requested before the tables are set up (5120 candidates)
+constexpr int kFuseSched = 40;  // chunk ends kept in LDS; what lies beyond them is ONE last chunk (split by key range)
+__device__ __forceinline__ int fuse_bin(int32_t score) {
+  if (score <= 0) return kFuseBins - 1;
+  const uint32_t s = (uint32_t)score;
+  const int e = 31 - __clz(s);
+  const int b = e >= 4 ? (e << 4) | (int)((s >> (e - 4)) & 15u) : (int)s;
+  return (kFuseBins - 1) - b;
+}
+// SORTS = true (round 4, default): the kernel takes the UNSORTED candidate records and orders only what the
+// greedy pass consumes -- see "chunks" below; false: `sort_ws` holds the keys already sorted (launch_sort).
+template <bool SORTS>
 __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void select_lazy_kernel(
-    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
-    const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
+    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, const Candidate* __restrict__ cand, int cand_cap,
+    const int32_t* __restrict__ cand_count, uint64_t* sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
     okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, uint2* __restrict__ spill_ws,
-    size_t spill_stride, int bin_cap, DescribeSetup setup) {
+    size_t spill_stride, int bin_cap, int round_cap, DescribeSetup setup) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_kept;
   __shared__ int s_spill;       // points that did not fit their bin (HBM list)
   __shared__ int s_surv[2][4];  // survivor counts per wave, double-buffered by block parity
+  // SORTS: ends of the chunks in the bucket-ordered key array, their number, the highest score, and the
+  // scratch of the key-range split of an oversized chunk
+  __shared__ uint32_t s_sched[kFuseSched + 2];
+  __shared__ int s_nsched, s_max, s_cnt;
+  __shared__ unsigned long long s_kmin, s_kmax;
   const int bpitch = bins_x + 2;  // bordered bin grid: the border bins stay empty, so no range checks
   const int nbins = bpitch * (bins_y + 2);
   float* tab = reinterpret_cast<float*>(smem_raw);
@@ -946,14 +967,14 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
   // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
   n = n > cand_cap ? 0 : n;
-  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
+  uint64_t* keys = sort_ws + (size_t)img * ws_stride;
   const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   uint2* spill = spill_ws + (size_t)img * spill_stride;  // {cy << 16 | cx, level}
   int kept = 0;
   OKVFE_LAZY_TICK(t_start);
 #ifdef OKVFE_LAB
-  unsigned long long t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0, t_walk = 0, t_acc = 0, t_ins = 0, t_w0 = 0, t_w1 = 0, t_w2 = 0;
+  unsigned long long t_pa = t_start, t_pb = t_start, t_pc = t_start, t_p0 = t_start, t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0, t_walk = 0, t_acc = 0, t_ins = 0, t_w0 = 0, t_w1 = 0, t_w2 = 0;
   const unsigned long long c_start = clock64();
   int n_surv = 0;
 #endif
@@ -970,9 +991,28 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     if (tid == 0) {
       s_kept = 0;
       s_spill = 0;
+      if constexpr (SORTS) s_max = INT_MIN;
+    }
+    if constexpr (SORTS) {  // bucket counts: in the survivor buffer, which is idle until the first chunk
+      for (int i = tid; i <= kFuseBins; i += kLazyThreads) reinterpret_cast<uint32_t*>(surv)[i] = 0u;
+    }
+    // SORTS: the first 5120 candidate records are are read ONCE and STAY in registers as {score, y << 16 | x} for both bucket passes:
+    // in a batch every pass over the records is 53 KB per image from HBM (81 MB per 1536 images: 16 us)
+    const Candidate* crec = cand + (size_t)img * cand_cap;
+    int32_t scv0[SORTS ? kFuseFirst : 1];
+    uint32_t pyx0[SORTS ? kFuseFirst : 1];
+    if constexpr (SORTS) {
+#pragma unroll
+      for (int u = 0; u < kFuseFirst; ++u) {
+        const int i = tid + u * kLazyThreads;
+        const Candidate c = i < n ? crec[i] : Candidate{0, 0, INT_MIN};
+        scv0[u] = c.score;
+        pyx0[u] = ((uint32_t)c.y << 16) | (uint32_t)c.x;
+      }
     }
     const float scaling = (float)(15.0 / (double)radius);
-    const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
+    float max_score = 1.0f;  // the highest score of the image (SORTS: known after the bucket pass)
+    if constexpr (!SORTS) max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
     // sorted key -> candidate record {cell, level, pixel, score}
     auto make_rec = [&](uint64_t k) {
       const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
@@ -1048,47 +1088,9 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     }
     const int limit = min(min(max_kpts, kp_cap), cap);
     uint64_t* my_surv = surv + wave * kLazySurvPerWave;
-    __syncthreads();
-#ifdef OKVFE_LAB
-    t_init = __builtin_amdgcn_s_memrealtime();
-#endif
-    // this wave's quarter of a block: keys [lo, hi), up to kLazySurvPerWave = 4 x 64 of them, held in
-    // registers; the NEXT block's are requested before the current block is worked on, so their HBM /
-    // L2 round trip hides behind it
-    auto load_quarter = [&](int a_, int blen_, uint64_t kr[4]) {
-      const int q = blen_ >> 2;
-      const int lo = a_ + wave * q, hi = min(lo + q, min(a_ + blen_, n));
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = lo + 64 * t + lane;
-        kr[t] = i < hi ? keys[i] : 0ull;
-      }
-    };
-    uint64_t kcur[4] = {0ull, 0ull, 0ull, 0ull}, knxt[4];
-    int blen = 64, par = 0;
-    for (int a = 0; a < n; a += blen, blen = min(2 * blen, kLazyBlockMax), par ^= 1) {  // block-uniform
-      const int e = min(a + blen, n);
-#ifdef OKVFE_LAB
-      t_mark = __builtin_amdgcn_s_memrealtime();
-#endif
-      // ---- prefilter: this wave's quarter of the block, against the points accepted before the block
-      int my_cnt = 0;
-      if (a == 0) {
-        // nothing is accepted yet: every candidate of the first block survives
-        const int q = (e - a + 3) >> 2;
-        const int lo = wave * q, hi = min(lo + q, e - a);
-        for (int c = lo + lane; c < hi; c += 64) my_surv[c - lo] = keys[c];
-        my_cnt = hi > lo ? hi - lo : 0;
-      } else {
-        const int q = blen >> 2;  // multiple of 16
-        const int lo = a + wave * q, hi = min(lo + q, e);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int c0 = lo + 64 * t;
-          if (c0 >= hi) break;  // wave-uniform
-          const int i = c0 + lane;
-          const bool valid = i < hi;
-          const uint64_t kthis = kcur[t];
+    // one candidate against the points accepted so far, all nine bins from this lane: does it survive?
+    // (occupancy only grows, so a failure is final)
+    auto prefilter_key = [&](uint64_t kthis, bool valid) -> bool {
           uint4 rec = make_rec(kthis);
           if (!valid) rec.x = 0u;
           const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
@@ -1147,35 +1149,17 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
           if (s_spill != 0) occf += spill_terms(cx, cy);
           const int occ = (int)occf;
           const bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
-          const unsigned long long m = __ballot(pass);
-          if (pass) my_surv[my_cnt + __popcll(m & ((1ull << lane) - 1ull))] = kthis;
-          my_cnt += __popcll(m);
-        }
-      }
-      // the next block's keys: requested now, used after this block's ordered windows
-      load_quarter(a + blen, min(2 * blen, kLazyBlockMax), knxt);
-      // (a wave may run ahead into the next block's prefilter while another still reads these counts:
-      // the buffer written two blocks later is safe, that wave has passed the barrier in between)
-      if (lane == 0) s_surv[par][wave] = my_cnt;
-      lds_barrier();
-      const int c0n = s_surv[par][0], c1n = c0n + s_surv[par][1], c2n = c1n + s_surv[par][2],
-                total = c2n + s_surv[par][3];
-#ifdef OKVFE_LAB
-      n_surv += total;
-      t_pref += __builtin_amdgcn_s_memrealtime() - t_mark;
-#endif
-      // ---- ordered windows over the block's survivors (rank order: wave lists in turn)
+          return pass;
+    };
+    // ordered windows of 64 over `total` survivors; fetch(g) = the g-th of them in key order
+    auto windows = [&](int total, auto fetch) {
       for (int pos = 0; pos < total; pos += 64) {  // block-uniform
 #ifdef OKVFE_LAB
         t_w0 = __builtin_amdgcn_s_memrealtime();
 #endif
         const int g = pos + lane;
         const bool valid = g < total;
-        int li = 0, lo = g;
-        if (g >= c2n) { li = 3; lo = g - c2n; }
-        else if (g >= c1n) { li = 2; lo = g - c1n; }
-        else if (g >= c0n) { li = 1; lo = g - c0n; }
-        uint4 rec = make_rec(valid ? surv[li * kLazySurvPerWave + lo] : 0ull);
+        uint4 rec = make_rec(valid ? fetch(g) : 0ull);
         if (!valid) rec.x = 0u;  // a cell inside the grid; the lane never passes
         const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
         const float level = __uint_as_float(rec.y);
@@ -1334,9 +1318,469 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         kept = s_kept;
         if (kept >= limit) break;  // block-uniform
       }
-      if (kept >= limit) break;  // block-uniform
+    };
+    if constexpr (!SORTS) {
+      __syncthreads();
+#ifdef OKVFE_LAB
+      t_init = __builtin_amdgcn_s_memrealtime();
+#endif
+      // this wave's quarter of a block: keys [lo, hi), up to kLazySurvPerWave = 4 x 64 of them, held in
+      // registers; the NEXT block's are requested before the current block is worked on, so their HBM /
+      // L2 round trip hides behind it
+      auto load_quarter = [&](int a_, int blen_, uint64_t kr[4]) {
+        const int q = blen_ >> 2;
+        const int lo = a_ + wave * q, hi = min(lo + q, min(a_ + blen_, n));
 #pragma unroll
-      for (int t = 0; t < 4; ++t) kcur[t] = knxt[t];
+        for (int t = 0; t < 4; ++t) {
+          const int i = lo + 64 * t + lane;
+          kr[t] = i < hi ? keys[i] : 0ull;
+        }
+      };
+      uint64_t kcur[4] = {0ull, 0ull, 0ull, 0ull}, knxt[4];
+      int blen = 64, par = 0;
+      for (int a = 0; a < n; a += blen, blen = min(2 * blen, kLazyBlockMax), par ^= 1) {  // block-uniform
+        const int e = min(a + blen, n);
+#ifdef OKVFE_LAB
+        t_mark = __builtin_amdgcn_s_memrealtime();
+#endif
+        // ---- prefilter: this wave's quarter of the block, against the points accepted before the block
+        int my_cnt = 0;
+        if (a == 0) {
+          // nothing is accepted yet: every candidate of the first block survives
+          const int q = (e - a + 3) >> 2;
+          const int lo = wave * q, hi = min(lo + q, e - a);
+          for (int c = lo + lane; c < hi; c += 64) my_surv[c - lo] = keys[c];
+          my_cnt = hi > lo ? hi - lo : 0;
+        } else {
+          const int q = blen >> 2;  // multiple of 16
+          const int lo = a + wave * q, hi = min(lo + q, e);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c0 = lo + 64 * t;
+            if (c0 >= hi) break;  // wave-uniform
+            const uint64_t kthis = kcur[t];
+            const bool pass = prefilter_key(kthis, c0 + lane < hi);
+            const unsigned long long m = __ballot(pass);
+            if (pass) my_surv[my_cnt + __popcll(m & ((1ull << lane) - 1ull))] = kthis;
+            my_cnt += __popcll(m);
+          }
+        }
+        // the next block's keys: requested now, used after this block's ordered windows
+        load_quarter(a + blen, min(2 * blen, kLazyBlockMax), knxt);
+        // (a wave may run ahead into the next block's prefilter while another still reads these counts:
+        // the buffer written two blocks later is safe, that wave has passed the barrier in between)
+        if (lane == 0) s_surv[par][wave] = my_cnt;
+        lds_barrier();
+        const int c0n = s_surv[par][0], c1n = c0n + s_surv[par][1], c2n = c1n + s_surv[par][2],
+                  total = c2n + s_surv[par][3];
+#ifdef OKVFE_LAB
+        n_surv += total;
+        t_pref += __builtin_amdgcn_s_memrealtime() - t_mark;
+#endif
+        // ---- ordered windows over the block's survivors (rank order: wave lists in turn)
+        windows(total, [&](int g) {
+          int li = 0, lo = g;
+          if (g >= c2n) { li = 3; lo = g - c2n; }
+          else if (g >= c1n) { li = 2; lo = g - c1n; }
+          else if (g >= c0n) { li = 1; lo = g - c0n; }
+          return surv[li * kLazySurvPerWave + lo];
+        });
+        if (kept >= limit) break;  // block-uniform
+#pragma unroll
+        for (int t = 0; t < 4; ++t) kcur[t] = knxt[t];
+      }
+    } else {
+      // ---- the kernel orders its candidates itself (round 4) --------------------------------------
+      // Sorting all ~4.4 k candidates of an image cost as much as selecting among them, and most of the
+      // order is never used: a candidate that fails against the points accepted from HIGHER scores fails
+      // whatever its rank among its peers.  So: (A) count the candidates into log buckets of the score,
+      // (B) cut the bucket sequence into CHUNKS of about 64, 128, ... 1024 candidates (whole buckets), (C)
+      // scatter the keys into bucket order (HBM workspace, unordered inside a bucket); then per chunk:
+      // prefilter its keys in any order against the points accepted from the earlier chunks, rank-sort
+      // the SURVIVORS (a hundred or so) in LDS, and run the ordered windows over them.  A chunk larger
+      // than the buffer (a bucket of a thousand equal scores) is split by key range: histogram of the key
+      // over the bucket's own [min, max], narrowed until a prefix of it fits.
+      uint32_t* hist = reinterpret_cast<uint32_t*>(surv);  // [kFuseBins + 1], until the first chunk is worked on
+      __syncthreads();
+#ifdef OKVFE_LAB
+      t_p0 = __builtin_amdgcn_s_memrealtime();
+#endif
+      {
+        // (many records per thread in flight together: one at a time, each pass over the records was a
+        // chain of ~17 HBM round trips)
+        int mx = INT_MIN;
+#pragma unroll
+        for (int u = 0; u < kFuseFirst; ++u) {
+          if (tid + u * kLazyThreads < n) {
+            atomicAdd(&hist[fuse_bin(scv0[u])], 1u);
+            mx = max(mx, scv0[u]);
+          }
+        }
+        for (int base = tid + kFuseFirst * kLazyThreads; base < n; base += 8 * kLazyThreads) {  // (more than 5120)
+          int32_t scv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kLazyThreads;
+            scv[u] = i < n ? crec[i].score : INT_MIN;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (base + u * kLazyThreads < n) {
+              atomicAdd(&hist[fuse_bin(scv[u])], 1u);
+              mx = max(mx, scv[u]);
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+        if (lane == 0) atomicMax(&s_max, mx);
+      }
+      __syncthreads();
+#ifdef OKVFE_LAB
+      t_pa = __builtin_amdgcn_s_memrealtime();
+#endif
+      max_score = (float)s_max;
+      if (wave == 0) {
+        // bucket starts: exclusive prefix (lane = 8 buckets), hist[kFuseBins] = n
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int idx = lane * 8 + k;
+          v[k] = idx < kFuseBins ? hist[idx] : 0u;
+          sum += v[k];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(inc, d);
+          if (lane >= d) inc += t;
+        }
+        uint32_t run = inc - sum;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int idx = lane * 8 + k;
+          if (idx <= kFuseBins) hist[idx] = run;
+          run += v[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // chunk schedule: whole buckets, about 64, 128, ... kLazyBlockMax candidates each
+        int pos = 0, b = 0, k = 0;
+        uint32_t target = min(64u, (uint32_t)round_cap);
+        while (pos < n && k < kFuseSched) {  // wave-uniform
+          int x_last = b - 1;
+          for (int base = b; base < kFuseBins; base += 64) {
+            const int idx = base + lane;
+            const uint32_t ve = idx < kFuseBins ? hist[idx + 1] : 0xFFFFFFFFu;  // end of bucket idx
+            const bool ok = idx < kFuseBins && ve - (uint32_t)pos <= target;     // (a prefix of the lanes: ends ascend)
+            const int c = __popcll(__ballot(ok));
+            x_last += c;
+            if (c < 64) break;
+          }
+          int e = x_last >= b ? (int)hist[x_last + 1] : pos;
+          if (e == pos) {  // the next non-empty bucket alone exceeds the target: it is the chunk
+            for (int base = b; base < kFuseBins; base += 64) {
+              const int idx = base + lane;
+              const bool gt = idx < kFuseBins && (int)hist[idx + 1] > pos;
+              const unsigned long long m = __ballot(gt);
+              if (m != 0ull) {
+                x_last = base + (int)__ffsll((long long)m) - 1;
+                break;
+              }
+            }
+            e = (int)hist[x_last + 1];
+          }
+          if (lane == 0) s_sched[k] = (uint32_t)e;
+          ++k;
+          pos = e;
+          b = x_last + 1;
+          target = min(2u * target, (uint32_t)round_cap);
+        }
+        if (pos < n) {  // what the table cannot hold: one last chunk
+          if (lane == 0) s_sched[k] = (uint32_t)n;
+          ++k;
+        }
+        if (lane == 0) s_nsched = k;
+      }
+      __syncthreads();
+#ifdef OKVFE_LAB
+      t_pb = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+      for (int u = 0; u < kFuseFirst; ++u) {
+        if (tid + u * kLazyThreads < n) {
+          const uint32_t p = atomicAdd(&hist[fuse_bin(scv0[u])], 1u);
+          keys[p] = ((uint64_t)(uint32_t)(0x7FFFFFFF - scv0[u]) << 32) | pyx0[u];  // = make_key
+        }
+      }
+      for (int base = tid + kFuseFirst * kLazyThreads; base < n; base += kFuseUnroll * kLazyThreads) {  // (more than 5120)
+        Candidate cv[kFuseUnroll];
+#pragma unroll
+        for (int u = 0; u < kFuseUnroll; ++u) {
+          const int i = base + u * kLazyThreads;
+          cv[u] = i < n ? crec[i] : Candidate{0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < kFuseUnroll; ++u) {
+          if (base + u * kLazyThreads < n) {
+            const uint32_t p = atomicAdd(&hist[fuse_bin(cv[u].score)], 1u);
+            keys[p] = make_key(cv[u]);
+          }
+        }
+      }
+      __syncthreads();
+#ifdef OKVFE_LAB
+      t_init = __builtin_amdgcn_s_memrealtime();
+#endif
+      const int nsched = s_nsched;
+      uint64_t kcur[4] = {0ull, 0ull, 0ull, 0ull}, knxt[4] = {0ull, 0ull, 0ull, 0ull};
+      // this wave's quarter of keys[c0 .. c0 + m)
+      auto load_chunk = [&](int c0, int m, uint64_t kr[4]) {
+        const int q = (m + 3) >> 2;
+        const int lo = c0 + wave * q, hi = min(lo + q, c0 + m);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = lo + 64 * t + lane;
+          kr[t] = i < hi ? keys[i] : 0ull;
+        }
+      };
+      int cpos = 0, j = 0, par = 0;
+      bool have_next = false;
+      bool refining = false;  // inside an oversized chunk keys[r_base .. r_base + r_m): keys below r_lo are done
+      int r_base = 0, r_m = 0, r_rem = 0;
+      uint64_t r_lo = 0ull;
+      while (true) {  // one round = up to kLazyBlockMax keys, this wave's quarter of them in kcur (all block-uniform)
+        int cnt = 0;
+#ifdef OKVFE_LAB
+        t_mark = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (!refining) {
+          if (j >= nsched) break;
+          const int e = (int)s_sched[j];
+          const int m = e - cpos;
+          ++j;
+          if (m > round_cap) {  // (kLazyBlockMax; the lab build can shrink it to exercise the split)
+            refining = true;
+            r_base = cpos; r_m = m; r_rem = m; r_lo = 0ull;
+            cpos = e;
+            have_next = false;
+            continue;
+          }
+          if (have_next) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) kcur[t] = knxt[t];
+          } else {
+            load_chunk(cpos, m, kcur);
+          }
+          cnt = m;
+          cpos = e;
+          have_next = false;
+        } else {
+          uint64_t hi = ~0ull;
+          if (r_rem > round_cap) {
+            // [min, max] of the keys still to do
+            if (tid == 0) {
+              s_kmin = ~0ull;
+              s_kmax = 0ull;
+            }
+            __syncthreads();
+            unsigned long long mn = ~0ull, mxk = 0ull;
+            for (int i = tid; i < r_m; i += kLazyThreads) {
+              const unsigned long long k = keys[r_base + i];
+              if (k >= r_lo) {
+                mn = k < mn ? k : mn;
+                mxk = k > mxk ? k : mxk;
+              }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+              const unsigned long long a1 = __shfl_xor(mn, d), a2 = __shfl_xor(mxk, d);
+              mn = a1 < mn ? a1 : mn;
+              mxk = a2 > mxk ? a2 : mxk;
+            }
+            if (lane == 0) {
+              atomicMin(&s_kmin, mn);
+              atomicMax(&s_kmax, mxk);
+            }
+            __syncthreads();
+            const unsigned long long kmin = s_kmin, range = s_kmax - kmin;
+            int sh = range < 256ull ? 0 : (64 - __clzll((long long)range)) - 8;  // (range >> sh) < 256
+            uint32_t* sub = reinterpret_cast<uint32_t*>(part);  // [256] counts of (key - kmin) >> sh
+            while (true) {  // block-uniform
+              sub[tid] = 0u;
+              __syncthreads();
+              for (int i = tid; i < r_m; i += kLazyThreads) {
+                const unsigned long long k = keys[r_base + i];
+                if (k >= r_lo) {
+                  const unsigned long long d = (k - kmin) >> sh;
+                  if (d < 256ull) atomicAdd(&sub[(int)d], 1u);
+                }
+              }
+              __syncthreads();
+              // how many leading sub-buckets fit the buffer together (every wave computes it: lane = 4 of them)
+              uint32_t v4[4], sum = 0;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v4[k] = sub[lane * 4 + k];
+                sum += v4[k];
+              }
+              uint32_t inc = sum;
+#pragma unroll
+              for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(inc, d);
+                if (lane >= d) inc += t;
+              }
+              uint32_t run = inc - sum;
+              int nfit = 0;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                run += v4[k];
+                nfit += __popcll(__ballot(run <= (uint32_t)round_cap));
+              }
+              __syncthreads();  // (the counts are zeroed again if the range narrows)
+              if (nfit == 0 && sh > 0) {  // the first sub-bucket alone is too large: look inside it
+                sh = sh >= 8 ? sh - 8 : 0;
+                continue;
+              }
+              // (nfit == 0 at sh == 0 would be > kLazyBlockMax EQUAL keys; keys are unique.  The gather
+              // below drops what does not fit, so even that cannot overrun the buffer.)
+              hi = kmin + ((unsigned long long)(nfit > 0 ? nfit : 1) << sh);
+              break;
+            }
+          }
+          // gather the keys in [r_lo, hi) into the LDS buffer (any order)
+          if (tid == 0) s_cnt = 0;
+          __syncthreads();
+          for (int i0 = 0; i0 < r_m; i0 += kLazyThreads) {  // block-uniform
+            const int i = i0 + tid;
+            const unsigned long long k = i < r_m ? keys[r_base + i] : 0ull;
+            const bool pred = i < r_m && k >= r_lo && k < hi;
+            const unsigned long long m = __ballot(pred);
+            if (m != 0ull) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(&s_cnt, __popcll(m));
+              base = __builtin_amdgcn_readfirstlane(base);
+              const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+              if (pred && at < kLazyBlockMax) surv[at] = k;
+            }
+          }
+          __syncthreads();
+          const int got = s_cnt;
+          cnt = got < kLazyBlockMax ? got : kLazyBlockMax;
+          {
+            const int q = (cnt + 3) >> 2;
+            const int lo = wave * q, hi_i = min(lo + q, cnt);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int i = lo + 64 * t + lane;
+              kcur[t] = i < hi_i ? surv[i] : 0ull;
+            }
+          }
+          __syncthreads();  // the keys are in registers: the survivor lists may overwrite the buffer
+          r_rem -= got;
+          r_lo = hi;
+          if (r_rem <= 0 || got == 0) refining = false;
+        }
+        // ---- prefilter: this wave's quarter of the round, against the points accepted before it
+        int my_cnt = 0;
+        {
+          const int q = (cnt + 3) >> 2;
+          const int lo = wave * q, hi_i = min(lo + q, cnt);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c0 = lo + 64 * t;
+            if (c0 >= hi_i) break;  // wave-uniform
+            const uint64_t kthis = kcur[t];
+            const bool valid = c0 + lane < hi_i;
+            // (nothing accepted yet: every candidate survives)
+            const bool pass = kept > 0 ? prefilter_key(kthis, valid) : valid;
+            const unsigned long long m = __ballot(pass);
+            if (pass) my_surv[my_cnt + __popcll(m & ((1ull << lane) - 1ull))] = kthis;
+            my_cnt += __popcll(m);
+          }
+        }
+        // the next chunk's keys: requested now, used after this chunk's ordered windows
+        if (!refining && j < nsched) {
+          const int m2 = (int)s_sched[j] - cpos;
+          if (m2 <= round_cap) {
+            load_chunk(cpos, m2, knxt);
+            have_next = true;
+          }
+        }
+        int* racc = reinterpret_cast<int*>(part);  // rank accumulators of the survivor sort (the windows are not running)
+        racc[tid] = 0;
+        if (lane == 0) s_surv[par][wave] = my_cnt;
+        lds_barrier();
+        const int c0n = s_surv[par][0], c1n = c0n + s_surv[par][1], c2n = c1n + s_surv[par][2],
+                  total = c2n + s_surv[par][3];
+        par ^= 1;
+#ifdef OKVFE_LAB
+        n_surv += total;
+#endif
+        // ---- the survivors in key order: rank = number of smaller keys (keys are unique), in place
+        auto list_key = [&](int g) {
+          int li = 0, lo = g;
+          if (g >= c2n) { li = 3; lo = g - c2n; }
+          else if (g >= c1n) { li = 2; lo = g - c1n; }
+          else if (g >= c0n) { li = 1; lo = g - c0n; }
+          return surv[li * kLazySurvPerWave + lo];
+        };
+        auto list_len = [&](int w2) { return w2 == 0 ? c0n : (w2 == 1 ? c1n - c0n : (w2 == 2 ? c2n - c1n : total - c2n)); };
+        if (total <= kLazyThreads / 2) {
+          // the usual case, a hundred survivors or fewer: 2 or 4 threads per key, each counting in one or two
+          // of the four lists (whole waves: no divergence), partial ranks added up in LDS
+          const int per = total <= 64 ? 1 : 2;                  // lists per thread
+          const int g = total <= 64 ? lane : (tid & 127);       // this thread's key
+          const int w0 = total <= 64 ? wave : 2 * (wave >> 1);  // its first list
+          const uint64_t mykey = g < total ? list_key(g) : ~0ull;
+          int r = 0;
+          for (int w2 = w0; w2 < w0 + per; ++w2) {  // wave-uniform
+            const uint64_t* lst = surv + w2 * kLazySurvPerWave;
+            const int c = list_len(w2);
+#pragma unroll 8
+            for (int jj = 0; jj < c; ++jj) r += lst[jj] < mykey ? 1 : 0;
+          }
+          if (g < total && r != 0) atomicAdd(&racc[g], r);
+          lds_barrier();  // every list has been read, every partial rank added
+          if (w0 == 0 && g < total) surv[racc[g]] = mykey;
+          lds_barrier();
+        } else {
+          const int nu = (total + kLazyThreads - 1) / kLazyThreads;  // keys per thread, <= 4 (block-uniform)
+          uint64_t mykey[4];
+          int rank[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int g = tid + u * kLazyThreads;
+            mykey[u] = (u < nu && g < total) ? list_key(g) : ~0ull;
+            rank[u] = 0;
+          }
+#pragma unroll
+          for (int w2 = 0; w2 < 4; ++w2) {
+            const uint64_t* lst = surv + w2 * kLazySurvPerWave;
+            const int c = list_len(w2);
+            if (nu <= 1) {
+#pragma unroll 8
+              for (int jj = 0; jj < c; ++jj) rank[0] += lst[jj] < mykey[0] ? 1 : 0;
+            } else {
+              for (int jj = 0; jj < c; ++jj) {
+                const uint64_t k2 = lst[jj];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rank[u] += k2 < mykey[u] ? 1 : 0;
+              }
+            }
+          }
+          lds_barrier();  // every list has been read
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < nu && tid + u * kLazyThreads < total) surv[rank[u]] = mykey[u];
+          lds_barrier();
+        }
+#ifdef OKVFE_LAB
+        t_pref += __builtin_amdgcn_s_memrealtime() - t_mark;
+#endif
+        windows(total, [&](int g) { return surv[g]; });
+        if (kept >= limit) break;  // block-uniform
+      }
     }
   }
   // ---- K4: sub-pixel refinement and keypoint emission (all four waves)
@@ -1381,6 +1825,10 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     atomicAdd(&g_lazy_prof[9], t_acc);
     atomicAdd(&g_lazy_prof[10], t_ins);
     atomicAdd(&g_lazy_prof[11], (unsigned long long)(clock64() - c_start));
+    atomicAdd(&g_lazy_prof[12], t_p0 - t_start);
+    atomicAdd(&g_lazy_prof[13], t_pa - t_p0);
+    atomicAdd(&g_lazy_prof[14], t_pb - t_pa);
+    atomicAdd(&g_lazy_prof[15], t_init - t_pb);
   }
 #endif
 }
@@ -1703,6 +2151,48 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   }
 }
 
+namespace {
+struct LazyPlan {
+  bool list, array;  // which lazy-occupancy kernel runs (neither: the grid kernels)
+  int bins_x, bins_y, cap;
+  size_t lds, lds_list;
+};
+constexpr size_t kLazyMaxLds = 159 * 1024;  // the kernels also have a few bytes of static LDS
+LazyPlan lazy_plan(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
+                   int occ_rows, int occ_cols) {
+  LazyPlan p{};
+  static const bool legacy = lab_env("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
+  static const bool grid = lab_env("OKVFE_SELECT_GRID") != nullptr;      // A/B knob: the occupancy-grid kernels
+  if (!(radius > 0.0f) || legacy || grid || occ_cols > 65535 || occ_rows > 65535) return p;
+  // lazy occupancy (no grid): any image size / radius whose bin heads and keypoint slots fit in LDS
+  p.bins_x = (occ_cols + 15) >> 4;
+  p.bins_y = (occ_rows + 15) >> 4;
+  p.cap = max_kpts < kp_cap ? max_kpts : kp_cap;
+  p.lds = lazy_lds_bytes(p.bins_x, p.bins_y);
+  p.lds_list = list_lds_bytes(p.bins_x, p.bins_y, p.cap);
+  // Array bins cost 32 B of LDS per bin, linked lists 4 B per bin + 8 B per keypoint slot: a fine
+  // grid with few keypoints per bin (640x480 at radius 10: 3136 bins, ~800 keypoints) takes the list
+  // form when that keeps at least one more image on a CU
+  // (the occupancy workspace doubles as the spill list of full bins: 8 bytes per point at worst)
+  const bool array_ok = p.lds <= kLazyMaxLds && occupancy != nullptr && occ_image_bytes >= (size_t)p.cap * 8;
+  const bool prefer_list = !array_ok || (p.lds > 48 * 1024 && kLazyMaxLds / p.lds_list > kLazyMaxLds / p.lds);
+  p.list = prefer_list && p.lds_list <= kLazyMaxLds;
+  p.array = !p.list && array_ok;
+  return p;
+}
+// lab knob: the array-bin kernel on keys sorted by launch_sort (the round-3 / early round-4 form)
+bool lazy_presorted() {
+  static const bool v = lab_env("OKVFE_SELECT_PRESORTED") != nullptr;
+  return v;
+}
+}  // namespace
+
+// true: launch_select orders the candidates itself for this configuration -- no launch_sort before it
+bool select_sorts_candidates(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
+                             int occ_rows, int occ_cols) {
+  return lazy_plan(radius, max_kpts, kp_cap, occupancy, occ_image_bytes, occ_rows, occ_cols).array && !lazy_presorted();
+}
+
 bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_image_bytes, int occ_rows,
@@ -1720,52 +2210,52 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   const bool wide = cand_cap > 65536;
   const size_t acc_bytes = ((size_t)kp_cap * (wide ? 4 : 2) + 15) & ~(size_t)15;
   static const bool legacy = lab_env("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
-  static const bool grid = lab_env("OKVFE_SELECT_GRID") != nullptr;      // A/B knob: the occupancy-grid kernels
-  if (radius > 0.0f && !legacy && !grid) {
-    // lazy occupancy (no grid): any image size / radius whose bin heads and keypoint slots fit in LDS
-    const int bins_x = (occ_cols + 15) >> 4, bins_y = (occ_rows + 15) >> 4;
-    const int cap = max_kpts < kp_cap ? max_kpts : kp_cap;
-    const size_t lds = lazy_lds_bytes(bins_x, bins_y);
-    const size_t lds_list = list_lds_bytes(bins_x, bins_y, cap);
-    constexpr size_t kLazyMaxLds = 159 * 1024;  // the kernel also has a few bytes of static LDS
-    // Array bins cost 32 B of LDS per bin, linked lists 4 B per bin + 8 B per keypoint slot: a fine
-    // grid with few keypoints per bin (640x480 at radius 10: 3136 bins, ~800 keypoints) takes the list
-    // form when that keeps at least one more image on a CU
-    const bool array_ok = lds <= kLazyMaxLds && occupancy != nullptr && occ_image_bytes >= (size_t)cap * 8;
-    const bool prefer_list = !array_ok || (lds > 48 * 1024 && kLazyMaxLds / lds_list > kLazyMaxLds / lds);
-    if (prefer_list && lds_list <= kLazyMaxLds && occ_cols <= 65535 && occ_rows <= 65535) {
-      static bool attr_set_l = false;
-      if (!attr_set_l) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_list_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
-          (void)hipGetLastError();
-        attr_set_l = true;
-      }
-      hipLaunchKernelGGL(select_list_kernel, dim3(n_images), dim3(kLazyThreads), lds_list, stream, score, layout, w, h,
-                         cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, bins_x, bins_y, cap, kps,
-                         kp_cap, kp_count, setup ? *setup : DescribeSetup{});
-      return setup != nullptr;
+  const LazyPlan lp = lazy_plan(radius, max_kpts, kp_cap, occupancy, occ_image_bytes, occ_rows, occ_cols);
+  if (lp.list) {
+    static bool attr_set_l = false;
+    if (!attr_set_l) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_list_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
+        (void)hipGetLastError();
+      attr_set_l = true;
     }
-    // the occupancy workspace doubles as the spill list of full bins: 8 bytes per point at worst
-    if (array_ok && occ_cols <= 65535 && occ_rows <= 65535) {
-      static const int bin_cap = [] {  // lab knob: 1..kLazyBinCap slots per bin (fewer = more spills)
-        const char* e = lab_env("OKVFE_LAZY_BINCAP");
-        const int v = e ? atoi(e) : kLazyBinCap;
-        return v < 1 ? 1 : (v > kLazyBinCap ? kLazyBinCap : v);
-      }();
-      static bool attr_set = false;
-      if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
-          (void)hipGetLastError();  // launches above 64 KiB will then fail loudly on their own
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(select_lazy_kernel, dim3(n_images), dim3(kLazyThreads), lds, stream, score, layout, w, h,
-                         cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, bins_x, bins_y, cap, kps,
-                         kp_cap, kp_count, reinterpret_cast<uint2*>(occupancy), occ_image_bytes / 8, bin_cap,
-                         setup ? *setup : DescribeSetup{});
-      return setup != nullptr;  // the extractor's setup ran with the emission
+    hipLaunchKernelGGL(select_list_kernel, dim3(n_images), dim3(kLazyThreads), lp.lds_list, stream, score, layout, w, h,
+                       cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, lp.bins_x, lp.bins_y, lp.cap, kps,
+                       kp_cap, kp_count, setup ? *setup : DescribeSetup{});
+    return setup != nullptr;
+  }
+  if (lp.array) {
+    static const int bin_cap = [] {  // lab knob: 1..kLazyBinCap slots per bin (fewer = more spills)
+      const char* e = lab_env("OKVFE_LAZY_BINCAP");
+      const int v = e ? atoi(e) : kLazyBinCap;
+      return v < 1 ? 1 : (v > kLazyBinCap ? kLazyBinCap : v);
+    }();
+    static const int round_cap = [] {  // lab knob: keys per round of the self-ordering kernel (smaller = more key-range splits)
+      const char* e = lab_env("OKVFE_LAZY_ROUNDCAP");
+      const int v = e ? atoi(e) : kLazyBlockMax;
+      return v < 4 ? 4 : (v > kLazyBlockMax ? kLazyBlockMax : v);
+    }();
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
+        (void)hipGetLastError();  // launches above 64 KiB will then fail loudly on their own
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
+        (void)hipGetLastError();
+      attr_set = true;
     }
+#define OKVFE_LAZY_LAUNCH(SORTS)                                                                                     \
+  hipLaunchKernelGGL(select_lazy_kernel<SORTS>, dim3(n_images), dim3(kLazyThreads), lp.lds, stream, score, layout, w, \
+                     h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, lp.bins_x, lp.bins_y,  \
+                     lp.cap, kps, kp_cap, kp_count, reinterpret_cast<uint2*>(occupancy), occ_image_bytes / 8, bin_cap, round_cap, \
+                     setup ? *setup : DescribeSetup{})
+    if (lazy_presorted())
+      OKVFE_LAZY_LAUNCH(false);
+    else
+      OKVFE_LAZY_LAUNCH(true);
+#undef OKVFE_LAZY_LAUNCH
+    return setup != nullptr;  // the extractor's setup ran with the emission
   }
   if (occ_lds && !legacy) {
     const size_t fixed = occ_bytes + acc_bytes;

@@ -227,6 +227,10 @@ struct DescribeSetup {  // pat == nullptr: not requested
   uint8_t* valid_tmp;
   const PatternScales* scales;
 };
+// true: launch_select orders the candidates itself for this configuration (array-bin lazy selection): the
+// caller launches no sort before it
+bool select_sorts_candidates(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
+                             int occ_rows, int occ_cols);
 bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,

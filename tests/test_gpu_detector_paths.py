@@ -65,6 +65,29 @@ def test_select_many_candidates_and_limit(oracle):
         G.assert_keypoints_equal(fe.detect(img), ref)
 
 
+def test_selection_orders_thousands_of_tied_scores(oracle):
+    """The array-bin selection orders its candidates itself (round 4): log buckets of the score, chunks
+    of whole buckets, survivors rank-sorted in LDS.  An exact checkerboard gives a few distinct scores
+    shared by thousands of maxima: one bucket far above the 1024 keys a round holds, which is then split
+    by key range, i.e. by (y, x) -- the order the reference's sort gives tied scores.  Also with a cap
+    that falls inside such a run, and with a stripe of noise that adds ordinary buckets around it."""
+    w, h = 752, 480
+    yy, xx = np.mgrid[0:h, 0:w]
+    board = np.where(((xx // 9) + (yy // 9)) % 2 == 0, 40, 215).astype(np.uint8)
+    mixed = board.copy()
+    mixed[200:280] = synth.noise_image(w, 80, 5)
+    for img in (board, mixed):
+        for maxk, radius in ((700, 38.0), (150, 38.0), (700, 17.0)):
+            fe = capi.Frontend(w, h, radius, 0, 100, maxk, max_candidates=1 << 15)
+            ref = oracle.detect(img, radius, 0, 100, maxk)
+            assert len(ref) > 50
+            G.assert_keypoints_equal(fe.detect(img), ref)
+    # the tie run really is longer than one round of the kernel
+    cand = oracle.nms(oracle.harris_score(board), 100)
+    _, counts = np.unique(cand["score"], return_counts=True)
+    assert counts.max() > 1024, counts.max()
+
+
 def test_sort_network_sizes_around_its_limits(oracle):
     """Candidate counts around the limits of the register-blocked sort: one thread's 16 keys, one
     LDS pass, just below / above 4096 and 8192 keys (above 8192 the two-stride LDS network or the
@@ -166,11 +189,14 @@ print("KNOB-OK")
 
 
 @pytest.mark.parametrize("knob", ["OKVFE_LEGACY_SORT", "OKVFE_K1_NOPACK", "OKVFE_SELECT_OCC_HBM",
-                                  "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP", "OKVFE_K1_TH=61", "OKVFE_K1_TH=25"])
+                                  "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP", "OKVFE_K1_TH=61", "OKVFE_K1_TH=25",
+                                  "OKVFE_SELECT_PRESORTED", "OKVFE_LAZY_ROUNDCAP=64", "OKVFE_LAZY_ROUNDCAP=7"])
 def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     """The A/B switches the profiling notes refer to (read once per process, hence a child process
     each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
-    grid in HBM, one-accept-per-round selection.  Each must stay bit-exact."""
+    grid in HBM, one-accept-per-round selection, the array-bin selection on keys sorted by a launch
+    of their own (round 4: it orders its candidates itself), and that kernel with rounds of 64 / 7
+    keys, which sends every chunk through the key-range split.  Each must stay bit-exact."""
     env = _lab_environ()
     k, _, v = knob.partition("=")
     env[k] = v or "1"
