@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define OKVFE_ABI_VERSION 4
+#define OKVFE_ABI_VERSION 5
 #define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
@@ -231,7 +231,8 @@ typedef struct okvfe_device_outputs {
   const double* backproj;        /* [max_batch][max_keypoints][3] */
   const uint8_t* backproj_valid; /* [max_batch][max_keypoints] */
   const int32_t* scores;         /* [max_batch][H][score_pitch] score maps of the last detect call (layer 0);
-                                  * pixel (x, y) at y * score_pitch + okvfe_score_column(ctx, x) */
+                                  * pixel (x, y) at y * score_pitch + okvfe_score_column(ctx, x).  NULL when
+                                  * that call wrote no map: see okvfe_set_keep_score_map */
   const int32_t* detect_counts;  /* [max_batch] keypoints before descriptor-stage removal */
   const int32_t* candidate_counts; /* [max_batch] NMS maxima found (may exceed capacity) */
   int32_t score_pitch;           /* ints per score-map row (>= W: the fused score+NMS kernel pads rows so that
@@ -242,6 +243,13 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
 /* Column of pixel x within a row of okvfe_device_outputs.scores (x itself for dense maps).  For a
  * dense copy of the score map use okvfe_harris_score_device. */
 int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x);
+/* Single-scale Harris detection keeps NO score map by default (ABI 5): HarrisScoreCalculator's map
+ * (behind cv::FeatureDetector::detect, Frame.hpp:152) is only ever read at the maxima, so the fused
+ * score + NMS kernel writes the candidates alone -- one of its five bytes per pixel -- and the selection
+ * recomputes the nine sub-pixel scores of the keypoints it keeps from the image, bit-identical.  keep = 1
+ * makes the following detect calls of this context write the map again (okvfe_device_outputs.scores);
+ * scale-space and AGAST contexts always keep theirs. */
+okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep);
 
 /* Several contexts fed in turn from several host threads / streams on ONE GPU (a camera per context,
  * ThreadedSlam.cpp:434-448): mode 1 runs the score kernels of all contexts of the process on a device

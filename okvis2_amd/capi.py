@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("OKVFE_LIB") or os.path.join(_HERE, "libokvfe.so")  # 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
     ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
-ABI_VERSION = 4
+ABI_VERSION = 5
 SCORE_HARRIS, SCORE_AGAST_9_16, SCORE_BRISK_SCALESPACE = 0, 1, 2
 DESC_BYTES = 48
 
@@ -82,7 +82,7 @@ EXPORTS = [
     "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
     "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
     "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_ahead", "okvfe_detect_describe_batch_device",
-    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_set_heavy_kernel_chaining", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device", "okvfe_harris_byte_mover_device",
+    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_set_heavy_kernel_chaining", "okvfe_set_keep_score_map", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device", "okvfe_harris_byte_mover_device",
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
@@ -490,6 +490,11 @@ class Frontend:
         self._check(lib().okvfe_detect_describe_batch_host(self._h, _p(images_host_ptr),
                                                            int(n_images), _p(ids), _p(g),
                                                            _s(stream)))
+
+    def set_keep_score_map(self, keep: bool = True):
+        """okvfe_set_keep_score_map: single-scale Harris detection writes no score map by default
+        (device_outputs().scores is then null); keep=True restores it for the following calls."""
+        self._check(lib().okvfe_set_keep_score_map(self._h, int(bool(keep))))
 
     def device_outputs(self) -> DeviceOutputs:
         out = DeviceOutputs()

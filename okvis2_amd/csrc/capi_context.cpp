@@ -276,6 +276,12 @@ okvfe_status okvfe_set_heavy_kernel_chaining(int32_t mode) {
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  ctx->keep_score_map = keep != 0;
+  return OKVFE_OK;
+}
+
 const char* okvfe_last_error(const okvfe_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
@@ -457,6 +463,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
         okvfe_ctx* ch = nullptr;
         const okvfe_status cs = create_impl(&lc, true, &ch);
         if (cs != OKVFE_OK) return fail(c, cs, "layer %d (%dx%d): %s", l, lc.width, lc.height, g_create_error.c_str());
+        ch->layer_child = true;
         c->layers.push_back(ch);
         c->layer_w.push_back(lc.width);
         c->layer_h.push_back(lc.height);

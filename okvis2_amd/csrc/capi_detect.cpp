@@ -42,6 +42,8 @@ okvfe_status okvfe_harris_byte_mover_device(okvfe_ctx* ctx, const uint8_t* image
     ok = launch_harris_byte_mover(images_dev, ctx->w, ctx->h, n_images, ctx->d_scores, ctx->score_layout, s);
   }
   if (!ok) return fail(ctx, OKVFE_ERR_UNSUPPORTED, "okvfe_harris_byte_mover_device: image base or width not dword aligned");
+  ctx->map_free_live = false;  // the buffer holds (pixel bytes in) the fused kernel's layout
+  ctx->live_layout = ctx->score_layout;
   HIP_TRY(ctx, hipGetLastError());
   return OKVFE_OK;
 }
@@ -123,11 +125,19 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
     L->live_layout = L->score_layout;
     return;
   }
+  // map-free: a single-scale context whose selection kernel recomputes the sub-pixel scores from the
+  // image needs no map at all -- the fused kernel then writes candidates only (1 of 5 bytes per pixel)
+  static const bool lab_keep = lab_env("OKVFE_KEEP_SCORE_MAP") != nullptr;  // A/B knob
+  const bool map_free = !L->keep_score_map && !lab_keep && L->n_layers == 1 && !L->layer_child &&
+                        select_recomputes_scores(L->cfg.uniformity_radius, L->cfg.max_keypoints, L->kp_cap, L->d_occ,
+                                                 L->occ_image_bytes, L->occ_rows, L->occ_cols);
   // a slotted score layout exists only where the fused kernel applies (decided at creation)
   *fused = L->score_layout.strips >= 1 &&
            launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->score_layout,
                              L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count,
-                             L->d_cand_count + 2 * (size_t)L->B, s);
+                             L->d_cand_count + 2 * (size_t)L->B, s, !map_free);
+  L->map_free_live = *fused && map_free;
+  L->live_images = images_dev;
   if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
   // the unfused pair writes and reads a dense map (pitch w) into the same buffer: every later
   // reader of this call (selection, scale filter, okvfe_get_device_outputs) must follow it
@@ -137,7 +147,7 @@ void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
   int32_t* d_fix_count = L->d_cand_count + L->B;
   if (fused)
     launch_nms_fixup(L->d_scores, L->live_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
-                     L->d_cand_count, d_fix_count, L->d_cand_count + 2 * (size_t)L->B, s);
+                     L->d_cand_count, d_fix_count, L->d_cand_count + 2 * (size_t)L->B, s, L->map_free_live, L->d_scores);
   else
     launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
                L->d_cand_count, s);
@@ -158,7 +168,7 @@ void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
   L->setup_done = launch_select(L->d_scores, L->live_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
                                 L->d_cand_count, L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ,
                                 L->occ_image_bytes, L->occ_rows, L->occ_cols, L->d_kps_det, L->kp_cap, L->d_det_count,
-                                L->d_sort_ws, s, fuse ? &setup : nullptr);
+                                L->d_sort_ws, s, fuse ? &setup : nullptr, L->map_free_live ? L->live_images : nullptr);
 }
 
 // K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count.
@@ -478,7 +488,8 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
   out->descriptors = ctx->d_desc;
   out->backproj = ctx->d_bp;
   out->backproj_valid = ctx->d_bpv;
-  out->scores = ctx->d_scores;
+  // (null after a map-free call: see okvfe_set_keep_score_map)
+  out->scores = (ctx->n_layers == 1 && ctx->map_free_live) ? nullptr : ctx->d_scores;
   out->detect_counts = ctx->d_det_count;
   out->candidate_counts = ctx->d_cand_count;
   // the layout of the LAST batch's map (dense if that call took the unfused score + NMS kernels)

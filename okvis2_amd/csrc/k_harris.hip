@@ -279,6 +279,7 @@ struct NmsOut {
   int32_t* cand_count;
   int32_t* fix_count;
   int32_t* fix_list;  // [image][kFixListCap] list positions of the flagged records (fix_count = how many)
+  int no_map;         // 1: the score map is NOT written (candidates only) -- see launch_harris_nms
 };
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
@@ -613,7 +614,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     sc[0] &= m0;
     sc[3] &= m3;
   };
+  // (map-free calls, round 4: the selection recomputes the 3 x 3 scores of the few keypoints it keeps and
+  // the fix-up works on the candidate records, so four of the five bytes per pixel are never written;
+  // wave-uniform branch around the one store)
+  const bool store_map = MEMONLY || !NMS || nms.no_map == 0;
   auto store_row = [&](const int sc[4], int y) {
+    if (!store_map) return;
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = {sc[0], sc[1], sc[2], sc[3]};
     __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, 0);
@@ -953,9 +959,10 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                        ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
-                       int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream) {
+                       int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream,
+                       bool store_map) {
   if (layout.strips < 1) return false;
-  const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list};
+  const NmsOut nms{abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list, store_map ? 0 : 1};
   return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream);
 }
 
@@ -963,7 +970,7 @@ bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* 
 bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                               ScoreLayout layout, hipStream_t stream) {
   if (layout.strips < 1) return false;
-  const NmsOut nms{1, nullptr, 0, nullptr, nullptr, nullptr};
+  const NmsOut nms{1, nullptr, 0, nullptr, nullptr, nullptr, 0};
   return launch_harris_impl(img, w, h, n_images, score, layout, &nms, stream, true);
 }
 

@@ -259,17 +259,26 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
 constexpr int kFixupHoles = 128;
 constexpr int kFixupThreads = 256;  // (eight workgroups per CU: the few images with flagged records overlap)
 constexpr int kFixupBatch = 8;
+// MAPFREE (round 4): the score map was not written.  A flagged record is kept iff the run of hits to its
+// left has even length, and every hit of such a run is a flagged record itself (the fused kernel flags a
+// whole row of a wave as soon as two of its hits touch, halo lanes included), so the record set answers
+// "is (x - k, y) a hit?": up to 256 flagged records are looked up in a list in LDS, more of them (plateaus,
+// checkerboards) in a bitmap of the image built in the idle score-map buffer.
+constexpr int kFixupSmall = 256;
+template <bool MAPFREE>
 __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t* __restrict__ scores,
                                                         ScoreLayout layout, int w,
                                                         int h, int thr, Candidate* __restrict__ cand,
                                                         int cand_cap,
                                                         int32_t* __restrict__ cand_count,
                                                         const int32_t* __restrict__ fix_count,
-                                                        const int32_t* __restrict__ fix_list) {
+                                                        const int32_t* __restrict__ fix_list,
+                                                        uint32_t* bitmap_ws, size_t bitmap_stride) {
   __shared__ int wave_cnt[kFixupThreads / 64];
   __shared__ int s_base;
   __shared__ int n_rej;
   __shared__ int holes[kFixupHoles];
+  __shared__ uint32_t fkeys[MAPFREE ? kFixupSmall : 1];
   const int img = blockIdx.x;
   if (fix_count[img] == 0) return;
   const LayoutMap s{scores + (size_t)img * layout.pitch * h, layout};
@@ -282,15 +291,81 @@ __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t*
     n_rej = 0;
   }
   __syncthreads();
-  auto settle = [&](int i, int y) {
-    if (accepted_slow(s, w, c[i].x, y & ~kCandidateFixupFlag, thr)) {
+  const int n_flagged = fix_count[img];
+  auto keep_or_hole = [&](int i, int y, bool accepted) {
+    if (accepted) {
       c[i].y = y & ~kCandidateFixupFlag;
     } else {  // stays flagged = to be removed
       const int k = atomicAdd(&n_rej, 1);
       if (k < kFixupHoles) holes[k] = i;
     }
   };
-  const int n_flagged = fix_count[img];
+  if constexpr (MAPFREE) {
+    const bool listed = fix_list && n_flagged <= kFixListCap;
+    if (listed && n_flagged <= kFixupSmall) {
+      int i = -1, y = 0;
+      uint32_t key = 0xFFFFFFFFu;
+      if (tid < n_flagged) {
+        i = fix_list[(size_t)img * kFixListCap + tid];
+        if (i < n) {
+          y = c[i].y;
+          key = ((uint32_t)(y & ~kCandidateFixupFlag) << 16) | (uint32_t)c[i].x;
+        } else {
+          i = -1;
+        }
+      }
+      fkeys[tid] = key;
+      __syncthreads();
+      if (i >= 0) {
+        int run = 0;
+        for (;;) {  // (x >= 2 for every hit: the subtraction never borrows from y before the run ends)
+          const uint32_t target = key - (uint32_t)(run + 1);
+          bool found = false;
+          for (int j = 0; j < n_flagged; ++j) found = found || fkeys[j] == target;
+          if (!found) break;
+          ++run;
+        }
+        keep_or_hole(i, y, (run & 1) == 0);
+      }
+    } else {
+      uint32_t* bm = bitmap_ws + (size_t)img * bitmap_stride;
+      const int words = (w * h + 31) >> 5;
+      for (int k = tid; k < words; k += kFixupThreads) bm[k] = 0u;
+      __syncthreads();
+      auto for_each_flagged = [&](auto f) {
+        if (listed) {
+          for (int t = tid; t < n_flagged; t += kFixupThreads) {
+            const int i = fix_list[(size_t)img * kFixListCap + t];
+            if (i < n) f(i, c[i].y);
+          }
+        } else {
+          for (int i = tid; i < n; i += kFixupThreads) {
+            const int y = c[i].y;
+            if (y & kCandidateFixupFlag) f(i, y);
+          }
+        }
+      };
+      for_each_flagged([&](int i, int y) {
+        const int p = (y & ~kCandidateFixupFlag) * w + c[i].x;
+        atomicOr(&bm[p >> 5], 1u << (p & 31));
+      });
+      __threadfence_block();
+      __syncthreads();
+      for_each_flagged([&](int i, int y) {
+        const int x = c[i].x, p0 = (y & ~kCandidateFixupFlag) * w;
+        int run = 0;
+        while (x - 1 - run >= 2) {
+          const int p = p0 + x - 1 - run;
+          if (!((__atomic_load_n(&bm[p >> 5], __ATOMIC_RELAXED) >> (p & 31)) & 1u)) break;
+          ++run;
+        }
+        keep_or_hole(i, y, (run & 1) == 0);
+      });
+    }
+  } else {
+  auto settle = [&](int i, int y) {
+    keep_or_hole(i, y, accepted_slow(s, w, c[i].x, y & ~kCandidateFixupFlag, thr));
+  };
   if (fix_list && n_flagged <= kFixListCap) {
     // the fused kernel listed where its flagged records are: no pass over the whole list (reading
     // 13 k records per 1024 x 1024 image cost 0.04 ms per launch for a handful of ties)
@@ -313,6 +388,7 @@ __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t*
       const int i = i0 + u * kFixupThreads, y = ys[u];
       if (y & kCandidateFixupFlag) settle(i, y);
     }
+  }
   }
   // (workgroup scope: an agent-scope fence writes the XCD's L2 back -- 0.1 ms per launch right after
   // the score kernel; thread 0 reads the flags back past the L1 instead)
@@ -372,10 +448,18 @@ __global__ __launch_bounds__(kFixupThreads) void nms_fixup_kernel(const int32_t*
 
 void launch_nms_fixup(const int32_t* score, ScoreLayout layout, int w, int h, int n_images,
                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
-                      const int32_t* fix_count, const int32_t* fix_list, hipStream_t stream) {
+                      const int32_t* fix_count, const int32_t* fix_list, hipStream_t stream, bool map_free,
+                      int32_t* idle_score_buffer) {
   if (n_images <= 0) return;
-  hipLaunchKernelGGL(nms_fixup_kernel, dim3(n_images), dim3(kFixupThreads), 0, stream, score, layout, w, h,
-                     abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list);
+  if (map_free) {
+    // the score map was not written by this call: its buffer is free, and serves as bitmap scratch
+    hipLaunchKernelGGL(nms_fixup_kernel<true>, dim3(n_images), dim3(kFixupThreads), 0, stream, score, layout, w, h,
+                       abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list,
+                       reinterpret_cast<uint32_t*>(idle_score_buffer), (size_t)layout.pitch * h);
+    return;
+  }
+  hipLaunchKernelGGL(nms_fixup_kernel<false>, dim3(n_images), dim3(kFixupThreads), 0, stream, score, layout, w, h,
+                     abs_threshold, cand, cand_cap, cand_count, fix_count, fix_list, (uint32_t*)nullptr, (size_t)0);
 }
 
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,

@@ -311,6 +311,83 @@ __global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restr
 
 // 2-D quadratic sub-pixel refinement; mirrors the published BRISK Subpixel2D with 64-bit
 // coefficients (Harris scores overflow 32-bit products) and double Hessian terms.
+// The nine Harris scores around pixel (u, v), 2 <= u < w - 2, 2 <= v < h - 2, straight from the image: exactly
+// what the score map of harris_kernel holds there (k_harris.hip; HarrisScoreCalculator of the brisk library):
+// Scharr (3, 10, 3) gradients, products >> 14 (zero on the image rim), 3 x 3 binomial, det - (trace / 4)^2.
+// Map-free calls (round 4): the score kernel writes no map -- four of its five bytes per pixel -- and the
+// selection recomputes these nine values for the ~230 keypoints per image it keeps (7 x 7 pixels, ~1 k
+// integer operations each; +18 us on the selection of 1536 EuRoC images against -105 us on the score kernel.
+// A kernel of its own for this -- one thread per keypoint of the batch -- was measured and is slower (111 us:
+// it is all scattered line fetches, which hide behind other images' arithmetic in here).
+// xx | yy << 16 share a register (both < 2^14 after the binomial).
+__device__ __forceinline__ void harris_scores_3x3(const uint8_t* __restrict__ im, int w, int h, int u, int v,
+                                                  int32_t out[9]) {
+  // (requires w % 4 == 0 and a dword-aligned image, like the fused score kernel this stands in for)
+  // Pixels u - 3 .. u + 3 of rows v - 3 .. v + 3 as three aligned dwords per row (one keypoint per lane: every
+  // load instruction of the wave touches 64 different lines, so the count of loads is what this costs); the
+  // dword before the row / past its end is not read -- the pixel it would supply only feeds gradient products
+  // on the image rim, which are zero by definition.
+  const int base = (u - 3) & ~3;  // -4 for u = 2
+  const int sh = (u - 3) - base;  // 0..3
+  uint32_t q0[7], q1[7];          // pixels 0..3 and 4..6 of each row
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const int y = v - 3 + r;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(im + (size_t)(y < 0 ? 0 : (y > h - 1 ? h - 1 : y)) * w);
+    const uint32_t d0 = base >= 0 ? row[base >> 2] : 0u;
+    const uint32_t d1 = row[(base >> 2) + 1];
+    const uint32_t d2 = base + 8 < w ? row[(base >> 2) + 2] : 0u;
+    q0[r] = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh);
+    q1[r] = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)sh);
+  }
+  auto px = [&](int r, int k) { return (int)(((k < 4 ? q0[r] : q1[r]) >> (8 * (k & 3))) & 0xFFu); };
+  int acc_p[9], acc_xy[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc_p[k] = acc_xy[k] = 0;
+  // The Scharr pair is separable: a = 3 p(y-1) + 10 p(y) + 3 p(y+1), b = p(y+1) - p(y-1) per pixel column,
+  // then gx = a(x+1) - a(x-1), gy = 3 b(x-1) + 10 b(x) + 3 b(x+1).
+#pragma unroll
+  for (int r = -2; r <= 2; ++r) {  // gradient row v + r: pixel rows r + 2, r + 3, r + 4 of the window
+    const bool yin = v + r >= 1 && v + r <= h - 2;
+    int a[7], b[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int t0 = px(r + 2, k), t1 = px(r + 3, k), t2 = px(r + 4, k);
+      a[k] = 3 * (t0 + t2) + 10 * t1;
+      b[k] = t2 - t0;
+    }
+    int gp[5], gxy[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int x = u - 2 + k;
+      const int gx = a[k + 2] - a[k];
+      const int gy = 3 * (b[k] + b[k + 2]) + 10 * b[k + 1];
+      const bool in = yin && x >= 1 && x <= w - 2;  // gradient products are zero on the image rim
+      gp[k] = in ? ((gx * gx) >> 14) | (((gy * gy) >> 14) << 16) : 0;
+      gxy[k] = in ? (gx * gy) >> 14 : 0;  // arithmetic shift: floor, like the reference's 16-bit products
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int hp = gp[c] + 2 * gp[c + 1] + gp[c + 2];
+      const int hxy = gxy[c] + 2 * gxy[c + 1] + gxy[c + 2];
+#pragma unroll
+      for (int j = -1; j <= 1; ++j) {
+        const int d = j - r;
+        if (d >= -1 && d <= 1) {
+          acc_p[(j + 1) * 3 + c] += d == 0 ? 2 * hp : hp;
+          acc_xy[(j + 1) * 3 + c] += d == 0 ? 2 * hxy : hxy;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int s0 = acc_p[k] & 0xFFFF, s1 = (int)((unsigned)acc_p[k] >> 16), s2 = acc_xy[k];
+    const int tq = ((s0 >> 1) + (s1 >> 1)) >> 1;
+    out[k] = s0 * s1 - s2 * s2 - tq * tq;
+  }
+}
+
 __device__ void subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
   // s_i_j of the published formula = score(x-1+i, y-1+j): first index along x
   const int64_t s00 = s[0], s01 = s[3], s02 = s[6];
@@ -939,7 +1016,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     const int32_t* __restrict__ cand_count, uint64_t* sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
     okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, uint2* __restrict__ spill_ws,
-    size_t spill_stride, int bin_cap, int round_cap, DescribeSetup setup) {
+    size_t spill_stride, int bin_cap, int round_cap, DescribeSetup setup, const uint8_t* __restrict__ images) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_kept;
   __shared__ int s_spill;       // points that did not fit their bin (HBM list)
@@ -968,7 +1045,6 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
   n = n > cand_cap ? 0 : n;
   uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   uint2* spill = spill_ws + (size_t)img * spill_stride;  // {cy << 16 | cx, level}
   int kept = 0;
@@ -1792,11 +1868,16 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     okvfe_keypoint kp = out[i];
     const int u = (int)kp.x, v = (int)kp.y;
     int32_t patch[9];
+    if (images) {  // map-free call: the nine scores from the pixels (block-uniform)
+      harris_scores_3x3(images + (size_t)img * w * h, w, h, u, v, patch);
+    } else {
+      const int32_t* sc = scores + (size_t)img * layout.pitch * h;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+      for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx)
-        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
+        for (int dx = -1; dx <= 1; ++dx)
+          patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
+    }
     float ddx, ddy;
     subpixel2d(patch, &ddx, &ddy);
     kp.x = (float)u + ddx;
@@ -1860,7 +1941,8 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
     const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,
-    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, DescribeSetup setup) {
+    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count, DescribeSetup setup,
+    const uint8_t* __restrict__ images) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_kept;
   const int bpitch = bins_x + 2;  // bordered bin grid: the border bins stay empty, so no range checks
@@ -1883,7 +1965,6 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
   n = n > cand_cap ? 0 : n;
   const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
   okvfe_keypoint* out = kps + (size_t)img * kp_cap;
   int kept = 0;
   if (n > 0) {  // block-uniform
@@ -2079,11 +2160,16 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     okvfe_keypoint kp = out[i];
     const int u = (int)kp.x, v = (int)kp.y;
     int32_t patch[9];
+    if (images) {  // map-free call: the nine scores from the pixels (block-uniform)
+      harris_scores_3x3(images + (size_t)img * w * h, w, h, u, v, patch);
+    } else {
+      const int32_t* sc = scores + (size_t)img * layout.pitch * h;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+      for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx)
-        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
+        for (int dx = -1; dx <= 1; ++dx)
+          patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
+    }
     float ddx, ddy;
     subpixel2d(patch, &ddx, &ddy);
     kp.x = (float)u + ddx;
@@ -2187,6 +2273,13 @@ bool lazy_presorted() {
 }
 }  // namespace
 
+// true: launch_select runs a kernel that can recompute the sub-pixel scores from the image (`images` != null):
+// the score map need not exist for this configuration
+bool select_recomputes_scores(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
+                              int occ_rows, int occ_cols) {
+  const LazyPlan p = lazy_plan(radius, max_kpts, kp_cap, occupancy, occ_image_bytes, occ_rows, occ_cols);
+  return p.array || p.list;
+}
 // true: launch_select orders the candidates itself for this configuration -- no launch_sort before it
 bool select_sorts_candidates(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
                              int occ_rows, int occ_cols) {
@@ -2197,7 +2290,7 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_image_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
-                   uint64_t* sort_ws, hipStream_t stream, const DescribeSetup* setup) {
+                   uint64_t* sort_ws, hipStream_t stream, const DescribeSetup* setup, const uint8_t* images) {
   if (n_images <= 0) return false;
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
@@ -2221,7 +2314,7 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
     }
     hipLaunchKernelGGL(select_list_kernel, dim3(n_images), dim3(kLazyThreads), lp.lds_list, stream, score, layout, w, h,
                        cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, lp.bins_x, lp.bins_y, lp.cap, kps,
-                       kp_cap, kp_count, setup ? *setup : DescribeSetup{});
+                       kp_cap, kp_count, setup ? *setup : DescribeSetup{}, images);
     return setup != nullptr;
   }
   if (lp.array) {
@@ -2249,7 +2342,7 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   hipLaunchKernelGGL(select_lazy_kernel<SORTS>, dim3(n_images), dim3(kLazyThreads), lp.lds, stream, score, layout, w, \
                      h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, lp.bins_x, lp.bins_y,  \
                      lp.cap, kps, kp_cap, kp_count, reinterpret_cast<uint2*>(occupancy), occ_image_bytes / 8, bin_cap, round_cap, \
-                     setup ? *setup : DescribeSetup{})
+                     setup ? *setup : DescribeSetup{}, images)
     if (lazy_presorted())
       OKVFE_LAZY_LAUNCH(false);
     else

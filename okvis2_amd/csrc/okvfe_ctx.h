@@ -38,6 +38,12 @@ struct okvfe_ctx {
   size_t map_perm_frames = 0;     // frames d_map_perm holds
   ScoreLayout score_layout{0, 0};  // of d_scores: slotted where the fused score+NMS kernel applies
   ScoreLayout live_layout{0, 0};   // the layout the LAST score launch actually wrote (dense when the fused kernel refused the call)
+  // Map-free detection (round 4): single-scale Harris calls whose selection kernel can recompute the nine
+  // sub-pixel scores from the image write NO score map (okvfe_set_keep_score_map(ctx, 1) restores it).
+  bool keep_score_map = false;
+  bool layer_child = false;        // detect-only context of one scale-space layer: its map is read by the other layers
+  bool map_free_live = false;      // the LAST detect call wrote no map: okvfe_device_outputs.scores is null
+  const uint8_t* live_images = nullptr;  // images of the running detect call (map-free: read again by the selection)
   Candidate* d_cand = nullptr;
   int32_t* d_cand_count = nullptr;
   uint64_t* d_sort_ws = nullptr;

@@ -186,7 +186,8 @@ void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* scor
 // launch_nms_fixup.
 bool launch_harris_nms(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                        ScoreLayout layout, int abs_threshold, Candidate* cand, int cand_cap,
-                       int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream);
+                       int32_t* cand_count, int32_t* fix_count, int32_t* fix_list, hipStream_t stream,
+                       bool store_map = true);
 void launch_param_copy(void* dst_dev, const void* src_host_mapped, size_t bytes, int32_t* zero_dev, int n_zero,
                        hipStream_t stream, int32_t* poke_dev = nullptr, int32_t poke_value = 0);
 // one image's results -> one block of pinned host memory (k_util.hip); null sources are skipped
@@ -211,7 +212,8 @@ bool launch_harris_byte_mover(const uint8_t* img, int w, int h, int n_images, in
 ScoreLayout harris_nms_layout(int w, int h);
 void launch_nms_fixup(const int32_t* score, ScoreLayout layout, int w, int h, int n_images,
                       int abs_threshold, Candidate* cand, int cand_cap, int32_t* cand_count,
-                      const int32_t* fix_count, const int32_t* fix_list, hipStream_t stream);
+                      const int32_t* fix_count, const int32_t* fix_list, hipStream_t stream, bool map_free = false,
+                      int32_t* idle_score_buffer = nullptr);
 void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_threshold,
                 Candidate* cand, int cand_cap, int32_t* cand_count, hipStream_t stream);
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
@@ -235,7 +237,10 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
                    int occ_cols, okvfe_keypoint* kps, int kp_cap, int32_t* kp_count,
-                   uint64_t* sort_ws, hipStream_t stream, const DescribeSetup* setup = nullptr);
+                   uint64_t* sort_ws, hipStream_t stream, const DescribeSetup* setup = nullptr,
+                   const uint8_t* images = nullptr);  // images != null: map-free call, see select_recomputes_scores
+bool select_recomputes_scores(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
+                              int occ_rows, int occ_cols);
 void launch_describe(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,

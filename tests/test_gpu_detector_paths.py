@@ -51,6 +51,8 @@ def test_fused_nms_plateaus_across_borders(oracle, w, h, bx, by):
         ref = oracle.detect(img, radius, 0, thr, maxk)
         assert len(ref) > 20
         G.assert_keypoints_equal(fe.detect(img), ref)
+        fe.set_keep_score_map(True)   # (round 4: the default writes no map where the selection can do without)
+        G.assert_keypoints_equal(fe.detect(img), ref)
 
 
 def test_select_many_candidates_and_limit(oracle):
@@ -81,6 +83,10 @@ def test_selection_orders_thousands_of_tied_scores(oracle):
             fe = capi.Frontend(w, h, radius, 0, 100, maxk, max_candidates=1 << 15)
             ref = oracle.detect(img, radius, 0, 100, maxk)
             assert len(ref) > 50
+            G.assert_keypoints_equal(fe.detect(img), ref)      # map-free: fix-up on the records (bitmap path)
+            fe.set_keep_score_map(True)
+            G.assert_keypoints_equal(fe.detect(img), ref)      # the same through the score map
+            fe.set_keep_score_map(False)
             G.assert_keypoints_equal(fe.detect(img), ref)
     # the tie run really is longer than one round of the kernel
     cand = oracle.nms(oracle.harris_score(board), 100)
@@ -190,7 +196,8 @@ print("KNOB-OK")
 
 @pytest.mark.parametrize("knob", ["OKVFE_LEGACY_SORT", "OKVFE_K1_NOPACK", "OKVFE_SELECT_OCC_HBM",
                                   "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP", "OKVFE_K1_TH=61", "OKVFE_K1_TH=25",
-                                  "OKVFE_SELECT_PRESORTED", "OKVFE_LAZY_ROUNDCAP=64", "OKVFE_LAZY_ROUNDCAP=7"])
+                                  "OKVFE_SELECT_PRESORTED", "OKVFE_LAZY_ROUNDCAP=64", "OKVFE_LAZY_ROUNDCAP=7",
+                                  "OKVFE_KEEP_SCORE_MAP"])
 def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     """The A/B switches the profiling notes refer to (read once per process, hence a child process
     each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
@@ -604,6 +611,18 @@ def test_unaligned_image_pointer_takes_the_dense_fallback(oracle):
         want.append(oracle.detect_describe(imgs[ci], cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
                                            oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cfg.cams[ci].fu),
                                            (0.0, 1.0, 0.0)))
+    # round 4: aligned single-scale Harris calls write no score map unless asked to; the unfused fallback
+    # always does (its NMS kernel reads it)
+    for off in (0, 1, 4):
+        buf[off:off + 2 * P] = torch.from_numpy(imgs.reshape(-1)).cuda()
+        fe.detect_describe_batch_device(buf.data_ptr() + off, 2, cams, grav, stream)
+        torch.cuda.synchronize()
+        assert (fe.device_outputs().scores is None) == (off % 4 == 0)
+        for ci in range(2):
+            k, d, _, _ = fe.download(ci)
+            G.assert_keypoints_equal(k, want[ci][0])
+            assert np.array_equal(d, want[ci][1])
+    fe.set_keep_score_map(True)
     for off, strips_expected in ((1, 0), (0, None), (3, 0), (4, None)):
         buf[off:off + 2 * P] = torch.from_numpy(imgs.reshape(-1)).cuda()
         fe.detect_describe_batch_device(buf.data_ptr() + off, 2, cams, grav, stream)
