@@ -445,32 +445,79 @@ def latency_b1(cfg, base, n_frames=8, iters=300, warmup=30):
     return res
 
 
-def k1_name(h):
-    return "harris_kernel<61, true> (K1 score map + fused K2 NMS)"
+def k1_name(map_free):
+    return ("harris_kernel<61, true> (K1 score + fused K2 NMS, candidates only: no score map)" if map_free
+            else "harris_kernel<61, true> (K1 score map + fused K2 NMS)")
 
 
-def roofline_block(P, n_img_launch, harris_ms, extra):
-    achieved = 5.0 * P * n_img_launch / (harris_ms * 1e-3) / 1e9
-    traffic, traffic_src = None, None
+def mean_candidates(capi, fe, n_images):
+    """Mean NMS maxima per image of the last detect call of `fe` (okvfe_device_outputs.candidate_counts)."""
+    import ctypes
+    out = fe.device_outputs()
+    host = np.zeros(n_images, dtype=np.int32)
+    st = capi.lib().okvfe_copy_to_host(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(out.candidate_counts),
+                                       ctypes.c_size_t(host.nbytes), None)
+    return float(host.mean()) if st == 0 and n_images > 0 else 0.0
+
+
+def k1_map_free(fe):
+    """True when the last detect call of `fe` wrote no score map (okvfe_set_keep_score_map)."""
+    return fe.device_outputs().scores is None
+
+
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # wave-instructions/ns: 1024 SIMDs, one wave64 VALU op per 4 cycles at 2.4 GHz
+
+
+def k1_pmc_for(w, h, map_free):
+    """Newest committed PMC collection of K1 taken on THIS image shape and map mode (None: none)."""
     import glob
-    # newest PMC collection (this round's first) taken on THIS image shape; none -> null
     cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "round4_*_k1_pmc*.json")), reverse=True) +
              sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_k1_pmc*.json")), reverse=True) +
              sorted(glob.glob(os.path.join(ROOT, "profiles", "round2_*_k1_pmc*.json")), reverse=True))
     for pmc_path in cands:
         pmc = json.load(open(pmc_path))
-        # same kernel, same image shape: per-image HBM bytes x the images of one launch here
-        if pmc.get("algorithmic_bytes_per_launch") == 5 * P * pmc.get("images_per_launch", 0):
-            traffic = pmc["hbm_bytes_per_image"] * n_img_launch
-            traffic_src = ("profiles/%s (FETCH_SIZE/WRITE_SIZE passes at %d images per launch, scaled "
-                           "per image; rocprofv3 cannot run inside this process)"
-                           % (os.path.basename(pmc_path), pmc["images_per_launch"]))
-            break
-    r = {"kernel": k1_name(0), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        if bool(pmc.get("map_free", False)) != bool(map_free):
+            continue
+        # (files written before round 4 carry no shape: same kernel and shape <=> same 5 P n)
+        same = (pmc.get("width") == w and pmc.get("height") == h) if "width" in pmc else \
+            pmc.get("algorithmic_bytes_per_launch") == 5 * w * h * pmc.get("images_per_launch", 0)
+        if same:
+            return pmc, os.path.basename(pmc_path)
+    return None, None
+
+
+def roofline_block(P, n_img_launch, harris_ms, extra, w=None, h=None, map_free=False, cand_per_image=0.0):
+    """SURVEY.md 8 D4: K1 moves 5 P bytes per image (1 B in, 4 B out per pixel) when it writes the score map;
+    fused with the NMS and the map never materialised (the default since round 4) the algorithmic figure is
+    P + 12 C (C = candidate records of 12 B) and the kernel is bound by vector-ALU issue, not by HBM: both
+    fractions are reported, `bound` names the memory roofline the contract asks for, `live_bound` the unit
+    that is actually saturated."""
+    per_image = (P + 12.0 * cand_per_image) if map_free else 5.0 * P
+    alg = per_image * n_img_launch
+    achieved = alg / (harris_ms * 1e-3) / 1e9
+    traffic, traffic_src, valu = None, None, None
+    pmc, pmc_name = k1_pmc_for(w, h, map_free) if w else (None, None)
+    if pmc:
+        traffic = pmc["hbm_bytes_per_image"] * n_img_launch
+        traffic_src = ("profiles/%s (FETCH_SIZE/WRITE_SIZE passes at %d images per launch, scaled "
+                       "per image; rocprofv3 cannot run inside this process)" % (pmc_name, pmc["images_per_launch"]))
+        if pmc.get("valu_insts_per_image"):
+            ginst = pmc["valu_insts_per_image"] * n_img_launch / (harris_ms * 1e-3) / 1e9
+            valu = {"achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
+                    "frac": ginst / VALU_PEAK_GINST,
+                    "insts_per_launch": pmc["valu_insts_per_image"] * n_img_launch,
+                    "source": "SQ_INSTS_VALU of profiles/%s; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 op" % pmc_name}
+    r = {"kernel": k1_name(map_free), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-         "traffic_over_algorithmic": (traffic / (5.0 * P * n_img_launch)) if traffic else None,
-         "algorithmic_bytes_per_launch": 5 * P * n_img_launch, "avg_launch_ms": harris_ms}
+         "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+         "algorithmic_bytes_per_launch": alg,
+         "algorithmic_note": ("P + 12 C per image: 1 B per pixel in, 12 B per candidate out (%.0f candidates per image); the "
+                              "score map is not written (SURVEY.md 8 D4, fused form)" % cand_per_image) if map_free
+         else "5 P per image: 1 B per pixel in, 4 B per pixel out",
+         "avg_launch_ms": harris_ms,
+         "live_bound": "valu" if map_free else "hbm",
+         "valu": valu}
     r.update(extra)
     return r
 
@@ -560,7 +607,8 @@ def run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev):
                    "rank0_matches_per_step": sum(n_matches.values())},
         "roofline": roofline_block(cfg.w * cfg.h, B, harris_ms,
                                    {"note": "one launch per local camera; the cameras of a rank run on "
-                                            "their own streams and may overlap"}),
+                                            "their own streams and may overlap"}, cfg.w, cfg.h,
+                                   k1_map_free(engines[local[0]]), mean_candidates(capi, engines[local[0]], B)),
     }
     return res
 
@@ -806,6 +854,8 @@ def main():
         kp_total += len(k)
         kp_counts.append(len(k))
     m_host = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts).copy()
+    map_free = k1_map_free(fe)
+    cand_mean = mean_candidates(capi, fe, n_lane_img)
 
     def read_profiles():
         acc = {}
@@ -836,6 +886,20 @@ def main():
         lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav_v[0], lanes[0][1])
         torch.cuda.synchronize()
     iso = lanes[0][0].profile_read()["harris"]
+    # ... and the same launch WITH the score map written (okvfe_set_keep_score_map(1): the form of rounds 1-3,
+    # 5 P algorithmic bytes per image, HBM-bound) -- what the byte mover below is the floor of
+    with_map = iso
+    # (not under a PMC collection: its per-dispatch means must see ONE form of the kernel)
+    if map_free and not os.environ.get("OKVFE_PMC_CALIB"):
+        lanes[0][0].set_keep_score_map(True)
+        lanes[0][0].profile_enable(True, stages=("harris",))
+        for _ in range(5):
+            lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav_v[0], lanes[0][1])
+            torch.cuda.synchronize()
+        with_map = lanes[0][0].profile_read()["harris"]
+        lanes[0][0].set_keep_score_map(False)
+        lanes[0][0].detect_describe_batch_device(lanes[0][2], n_lane_img, cam_ids, grav_v[0], lanes[0][1])
+        torch.cuda.synchronize()
     # ... and its byte mover: the same loads and stores on the same layout without the arithmetic
     # (okvfe_harris_byte_mover_device) -- the kernel's own memory floor, same box, same minute
     mover = None
@@ -962,29 +1026,37 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": roofline_block(P, n_lane_img, harris_ms, {
                 "isolated_launch_ms": iso[0] / iso[1],
-                "isolated_frac": 5.0 * P * n_lane_img / (iso[0] / iso[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "byte_mover_ms": (mover[0] / mover[1]) if mover and mover[1] else None,
-                "frac_of_byte_mover": (mover[0] / mover[1]) / (iso[0] / iso[1]) if mover and mover[1] else None,
-                "byte_mover_note": "harris_kernel<61, true, PACK, MEMONLY>: the kernel's own loads and stores "
-                                   "(same tiles, same slotted layout, same launch geometry) with the arithmetic, "
-                                   "the NMS and the candidate records removed; frac_of_byte_mover = byte mover / "
-                                   "isolated kernel duration",
-                "copy_kernel_GBps": copy_gbps, "fill_kernel_GBps": fill_gbps,
-                "frac_of_copy_kernel": 5.0 * P * n_lane_img / (harris_ms * 1e-3) / 1e9 / copy_gbps,
-                "widen_kernel_ms": widen_ms,
-                "widen_kernel_note": "torch u8 -> int32 conversion of the same images into the same "
-                                     "buffer: the score kernel's algorithmic bytes (1 B in, 4 B out "
-                                     "per pixel) through a kernel that computes nothing",
-                "frac_of_widen_kernel": (widen_ms / harris_ms) if widen_ms else None,
+                "with_score_map": {
+                    "note": "the same launch with okvfe_set_keep_score_map(1): 5 P algorithmic bytes per image, "
+                            "HBM-bound (the kernel of rounds 1-3); 5 isolated launches after the timed region",
+                    "avg_launch_ms": with_map[0] / with_map[1],
+                    "achieved": 5.0 * P * n_lane_img / (with_map[0] / with_map[1] * 1e-3) / 1e9,
+                    "frac": 5.0 * P * n_lane_img / (with_map[0] / with_map[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "algorithmic_bytes_per_launch": 5 * P * n_lane_img,
+                    "byte_mover_ms": (mover[0] / mover[1]) if mover and mover[1] else None,
+                    "frac_of_byte_mover": (mover[0] / mover[1]) / (with_map[0] / with_map[1]) if mover and mover[1] else None,
+                    "byte_mover_note": "harris_kernel<61, true, PACK, MEMONLY>: the map-writing kernel's own loads and "
+                                       "stores (same tiles, same slotted layout, same launch geometry) with the "
+                                       "arithmetic, the NMS and the candidate records removed",
+                    "copy_kernel_GBps": copy_gbps, "fill_kernel_GBps": fill_gbps,
+                    "widen_kernel_ms": widen_ms,
+                    "widen_kernel_note": "torch u8 -> int32 conversion of the same images into the same buffer: 1 B in, "
+                                         "4 B out per pixel through a kernel that computes nothing",
+                    "traffic_over_algorithmic": (lambda pm: pm["hbm_bytes_per_image"] / (5.0 * P) if pm else None)(
+                        k1_pmc_for(cfg.w, cfg.h, False)[0]),
+                },
+                "frac_if_counted_as_5P": 5.0 * P * n_lane_img / (harris_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "frac_if_counted_as_5P_note": "the launch's duration against the bytes the map-writing form moves "
+                                              "(continuity with rounds 1-3; NOT this kernel's algorithmic bytes when "
+                                              "live_bound is valu)",
                 "score_only_launch_ms": solo[0] / solo[1],
-                "score_only_frac": 5.0 * P * n_lane_img / (solo[0] / solo[1] * 1e-3) / 1e9
-                                   / HBM_PEAK_GBPS,
                 "score_only_note": "harris_kernel<30, false>: the score map alone (no NMS), 5 launches "
                                    "after the timed region",
                 "note": ("one lane: the launch has the GPU to itself in the timed region as well"
                          if S == 1 else
                          "avg_launch_ms is taken while the other lanes' kernels share the GPU; "
-                         "isolated_* is the same launch with the GPU to itself")}),
+                         "isolated_* is the same launch with the GPU to itself")},
+                cfg.w, cfg.h, map_free, cand_mean),
             "rooflines_other": alu_rooflines(
                 stage_ms,
                 (sum(kp_counts[C * i] * kp_counts[C * i + 1] for i in range(len(kp_counts) // C)) *

@@ -38,11 +38,16 @@ for W in tumvi mono640 hilti; do
     python $R/tools/pmc_summary.py $(find /tmp/prof_${W}_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_${W}_pmc_$C.json > /dev/null
   done
 done
-unset OKVFE_PMC_CALIB
-# K1 against its own byte-mover floor on the same (slotted) score layout, and the A/B knobs
-if [ -f $R/okvis2_amd/libokvfe_memonly.so ]; then
-  ( cd $R && ROUNDS=2 bash tools/k1ab_env.sh - -:OKVFE_K1_DENSE=1 memonly memonly:OKVFE_K1_DENSE=1 valu noepi 2>&1 | sort ) > $OUT/${TAG}_k1_floor.txt
-fi
+# (still under OKVFE_PMC_CALIB: bench.py then skips its score-map leg, so every K1 dispatch is the product form)
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -o p -- $BENCH --steps 3 > /tmp/prof_sq.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/prof_sq -name '*counter_collection.csv' | head -1) $OUT/${TAG}_pmc_sq.json > /dev/null
+# the same two byte passes with the score map kept (okvfe_set_keep_score_map through the lab knob): the
+# 5 P form of the kernel, for the with_score_map block of the bench line
+if [ -f $R/okvis2_amd/libokvfe_lab.so ]; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    OKVFE_LIB=$R/okvis2_amd/libokvfe_lab.so OKVFE_KEEP_SCORE_MAP=1 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_map_$C -o p -- $BENCH --steps 3 > /tmp/prof_map_$C.log 2>&1
+    python $R/tools/pmc_summary.py $(find /tmp/prof_map_$C -name '*counter_collection.csv' | head -1) $OUT/${TAG}_withmap_pmc_$C.json > /dev/null
+  done
+fi
+unset OKVFE_PMC_CALIB
 ls -la $OUT | tail -12

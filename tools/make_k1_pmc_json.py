@@ -12,9 +12,16 @@ import sys
 
 tag = sys.argv[1]
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_map_free, _cand = False, 0.0
 try:  # images per launch of the profiled command = the bench line of the same collection
-    _b = json.load(open(os.path.join(_root, "gpurun_out", f"{tag}_bench.json")))
-    _default_n = 2 * int(_b["config"]["stereo_frames_per_launch"])
+    _bn = os.path.join(_root, "gpurun_out", f"{tag}_bench.json")
+    if not os.path.exists(_bn):  # shape tags (round4_v3_hilti): the bench line of that workload
+        _base, _, _shape = tag.rpartition("_")
+        _bn = os.path.join(_root, "gpurun_out", f"{_base}_bench_{_shape}.json")
+    _b = json.load(open(_bn))
+    _default_n = int(_b["config"].get("cameras_per_multiframe", 2)) * int(_b["config"]["stereo_frames_per_launch"])
+    _r = _b.get("roofline", {})
+    _map_free = _r.get("live_bound") == "valu"  # the launch wrote no score map (round 4 default)
 except Exception:
     _default_n = 512
 n_img = int(sys.argv[2]) if len(sys.argv) > 2 else _default_n
@@ -35,6 +42,18 @@ def rows(counter):
     return name, k1["mean_per_dispatch"][counter], cal["mean_per_dispatch"][counter]
 
 
+if _map_free:  # candidates per image: algorithmic bytes of the bench line = (P + 12 C) images
+    try:
+        _cand = (_r["algorithmic_bytes_per_launch"] / float(_default_n) - w * h) / 12.0
+    except Exception:
+        _cand = 0.0
+valu_insts = None
+try:  # vector-ALU instructions of the same kernel (the SQ pass of the same collection)
+    _sq = json.load(open(os.path.join(src, f"{tag}_pmc_sq.json")))
+    _k = next((k for k in _sq if k.startswith("harris_kernel") and "true" in k), None)
+    valu_insts = _sq[_k]["mean_per_dispatch"]["SQ_INSTS_VALU"] if _k else None
+except Exception:
+    pass
 name, fetch, fetch_cal = rows("FETCH_SIZE")
 _, write, write_cal = rows("WRITE_SIZE")
 CAL_KIB = 262144.0
@@ -67,8 +86,10 @@ out = {
     "hbm_bytes_per_launch": rd + wr,
     "images_per_launch": n_img,
     "hbm_bytes_per_image": (rd + wr) / n_img,
-    "algorithmic_bytes_per_launch": 5 * w * h * n_img,
-    "ratio_to_algorithmic": (rd + wr) / (5.0 * w * h * n_img),
+    "width": w, "height": h, "map_free": _map_free, "candidates_per_image": _cand,
+    "algorithmic_bytes_per_launch": ((w * h + 12.0 * _cand) if _map_free else 5 * w * h) * n_img,
+    "ratio_to_algorithmic": (rd + wr) / (((w * h + 12.0 * _cand) if _map_free else 5.0 * w * h) * n_img),
+    "valu_insts_per_image": (valu_insts / n_img) if valu_insts else None,
     "read_ratio": rd / (1.0 * w * h * n_img), "write_ratio": wr / (4.0 * w * h * n_img),
     "calibration_on_k1_access_shapes": calib_shapes,
 }
