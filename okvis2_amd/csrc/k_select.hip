@@ -1050,9 +1050,8 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   int kept = 0;
   OKVFE_LAZY_TICK(t_start);
 #ifdef OKVFE_LAB
-  unsigned long long t_pa = t_start, t_pb = t_start, t_pc = t_start, t_p0 = t_start, t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0, t_walk = 0, t_acc = 0, t_ins = 0, t_w0 = 0, t_w1 = 0, t_w2 = 0;
-  const unsigned long long c_start = clock64();
-  int n_surv = 0;
+  unsigned long long t_pa = t_start, t_pb = t_start, t_p0 = t_start, t_init = t_start, t_blocks = t_start, t_pref = 0, t_mark = 0, t_walk = 0, t_acc = 0, t_ins = 0, t_w0 = 0, t_w1 = 0, t_w2 = 0;
+  int n_surv = 0, n_rounds = 0;
 #endif
   if (n > 0) {  // block-uniform
     // weight(|dx|, |dy|) at [|dy| << 5 | |dx|], zero outside the 31 x 31 stamp
@@ -1792,6 +1791,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         par ^= 1;
 #ifdef OKVFE_LAB
         n_surv += total;
+        ++n_rounds;
 #endif
         // ---- the survivors in key order: rank = number of smaller keys (keys are unique), in place
         auto list_key = [&](int g) {
@@ -1905,7 +1905,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
     atomicAdd(&g_lazy_prof[8], t_walk);
     atomicAdd(&g_lazy_prof[9], t_acc);
     atomicAdd(&g_lazy_prof[10], t_ins);
-    atomicAdd(&g_lazy_prof[11], (unsigned long long)(clock64() - c_start));
+    atomicAdd(&g_lazy_prof[11], (unsigned long long)n_rounds);
     atomicAdd(&g_lazy_prof[12], t_p0 - t_start);
     atomicAdd(&g_lazy_prof[13], t_pa - t_p0);
     atomicAdd(&g_lazy_prof[14], t_pb - t_pa);

@@ -14,7 +14,7 @@ def prof(reset=True):
     assert capi.lib().okvfe_lab_lazy_prof(out, int(reset)) == 0
     v = list(out); n = max(v[0], 1)
     return {"launches": v[0], "init_us": v[1] / n / 100, "blocks_us": v[2] / n / 100, "tail_us": v[3] / n / 100,
-            "total_us": v[4] / n / 100, "prefilter_us": v[5] / n / 100, "survivors": v[6] / n, "win_walk_us": v[8] / n / 100, "win_accept_us": v[9] / n / 100, "win_insert_us": v[10] / n / 100, "clock_GHz": v[11] / max(v[4], 1) / 10.0, "candidates": v[7] / n, "tables_us": v[12] / n / 100, "count_us": v[13] / n / 100, "sched_us": v[14] / n / 100, "scatter_us": v[15] / n / 100}
+            "total_us": v[4] / n / 100, "prefilter_us": v[5] / n / 100, "survivors": v[6] / n, "win_walk_us": v[8] / n / 100, "win_accept_us": v[9] / n / 100, "win_insert_us": v[10] / n / 100, "rounds": v[11] / n, "candidates": v[7] / n, "tables_us": v[12] / n / 100, "count_us": v[13] / n / 100, "sched_us": v[14] / n / 100, "scatter_us": v[15] / n / 100}
 for B in (1, 1536):
     fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, max_batch=B, num_cameras=2,
                        max_candidates=16384)
