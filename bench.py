@@ -52,6 +52,31 @@ def make_inputs(cfg, n_frames, n_distinct, seed0, content="corners"):
     return np.concatenate([base] * reps)[: C * n_frames], base
 
 
+def real_inputs(cfg, n_frames, n_distinct):
+    """Stereo frames cut from the reference's own camera image (okvis_multisensor_processing/test/testImage.jpg,
+    decoded into tests/golden/real_image.npz by tools/make_real_image_fixture.py: 1280x960, a checkerboard on a
+    carpet, 28 % saturated pixels, JPEG blocks): windows of the configuration's size at `n_distinct` offsets,
+    the right image the same window shifted by 23 px (tests/real_image_cases.py: STEREO_DISPARITY).  None when
+    the fixture or the shape does not allow it."""
+    path = os.path.join(ROOT, "tests", "golden", "real_image.npz")
+    if not os.path.exists(path) or len(cfg.cams) != 2:
+        return None
+    full = np.load(path)["image"]
+    H, W = full.shape
+    disp = 23
+    if cfg.w + disp > W or cfg.h > H:
+        return None
+    base = []
+    for i in range(n_distinct):
+        x0 = ((i * 67) % max(1, W - cfg.w - disp)) & ~3  # (dword-aligned windows of a u8 image are still arbitrary content)
+        y0 = (i * 41) % max(1, H - cfg.h + 1)
+        base.append(full[y0:y0 + cfg.h, x0:x0 + cfg.w])
+        base.append(full[y0:y0 + cfg.h, x0 + disp:x0 + disp + cfg.w])
+    base = np.ascontiguousarray(np.stack(base))
+    reps = (n_frames + n_distinct - 1) // n_distinct
+    return np.concatenate([base] * reps)[: 2 * n_frames]
+
+
 N_VARIANTS = 4  # distinct per-step host parameter sets (gravity directions, poses)
 
 
@@ -985,6 +1010,31 @@ def main():
                 "mean_keypoints_per_image": kp_d / max(1, min(n_img, C * distinct)),
                 "note": "exact two-level checker cells: tied maxima all pass the uniformity stage, "
                         "the stereo matcher works on ~700 x 700 descriptors per frame"}
+        # (2b) real content: windows of the reference's own test image (natural texture: carpet, a
+        # checkerboard, saturated regions, JPEG blocks -- candidate density, plateaus and match ambiguity
+        # differ from the synthetic cells)
+        if args.content == "corners" and C == 2:
+            imgs_r = real_inputs(cfg, B, distinct)
+            if imgs_r is not None:
+                d_img.copy_(torch.from_numpy(imgs_r).to(dev))
+                for _ in range(2):
+                    step("device")
+                n_r = max(3, min(args.steps, 8))
+                el_r, _ = timed(n_r, "device")
+                for lane in lanes:
+                    lane[0].check_capacity(n_lane_img)
+                n_r_img = min(n_img, C * distinct)
+                kp_each = [len(fe.download(i)[0]) for i in range(n_r_img)]
+                kp_r = sum(kp_each)
+                m_all = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(B, cfg.max_kpts)
+                n_match = sum(int((m_all[f, :kp_each[2 * f]]["k1"] >= 0).sum()) for f in range(n_r_img // 2))
+                extras["real_content"] = {
+                    "value": world * B * n_r / el_r, "steps": n_r, "ms_per_step": 1e3 * el_r / n_r,
+                    "mean_keypoints_per_image": kp_r / max(1, min(n_img, C * distinct)),
+                    "mean_candidates_per_image": mean_candidates(capi, fe, n_lane_img),
+                    "mean_matches_per_frame": n_match / max(1, n_r_img // 2),
+                    "note": "stereo windows of the reference's testImage.jpg (tests/golden/real_image.npz), right "
+                            "image = the window 23 px further right; the same parameters and poses as `value`"}
         # (3) SURVEY.md 8 D2: B in {1, 16, 256} through the batch entry points, and the B = 1 latency of
         # the C++ seams (rank 0 of a single-GPU run only: other ranks would share the host)
         if rank == 0 and world == 1 and C == 2:
@@ -1071,6 +1121,7 @@ def main():
             result["long_region"] = long_region
         # the less favourable legs next to `value`, at the top level
         result["value_dense"] = extras.get("dense_content", {}).get("value")
+        result["value_real_content"] = extras.get("real_content", {}).get("value")
         result["value_host_fed"] = extras.get("host_fed", {}).get("value")
         if cpu is not None:
             result["cpu_baseline"] = cpu
