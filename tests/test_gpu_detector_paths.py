@@ -94,6 +94,34 @@ def test_selection_orders_thousands_of_tied_scores(oracle):
     assert counts.max() > 1024, counts.max()
 
 
+@pytest.mark.parametrize("w,h,radius,thr,maxk", [(752, 480, 38.0, 40, 700), (640, 480, 10.0, 30, 800),
+                                                 (256, 64, 12.0, 20, 500), (1024, 128, 25.0, 30, 700)])
+def test_keypoints_on_the_image_rim_without_a_score_map(oracle, w, h, radius, thr, maxk):
+    """Map-free detection recomputes the nine sub-pixel scores of a kept keypoint from 7 x 7 pixels
+    (harris_scores_3x3: three aligned dwords per row, the dword before a row / past its end is not read,
+    gradient products on the image rim are zero).  Structure two pixels inside the rim puts a quarter of the
+    kept keypoints on columns 2 / 3 / w - 4 / w - 3 and the same rows -- the array-bin, the linked-list
+    (radius 10) and the packed-strip (1024 px) forms, against the oracle and against the score-map form."""
+    fe = capi.Frontend(w, h, radius, 0, thr, maxk, max_candidates=1 << 16)
+    on_rim = 0
+    for seed in (100, 101):
+        img = synth.noise_image(w, h, seed).copy()
+        img[2:4, :] = np.where((np.arange(w) // 3) % 2 == 0, 250, 5)
+        img[-4:-2, :] = img[2:4, :]
+        img[:, 2:4] = np.where((np.arange(h) // 3) % 2 == 0, 250, 5)[:, None]
+        img[:, -4:-2] = img[:, 2:4]
+        ref = oracle.detect(img, radius, 0, thr, maxk)
+        G.assert_keypoints_equal(fe.detect(img), ref)
+        assert fe.device_outputs().scores is None
+        fe.set_keep_score_map(True)
+        G.assert_keypoints_equal(fe.detect(img), ref)
+        assert fe.device_outputs().scores is not None
+        fe.set_keep_score_map(False)
+        xs, ys = np.floor(ref["x"] + 0.5), np.floor(ref["y"] + 0.5)
+        on_rim += int(((xs <= 3) | (xs >= w - 4) | (ys <= 3) | (ys >= h - 4)).sum())
+    assert on_rim > 50
+
+
 def test_sort_network_sizes_around_its_limits(oracle):
     """Candidate counts around the limits of the register-blocked sort: one thread's 16 keys, one
     LDS pass, just below / above 4096 and 8192 keys (above 8192 the two-stride LDS network or the
