@@ -52,6 +52,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
                                         const float* gravity, hipStream_t s, bool before_detect = false) {
   std::vector<ImageParams> prm(n_images);
   ctx->wide_patches = false;
+  ctx->all_aware = n_images > 0;
   for (int i = 0; i < n_images; ++i) {
     ImageParams& p = prm[i];
     p.cam = cam_ids ? cam_ids[i] : -1;
@@ -70,6 +71,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
       if (ctx->cam_wide[p.cam]) ctx->wide_patches = true;
     } else {
       p.mode = ctx->mode_default;
+      ctx->all_aware = false;
       p.dir[0] = 0.0f; p.dir[1] = 1.0f; p.dir[2] = 0.0f;
       p.fu = 1.0f;
     }
@@ -350,7 +352,8 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     StageTimer t(ctx, OKVFE_STAGE_DESCRIBE, s);
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
-                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done);
+                    ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
+                    ctx->all_aware);
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -775,7 +778,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   }
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
-                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s);
+                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false, ctx->all_aware);
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

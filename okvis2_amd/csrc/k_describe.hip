@@ -244,7 +244,10 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
 // kWavesPerSimd = 6 (80 VGPRs) is the fastest form when nearly every patch fits the LDS buffer; the
 // banded path of the wide-angle cameras spills at 80 registers and runs 26 % faster with 96 (five
 // waves per SIMD): launch_describe picks the instantiation from the cameras' patch statistics.
-template <int kWavesPerSimd>
+// AWARE: every image of the launch is extracted camera-aware (the production mode, Frontend.cpp:2410-2412 with
+// setExtractionDirection): the gradient-orientation pass and the fixed-box staging are compiled out -- a
+// third of the kernel's code and the registers that had to live across it.
+template <int kWavesPerSimd, bool AWARE = false>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(kWavesPerSimd, 8))) void describe_kernel(
     const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
     const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
@@ -498,7 +501,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   M[0] = uni(nxt_M.x); M[1] = uni(nxt_M.y); M[2] = uni(nxt_M.z); M[3] = uni(nxt_M.w);
   if (k + k_step < n) fetch(k + k_step);  // scalar branch
   bool new_angle = false;
-  if (valid && ip.mode == kGradient) {
+  const int mode = AWARE ? (int)kCameraAware : (int)ip.mode;
+  if (valid && mode == kGradient) {
     valid = sample_all(true);
     if (valid) {
       int d0 = 0, d1 = 0;
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       M[3] = pat->rot_cosf[best_k];
     }
   }
-  if (valid) valid = sample_all(ip.mode != kCameraAware);
+  if (valid) valid = sample_all(mode != kCameraAware);
   if (valid) {
     unsigned long long words[6];
 #pragma unroll
@@ -622,7 +626,8 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const ImageParams* prm, const float* const* rays, const float* const* jac,
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
-                     const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done) {
+                     const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done,
+                     bool all_camera_aware) {
   if (n_images <= 0) return;
   static const char* force = lab_env("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
@@ -635,14 +640,20 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
   if (tiles > kDescBlocksPerImage) tiles = kDescBlocksPerImage;
   const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
-  if (wide_patches)
-    hipLaunchKernelGGL(describe_kernel<5>, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
-                       w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                       valid_tmp, n_images, tiles, inv_tiles, scales);
-  else
-    hipLaunchKernelGGL(describe_kernel<6>, dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img,
-                       w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                       valid_tmp, n_images, tiles, inv_tiles, scales);
+#define OKVFE_DESC_LAUNCH(WAVES, AWARE)                                                                          \
+  hipLaunchKernelGGL((describe_kernel<WAVES, AWARE>), dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img, \
+                     w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images, \
+                     tiles, inv_tiles, scales)
+  static const bool no_aware = lab_env("OKVFE_DESC_GENERIC") != nullptr;  // A/B knob: the all-modes kernel
+  if (no_aware) all_camera_aware = false;
+  if (wide_patches) {
+    // (the camera-aware-only form of the 96-register instantiation measured 10 % SLOWER: 1.67 against 1.51 ms
+    // per 1536 wide-angle 640x480 frames; the 80-register one gains 2.5 %)
+    OKVFE_DESC_LAUNCH(5, false);
+  } else {
+    if (all_camera_aware) OKVFE_DESC_LAUNCH(6, true); else OKVFE_DESC_LAUNCH(6, false);
+  }
+#undef OKVFE_DESC_LAUNCH
 }
 
 // Does the camera-aware patch of a keypoint with the row norms (nx, ny) of M fit the wave's LDS

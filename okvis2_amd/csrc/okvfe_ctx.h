@@ -106,6 +106,7 @@ struct okvfe_ctx {
   std::vector<float> cam_fu;
   std::vector<uint8_t> cam_wide;  // camera-aware patches of this camera often exceed the LDS buffer (describe_kernel<5>)
   bool wide_patches = false;      // of the images of the current batch
+  bool all_aware = false;         // every image of the current batch is extracted camera-aware
   bool counters_cleared = false;  // upload_image_params zeroed d_cand_count on the call's stream
   bool fuse_setup = false;        // the current call describes what it detects: setup rides in the selection kernel
   bool setup_done = false;        // ... and did

@@ -261,7 +261,7 @@ print("KNOB-OK")
 """
 
 
-@pytest.mark.parametrize("knob", ["OKVFE_PARAM_MEMCPY", "OKVFE_NO_FUSED_SETUP", "OKVFE_DESC_WAVES=5"])
+@pytest.mark.parametrize("knob", ["OKVFE_PARAM_MEMCPY", "OKVFE_NO_FUSED_SETUP", "OKVFE_DESC_WAVES=5", "OKVFE_DESC_GENERIC"])
 def test_ab_knobs_of_the_describe_path(oracle, knob):
     """Parameter upload through the DMA engine instead of the copy kernel, the extractor's setup as
     its own launch instead of inside the selection kernel, the 5-wave describe instantiation."""
