@@ -122,6 +122,46 @@ def test_keypoints_on_the_image_rim_without_a_score_map(oracle, w, h, radius, th
     assert on_rim > 50
 
 
+def test_few_or_no_candidates(oracle):
+    """The self-ordering selection on candidate sets around its first chunk sizes (0, a handful, 63 .. 129 boxes
+    = 100 .. 155 kept corners), and a batch that mixes empty and ordinary images."""
+    w, h = 752, 480
+    fe = capi.Frontend(w, h, 38.0, 0, 150, 700, max_candidates=1 << 15)
+
+    def check(img):
+        ref = oracle.detect(img, 38.0, 0, 150, 700)
+        G.assert_keypoints_equal(fe.detect(img), ref)
+        return len(ref)
+
+    assert check(np.full((h, w), 128, np.uint8)) == 0
+    rng = np.random.default_rng(3)
+    kept = []
+    for n in (1, 3, 63, 64, 65, 127, 129):
+        img = np.full((h, w), 20, np.uint8)
+        for _ in range(n):
+            x, y, s = int(rng.integers(10, w - 30)), int(rng.integers(10, h - 30)), int(rng.integers(6, 14))
+            img[y:y + s, x:x + s] = int(rng.integers(120, 255))
+        kept.append(check(img))
+    assert kept[0] >= 1 and kept[-1] > 100
+    cfg = synth.euroc_config()
+    fb = G.make_frontend(cfg, max_batch=4)
+    for ci, cam in enumerate(cfg.cams):
+        fb.set_camera(ci, cam)
+    imgs = np.stack([np.full((h, w), 128, np.uint8), G.image_for(cfg, 5), np.zeros((h, w), np.uint8), G.image_for(cfg, 6)])
+    d = torch.from_numpy(imgs).cuda()
+    cams = np.array([0, 1, 0, 1], np.int32)
+    fb.detect_describe_batch_device(d.data_ptr(), 4, cams, np.tile(np.array([0, 1, 0], np.float32), (4, 1)), None)
+    torch.cuda.synchronize()
+    for i in range(4):
+        cam = cfg.cams[cams[i]]
+        rays, jac = oracle.awareness_maps(cam)
+        rk, rd = oracle.detect_describe(imgs[i], cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                        oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.0, 1.0, 0.0))
+        k, dd, _, _ = fb.download(i)
+        G.assert_keypoints_equal(k, rk)
+        assert np.array_equal(dd, rd) and (len(k) == 0) == (i % 2 == 0)
+
+
 def test_sort_network_sizes_around_its_limits(oracle):
     """Candidate counts around the limits of the register-blocked sort: one thread's 16 keys, one
     LDS pass, just below / above 4096 and 8192 keys (above 8192 the two-stride LDS network or the
