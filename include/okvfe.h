@@ -284,8 +284,8 @@ okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_ke
  * n_images) extracts descriptors, compacts and back-projects.  Splitting lets a caller with
  * several contexts / streams enqueue detect for all of them before describe for all of them.
  *
- * Environment: OKVFE_SCORE_TOKEN=1 makes the score kernels of all contexts of the process (per
- * device) run one after the other, in enqueue order, through events; =2 chains the describe
+ * okvfe_set_heavy_kernel_chaining(1) makes the score kernels of all contexts of the process (per
+ * device) run one after the other, in enqueue order, through events; 2 chains the describe
  * kernels as well.  Contexts fed in turn from different streams then run out of phase, so the
  * latency-bound stages of one overlap the throughput-bound ones of another (bench.py --lanes). */
 okvfe_status okvfe_detect_batch_device(okvfe_ctx* ctx, const uint8_t* images_dev,

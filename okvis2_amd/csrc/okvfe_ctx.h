@@ -20,7 +20,7 @@ using namespace okvfe;  // internal header of the runtime's own translation unit
 struct okvfe_ctx {
   okvfe_config cfg{};
   hipStream_t stream = nullptr;
-  hipEvent_t heavy_done[2] = {nullptr, nullptr};  // OKVFE_SCORE_TOKEN: after the score / describe kernel
+  hipEvent_t heavy_done[2] = {nullptr, nullptr};  // okvfe_set_heavy_kernel_chaining: after the score / describe kernel
   int detected_images = 0;  // images covered by the last okvfe_detect_batch_device
   std::string err;
   int w = 0, h = 0, B = 0, kp_cap = 0, cand_cap = 0, ws_stride = 0;
