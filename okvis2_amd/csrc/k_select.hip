@@ -962,10 +962,20 @@ __global__ __launch_bounds__(256) void brisk_refine_kernel(
 // 119 (the blocks grow geometrically because early blocks reject little: nothing is accepted yet).
 //
 // Ordered window of 64 survivors (lane = candidate): the nine bins are split over the four waves
-// (2 + 2 + 2 + 3), partial sums go to LDS; wave 0 accepts: passing candidates without another
-// passing candidate of the window within 15 cells are accepted in one step, the others in order (a
-// newly accepted point adds its weight to the later lanes within reach, which re-evaluate their
-// test) -- a window never restarts.  Two workgroup barriers per window.
+// (2 + 2 + 2 + 3), partial sums go to LDS; wave 0 accepts in ROUNDS: a passing lane is decided once
+// every earlier passing lane within reach of it is (found through 128 bin-hashed lane masks), all
+// such lanes together; a newly accepted point adds its weight to the undecided lanes it reaches --
+// a window never restarts.  Two workgroup barriers per window.
+//
+// Ordering (round 4, select_lazy_kernel<true>, the default): the kernel takes the UNSORTED candidate
+// records and orders only what the greedy pass consumes -- log buckets of the score, chunks of whole
+// buckets scattered into bucket order, chunk prefilter in any order, survivors rank-sorted in LDS,
+// oversized chunks split by key range (see the SORTS branch below).  select_lazy_kernel<false> reads
+// keys sorted by launch_sort (lab knob OKVFE_SELECT_PRESORTED).
+//
+// K4 runs in the tail: 2-D sub-pixel fit of the kept keypoints, from the score map or -- map-free calls
+// -- from nine scores recomputed out of 7 x 7 pixels (harris_scores_3x3), then the extractor's
+// per-keypoint setup when detection and description are one call.
 constexpr int kLazyTabBytes = 32 * 32 * 4;  // weight(|dx|, |dy|), zero beyond 15
 constexpr int kLazyThreads = 256;
 constexpr int kLazyBinCap = 4;
@@ -989,7 +999,8 @@ __device__ __forceinline__ void lds_barrier() {
 
 #ifdef OKVFE_LAB
 // lab build: where does an image's time go?  [0] launches, [1..4] 10-ns ticks (s_memrealtime) of image 0's
-// phases init / blocks / tail / total, [5] prefilter ticks, [6] survivors, [7] candidates
+// phases init / blocks / tail / total, [5] prefilter (+ rank sort) ticks, [6] survivors, [7] candidates,
+// [8..10] window walk / accept / insert, [11] rounds, [12..15] tables / bucket count / schedule / scatter
 __device__ unsigned long long g_lazy_prof[16];
 #define OKVFE_LAZY_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #else
