@@ -993,6 +993,23 @@ def main():
             "note": "okvfe_detect_describe_batch_host: pinned host images, H2D copy on the "
                     "library's copy stream into a double buffer, kernels wait through events; "
                     "PCIe-inclusive, never `value`"}
+        # (1b) the whole step with the score map kept (okvfe_set_keep_score_map(1)): the HBM-bound form of K1,
+        # what rounds 1-3 measured
+        if map_free:
+            for lane in lanes:
+                lane[0].set_keep_score_map(True)
+            for _ in range(2):
+                step("device")
+            n_m = max(3, min(args.steps, 8))
+            el_m, _ = timed(n_m, "device")
+            for lane in lanes:
+                lane[0].set_keep_score_map(False)
+            step("device")
+            torch.cuda.synchronize()
+            extras["score_map_kept"] = {
+                "value": world * B * n_m / el_m, "steps": n_m, "ms_per_step": 1e3 * el_m / n_m,
+                "note": "the same step with okvfe_set_keep_score_map(1): K1 writes its 4 B per pixel again "
+                        "(roofline.with_score_map is that kernel)"}
         # (2) dense content: tied checker corners that all pass the uniformity stage (~700
         # keypoints per image): the matcher's 700 x 700 regime
         if args.content == "corners" and C > 1:
@@ -1122,6 +1139,7 @@ def main():
         # the less favourable legs next to `value`, at the top level
         result["value_dense"] = extras.get("dense_content", {}).get("value")
         result["value_real_content"] = extras.get("real_content", {}).get("value")
+        result["value_score_map_kept"] = extras.get("score_map_kept", {}).get("value")
         result["value_host_fed"] = extras.get("host_fed", {}).get("value")
         if cpu is not None:
             result["cpu_baseline"] = cpu
