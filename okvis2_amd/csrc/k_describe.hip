@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
   const int vbyte = __builtin_amdgcn_readfirstlane(nxt_valid);  // valid | scale index << 1
   bool valid = (vbyte & 1) != 0;
-  if (scales) {  // wave-uniform: this keypoint's pattern scale
+  if (!AWARE && scales) {  // wave-uniform: this keypoint's pattern scale (the AWARE form is launched without a ladder)
     const int sc = vbyte >> 1;
     px = scales->px[sc][li];
     py = scales->py[sc][li];
@@ -645,7 +645,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images, \
                      tiles, inv_tiles, scales)
   static const bool no_aware = lab_env("OKVFE_DESC_GENERIC") != nullptr;  // A/B knob: the all-modes kernel
-  if (no_aware) all_camera_aware = false;
+  if (no_aware || scales != nullptr) all_camera_aware = false;  // (scale-invariant extraction: generic form)
   if (wide_patches) {
     // (the camera-aware-only form of the 96-register instantiation measured 10 % SLOWER: 1.67 against 1.51 ms
     // per 1536 wide-angle 640x480 frames; the 80-register one gains 2.5 %)
