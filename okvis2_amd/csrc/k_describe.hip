@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   int* vals = values[wv];
   uint8_t* patch = patches[wv] + kZeroRowBytes;
   if (lane < kZeroRowBytes / 4) reinterpret_cast<uint32_t*>(patches[wv])[lane] = 0u;
-  const bool dword_ok = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0);
+  // (the AWARE form is only launched on dword-aligned images of a width that is a multiple of 4)
+  const bool dword_ok = AWARE || ((w % 4 == 0) && ((reinterpret_cast<uintptr_t>(images) & 3) == 0));
   const __amdgpu_buffer_rsrc_t img_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
 
@@ -645,7 +646,8 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images, \
                      tiles, inv_tiles, scales)
   static const bool no_aware = lab_env("OKVFE_DESC_GENERIC") != nullptr;  // A/B knob: the all-modes kernel
-  if (no_aware || scales != nullptr) all_camera_aware = false;  // (scale-invariant extraction: generic form)
+  if (no_aware || scales != nullptr || w % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3) != 0)
+    all_camera_aware = false;  // (scale-invariant extraction, unaligned images: generic form)
   if (wide_patches) {
     // (the camera-aware-only form of the 96-register instantiation measured 10 % SLOWER: 1.67 against 1.51 ms
     // per 1536 wide-angle 640x480 frames; the 80-register one gains 2.5 %)
