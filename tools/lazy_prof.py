@@ -8,7 +8,7 @@ import numpy as np, torch
 from okvis2_amd import capi, synth
 import bench
 cfg = synth.euroc_config()
-imgs, base = bench.make_inputs(cfg, 768, 16, 1000, "corners")
+imgs, base = bench.make_inputs(cfg, 768, 16, 1000, os.environ.get("LAZY_PROF_CONTENT", "corners"))
 def prof(reset=True):
     out = (C.c_ulonglong * 16)()
     assert capi.lib().okvfe_lab_lazy_prof(out, int(reset)) == 0
