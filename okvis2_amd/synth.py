@@ -123,6 +123,29 @@ def tumvi1024_config() -> Config:
     return Config("tumvi1024", 1024, 1024, [c0, c1], 0.101, 50.0, 5, 60, 0, 1000)
 
 
+def tumvi512_config() -> Config:
+    """config/tumvi_slam_512.yaml:8-12,21-25,64-68 (equidistant, 512x512)."""
+    c0 = Camera(512, 512, 190.97847715128717, 190.9733070521226, 254.93170605935475, 256.8974428996504, 2,
+                (0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202,
+                 0.00020293673591811182))
+    c1 = Camera(512, 512, 190.44236969414825, 190.4344384721956, 252.59949716835982, 254.91723064636983, 2,
+                (0.0034003170790442797, 0.001766278153469831, -0.00266312569781606,
+                 0.0003299517423931039))
+    return Config("tumvi512", 512, 512, [c0, c1], 0.101, 40.0, 4, 55, 0, 800)
+
+
+def d455_config() -> Config:
+    """config/realsense_D455.yaml:8-12,21-25,79-83 (rectified 640x480 pair, zero distortion, 2500 keypoints)."""
+    c = Camera(640, 480, 390.598938, 390.598938, 320.581665, 237.712845, 1, (0.0, 0.0, 0.0, 0.0))
+    return Config("d455", 640, 480, [c, c], 0.095, 30.0, 5, 60, 0, 2500)
+
+
+def d435i_config() -> Config:
+    """config/realsense_D435i.yaml:9-13,22-26,63-67 (rectified 640x480 pair, zero distortion, 400 keypoints)."""
+    c = Camera(640, 480, 386.235, 386.235, 323.074, 238.489, 1, (0.0, 0.0, 0.0, 0.0))
+    return Config("d435i", 640, 480, [c, c], 0.05, 30.0, 5, 60, 0, 400)
+
+
 def hilti_config() -> Config:
     """config/hilti_challenge_2022.yaml:9-13,23-27,37-41,51-55,65-69,106-110
     (5 equidistant 720x540 cameras)."""

@@ -247,6 +247,55 @@ def test_stereo_pipeline_device_resident(oracle):
         assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
 
 
+@pytest.mark.parametrize("name", ["tumvi512", "d455", "d435i"])
+def test_remaining_shipped_configurations(oracle, name):
+    """The shipped configurations BASELINE does not name: TUM-VI 512x512 (equidistant,
+    radius 40, threshold 4, 800 keypoints, match threshold 55), RealSense D455 (640x480 rectified, radius 30,
+    threshold 5, 2500 keypoints: the largest cap a shipped file asks for) and D435i (400 keypoints) -- device-
+    resident detect + describe + matchStereo against the oracle with each file's own intrinsics and parameters."""
+    cfg = {"tumvi512": synth.tumvi512_config, "d455": synth.d455_config, "d435i": synth.d435i_config}[name]()
+    nfr = 2
+    fe = G.make_frontend(cfg, max_batch=2 * nfr)
+    for ci, cam in enumerate(cfg.cams):
+        fe.set_camera(ci, cam)
+    frames = [_stereo_inputs(oracle, cfg, 70 + i) for i in range(nfr)]
+    imgs = np.stack([im for (L, R, _) in frames for im in (L, R)])
+    d_img = _dev(imgs)
+    cam_ids = np.array([0, 1] * nfr, dtype=np.int32)
+    grav = np.tile(np.array([0.0, 1.0, 0.0], dtype=np.float32), (2 * nfr, 1))
+    stream = torch.cuda.current_stream().cuda_stream
+    fe.detect_describe_batch_device(d_img.data_ptr(), 2 * nfr, cam_ids, grav, stream)
+    fe.check_capacity(2 * nfr)
+    T0, T1 = synth.stereo_poses(cfg.baseline)
+    f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
+    f1 = 0.5 * (cfg.cams[1].fu + cfg.cams[1].fv)
+    pairs = []
+    for i in range(nfr):
+        sp = capi.StereoPair()
+        sp.image0, sp.image1 = 2 * i, 2 * i + 1
+        sp.T_WC0, sp.T_WC1 = capi.make_pose(*T0), capi.make_pose(*T1)
+        sp.f0, sp.f1 = f0, f1
+        pairs.append(sp)
+    d_m = torch.zeros((nfr, cfg.max_kpts, capi.STEREO_MATCH_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+    fe.match_stereo_batch_device(pairs, d_m.data_ptr(), stream)
+    torch.cuda.synchronize()
+    m = d_m.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(nfr, cfg.max_kpts)
+    total = 0
+    for i, (_, _, ((k0, d0, b0, v0), (k1, d1, b1, v1))) in enumerate(frames):
+        g0, g1 = fe.download(2 * i), fe.download(2 * i + 1)
+        G.assert_keypoints_equal(g0[0], k0)
+        G.assert_keypoints_equal(g1[0], k1)
+        assert np.array_equal(g0[1], d0) and np.array_equal(g1[1], d1)
+        assert np.array_equal(g0[2].view(np.uint64), b0.view(np.uint64)) and np.array_equal(g0[3], v0)
+        ref = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, T0, T1, f0, f1, cfg.match_threshold)
+        got = m[i, :len(k0)]
+        for f in ("k1", "dist", "initialisable"):
+            assert np.array_equal(got[f], ref[f]), f
+        assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
+        total += len(k0)
+    assert total > 200
+
+
 def test_hamming_candidates_and_argmin(oracle):
     rng = np.random.default_rng(5)
     fe = capi.Frontend(752, 480, 38.0, 0, 150, 700)
