@@ -191,6 +191,14 @@ WORKLOAD_TEXT = {
               "params (radius 50, thr 20, <=700 kpts, match thr 60)"),
     "mono640": ("front-end frames/s (detect+describe), 640x480 mono",
                 "640x480 mono (radius 10, thr 5, <=1000 kpts), detect+describe"),
+    # the shipped configurations BASELINE does not name
+    "tumvi512": ("front-end stereo-frames/s (detect+describe+match), 512x512 stereo (TUM-VI 512)",
+                 "TUM-VI-shaped 512x512 equidistant stereo, tumvi_slam_512.yaml front-end params (radius 40, thr 4, "
+                 "<=800 kpts, match thr 55)"),
+    "d455": ("front-end stereo-frames/s (detect+describe+match), 640x480 stereo (RealSense D455)",
+             "640x480 rectified stereo, realsense_D455.yaml front-end params (radius 30, thr 5, <=2500 kpts, match thr 60)"),
+    "d435i": ("front-end stereo-frames/s (detect+describe+match), 640x480 stereo (RealSense D435i)",
+              "640x480 rectified stereo, realsense_D435i.yaml front-end params (radius 30, thr 5, <=400 kpts, match thr 60)"),
 }
 
 
@@ -657,7 +665,7 @@ def main():
                          "mode 1) so that the lanes run out of phase")
     ap.add_argument("--map-radius", type=float, default=20.0,
                     help="--workload map: reprojection threshold in px (20 with IMU, 150 without; Frontend.cpp:1530)")
-    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640", "map"), default="euroc",
+    ap.add_argument("--workload", choices=("euroc", "tumvi", "hilti", "mono640", "map", "tumvi512", "d455", "d435i"), default="euroc",
                     help="euroc = the BASELINE.json metric (752x480 stereo); tumvi = configs[3]; "
                          "hilti = configs[4] (5 cameras); mono640 = configs[1] (informational; batch "
                          "192 by default for these)")
@@ -717,7 +725,7 @@ def main():
     if args.workload != "euroc" and args.batch == 768:
         # frames per step that fill the 256 CUs for a whole number of workgroup rounds of the score
         # kernel (1536 resident workgroups): 512 TUM-VI images = 6.9 rounds, 1536 VGA images = 6
-        args.batch = {"tumvi": 256, "hilti": 192, "mono640": 1536}[args.workload]
+        args.batch = {"tumvi": 256, "hilti": 192, "mono640": 1536, "tumvi512": 768, "d455": 768, "d435i": 768}[args.workload]
     if args.workload == "hilti" and args.split == "cameras":
         res = run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev)
         if res is not None:
@@ -727,7 +735,8 @@ def main():
         return
 
     cfg = {"euroc": synth.euroc_config, "tumvi": synth.tumvi1024_config,
-           "hilti": synth.hilti_config, "mono640": synth.mono640_config}[args.workload]()
+           "hilti": synth.hilti_config, "mono640": synth.mono640_config, "tumvi512": synth.tumvi512_config,
+           "d455": synth.d455_config, "d435i": synth.d435i_config}[args.workload]()
     if args.workload == "hilti":
         # frame-sharded variant: cameras 0/1 form the forward stereo pair (shared intrinsics so that
         # the synthetic disparity is epipolar-consistent), 2..4 get independent images
