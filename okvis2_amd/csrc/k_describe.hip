@@ -42,6 +42,9 @@ constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigm
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
 constexpr int kZeroRowBytes = 160;  // >= the widest patch row (152 B) + the 3-dword reads past a box
 constexpr int kPatchBufBytes = 6144;
+#ifndef OKVFE_DESC_WIDE_BUF
+#define OKVFE_DESC_WIDE_BUF 7552  // 4 x 7552 + 1792 B of tables = 32000 B = 25 allocation granules: five workgroups per CU
+#endif
 constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
 // intensity): float reciprocal estimate (off by at most 1) + exact integer correction, instead of
@@ -255,7 +258,10 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     const int32_t* __restrict__ kp_count_in, okvfe_keypoint* __restrict__ kps_tmp,
     uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images, int tiles,
     uint32_t inv_tiles, const PatternScales* __restrict__ scales) {
-  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kPatchBufBytes];
+  // (the 96-register instantiation leaves LDS for five workgroups of 32 KB: its waves get 7.5 KB buffers)
+  constexpr int kBufBytes = kWavesPerSimd >= 6 ? kPatchBufBytes : OKVFE_DESC_WIDE_BUF;
+  constexpr int kDataBytes = kBufBytes - kZeroRowBytes - 16;
+  __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kBufBytes];
   __shared__ int values[kDescWaves][64];
   // the 383 short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
   // they were a third dependent round trip in every keypoint's chain
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       const uint32_t inv = (65536u + (uint32_t)nq - 1u) / (uint32_t)nq;
       const int R = (int)((64u * inv) >> 16);
       const int trips = (ph + R - 1) / R;
-      if (trips * R * pitch <= kPatchDataBytes) {  // wave-uniform
+      if (trips * R * pitch <= kDataBytes) {  // wave-uniform
         __builtin_amdgcn_wave_barrier();
         const uint32_t rr = ((uint32_t)lane * inv) >> 16;
         const uint32_t c = (uint32_t)lane - rr * (uint32_t)nq;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       const uint32_t inv = (65536u + (uint32_t)ndw - 1u) / (uint32_t)ndw;  // i / ndw, i < 2730
       const int R = (int)((64u * inv) >> 16);
       const int trips = (ph + R - 1) / R;
-      if (trips * R * pitch > kPatchDataBytes) return false;  // wave-uniform
+      if (trips * R * pitch > kDataBytes) return false;  // wave-uniform
       const uint32_t rr = ((uint32_t)lane * inv) >> 16;
       const uint32_t c = (uint32_t)lane - rr * (uint32_t)ndw;
       const uint32_t src_lane = rr * (uint32_t)w + c * 4u;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       }
       __builtin_amdgcn_s_waitcnt(0);
     } else {
-      if (ph * pitch > kPatchDataBytes) return false;
+      if (ph * pitch > kDataBytes) return false;
       for (int r = 0; r < ph; ++r)
         for (int c = lane; c < pw; c += 64) patch[r * pitch + c] = im[(size_t)(by0 + r) * w + px0 + c];
     }
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       int rows_fit = 0;  // whole trips of R rows (stage_patch: R = 64 / chunks per row)
       if (pitch16 <= kZeroRowBytes - 8) {
         const int R = 64 / (pitch16 >> 4);
-        rows_fit = (kPatchDataBytes / (R * pitch16)) * R;
+        rows_fit = (kDataBytes / (R * pitch16)) * R;
       }
       // rows this lane's box touches (one spare row either side, inside the staged rectangle)
       const int fy0 = __builtin_amdgcn_readfirstlane(by0), fy1 = __builtin_amdgcn_readfirstlane(by1);
