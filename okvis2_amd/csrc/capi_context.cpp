@@ -579,7 +579,10 @@ okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* ray
       ++seen;
       if (!describe_patch_fits(nx, ny, ctx->host_pattern.border)) ++large;
     }
-  ctx->cam_wide[cam] = seen > 0 && large * 20 > seen;  // more than 5 %
+  // (the 96-register instantiation with its 7.5 KB buffers pays when MANY patches need bands: measured with the
+  // camera-aware-only six-wave form as the alternative -- 57 % / 60 % of the pixels (640x480 at fu 350, RealSense
+  // D455): 1.13 against 1.33 ms, 0.53 against 0.58; 30 % (TUM-VI 512 / 1024): 0.27 against 0.22 ms, 0.26 against 0.27)
+  ctx->cam_wide[cam] = seen > 0 && large * 5 > seen * 2;  // more than 40 %
   return OKVFE_OK;
 }
 
