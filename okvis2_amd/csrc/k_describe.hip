@@ -655,9 +655,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   if (no_aware || scales != nullptr || w % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3) != 0)
     all_camera_aware = false;  // (scale-invariant extraction, unaligned images: generic form)
   if (wide_patches) {
-    // (the camera-aware-only form of the 96-register instantiation measured 10 % SLOWER: 1.67 against 1.51 ms
-    // per 1536 wide-angle 640x480 frames; the 80-register one gains 2.5 %)
-    OKVFE_DESC_LAUNCH(5, false);
+    if (all_camera_aware) OKVFE_DESC_LAUNCH(5, true); else OKVFE_DESC_LAUNCH(5, false);
   } else {
     if (all_camera_aware) OKVFE_DESC_LAUNCH(6, true); else OKVFE_DESC_LAUNCH(6, false);
   }
