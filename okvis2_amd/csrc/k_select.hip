@@ -2085,54 +2085,76 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         unsigned long long rem = __ballot(pass), accm = 0;
         int nacc = 0;
         if (rem != 0) {
-          // Which passing candidates may have another passing candidate of the window within 15
-          // cells?  Two such candidates sit in the same or in adjacent bins (a bin is 16 cells wide):
-          // every passing lane counts itself into the top byte of its bin's head word (the address
-          // below it needs 18 bits; the walks of the other waves never overlap with this phase), reads
-          // the nine counts around it and removes itself again -- two LDS round trips whatever the
-          // number of passing lanes.  Conservative (adjacent bins may be farther apart than 15 cells):
-          // the ordered loop below treats the flagged lanes exactly.
-          bool linked = false;
-          if (pass) {
-            atomicAdd(&head[bin], 1u << 24);
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (pass) {
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int b = 0; b < 9; ++b) {
-              const uint32_t c = head[bin + ((b / 3) - 1) * bpitch + (b % 3) - 1] >> 24;
-              cnt += b == 4 ? c - 1u : c;  // own bin: the others in it
-            }
-            linked = cnt != 0;
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (pass) atomicSub(&head[bin], 1u << 24);
-          const unsigned long long seq = __ballot(linked && pass);
           const int room = limit - kept;
           if (__popcll(rem) <= room) {
-            // the unlinked ones neither change nor are changed by anything in this window: accepted
-            // at once; the linked ones go through the ordered loop below
-            accm = rem & ~seq;
-            nacc = __popcll(accm);
-            rem = seq;
-          }  // else: the cap falls inside this window -- everything in order
-          while (rem != 0 && kept + nacc < limit) {  // one iteration per accepted point
-            const int f = (int)__ffsll((long long)rem) - 1;
-            accm |= 1ull << f;
-            ++nacc;
-            const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
-            const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
-            const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
-            const bool near = pass && lane > f && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
-            if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
-              if (near) {
-                occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * wnsc);
-                pass = !(level < (float)(occ > 255 ? 255 : occ));
+            // Acceptance in ROUNDS, as in select_lazy_kernel (round 4): a passing lane is decided once every
+            // EARLIER passing lane within reach of it is; all such lanes are decided together.  nb = the
+            // earlier passing lanes within the stamp's square around this lane, found through 128 lane masks
+            // hashed by bin in the `part` array (idle in this phase) and checked exactly.
+            unsigned long long* wm = reinterpret_cast<unsigned long long*>(part);
+            wm[lane] = 0ull;
+            wm[64 + lane] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            if (pass) atomicOr(&wm[bin & 127], 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long lower_ = (1ull << lane) - 1ull;
+            unsigned long long cm = 0ull;
+#pragma unroll
+            for (int b = 0; b < 9; ++b) cm |= wm[(bin + ((b / 3) - 1) * bpitch + (b % 3) - 1) & 127];
+            cm &= rem & lower_;
+            if (!pass) cm = 0ull;
+            unsigned long long nb = 0ull;
+            while (__any(cm != 0ull)) {
+              const int el = cm != 0ull ? (int)__ffsll((long long)cm) - 1 : lane;
+              const uint32_t exy = (uint32_t)__builtin_amdgcn_ds_bpermute(el << 2, (int)rec.x);
+              if (cm != 0ull) {
+                cm &= cm - 1ull;
+                const uint32_t ddx = (uint32_t)(cx - (int)(exy & 0xFFFF) + 15);
+                const uint32_t ddy = (uint32_t)(cy - (int)(exy >> 16) + 15);
+                nb |= (ddx <= 30u && ddy <= 30u) ? (1ull << el) : 0ull;
               }
-              rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
-            } else {
-              rem &= rem - 1;
+            }
+            while (rem != 0ull) {
+              const bool in = ((rem >> lane) & 1ull) != 0ull;
+              const bool ready = in && (nb & rem) == 0ull;  // (the lowest lane of rem always is)
+              const unsigned long long rdy = __ballot(ready);
+              const unsigned long long accn = __ballot(ready && pass);
+              accm |= accn;
+              rem &= ~rdy;
+              unsigned long long m = (in && !ready) ? (nb & accn) : 0ull;  // undecided lanes a new point reaches
+              while (__any(m != 0ull)) {
+                const int jl = m != 0ull ? (int)__ffsll((long long)m) - 1 : lane;
+                const uint32_t jxy = (uint32_t)__builtin_amdgcn_ds_bpermute(jl << 2, (int)rec.x);
+                const float jnsc = __int_as_float(__builtin_amdgcn_ds_bpermute(jl << 2, __float_as_int(nsc)));
+                if (m != 0ull) {
+                  m &= m - 1ull;
+                  const int dx = cx - (int)(jxy & 0xFFFF), dy = cy - (int)(jxy >> 16);
+                  occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * jnsc);
+                }
+              }
+              if (in && !ready) pass = !(level < (float)(occ > 255 ? 255 : occ));
+              rem &= __ballot(pass);  // lanes that fail now fail at their turn as well: decided
+            }
+            nacc = __popcll(accm);
+          } else {
+            // the cap falls inside this window: one candidate at a time, in order
+            while (rem != 0 && kept + nacc < limit) {
+              const int f = (int)__ffsll((long long)rem) - 1;
+              accm |= 1ull << f;
+              ++nacc;
+              const uint32_t wxy = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, f);
+              const float wnsc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nsc), f));
+              const int dx = cx - (int)(wxy & 0xFFFF), dy = cy - (int)(wxy >> 16);
+              const bool near = pass && lane > f && (dx < 0 ? -dx : dx) <= 15 && (dy < 0 ? -dy : dy) <= 15;
+              if (__any(near)) {  // the new point's stamp reaches later passing candidates of this window
+                if (near) {
+                  occ += (int)ceilf(lut_s[((dy + 32) << 6) | (dx + 32)] * wnsc);
+                  pass = !(level < (float)(occ > 255 ? 255 : occ));
+                }
+                rem &= __ballot(pass) & ~(((2ull << f) - 1ull));
+              } else {
+                rem &= rem - 1;
+              }
             }
           }
           if ((accm >> lane) & 1) {
