@@ -2077,7 +2077,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         }
       }
       part[wave * 64 + lane] = occf;
-      __syncthreads();
+      lds_barrier();  // (LDS traffic only: see select_lazy_kernel)
       if (wave == 0) {
         int occ = (int)(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]);
         bool pass = valid && !(level < (float)(occ > 255 ? 255 : occ));
@@ -2182,7 +2182,7 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
         convert();
         request(pos + 64 + kListChunk);
       }
-      __syncthreads();
+      lds_barrier();  // (the keypoint records written above are read only after the loop, behind a full barrier)
       kept = s_kept;
       if (kept >= limit) break;  // block-uniform
     }
