@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off extended fuzz (GPU): random image sizes / content / thresholds / radii / caps with CAMERA-AWARE extraction on
 random radial-tangential and equidistant cameras and random extraction directions, detect + describe against the oracle.
-usage: python tools/fuzz_aware.py [first_seed] [count]"""
+usage: python tools/fuzz_aware.py [first_seed] [count] [all]   (all: seeds also cycle through upright / gradient /
+scale-invariant extraction)"""
 import sys, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +12,7 @@ import oracle_lib as O, gpu_common as G
 import test_gpu_fuzz as F
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ALL_MODES = len(sys.argv) > 3 and sys.argv[3] == "all"
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(5000 + seed)
@@ -27,11 +29,18 @@ for seed in range(first, first + count):
         else tuple(rng.uniform(-0.02, 0.02, 4))
     cam = synth.Camera(w, h, f, f * float(rng.uniform(0.97, 1.03)), w / 2 + float(rng.uniform(-8, 8)), h / 2 + float(rng.uniform(-8, 8)), dist, tuple(float(x) for x in d))
     g = rng.normal(0, 1, 3); g[1] += 2.0; g = (g / np.linalg.norm(g)).astype(np.float32)
-    fe = capi.Frontend(w, h, radius, 0, thr, maxk, max_candidates=1 << 16)
-    fe.set_camera(0, cam)
-    rays, jac = O.awareness_maps(cam)
-    rk, rd = O.detect_describe(img, radius, 0, thr, maxk, O.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), tuple(float(x) for x in g))
-    kps, desc, bp, bpv = fe.detect_describe(img, cam=0, gravity=tuple(float(x) for x in g))
+    mode = seed % 4 if ALL_MODES else 0  # 0 camera-aware, 1 upright, 2 gradient, 3 gradient + scale-invariant
+    if mode == 0:
+        fe = capi.Frontend(w, h, radius, 0, thr, maxk, max_candidates=1 << 16)
+        fe.set_camera(0, cam)
+        rays, jac = O.awareness_maps(cam)
+        rk, rd = O.detect_describe(img, radius, 0, thr, maxk, O.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), tuple(float(x) for x in g))
+        kps, desc, bp, bpv = fe.detect_describe(img, cam=0, gravity=tuple(float(x) for x in g))
+    else:
+        si = mode == 3
+        fe = capi.Frontend(w, h, radius, 0, thr, maxk, rotation_invariant=(mode >= 2), scale_invariant=si, max_candidates=1 << 16)
+        rk, rd = O.detect_describe(img, radius, 0, thr, maxk, O.MODE_GRADIENT if mode >= 2 else O.MODE_UPRIGHT, scale_invariant=si)
+        kps, desc, _, _ = fe.detect_describe(img)
     try:
         G.assert_keypoints_equal(kps, rk)
         assert np.array_equal(desc, rd)
