@@ -656,10 +656,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
     ap.add_argument("--max-candidates", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=1,
-                    help="independent contexts/streams the batch is split over on each GPU.  With "
-                         "3 lanes and the score kernels serialised across them (--stagger) the "
-                         "latency-bound kernels of one lane hide behind the score kernel of "
-                         "another, but the score kernel then shares the GPU while it is being timed")
+                    help="independent contexts/streams the batch is split over on each GPU.  With 3-4 lanes the "
+                         "latency-bound kernels of one lane hide behind the VALU-bound score kernel of another "
+                         "(+9-11 %% at the same frames per step), but the score kernel then shares the GPU while it "
+                         "is being timed; the default run reports that configuration as the `four_lanes` leg")
     ap.add_argument("--stagger", type=int, default=1,
                     help="with --lanes > 1: serialise the score kernels of the lanes (okvfe_set_heavy_kernel_chaining "
                          "mode 1) so that the lanes run out of phase")
@@ -1021,6 +1021,67 @@ def main():
                 "value": world * B * n_m / el_m, "steps": n_m, "ms_per_step": 1e3 * el_m / n_m,
                 "note": "the same step with okvfe_set_keep_score_map(1): K1 writes its 4 B per pixel again "
                         "(roofline.with_score_map is that kernel)"}
+        # (1c) the same B frames per step through FOUR contexts on four HIP streams (B / 4 frames each, no
+        # chaining between them): the latency-bound selection / descriptor / matcher kernels of one lane run
+        # under the VALU-bound score kernel of another.  Same sharding as across GPUs, inside one GPU.
+        if S == 1 and C == 2 and B % 4 == 0 and B // 4 >= distinct:
+            B4 = B // 4
+            n4 = C * B4
+            lanes4 = []
+            for l in range(4):
+                lfe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold,
+                                    cfg.max_kpts, match_threshold=cfg.match_threshold, max_batch=n4,
+                                    num_cameras=C, device=local_rank, max_candidates=args.max_candidates)
+                for ci, cam in enumerate(cfg.cams):
+                    lfe.set_camera(ci, cam)
+                lanes4.append((lfe, torch.cuda.Stream(device=dev), d_img[C * l * B4:].data_ptr(),
+                               d_match[l * B4:].data_ptr()))
+            pairs4 = [(capi.StereoPair * B4)(*pv[:B4]) for pv in pairs_v]
+
+            def step4():
+                v = state["step"] % N_VARIANTS
+                state["step"] += 1
+                for lfe, st, img_ptr, match_ptr in lanes4:
+                    lfe.detect_describe_batch_device(img_ptr, n4, cam_ids[:n4], grav_v[v][:n4], st)
+                    lfe.match_stereo_batch_device(pairs4[v], match_ptr, st)
+
+            for _ in range(3):
+                step4()
+            n_4 = max(3, min(args.steps, 40))
+            barrier()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(n_4):
+                step4()
+            torch.cuda.synchronize()
+            barrier()
+            el_4 = time.perf_counter() - t4
+            if dist is not None:
+                t = torch.tensor([el_4], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el_4 = float(t.item())
+            for lane in lanes4:
+                lane[0].check_capacity(n4)
+            # the lanes computed what one context computes: the same host parameters through the single context,
+            # then keypoints, descriptors, back-projections and match rows of the checked frames byte by byte
+            m4 = d_match[:distinct].cpu().numpy().copy()
+            out4 = [lanes4[0][0].download(i) for i in range(C * distinct)]
+            state["step"] -= 1
+            step("device")
+            torch.cuda.synchronize()
+            m1 = d_match[:distinct].cpu().numpy()
+            same = all(np.array_equal(p.view(np.uint8), q.view(np.uint8))
+                       for i in range(C * distinct) for p, q in zip(out4[i], fe.download(i)))
+            same = same and all(np.array_equal(m4[f, :len(out4[C * f][0])], m1[f, :len(out4[C * f][0])])
+                                for f in range(distinct))
+            extras["four_lanes"] = {
+                "value": world * B * n_4 / el_4, "steps": n_4, "ms_per_step": 1e3 * el_4 / n_4,
+                "stereo_frames_per_launch": B4, "outputs_equal_single_context": bool(same),
+                "note": "the same %d stereo frames per step as `value`, split over 4 contexts / HIP streams per GPU; "
+                        "`value` stays on one context so that the K1 roofline is taken with the GPU to itself" % B}
+            for lane in lanes4:
+                lane[0].close()
+            del lanes4
         # (2) dense content: tied checker corners that all pass the uniformity stage (~700
         # keypoints per image): the matcher's 700 x 700 regime
         if args.content == "corners" and C > 1:
@@ -1152,6 +1213,7 @@ def main():
         result["value_real_content"] = extras.get("real_content", {}).get("value")
         result["value_score_map_kept"] = extras.get("score_map_kept", {}).get("value")
         result["value_host_fed"] = extras.get("host_fed", {}).get("value")
+        result["value_four_lanes"] = extras.get("four_lanes", {}).get("value")
         if cpu is not None:
             result["cpu_baseline"] = cpu
         print(json.dumps(result), flush=True)

@@ -133,3 +133,16 @@ def test_full_size_batch_replicas_permutation_idempotence(oracle, workload, FRAM
             for x, y in zip(res_r[2 * j + c], res[2 * fr + c]):
                 assert x.tobytes() == y.tobytes(), (j, fr, c)
         assert matches_r[j].tobytes() == matches[fr].tobytes(), (j, fr)
+
+
+def test_concurrent_contexts_equal_one_context_alone():
+    """Four contexts on four HIP streams, several steps in flight, each lane on different content at the same time
+    (the `four_lanes` leg of bench.py; frames sharded over streams, the sharding the reference does over cameras with
+    threads, Frontend.cpp:119-135): every frame of every lane is byte-identical to the same frame through one context
+    with the GPU to itself (tools/stress_lanes.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_lanes.py"), "4", "48", "4"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "0 mismatching frames" in out.stdout
