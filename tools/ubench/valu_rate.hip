@@ -65,6 +65,27 @@
 #define XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b));
 #define ADDSGPR(x) asm volatile("v_add_u32 %0, s4, %0" : "+v"(x));
 #define CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b));
+#define DECL_H int a0 = seed | 0x64006400, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, b = threadIdx.x | 0x64016401
+#define PKMIN3H(x) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define PKMINH(x) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define PKMINI16(x) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define PKMAXU16(x) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MIN3I16(x) asm volatile("v_min3_i16 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define MIN3F16(x) asm volatile("v_min3_f16 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define MIN3U32(x) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define MINU32(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define MINIMUM3F32(x) asm volatile("v_minimum3_f32 %0, %0, %1, %1" : "+v"(x) : "v"(b));
+#define MINU16(x) asm volatile("v_min_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+KERNEL(k_pkmin3h, DECL_H, OP8(PKMIN3H))
+KERNEL(k_pkminh, DECL_H, OP8(PKMINH))
+KERNEL(k_pkmini16, DECL_H, OP8(PKMINI16))
+KERNEL(k_pkmaxu16, DECL_H, OP8(PKMAXU16))
+KERNEL(k_min3i16, DECL_H, OP8(MIN3I16))
+KERNEL(k_min3f16, DECL_H, OP8(MIN3F16))
+KERNEL(k_min3u32, DECL_H, OP8(MIN3U32))
+KERNEL(k_minu32, DECL_H, OP8(MINU32))
+KERNEL(k_minimum3f32, DECL_H, OP8(MINIMUM3F32))
+KERNEL(k_minu16, DECL_H, OP8(MINU16))
 KERNEL(k_lshrb16, DECL_I, OP8(LSHRB16))
 KERNEL(k_addu16, DECL_I, OP8(ADDU16))
 KERNEL(k_mulhi32, DECL_I, OP8(MULHI32))
@@ -142,5 +163,8 @@ int main() {
   RUN(k_mulu24sdwa) RUN(k_pklshr) RUN(k_addsdwa) RUN(k_dppadd) RUN(k_dpprow) RUN(k_sadu8) RUN(k_mov)
   RUN(k_sub) RUN(k_lshr) RUN(k_madu24) RUN(k_addmul2)
   RUN(k_lshrb16) RUN(k_addu16) RUN(k_mulhi32) RUN(k_dot4i8) RUN(k_xor) RUN(k_cndmask)
+  printf("-- round 4: minima / maxima (AGAST kernel)\n");
+  RUN(k_pkmin3h) RUN(k_pkminh) RUN(k_pkmini16) RUN(k_pkmaxu16) RUN(k_min3i16) RUN(k_min3f16) RUN(k_min3u32)
+  RUN(k_minu32) RUN(k_minimum3f32) RUN(k_minu16)
   return 0;
 }
