@@ -1,4 +1,5 @@
-// k_agast.hip -- AGAST / FAST 9-16 corner score map (okvfe_config.score_type = OKVFE_SCORE_AGAST_9_16).
+// k_agast.hip -- AGAST / FAST 9-16 corner score map (okvfe_config.score_type = OKVFE_SCORE_AGAST_9_16) and the
+// FAST 5-8 map of the published BRISK scale space's virtual first layer (OKVFE_SCORE_BRISK_SCALESPACE).
 //
 // Score calculator of brisk::BriskFeatureDetector, the detector the reference instantiates on ARM
 // (okvis_cv/test/TestFrame.cpp:71-72: BriskFeatureDetector(34, 2)); the x86 path and every shipped
@@ -59,8 +60,6 @@ __device__ __forceinline__ int score_of(uint32_t best, uint32_t centre) {
   const _Float16 m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(bd.x, bd.y), (_Float16)1.0f);
   return (int)(unsigned short)(short)(m - (_Float16)1.0f);
 }
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
-__device__ __forceinline__ int max3i_(int a, int b, int c) { return max(max(a, b), c); }
 
 // rows y0 - 3 .. y0 + kTileH + 2 of the strip's columns into one LDS buffer, in two steps: the loads (issued
 // before the previous tile is scored) and the expansion + LDS writes (after it).  Coordinates outside the image
@@ -129,14 +128,30 @@ __device__ __forceinline__ void stage_bytes(uint32_t* buf, const uint8_t* __rest
 // FULL: all rows of the tile are inside the image -- one basic block (the border rule is a select, not a
 // branch: every address read is inside the staged tile), so that the next pixel's LDS reads are issued under
 // this pixel's minima.
-template <bool FULL>
+template <bool FULL, bool F58>
 __device__ __forceinline__ void score_rows(const uint32_t* c0, int32_t* __restrict__ out, uint32_t off, int w, int h,
                                            int y_first, bool x_inner) {
+  constexpr int kB = F58 ? 1 : 3;  // pixels closer to the border score 0
 #pragma unroll
   for (int k = 0; k < kTileH / 4; ++k) {
     const int y = y_first + 4 * k;  // uniform over the wave
     if (!FULL && y >= h) break;
     const uint32_t* c = c0 + 4 * k * kLdsPitch;
+    uint32_t best;
+    if (F58) {
+      // ring of radius 1 in the oracle's order: (0,1) (1,1) (1,0) (1,-1) (0,-1) (-1,-1) (-1,0) (-1,1); arcs of 5:
+      // m5[i] = min(m3[i], m3[i + 2])
+      uint32_t d[8];
+      d[0] = c[kLdsPitch];       d[1] = c[kLdsPitch + 1];   d[2] = c[1];   d[3] = c[-kLdsPitch + 1];
+      d[4] = c[-kLdsPitch];      d[5] = c[-kLdsPitch - 1];  d[6] = c[-1];  d[7] = c[kLdsPitch - 1];
+      uint32_t m3[8], m5[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m3[i] = pk_min3(d[i], d[(i + 1) & 7], d[(i + 2) & 7]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m5[i] = pk_min3(m3[i], m3[(i + 2) & 7], m3[(i + 2) & 7]);
+      const uint32_t t0 = pk_max3(m5[0], m5[1], m5[2]), t1 = pk_max3(m5[3], m5[4], m5[5]);
+      best = pk_max3(t0, t1, pk_max3(m5[6], m5[7], m5[7]));
+    } else {
     // circle in the order of the oracle's table: (0,3) (1,3) (2,2) (3,1) (3,0) (3,-1) (2,-2) (1,-3)
     // (0,-3) (-1,-3) (-2,-2) (-3,-1) (-3,0) (-3,1) (-2,2) (-1,3)
     uint32_t d[16];
@@ -158,18 +173,19 @@ __device__ __forceinline__ void score_rows(const uint32_t* c0, int32_t* __restri
     const uint32_t t2 = pk_max3(m9[6], m9[7], m9[8]), t3 = pk_max3(m9[9], m9[10], m9[11]);
     const uint32_t t4 = pk_max3(m9[12], m9[13], m9[14]);
     const uint32_t u0 = pk_max3(t0, t1, t2), u1 = pk_max3(t3, t4, m9[15]);
-    const uint32_t best = __builtin_bit_cast(
+    best = __builtin_bit_cast(
         uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(half2_t, u0), __builtin_bit_cast(half2_t, u1)));
+    }
     const int s = score_of(best, c[0]);
     // streamed: the map is 4 B per pixel of a batch that does not fit any cache; a 32-bit byte offset keeps the
     // store on the scalar-base form
-    __builtin_nontemporal_store((x_inner && y >= 3 && y < h - 3) ? s : 0,
+    __builtin_nontemporal_store((x_inner && y >= kB && y < h - kB) ? s : 0,
                                 reinterpret_cast<int32_t*>(reinterpret_cast<char*>(out) + off));
     off += 16u * (uint32_t)w;
   }
 }
 
-template <bool DWORDS>
+template <bool DWORDS, bool F58>
 __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restrict__ images, int w, int h,
                                                           int32_t* __restrict__ scores, int tiles_x,
                                                           int strips_y, int chunks, int n_images) {
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restr
   const int tx = tid & 63;
   const int tyy = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave's row phase: uniform
   const int x = x0 + tx;
-  const bool x_inner = x >= 3 && x < w - 3;
+  const bool x_inner = F58 ? (x >= 1 && x < w - 1) : (x >= 3 && x < w - 3);
   const int y_first = ty0 * chunks * kTileH;
   int n_chunks = (h - y_first + kTileH - 1) / kTileH;
   n_chunks = n_chunks < chunks ? n_chunks : chunks;
@@ -206,9 +222,9 @@ __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restr
     if (x < w) {
       const uint32_t off = (uint32_t)(y0 + tyy) * (uint32_t)w + (uint32_t)x;
       if (y0 + kTileH <= h)
-        score_rows<true>(c0, out, 4u * off, w, h, y0 + tyy, x_inner);
+        score_rows<true, F58>(c0, out, 4u * off, w, h, y0 + tyy, x_inner);
       else
-        score_rows<false>(c0, out, 4u * off, w, h, y0 + tyy, x_inner);
+        score_rows<false, F58>(c0, out, 4u * off, w, h, y0 + tyy, x_inner);
     }
     if (more) {
       if (DWORDS)
@@ -220,44 +236,10 @@ __global__ __launch_bounds__(256) void agast_score_kernel(const uint8_t* __restr
   }
 }
 
-// FAST 5-8 score of c0: the virtual intra-octave below the first octave of the published BRISK
-// scale space (oracle: orc_fast58_score).  One thread per pixel, direct reads (a small fraction of
-// the 9-16 kernel's work; the 3 x 3 neighbourhood comes out of L1 / L2).
-__global__ __launch_bounds__(256) void fast58_score_kernel(const uint8_t* __restrict__ images, int w, int h,
-                                                           int32_t* __restrict__ scores) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  const uint8_t* img = images + (size_t)blockIdx.z * w * h;
-  int s = 0;
-  if (x >= 1 && y >= 1 && x < w - 1 && y < h - 1) {
-    const uint8_t* c = img + (size_t)y * w + x;
-    const int p = c[0];
-    // ring in the oracle's order: (0,1) (1,1) (1,0) (1,-1) (0,-1) (-1,-1) (-1,0) (-1,1)
-    int d[8];
-    d[0] = c[w] - p;       d[1] = c[w + 1] - p;  d[2] = c[1] - p;   d[3] = c[-w + 1] - p;
-    d[4] = c[-w] - p;      d[5] = c[-w - 1] - p; d[6] = c[-1] - p;  d[7] = c[w - 1] - p;
-    int bright = -256, most = 256;
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      const int mn = min(min3i(d[st], d[(st + 1) & 7], d[(st + 2) & 7]), min(d[(st + 3) & 7], d[(st + 4) & 7]));
-      const int mx = max(max3i_(d[st], d[(st + 1) & 7], d[(st + 2) & 7]), max(d[(st + 3) & 7], d[(st + 4) & 7]));
-      bright = max(bright, mn);
-      most = min(most, mx);
-    }
-    s = max(bright, -most) - 1;
-    s = s < 0 ? 0 : s;
-  }
-  scores[(size_t)blockIdx.z * w * h + (size_t)y * w + x] = s;
-}
-
 }  // namespace
 
-void launch_fast58_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
-  if (n_images <= 0) return;
-  hipLaunchKernelGGL(fast58_score_kernel, dim3((w + 255) / 256, h, n_images), dim3(256), 0, stream, img, w, h, score);
-}
-
-void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
+template <bool F58>
+void launch_ring_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
   if (n_images <= 0) return;
   const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
   // tiles a workgroup walks: as many as leave >= 8192 workgroups, at most kMaxChunks (128 rows)
@@ -266,11 +248,21 @@ void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t*
   const int strips_y = (tiles_y + chunks - 1) / chunks;
   const dim3 grid(tiles_x * strips_y * n_images);
   if ((w & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0)
-    hipLaunchKernelGGL(agast_score_kernel<true>, grid, dim3(256), 0, stream, img, w, h, score, tiles_x, strips_y,
-                       chunks, n_images);
+    hipLaunchKernelGGL((agast_score_kernel<true, F58>), grid, dim3(256), 0, stream, img, w, h, score, tiles_x,
+                       strips_y, chunks, n_images);
   else
-    hipLaunchKernelGGL(agast_score_kernel<false>, grid, dim3(256), 0, stream, img, w, h, score, tiles_x, strips_y,
-                       chunks, n_images);
+    hipLaunchKernelGGL((agast_score_kernel<false, F58>), grid, dim3(256), 0, stream, img, w, h, score, tiles_x,
+                       strips_y, chunks, n_images);
+}
+
+// FAST 5-8 score of c0: the virtual intra-octave below the first octave of the published BRISK scale space
+// (oracle: orc_fast58_score): the same kernel on the 8-pixel ring of radius 1, arcs of 5, 1-pixel border
+void launch_fast58_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
+  launch_ring_score<true>(img, w, h, n_images, score, stream);
+}
+
+void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream) {
+  launch_ring_score<false>(img, w, h, n_images, score, stream);
 }
 
 }  // namespace okvfe
