@@ -12,12 +12,13 @@ BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --
 $BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- $BENCH > /tmp/prof_stats.log 2>&1
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
-# three staggered lanes (the higher-throughput mode): the same kernels sharing the GPU
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats3 -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --lanes 3 > /tmp/prof_stats3.log 2>&1
-cp $(find /tmp/prof_stats3 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats_3lanes.csv
-grep '^{"metric"' /tmp/prof_stats3.log | tail -1 > $OUT/${TAG}_bench_3lanes.json
+# four lanes, no chaining (the higher-throughput mode, bench.py's four_lanes leg): the same kernels sharing the GPU
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats4 -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --lanes 4 --stagger 0 > /tmp/prof_stats4.log 2>&1
+cp $(find /tmp/prof_stats4 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats_4lanes.csv
+grep '^{"metric"' /tmp/prof_stats4.log | tail -1 > $OUT/${TAG}_bench_4lanes.json
+python $R/bench.py --lanes 4 --stagger 0 --no-cpu-baseline --no-extras 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_4lanes_unprofiled.json
 # the other BASELINE shapes (informational bench lines, CPU baseline + parity leg included)
-for W in tumvi hilti mono640 map; do
+for W in tumvi hilti mono640 map tumvi512 d455 d435i; do
   python $R/bench.py --workload $W 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_$W.json
 done
 python $R/bench.py --workload hilti --split cameras 2>/dev/null | grep '^{"metric"' | tail -1 > $OUT/${TAG}_bench_hilti_split_cameras.json
