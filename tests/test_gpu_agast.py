@@ -31,6 +31,22 @@ def test_agast_score_map(oracle, w, h, kind):
     assert got.max() > 34
 
 
+@pytest.mark.parametrize("w,h,n", [(752, 480, 96), (640, 483, 64), (330, 250, 200)])
+def test_agast_score_map_column_walk(oracle, w, h, n):
+    """Launches large enough that a workgroup walks several vertically adjacent tiles (double-buffered staging, the
+    next tile's loads in flight under the current one's scoring), incl. a partial last tile and the byte-staged
+    form (330 px): every replica of the 8 distinct images equals the oracle's map."""
+    fe = capi.Frontend(w, h, 20.0, 0, 34, 500, max_batch=n, score_type=capi.SCORE_AGAST_9_16)
+    base = np.stack([synth.noise_image(w, h, 61 + i) if i % 2 else synth.corners_image(w, h, 61 + i) for i in range(8)])
+    d_img = torch.from_numpy(np.concatenate([base] * (n // 8))).cuda()
+    d_sc = torch.full((n, h, w), -7, dtype=torch.int32, device="cuda")
+    fe.harris_score_device(d_img.data_ptr(), n, d_sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(np.stack([oracle.agast_score(base[i]) for i in range(8)])).cuda()
+    got = d_sc.view(n // 8, 8, h, w)
+    assert bool((got == ref[None]).all()), torch.nonzero(got != ref[None])[:5]
+
+
 def test_agast_extremes(oracle):
     w, h = 128, 64
     fe = capi.Frontend(w, h, 20.0, 0, 34, 500, max_batch=4, score_type=capi.SCORE_AGAST_9_16)
