@@ -1011,7 +1011,7 @@ def main():
                 lane[0].set_keep_score_map(True)
             for _ in range(2):
                 step("device")
-            n_m = max(3, min(args.steps, 8))
+            n_m = max(3, min(args.steps, 60))
             el_m, _ = timed(n_m, "device")
             for lane in lanes:
                 lane[0].set_keep_score_map(False)
@@ -1087,9 +1087,9 @@ def main():
         if args.content == "corners" and C > 1:
             imgs_d, _ = make_inputs(cfg, B, distinct, 5000 + 977 * rank, "checker")
             d_img.copy_(torch.from_numpy(imgs_d).to(dev))
-            for _ in range(2):
+            for _ in range(4):
                 step("device")
-            n_d = max(3, min(args.steps, 8))
+            n_d = max(3, min(args.steps, 60))
             el_d, _ = timed(n_d, "device")
             for lane in lanes:
                 lane[0].check_capacity(n_lane_img)
@@ -1108,7 +1108,7 @@ def main():
                 d_img.copy_(torch.from_numpy(imgs_r).to(dev))
                 for _ in range(2):
                     step("device")
-                n_r = max(3, min(args.steps, 8))
+                n_r = max(3, min(args.steps, 60))
                 el_r, _ = timed(n_r, "device")
                 for lane in lanes:
                     lane[0].check_capacity(n_lane_img)
