@@ -234,7 +234,8 @@ def alu_rooflines(stage_ms, pair_evals_per_launch, kp_described_per_launch, patc
                            "keypoints_per_launch": kp_described_per_launch,
                            "note": "a keypoint's pattern patch (64 rows x 64..80 B) goes L2 -> LDS once; the box "
                                    "sums (~420 VALU per keypoint, profiles/round3 SQ counters) overlap with it; "
-                                   "stage time includes describe_setup_kernel"}
+                                   "stage time includes describe_setup_kernel; since round 4 the tighter bound is vector-ALU "
+                                   "issue (valu_issue block, when the counters of this workload are committed)"}
     if stage_ms.get("select"):
         out["select"] = {"kernel": "select_lazy_kernel (K3 uniformity + K4 sub-pixel)", "bound": "latency",
                          "achieved": n_img_launch / (stage_ms["select"] * 1e-3), "peak": None, "unit": "images/s",
@@ -247,6 +248,42 @@ def alu_rooflines(stage_ms, pair_evals_per_launch, kp_described_per_launch, patc
                        "unit": None, "frac": None,
                        "note": "bitonic network on 64-bit keys in LDS, 24 passes for 8192 keys; ~24 G keys/s"}
     return out
+
+
+def valu_issue_blocks(rooflines, stage_ms, n_img_launch, workload, content):
+    """Adds a `valu_issue` block to the non-K1 kernels: wave64 vector-ALU instructions per launch (SQ_INSTS_VALU of the
+    newest committed SQ pass, taken on the default EuRoC workload at 1536 images per launch and scaled by the images of
+    this launch) over the stage time, against one VALU issue per SIMD per 4 cycles.  Only for the workload the counters
+    were taken on."""
+    import glob
+    if workload != "euroc" or content != "corners":
+        return
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round4_*_pmc_sq.json")), reverse=True)
+    files = [f for f in files if "_pmc_sq" in f and "withmap" not in f]
+    if not files:
+        return
+    # numeric order of the collection tags (v10 after v9)
+    files.sort(key=lambda f: int("".join(c for c in os.path.basename(f).split("_")[1] if c.isdigit()) or 0), reverse=True)
+    try:
+        sq = json.load(open(files[0]))
+    except Exception:
+        return
+    for key, prefix, stage in (("describe", "describe_kernel", "describe"), ("select", "select_lazy_kernel", "select"),
+                               ("match_stereo", "match_stereo_kernel", "match")):
+        hit = [v for k, v in sq.items() if k.startswith(prefix)]
+        if key not in rooflines or not hit or not stage_ms.get(stage):
+            continue
+        insts = hit[0]["mean_per_dispatch"].get("SQ_INSTS_VALU")
+        if not insts:
+            continue
+        insts = insts * n_img_launch / 1536.0
+        g = insts / (stage_ms[stage] * 1e-3) / 1e9
+        rooflines[key]["valu_issue"] = {
+            "insts_per_launch": insts, "achieved": g, "peak": VALU_PEAK_GINST, "frac": g / VALU_PEAK_GINST,
+            "unit": "G wave64 VALU instructions/s",
+            "source": "SQ_INSTS_VALU of profiles/%s (1536 EuRoC images per launch, scaled); peak = 1024 SIMDs x 2.4 GHz / "
+                      "4 cycles per wave64 op; simple VOP2 forms issue faster, so 1.0 is not a hard ceiling" %
+                      os.path.basename(files[0])}
 
 
 def run_map_workload(args, torch, capi, synth, dev):
@@ -1205,6 +1242,7 @@ def main():
             "stage_ms_note": "all-stage event pass of 3 steps after the timed region; avg_launch_ms of "
                              "the roofline comes from the timed region itself",
         }
+        valu_issue_blocks(result["rooflines_other"], stage_ms, n_lane_img, args.workload, args.content)
         result.update(extras)
         if long_region is not None:
             result["long_region"] = long_region
