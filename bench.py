@@ -5,7 +5,7 @@ Workload (BASELINE.json metric, configs[2]): synthetic EuRoC-shaped stereo, 752x
 front-end parameters of config/euroc.yaml:63-67 (uniformity radius 38, Harris threshold 150,
 <= 700 keypoints, Hamming threshold 60), camera-aware gravity-aligned BRISK2 extraction,
 matchStereo with the FP64 triangulation gate.  One "step" = one batch of `--batch` stereo frames
-(default 768 = 1536 images) through the whole hot path (K1 score map with the K2 NMS fused in ->
+(default 3072 = 6144 images since the end of round 4; rounds 1-3 and most of round 4 quote 768) through the whole hot path (K1 score map with the K2 NMS fused in ->
 K3 sort + greedy selection, K4 sub-pixel -> K6 describe -> compaction + back-projection -> K7 gated
 stereo match), inputs resident in HBM.
 
@@ -293,7 +293,7 @@ def run_map_workload(args, torch, capi, synth, dev):
     VALU roofline of the Hamming work; rank 0 / one GPU (replicas only: the map needs estimator state)."""
     from okvis2_amd import multigpu
     cfg = synth.euroc_config()
-    B = args.batch if args.batch != 768 else 256
+    B = args.batch if args.batch is not None else 256
     K, L = cfg.max_kpts, 5000
     fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, K,
                        match_threshold=cfg.match_threshold, max_batch=1, num_cameras=1, device=dev.index)
@@ -387,7 +387,7 @@ def run_map_workload(args, torch, capi, synth, dev):
 
 
 def batch_sweep(cfg, capi, torch, dev, local_rank, base, max_candidates, budget_s=0.35):
-    """the hot path at B in {1, 16, 256, 3072} stereo frames per call.  The reference's
+    """the hot path at B in {1, 16, 256, 768} stereo frames per call.  The reference's
     seams are B = 1 calls; the batch entry points amortise launches over B frames.  Per B, device-
     and host-fed: `pipelined` = calls enqueued back to back on one stream (throughput), `latency_ms`
     = one call with a host synchronisation after it (what a caller waiting for the result sees)."""
@@ -396,7 +396,7 @@ def batch_sweep(cfg, capi, torch, dev, local_rank, base, max_candidates, budget_
     n_distinct = len(base) // C
     f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
     f1 = 0.5 * (cfg.cams[min(1, C - 1)].fu + cfg.cams[min(1, C - 1)].fv)
-    for B in (1, 16, 256, 3072):  # (3072: four times the batch `value` is quoted on -- where the rate saturates)
+    for B in (1, 16, 256, 768):  # (768: the batch rounds 1-3 quoted `value` on; the default step holds 3072)
         fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold, cfg.max_kpts,
                            match_threshold=cfg.match_threshold, max_batch=C * B, num_cameras=C,
                            device=local_rank, max_candidates=max_candidates)
@@ -689,7 +689,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None,
                     help="steps of the timed region, timed EXACTLY; without the flag: 340 (about 0.5 s)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=768, help="stereo frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="stereo frames per step per GPU (default: 3072 EuRoC frames; per workload otherwise, see below)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
     ap.add_argument("--max-candidates", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=1,
@@ -723,7 +724,7 @@ def main():
     args = ap.parse_args()
     steps_flag = args.steps is not None
     if args.steps is None:
-        args.steps = 340 if args.workload == "euroc" else 100
+        args.steps = 85 if args.workload == "euroc" and args.batch is None else (340 if args.workload == "euroc" else 100)
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
@@ -759,12 +760,12 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if args.workload != "euroc" and args.batch == 768:
-        # frames per step that fill the 256 CUs for a whole number of workgroup rounds of the score
-        # kernel (1536 resident workgroups): 512 TUM-VI images = 6.9 rounds, 1536 VGA images = 6
-        # frames per step of the other workloads: large enough that the latency-bound selection has several
-        # images per CU in flight (TUM-VI 256 -> 1024 frames: +16 %, Hilti 192 -> 960 multiframes: +17 %)
-        args.batch = {"tumvi": 1024, "hilti": 960, "mono640": 3072, "tumvi512": 1536, "d455": 1536, "d435i": 1536}[args.workload]
+    if args.batch is None:
+        # frames per step: large enough that the latency-bound selection has several images per CU in flight and
+        # the launch tails are amortised (EuRoC 768 -> 1536 -> 3072 frames: 638 -> 667 -> 685 k stereo-frames/s,
+        # TUM-VI 256 -> 1024: +16 %, Hilti 192 -> 960 multiframes: +17 %); `batch_sweep` carries the curve
+        args.batch = {"euroc": 3072, "tumvi": 1024, "hilti": 960, "mono640": 3072, "tumvi512": 1536, "d455": 1536,
+                      "d435i": 1536}[args.workload]
     if args.workload == "hilti" and args.split == "cameras":
         res = run_hilti_split_cameras(args, torch, dist, capi, synth, world, rank, dev)
         if res is not None:
