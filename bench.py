@@ -541,9 +541,14 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0  # wave-instructions/ns: 1024 SIMDs, one w
 def k1_pmc_for(w, h, map_free):
     """Newest committed PMC collection of K1 taken on THIS image shape and map mode (None: none)."""
     import glob
-    cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "round4_*_k1_pmc*.json")), reverse=True) +
-             sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_*_k1_pmc*.json")), reverse=True) +
-             sorted(glob.glob(os.path.join(ROOT, "profiles", "round2_*_k1_pmc*.json")), reverse=True))
+    import re
+
+    def tag(path):  # (round, collection) as numbers: round4_v12 is newer than round4_v5
+        m = re.match(r"round(\d+)(?:_v(\d+))?_", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_k1_pmc*.json")), key=tag, reverse=True)
+    cands = [c for c in cands if c.endswith(".json") and "_sq" not in os.path.basename(c)]
     for pmc_path in cands:
         pmc = json.load(open(pmc_path))
         if bool(pmc.get("map_free", False)) != bool(map_free):
