@@ -268,6 +268,13 @@ def valu_issue_blocks(rooflines, stage_ms, n_img_launch, workload, content):
         sq = json.load(open(files[0]))
     except Exception:
         return
+    # images per launch of that pass = the bench line of the same collection (1536 before round4_v12)
+    sq_images = 1536.0
+    try:
+        line = json.load(open(files[0].replace("_pmc_sq.json", "_bench.json")))
+        sq_images = float(line["config"]["stereo_frames_per_launch"] * line["config"].get("cameras_per_multiframe", 2))
+    except Exception:
+        pass
     for key, prefix, stage in (("describe", "describe_kernel", "describe"), ("select", "select_lazy_kernel", "select"),
                                ("match_stereo", "match_stereo_kernel", "match")):
         hit = [v for k, v in sq.items() if k.startswith(prefix)]
@@ -276,12 +283,12 @@ def valu_issue_blocks(rooflines, stage_ms, n_img_launch, workload, content):
         insts = hit[0]["mean_per_dispatch"].get("SQ_INSTS_VALU")
         if not insts:
             continue
-        insts = insts * n_img_launch / 1536.0
+        insts = insts * n_img_launch / sq_images
         g = insts / (stage_ms[stage] * 1e-3) / 1e9
         rooflines[key]["valu_issue"] = {
             "insts_per_launch": insts, "achieved": g, "peak": VALU_PEAK_GINST, "frac": g / VALU_PEAK_GINST,
             "unit": "G wave64 VALU instructions/s",
-            "source": "SQ_INSTS_VALU of profiles/%s (1536 EuRoC images per launch, scaled); peak = 1024 SIMDs x 2.4 GHz / "
+            "source": "SQ_INSTS_VALU of profiles/%s (per image, times the images of this launch); peak = 1024 SIMDs x 2.4 GHz / "
                       "4 cycles per wave64 op; simple VOP2 forms issue faster, so 1.0 is not a hard ceiling" %
                       os.path.basename(files[0])}
 
