@@ -341,7 +341,7 @@ constexpr int kCandStage = OKVFE_K1_STAGE;  // candidate records staged per wave
 // MEMONLY: the byte mover of this kernel -- the same loads, the same stores on the same layout, no
 // arithmetic (a stored row = the unpacked pixel row three steps ahead).  Its duration is the
 // kernel's own memory floor (okvfe_harris_byte_mover_device; bench.py reports both).
-template <int kTHF, bool NMS, bool PACK = false, bool MEMONLY = false>
+template <int kTHF, bool NMS, bool PACK = false, bool MEMONLY = false, bool NOMAP = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_kernel(
     const uint8_t* __restrict__ images, int w, int h, int32_t* __restrict__ scores, int pitch, int strips,
     int rtiles, int n_images, NmsOut nms, int pack_g, int pack_u, int main_blocks) {
@@ -616,8 +616,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   };
   // (map-free calls, round 4: the selection recomputes the 3 x 3 scores of the few keypoints it keeps and
   // the fix-up works on the candidate records, so four of the five bytes per pixel are never written;
-  // wave-uniform branch around the one store)
-  const bool store_map = MEMONLY || !NMS || nms.no_map == 0;
+  // the map-free call takes the NOMAP instantiation, compiled without the store; the run-time flag keeps the
+  // map-writing instantiation usable for it as well: lab knob OKVFE_K1_GENERIC_NOMAP)
+  const bool store_map = !NOMAP && (MEMONLY || !NMS || nms.no_map == 0);  // NOMAP: the map-free instantiation carries no store
   auto store_row = [&](const int sc[4], int y) {
     if (!store_map) return;
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -899,16 +900,26 @@ static bool launch_harris_impl(const uint8_t* img, int w, int h, int n_images, i
       const int main_blocks = main_blocks_of(strips - 1);                                        \
       const int groups = (n_images + pack_g - 1) / pack_g;                                       \
       const int pblocks = (groups * rtiles + kWavesPerBlock - 1) / kWavesPerBlock;               \
+      if (!MEM && nms->no_map && !generic_nomap)                                                 \
+        hipLaunchKernelGGL((harris_kernel<TH, true, true, MEM, !MEM>), dim3(main_blocks + pblocks), \
+                           block, 0, stream, img, w, h, score, layout.pitch, strips - 1, rtiles, n_images, *nms, \
+                           pack_g, pack_u, main_blocks);                                         \
+      else                                                                                       \
       hipLaunchKernelGGL((harris_kernel<TH, true, true, MEM>), dim3(main_blocks + pblocks),      \
                          block, 0, stream, img, w, h, score, layout.pitch, strips - 1, rtiles, n_images, *nms, \
                          pack_g, pack_u, main_blocks);                                           \
     } else {                                                                                     \
+      if (!MEM && nms->no_map && !generic_nomap)                                                 \
+        hipLaunchKernelGGL((harris_kernel<TH, true, false, MEM, !MEM>), dim3(main_blocks_of(strips)), block, 0, \
+                           stream, img, w, h, score, layout.pitch, strips, rtiles, n_images, *nms, 1, 64, 0);  \
+      else                                                                                       \
       hipLaunchKernelGGL((harris_kernel<TH, true, false, MEM>), dim3(main_blocks_of(strips)), block, 0,  \
                          stream, img, w, h, score, layout.pitch, strips, rtiles, n_images, *nms, 1, 64, 0);    \
     }                                                                                            \
   }
 #define OKVFE_K1_NMS_LAUNCH(TH) OKVFE_K1_NMS_LAUNCH_M(TH, false)
     static const bool no_pack = lab_env("OKVFE_K1_NOPACK") != nullptr;  // A/B knob
+    static const bool generic_nomap = lab_env("OKVFE_K1_GENERIC_NOMAP") != nullptr;  // A/B knob: map-free through the map-writing instantiation's branch
     if (nms && byte_mover) {
       OKVFE_K1_NMS_LAUNCH_M(61, true);
     } else if (nms) {

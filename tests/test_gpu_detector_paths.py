@@ -265,13 +265,15 @@ print("KNOB-OK")
 @pytest.mark.parametrize("knob", ["OKVFE_LEGACY_SORT", "OKVFE_K1_NOPACK", "OKVFE_SELECT_OCC_HBM",
                                   "OKVFE_LEGACY_SELECT", "OKVFE_LAZY_BINCAP", "OKVFE_K1_TH=61", "OKVFE_K1_TH=25",
                                   "OKVFE_SELECT_PRESORTED", "OKVFE_LAZY_ROUNDCAP=64", "OKVFE_LAZY_ROUNDCAP=7",
-                                  "OKVFE_KEEP_SCORE_MAP"])
+                                  "OKVFE_KEEP_SCORE_MAP", "OKVFE_K1_GENERIC_NOMAP"])
 def test_ab_knobs_keep_their_paths_exact(oracle, knob):
     """The A/B switches the profiling notes refer to (read once per process, hence a child process
     each) select older or alternative kernels: two-stride LDS sort, unpacked last strips, occupancy
     grid in HBM, one-accept-per-round selection, the array-bin selection on keys sorted by a launch
     of their own (round 4: it orders its candidates itself), and that kernel with rounds of 64 / 7
-    keys, which sends every chunk through the key-range split.  Each must stay bit-exact."""
+    keys, which sends every chunk through the key-range split; map-free detection through the map-writing
+    instantiation of the score kernel (its run-time branch) instead of the one compiled without the store.
+    Each must stay bit-exact."""
     env = _lab_environ()
     k, _, v = knob.partition("=")
     env[k] = v or "1"
