@@ -93,6 +93,15 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
 
 // ---- batch pipeline ----------------------------------------------------------------------------
 // OKVFE_SCORE_TOKEN: see g_score_token.
+// The camera-aware-only descriptor kernel carries the fixed-trip box sum alone: every box of the installed pattern has
+// to fit its 11 x 11 slots (sigma_half <= 4.75: the built-in pattern; okvfe_set_pattern may install wider samples,
+// which take the all-modes kernel).
+static bool pattern_small_boxes(const okvfe::Pattern& P) {
+  for (int i = 0; i < P.n_points && i < okvfe::kPatternPoints; ++i)
+    if (!(P.sigma_half[i] <= 4.75f)) return false;
+  return true;
+}
+
 namespace {
 // The token mutex is held from the wait on the previous holder's event to the record of this
 // launch's event, so two host threads can never chain on the same predecessor.
@@ -353,7 +362,7 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
-                    ctx->all_aware);
+                    ctx->all_aware && pattern_small_boxes(ctx->host_pattern));
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -778,7 +787,8 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   }
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
-                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false, ctx->all_aware);
+                  ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false,
+                  ctx->all_aware && pattern_small_boxes(ctx->host_pattern));
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

@@ -71,7 +71,9 @@ __device__ __forceinline__ int div_nonneg(int num, int den) {
   return q;
 }
 
-template <typename PX>
+// FASTONLY: every box of the pattern is at most 11 x 11 (sigma_half <= 4.75, checked on the host): the plain-loop
+// form and the test for it are compiled out.
+template <bool FASTONLY = false, typename PX>
 __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
                                                   float sigma_half, int scaling, int scaling2) {
   if (sigma_half < 0.5f) {
@@ -107,7 +109,7 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
   int upper = 0, middle = 0, left = 0, right = 0, bottom = 0;
   const int bw = x_right - x_left, bh = y_bottom - y_top;  // >= 1 for sigma_half >= 0.5
   if constexpr (PX::kFixedTrip) {
-  if (__all(bw <= kMaxBox && bh <= kMaxBox)) {
+  if (FASTONLY || __all(bw <= kMaxBox && bh <= kMaxBox)) {
     // Fixed trip counts, no data-dependent selects: the top and the bottom row are read once each,
     // then kMaxBox - 1 interior slots, where a slot past the box (dy >= bh) reads the all-zero
     // row of the patch instead, so every accumulation is unconditional.  Interior columns
@@ -249,7 +251,8 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
 // waves per SIMD): launch_describe picks the instantiation from the cameras' patch statistics.
 // AWARE: every image of the launch is extracted camera-aware (the production mode, Frontend.cpp:2410-2412 with
 // setExtractionDirection): the gradient-orientation pass and the fixed-box staging are compiled out -- a
-// third of the kernel's code and the registers that had to live across it.
+// third of the kernel's code and the registers that had to live across it.  It is launched for patterns whose boxes
+// all fit the fixed-trip box sum only (sigma_half <= 4.75: capi_detect.cpp), so the plain-loop form is compiled out too.
 template <int kWavesPerSimd, bool AWARE = false>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(kWavesPerSimd, 8))) void describe_kernel(
     const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     PatchPx ppx;
     int v = 0;
     if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
-      if (active) v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
+      if (active) v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
     } else {
       // The patch does not fit in the wave's LDS buffer (wide-angle cameras stretch the camera-aware
       // pattern towards the image rim: fu = 350 on 640 px gives |M| up to ~1.6).  It is staged in
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         }
         const bool mine = !done && ly0 >= band0 && ly1 <= band1;
         if (mine) {
-          v = smoothed_intensity(ppx, xf, yf, sg, bsc, bsc2);
+          v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
           done = true;
         }
         if (band1 >= by1) break;

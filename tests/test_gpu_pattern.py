@@ -42,7 +42,10 @@ def test_default_pattern_round_trips_and_equals_the_oracles(oracle):
     assert np.array_equal(d, rd)
 
 
-def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch):
+@pytest.mark.parametrize("widen", [1.05, 0.97])
+def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch, widen):
+    # widen 1.05: some boxes exceed 11 x 11 -> the all-modes descriptor kernel (plain-loop box sums); 0.97: every box
+    # fits -> the camera-aware-only kernel, which carries the fixed-trip box sum alone (round 4)
     cfg = synth.euroc_config()
     cam = cfg.cams[0]
     rng = np.random.default_rng(5)
@@ -59,7 +62,7 @@ def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch):
     for i in range(n):
         p.px[i] = np.float32(np.cos(a) * px[i] - np.sin(a) * py[i])
         p.py[i] = np.float32(np.sin(a) * px[i] + np.cos(a) * py[i])
-        p.sigma_half[i] = np.float32(base.sigma_half[i] * (0.9 if i % 3 else 1.05))
+        p.sigma_half[i] = np.float32(base.sigma_half[i] * (0.9 if i % 3 else widen))
     pairs = [(base.short_i[b], base.short_j[b]) for b in range(base.n_short)
              if base.short_i[b] < n and base.short_j[b] < n]
     order = rng.permutation(len(pairs))[:300]
@@ -77,6 +80,7 @@ def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch):
     for l, (i, j, wx, wy) in enumerate(longs):
         p.long_i[l], p.long_j[l], p.long_wdx[l], p.long_wdy[l] = i, j, wx + (l % 3) - 1, wy - (l % 2)
     p.border = base.border
+    assert (max(p.sigma_half[:n]) > 4.75) == (widen > 1.0)
     q = _to_orc(oracle, p)
     monkeypatch.setattr(oracle, "pattern", lambda: q)  # oracle.describe / detect_describe read it per call
     fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
