@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define OKVFE_ABI_VERSION 5
+#define OKVFE_ABI_VERSION 6
 #define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
@@ -581,15 +581,17 @@ okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0
                                               okvfe_stereo_match* matches_dev, void* stream);
 
 /* ---- sampling pattern as data ------------------------------------------------ */
-/* The extractor's sampling pattern is DATA: the pattern the library builds at okvfe_create restates
- * the published BRISK geometry (the BRISK2 pattern of the reference's
- * `brisk` submodule could not be read here); a pattern confirmed against a real brisk build --
- * sample offsets, smoothing half-widths, the short pairs IN BIT ORDER, the long pairs of the
- * orientation estimate -- is installed with okvfe_set_pattern and replaces it without touching a
- * kernel.  Limits of the kernels: <= 60 sample points (one lane each), <= 384 short pairs (bit b of
+/* The extractor's sampling pattern is DATA.  The pattern the library builds at okvfe_create carries
+ * BRISK2's pair table and bit order as recovered from the 819 real BRISK2 descriptors of the
+ * reference's vocabulary (66 sample points, 384 live bits; tools/pattern/README.md, INTEGRATION.md
+ * section 0) on the published BRISK ring radii and smoothing widths, which the reference tree cannot
+ * confirm (its `brisk` submodule is empty).  A pattern dumped from a real brisk build -- sample
+ * offsets, smoothing half-widths, the short pairs IN BIT ORDER, the long pairs of the orientation
+ * estimate -- is installed with okvfe_set_pattern and replaces it without touching a kernel.
+ * Limits of the kernels: <= 72 sample points (lane i; points 64.. take a second pass), <= 384 short pairs (bit b of
  * the 48-byte row = value[short_i[b]] > value[short_j[b]]; unused bits stay 0), <= 1100 long pairs,
  * border >= the farthest sample + its half-width + 1.  okvfe_set_pattern synchronises the context. */
-#define OKVFE_PATTERN_POINTS 60
+#define OKVFE_PATTERN_POINTS 72
 #define OKVFE_PATTERN_SHORT_PAIRS 384
 #define OKVFE_PATTERN_LONG_PAIRS 1100
 typedef struct okvfe_pattern {

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("OKVFE_LIB") or os.path.join(_HERE, "libokvfe.so")  # 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
     ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
-ABI_VERSION = 5
+ABI_VERSION = 6
 SCORE_HARRIS, SCORE_AGAST_9_16, SCORE_BRISK_SCALESPACE = 0, 1, 2
 DESC_BYTES = 48
 
@@ -57,8 +57,8 @@ class StereoPair(C.Structure):
 
 class PatternData(C.Structure):
     """okvfe_pattern: the extractor's sampling pattern as data (okvfe_get_pattern / okvfe_set_pattern)."""
-    _fields_ = [("n_points", C.c_int32), ("px", C.c_float * 60), ("py", C.c_float * 60),
-                ("sigma_half", C.c_float * 60), ("n_short", C.c_int32),
+    _fields_ = [("n_points", C.c_int32), ("px", C.c_float * 72), ("py", C.c_float * 72),
+                ("sigma_half", C.c_float * 72), ("n_short", C.c_int32),
                 ("short_i", C.c_uint8 * 384), ("short_j", C.c_uint8 * 384),
                 ("n_long", C.c_int32), ("long_i", C.c_uint8 * 1100), ("long_j", C.c_uint8 * 1100),
                 ("long_wdx", C.c_int32 * 1100), ("long_wdy", C.c_int32 * 1100), ("border", C.c_int32)]

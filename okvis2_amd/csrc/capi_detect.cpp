@@ -97,8 +97,11 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
 // to fit its 11 x 11 slots (sigma_half <= 4.75: the built-in pattern; okvfe_set_pattern may install wider samples,
 // which take the all-modes kernel).
 static bool pattern_small_boxes(const okvfe::Pattern& P) {
+  // first-pass samples (points extra ..): 11 x 11 slots; second-pass samples (points 0 .. extra-1 of a pattern with
+  // more than 64 points): 5 x 5 slots (k_describe.hip: kMaxBox, kSmallBox)
+  const int extra = P.n_points > 64 ? P.n_points - 64 : 0;
   for (int i = 0; i < P.n_points && i < okvfe::kPatternPoints; ++i)
-    if (!(P.sigma_half[i] <= 4.75f)) return false;
+    if (!(P.sigma_half[i] <= (i < extra ? 2.0f : 4.75f))) return false;
   return true;
 }
 

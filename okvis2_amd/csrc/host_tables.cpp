@@ -1,6 +1,6 @@
 // host_tables.cpp -- host-side tables and camera input preparation of libokvfe.so (product code).
 //
-//   build_pattern          BRISK2-style sampling pattern (data consumed by k_describe.hip).
+//   build_pattern          BRISK2 sampling pattern: recovered pair table + published ring geometry (data consumed by k_describe.hip).
 //   build_uniformity_lut   31x31 radial stamp of the uniformity enforcement (k_select.hip).
 //   build_awareness_maps   = okvis::cameras::PinholeCamera<D>::initialiseCameraAwarenessMaps
 //                            (okvis_cv/include/okvis/cameras/implementation/PinholeCamera.hpp:180-208):
@@ -20,18 +20,22 @@
 #include <cstring>
 
 #include "atan_fixed.h"
+#include "brisk2_pairs.h"
 #include "equidistant_jacobian.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
 
 void build_pattern(Pattern* p) {
-  // published BRISK geometry: rings of radius {0,2.9,4.9,7.4,10.8}*0.85 with {1,10,14,15,20}
-  // points, smoothing sigma 1.3 * (ring spacing), at the fixed scale of the non-scale-invariant
-  // extractor; the 383 pairs closer than 5.10 make the 384-bit row (bit 383 stays 0); pairs
-  // further apart than 8.2 feed the gradient orientation.
-  const double ring_radius[5] = {0.0, 2.9, 4.9, 7.4, 10.8};
-  const int ring_points[5] = {1, 10, 14, 15, 20};
+  // The BRISK2 pattern as recovered from the 819 real node descriptors of the reference's vocabulary
+  // (resources/small_voc.yml.gz; tools/pattern/README.md): 66 sample points -- centre, hexagon, rings of
+  // 10 / 14 / 15 / 20 -- and the 384 short pairs of brisk2_pairs.h in the generator's loop order (all 384
+  // bits live).  Assumed, not recoverable from bits: ring radii {0,1.4,2.9,4.9,7.4,10.8}*0.85 and box
+  // half-side 1.3 * r * sin(pi/n) (published BRISK constants + a hexagon radius inside the interval the pair
+  // rule allows), at the fixed scale of the non-scale-invariant extractor; pairs further apart than 8.2
+  // feed the gradient orientation.
+  const double ring_radius[6] = {0.0, 1.4, 2.9, 4.9, 7.4, 10.8};
+  const int ring_points[6] = {1, 6, 10, 14, 15, 20};
   const double lb_range = std::log(30.0) / std::log(2.0);
   const int scale_index = static_cast<int>(64.0 / lb_range * (std::log(1.45 / 0.6) / std::log(2.0)) + 0.5);
   const double scale = std::pow(2.0, static_cast<double>(scale_index) * (lb_range / 64.0));
@@ -39,7 +43,7 @@ void build_pattern(Pattern* p) {
   double ux[kPatternPoints], uy[kPatternPoints];
   int n = 0;
   double reach = 0.0;
-  for (int ring = 0; ring < 5; ++ring) {
+  for (int ring = 0; ring < 6; ++ring) {
     const double r = ring_radius[ring] * 0.85;
     for (int j = 0; j < ring_points[ring]; ++j, ++n) {
       const double alpha = static_cast<double>(j) * 2.0 * M_PI / static_cast<double>(ring_points[ring]);
@@ -64,16 +68,17 @@ void build_pattern(Pattern* p) {
     p->box_scaling[i] = scaling;
     p->box_scaling2[i] = static_cast<int>(s2 / 1024.0f);
   }
+  static_assert(OKVFE_BRISK2_PAIR_N_PAIRS == 384, "48-byte rows");
+  p->n_short = OKVFE_BRISK2_PAIR_N_PAIRS;
+  for (int b = 0; b < OKVFE_BRISK2_PAIR_N_PAIRS; ++b) {
+    p->short_i[b] = okvfe_brisk2_pair_i[b];
+    p->short_j[b] = okvfe_brisk2_pair_j[b];
+  }
   for (int i = 1; i < n; ++i) {
     for (int j = 0; j < i; ++j) {
       const double dx = ux[j] - ux[i], dy = uy[j] - uy[i];
       const double norm_sq = dx * dx + dy * dy;
-      const double d = std::sqrt(norm_sq);
-      if (d < 5.10 && p->n_short < 384) {
-        p->short_i[p->n_short] = static_cast<uint8_t>(i);
-        p->short_j[p->n_short] = static_cast<uint8_t>(j);
-        ++p->n_short;
-      } else if (d > 8.2 && p->n_long < kMaxLongPairs) {
+      if (std::sqrt(norm_sq) > 8.2 && p->n_long < kMaxLongPairs) {
         p->long_i[p->n_long] = static_cast<uint8_t>(i);
         p->long_j[p->n_long] = static_cast<uint8_t>(j);
         p->long_wdx[p->n_long] = static_cast<int32_t>(std::floor((dx / norm_sq) * 2048.0 + 0.5));

@@ -39,6 +39,7 @@ namespace {
 // float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
 constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
+constexpr int kSmallBox = 4;  // second pass of the camera-aware-only kernel: boxes of at most 5 x 5 (sigma_half <= 2.0)
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
 constexpr int kZeroRowBytes = 160;  // >= the widest patch row (152 B) + the 3-dword reads past a box
 constexpr int kPatchBufBytes = 6144;
@@ -73,7 +74,9 @@ __device__ __forceinline__ int div_nonneg(int num, int den) {
 
 // FASTONLY: every box of the pattern is at most 11 x 11 (sigma_half <= 4.75, checked on the host): the plain-loop
 // form and the test for it are compiled out.
-template <bool FASTONLY = false, typename PX>
+// MAXB: largest box side minus one the fixed-trip form serves (kMaxBox; the second-pass samples of a pattern
+// with more than 64 points are its innermost, smallest boxes and take kSmallBox: 4 row slots, 2 dwords).
+template <bool FASTONLY = false, int MAXB = 10, typename PX>
 __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
                                                   float sigma_half, int scaling, int scaling2) {
   if (sigma_half < 0.5f) {
@@ -109,7 +112,7 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
   int upper = 0, middle = 0, left = 0, right = 0, bottom = 0;
   const int bw = x_right - x_left, bh = y_bottom - y_top;  // >= 1 for sigma_half >= 0.5
   if constexpr (PX::kFixedTrip) {
-  if (FASTONLY || __all(bw <= kMaxBox && bh <= kMaxBox)) {
+  if (FASTONLY || __all(bw <= MAXB && bh <= MAXB)) {
     // Fixed trip counts, no data-dependent selects: the top and the bottom row are read once each,
     // then kMaxBox - 1 interior slots, where a slot past the box (dy >= bh) reads the all-zero
     // row of the patch instead, so every accumulation is unconditional.  Interior columns
@@ -119,9 +122,10 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     const int xi0 = cl + 1;
     const int q0 = xi0 >> 2;
     const int lo = xi0 & 3, ni = bw - 1;
-    uint32_t m[3];
+    constexpr int kDw = (MAXB + 5) / 4;  // interior <= MAXB - 1 bytes from byte 0..3 of the first dword
+    uint32_t m[kDw];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < kDw; ++j) {
       int sb = lo - 4 * j, eb = sb + ni;
       sb = sb < 0 ? 0 : sb;
       eb = eb > 4 ? 4 : eb;
@@ -141,9 +145,9 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
       pl = px.patch[off + cl];
       pr = px.patch[off + cr];
       const uint32_t* d = reinterpret_cast<const uint32_t*>(px.patch + off) + q0;
-      acc = __builtin_amdgcn_sad_u8(d[0] & m[0], 0u, acc);
-      acc = __builtin_amdgcn_sad_u8(d[1] & m[1], 0u, acc);
-      return __builtin_amdgcn_sad_u8(d[2] & m[2], 0u, acc);
+#pragma unroll
+      for (int j = 0; j < kDw; ++j) acc = __builtin_amdgcn_sad_u8(d[j] & m[j], 0u, acc);
+      return acc;
     };
     upper = (int)read_row(run, 0u);
     ret = mul24i(A, pl) + mul24i(B, pr);
@@ -151,7 +155,7 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     ret += mul24i(D, pl) + mul24i(C, pr);
     uint32_t mid = 0u;
 #pragma unroll
-    for (int dy = 1; dy < kMaxBox; ++dy) {
+    for (int dy = 1; dy < MAXB; ++dy) {
       run += pitch;
       mid = read_row(dy < bh ? run : -kZeroRowBytes, mid);
       left += pl;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   constexpr int kBufBytes = kWavesPerSimd >= 6 ? kPatchBufBytes : OKVFE_DESC_WIDE_BUF;
   constexpr int kDataBytes = kBufBytes - kZeroRowBytes - 16;
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kBufBytes];
-  __shared__ int values[kDescWaves][64];
+  __shared__ int values[kDescWaves][kPatternPoints];
   // the 383 short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
   // they were a third dependent round trip in every keypoint's chain
   __shared__ uint16_t short_pairs[384];
@@ -295,13 +299,18 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   const uint8_t* im = images + (size_t)img * w * h;
   const ImageParams ip = prm[img];
   int border = pat->border;  // (per keypoint with scale-invariant extraction)
-  const bool active = lane < pat->n_points;  // <= kPatternPoints (okvfe_set_pattern may install fewer samples)
-  const int li = active ? lane : 0;
+  // lane l samples point extra + l; a pattern of more than 64 points (the built-in one has 66) gives its first
+  // `extra` points -- the innermost, smallest boxes -- to lanes 0..extra-1 in a second pass over the same patch
+  const int extra = __builtin_amdgcn_readfirstlane(pat->n_points > 64 ? pat->n_points - 64 : 0);
+  const bool active = extra + lane < pat->n_points;  // <= kPatternPoints (okvfe_set_pattern may install fewer samples)
+  const bool active2 = lane < extra;
+  const int li = active ? extra + lane : 0;
   float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
   int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];
   okvfe_keypoint kp;
   float M[4];
   float xf, yf;
+  int scale_idx = 0;  // this keypoint's rung of the scale ladder (wave-uniform)
   int* vals = values[wv];
   uint8_t* patch = patches[wv] + kZeroRowBytes;
   if (lane < kZeroRowBytes / 4) reinterpret_cast<uint32_t*>(patches[wv])[lane] = 0u;
@@ -390,7 +399,24 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   // values of all 60 samples under the current M; false when a box leaves the image
   auto sample_all = [&](bool fixed_box) -> bool {
     const bool ok = sample_pos(M, kp.x, kp.y, px, py, sg, w, h, &xf, &yf);
-    if (!__all(ok || !active)) return false;
+    // second-pass sample of lanes < extra: its constants are re-read per keypoint and its position is computed
+    // twice (here for the inside-the-image test, again after the first pass) so that nothing of it stays in
+    // registers across the first pass's box sum
+    int l2 = active2 ? lane : 0;
+    const bool ladder = !AWARE && scales != nullptr;
+    const int sc2 = ladder ? scale_idx : 0;
+    bool ok2 = true;
+    auto second_pos = [&](float* x2, float* y2, float* s2) -> bool {
+      const float px2 = ladder ? scales->px[sc2][l2] : pat->px[l2];
+      const float py2 = ladder ? scales->py[sc2][l2] : pat->py[l2];
+      *s2 = ladder ? scales->sigma_half[sc2][l2] : pat->sigma_half[l2];
+      return sample_pos(M, kp.x, kp.y, px2, py2, *s2, w, h, x2, y2);
+    };
+    if (extra > 0) {  // wave-uniform
+      float x2, y2, s2;
+      ok2 = second_pos(&x2, &y2, &s2) || !active2;
+    }
+    if (!__all((ok || !active) && ok2)) return false;
     int bx0, bx1, by0, by1;
     if (fixed_box) {  // circle of the pattern: covers every rotation (upright / gradient modes)
       const int cx = (int)kp.x, cy = (int)kp.y;
@@ -414,10 +440,26 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
     }
     PatchPx ppx;
-    int v = 0;
+    int v = 0, v2 = 0;
     if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
       if (active) v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+      if (extra > 0) {  // wave-uniform; AWARE: the host checked sigma_half <= 2.0 for these points (5 x 5 boxes)
+        const int b1 = ladder ? scales->box_scaling[sc2][l2] : pat->box_scaling[l2];
+        const int b2 = ladder ? scales->box_scaling2[sc2][l2] : pat->box_scaling2[l2];
+        asm volatile("" : "+v"(l2));  // opaque: the position is recomputed, not carried over the first pass
+        float xf2, yf2, sg2;
+        second_pos(&xf2, &yf2, &sg2);
+        if (active2) v2 = smoothed_intensity<AWARE, AWARE ? kSmallBox : kMaxBox>(ppx, xf2, yf2, sg2, b1, b2);
+      }
     } else {
+      if (extra > 0 && active2) {  // rare path (patch larger than the wave's buffer): the few extra samples read the image
+        const GlobalPx gpx2{im, w};
+        float xf2, yf2, sg2;
+        second_pos(&xf2, &yf2, &sg2);
+        const int b1 = ladder ? scales->box_scaling[sc2][l2] : pat->box_scaling[l2];
+        const int b2 = ladder ? scales->box_scaling2[sc2][l2] : pat->box_scaling2[l2];
+        v2 = smoothed_intensity(gpx2, xf2, yf2, sg2, b1, b2);
+      }
       // The patch does not fit in the wave's LDS buffer (wide-angle cameras stretch the camera-aware
       // pattern towards the image rim: fu = 350 on 640 px gives |M| up to ~1.6).  It is staged in
       // horizontal BANDS instead: a band holds as many rows as fit, every lane computes its sample in
@@ -466,7 +508,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       }
     }
     __builtin_amdgcn_wave_barrier();
-    vals[lane] = v;
+    vals[extra + lane] = v;  // extra + 63 < kPatternPoints
+    if (active2) vals[lane] = v2;
     __builtin_amdgcn_wave_barrier();
     return true;
   };
@@ -501,6 +544,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   bool valid = (vbyte & 1) != 0;
   if (!AWARE && scales) {  // wave-uniform: this keypoint's pattern scale (the AWARE form is launched without a ladder)
     const int sc = vbyte >> 1;
+    scale_idx = sc;
     px = scales->px[sc][li];
     py = scales->py[sc][li];
     sg = scales->sigma_half[sc][li];

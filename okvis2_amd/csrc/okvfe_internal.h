@@ -24,7 +24,7 @@ inline const char* lab_env(const char*) { return nullptr; }
 #endif
 
 
-constexpr int kPatternPoints = 60;
+constexpr int kPatternPoints = 72;  // capacity (lane i and, past 64, a second sample on lane i - 64); built-in: 66
 constexpr int kMaxLongPairs = 1100;
 constexpr int kRot = 1024;
 

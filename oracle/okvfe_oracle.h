@@ -60,8 +60,8 @@ typedef struct orc_point_score {
 } orc_point_score;
 
 #define ORC_DESC_BYTES 48      /* FBrisk.hpp:35 (L = 48) */
-#define ORC_PATTERN_POINTS 60
-#define ORC_SHORT_PAIRS 383    /* bits 0..382 used, bit 383 always zero */
+#define ORC_PATTERN_POINTS 72     /* capacity; the default pattern has 66 */
+#define ORC_SHORT_PAIRS 384
 #define ORC_MAX_LONG_PAIRS 1100
 
 typedef struct orc_pattern {
@@ -112,7 +112,8 @@ int orc_detect(const uint8_t* img, int w, int h, int stride, float uniformity_ra
                int32_t* score_out /* optional h*w */);
 
 /* ---- extractor (A2) ------------------------------------------------------ */
-void orc_pattern_build(orc_pattern* p);
+void orc_pattern_build(orc_pattern* p);           /* recovered BRISK2 table, 66 points (default) */
+void orc_pattern_build_published(orc_pattern* p); /* published BRISK rings, 60 points, 383 pairs */
 void orc_integral(const uint8_t* img, int w, int h, int stride, int32_t* integral /* (h+1)*(w+1) */);
 int orc_smoothed_intensity(const uint8_t* img, const int32_t* integral, int w, int h, int stride,
                            float xf, float yf, float sigma_half);

@@ -10,12 +10,13 @@
  *
  * TEST INFRASTRUCTURE ONLY (see okvfe_oracle.h).  PARITY UNPINNED: the brisk
  * submodule (and with it the BRISK2 pattern file) is absent.  This restates
- * the published BRISK descriptor: a ring pattern of 60 sample points, each
- * smoothed by a box of half-side sigma with sub-pixel edge weights, short
- * point pairs compared into bits.  The pattern is DATA (orc_pattern): the
- * default built here uses the published BRISK rings {0,2.9,4.9,7.4,10.8}*0.85
- * with {1,10,14,15,20} points at the fixed non-scale-invariant scale, and the
- * 383 shortest pairs (d < 5.10) as bits 0..382 of the 384-bit row.
+ * the published BRISK descriptor arithmetic: a ring pattern of sample points,
+ * each smoothed by a box of half-side sigma with sub-pixel edge weights, short
+ * point pairs compared into bits.  The pattern is DATA (orc_pattern).  Its
+ * PAIR TABLE AND BIT ORDER are pinned on the 819 real BRISK2 descriptors of
+ * resources/small_voc.yml.gz (tools/pattern/README.md; 7 impossible outcomes
+ * over 740 implied point triangles, 384 live bits); radii and box sizes remain
+ * the published BRISK constants (assumed).
  *
  * Orientation modes:
  *   UPRIGHT       rotationInvariant=false: M = I.
@@ -37,22 +38,22 @@
 #include <string.h>
 
 /* ---- pattern ------------------------------------------------------------------------------ */
-void orc_pattern_build(orc_pattern* p) {
-  static const double radius[5] = {0.0, 2.9, 4.9, 7.4, 10.8};
-  static const int number[5] = {1, 10, 14, 15, 20};
-  const double pattern_scale = 0.85;
-  const double d_max = 5.10, d_min = 8.2;
-  const double sigma_scale = 1.3;
-  /* fixed scale of the non-scale-invariant extractor: index 17 of 64 scales over a range of 30
-   * = max(int(64/lb(30) * lb(1.45*12/(0.6*12)) + 0.5), 0) */
+#include "brisk2_pairs.h"
+
+/* geometry shared by both builders: rings of `number[]` points at `radius[] * 0.85`, box half-side
+ * 1.3 * r * sin(pi / n) (centre: 1.3 * 0.5), everything at the fixed scale of the non-scale-invariant
+ * extractor: index 17 of 64 scales over a range of 30
+ * = max(int(64/lb(30) * lb(1.45*12/(0.6*12)) + 0.5), 0) */
+static void pattern_points(orc_pattern* p, const double* radius, const int* number, int rings, double* ux,
+                           double* uy) {
+  const double pattern_scale = 0.85, sigma_scale = 1.3;
   const double lb_scalerange = log(30.0) / log(2.0);
   const int basicscale = (int)(64.0 / lb_scalerange * (log(1.45 / 0.6) / log(2.0)) + 0.5);
   const double scale = pow(2.0, (double)basicscale * (lb_scalerange / 64.0));
   memset(p, 0, sizeof(*p));
-  double ux[ORC_PATTERN_POINTS], uy[ORC_PATTERN_POINTS]; /* unscaled */
   int n = 0;
   double border = 0.0;
-  for (int ring = 0; ring < 5; ++ring) {
+  for (int ring = 0; ring < rings; ++ring) {
     const double r = radius[ring] * pattern_scale;
     for (int j = 0; j < number[ring]; ++j) {
       const double alpha = (double)j * 2.0 * M_PI / (double)number[ring];
@@ -61,7 +62,7 @@ void orc_pattern_build(orc_pattern* p) {
       p->px[n] = (float)(scale * ux[n]);
       p->py[n] = (float)(scale * uy[n]);
       double sigma;
-      if (ring == 0)
+      if (radius[ring] == 0.0)
         sigma = sigma_scale * scale * 0.5;
       else
         sigma = sigma_scale * scale * r * sin(M_PI / (double)number[ring]);
@@ -73,16 +74,21 @@ void orc_pattern_build(orc_pattern* p) {
   }
   p->n_points = n;
   p->border = (int)ceil(border) + 1;
-  for (int i = 1; i < n; ++i) {
+  for (int k = 0; k < 1024; ++k) {
+    const double a = (double)k * 2.0 * M_PI / 1024.0;
+    p->rot_cos[k] = (int32_t)lround(32768.0 * cos(a));
+    p->rot_sin[k] = (int32_t)lround(32768.0 * sin(a));
+    p->rot_cosf[k] = (float)cos(a);
+    p->rot_sinf[k] = (float)sin(a);
+  }
+}
+/* long pairs (gradient orientation): every pair further apart than d_min, published weights */
+static void pattern_long_pairs(orc_pattern* p, const double* ux, const double* uy, double d_min) {
+  for (int i = 1; i < p->n_points; ++i) {
     for (int j = 0; j < i; ++j) {
       const double dx = ux[j] - ux[i], dy = uy[j] - uy[i];
       const double norm_sq = dx * dx + dy * dy;
-      const double d = sqrt(norm_sq);
-      if (d < d_max && p->n_short < 384) {
-        p->short_i[p->n_short] = (uint8_t)i;
-        p->short_j[p->n_short] = (uint8_t)j;
-        p->n_short++;
-      } else if (d > d_min && p->n_long < ORC_MAX_LONG_PAIRS) {
+      if (sqrt(norm_sq) > d_min && p->n_long < ORC_MAX_LONG_PAIRS) {
         p->long_i[p->n_long] = (uint8_t)i;
         p->long_j[p->n_long] = (uint8_t)j;
         p->long_wdx[p->n_long] = (int32_t)floor((dx / norm_sq) * 2048.0 + 0.5);
@@ -91,13 +97,42 @@ void orc_pattern_build(orc_pattern* p) {
       }
     }
   }
-  for (int k = 0; k < 1024; ++k) {
-    const double a = (double)k * 2.0 * M_PI / 1024.0;
-    p->rot_cos[k] = (int32_t)lround(32768.0 * cos(a));
-    p->rot_sin[k] = (int32_t)lround(32768.0 * sin(a));
-    p->rot_cosf[k] = (float)cos(a);
-    p->rot_sinf[k] = (float)sin(a);
+}
+
+/* Default: the BRISK2 pattern as recovered from the reference's vocabulary (tools/pattern/README.md):
+ * 66 points -- centre, hexagon, rings of 10 / 14 / 15 / 20 -- and the 384 pairs of brisk2_pairs.h in the
+ * generator's loop order.  Radii and box sizes are the published BRISK constants plus a hexagon radius
+ * from the interval the pair rule leaves (assumptions, stated in the README). */
+void orc_pattern_build(orc_pattern* p) {
+  static const double radius[6] = {0.0, 1.4, 2.9, 4.9, 7.4, 10.8};
+  static const int number[6] = {1, 6, 10, 14, 15, 20};
+  double ux[ORC_PATTERN_POINTS], uy[ORC_PATTERN_POINTS]; /* unscaled */
+  pattern_points(p, radius, number, 6, ux, uy);
+  p->n_short = ORC_BRISK2_PAIR_N_PAIRS;
+  for (int b = 0; b < ORC_BRISK2_PAIR_N_PAIRS; ++b) {
+    p->short_i[b] = orc_brisk2_pair_i[b];
+    p->short_j[b] = orc_brisk2_pair_j[b];
   }
+  pattern_long_pairs(p, ux, uy, 8.2);
+}
+
+/* The published BRISK form used as the default until round 5: 60 points on {1,10,14,15,20} rings and the
+ * 383 pairs closer than 5.10 (bit 383 stays 0).  Kept as a second pattern for the pattern-is-data tests. */
+void orc_pattern_build_published(orc_pattern* p) {
+  static const double radius[5] = {0.0, 2.9, 4.9, 7.4, 10.8};
+  static const int number[5] = {1, 10, 14, 15, 20};
+  double ux[ORC_PATTERN_POINTS], uy[ORC_PATTERN_POINTS];
+  pattern_points(p, radius, number, 5, ux, uy);
+  for (int i = 1; i < p->n_points; ++i)
+    for (int j = 0; j < i; ++j) {
+      const double dx = ux[j] - ux[i], dy = uy[j] - uy[i];
+      if (sqrt(dx * dx + dy * dy) < 5.10 && p->n_short < 384) {
+        p->short_i[p->n_short] = (uint8_t)i;
+        p->short_j[p->n_short] = (uint8_t)j;
+        p->n_short++;
+      }
+    }
+  pattern_long_pairs(p, ux, uy, 8.2);
 }
 
 /* ---- scale invariance (scaleInvariant = true, Frontend.hpp:235-237 / Frontend.cpp:2410-2412) ----

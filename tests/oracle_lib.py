@@ -28,8 +28,8 @@ MODE_UPRIGHT, MODE_GRADIENT, MODE_CAMERA_AWARE = 0, 1, 2
 
 
 class Pattern(C.Structure):
-    _fields_ = [("n_points", C.c_int32), ("px", C.c_float * 60), ("py", C.c_float * 60),
-                ("sigma_half", C.c_float * 60), ("n_short", C.c_int32),
+    _fields_ = [("n_points", C.c_int32), ("px", C.c_float * 72), ("py", C.c_float * 72),
+                ("sigma_half", C.c_float * 72), ("n_short", C.c_int32),
                 ("short_i", C.c_uint8 * 384), ("short_j", C.c_uint8 * 384),
                 ("n_long", C.c_int32), ("long_i", C.c_uint8 * 1100), ("long_j", C.c_uint8 * 1100),
                 ("long_wdx", C.c_int32 * 1100), ("long_wdy", C.c_int32 * 1100),
@@ -102,6 +102,13 @@ def pattern() -> Pattern:
         _PATTERN = Pattern()
         lib().orc_pattern_build(C.byref(_PATTERN))
     return _PATTERN
+
+
+def pattern_published() -> Pattern:
+    """the 60-point / 383-pair published-BRISK form (the default until round 5), as a second pattern"""
+    p = Pattern()
+    lib().orc_pattern_build_published(C.byref(p))
+    return p
 
 
 def harris_score(img: np.ndarray) -> np.ndarray:

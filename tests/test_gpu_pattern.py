@@ -30,7 +30,7 @@ def test_default_pattern_round_trips_and_equals_the_oracles(oracle):
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg)
     p, o = fe.get_pattern(), oracle.pattern()
-    assert p.n_points == o.n_points == 60 and p.n_short == o.n_short == 383 and p.border == o.border
+    assert p.n_points == o.n_points == 66 and p.n_short == o.n_short == 384 and p.border == o.border
     for f in ("px", "py", "sigma_half", "short_i", "short_j", "long_wdx", "long_wdy"):
         assert bytes(getattr(p, f)) == bytes(getattr(o, f)), f
     fe.set_pattern(p)  # installing what is there changes nothing
@@ -42,29 +42,38 @@ def test_default_pattern_round_trips_and_equals_the_oracles(oracle):
     assert np.array_equal(d, rd)
 
 
-@pytest.mark.parametrize("widen", [1.05, 0.97])
-def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch, widen):
+@pytest.mark.parametrize("widen,n,fat_first", [(1.05, 52, False), (0.97, 52, False), (1.05, 66, False),
+                                                (0.97, 66, False), (0.97, 66, True), (0.97, 70, False)])
+def test_replaced_pattern_stays_bit_exact_in_every_mode(oracle, monkeypatch, widen, n, fat_first):
     # widen 1.05: some boxes exceed 11 x 11 -> the all-modes descriptor kernel (plain-loop box sums); 0.97: every box
-    # fits -> the camera-aware-only kernel, which carries the fixed-trip box sum alone (round 4)
+    # fits -> the camera-aware-only kernel, which carries the fixed-trip box sum alone (round 4).
+    # n > 64 (round 5: the built-in pattern has 66 points): points 0..n-65 are a second pass of lanes 0..n-65 --
+    # 5 x 5 slots in the camera-aware-only kernel, which fat_first (a second-pass box wider than that) must leave.
+    # n = 70: four synthetic extra points appended (six second-pass samples)
     cfg = synth.euroc_config()
     cam = cfg.cams[0]
     rng = np.random.default_rng(5)
     base = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts).get_pattern()
     p = capi.PatternData()
     C.memmove(C.byref(p), C.byref(base), C.sizeof(p))
-    # 52 samples (the last 8 of the outer ring dropped), offsets shrunk and rotated by 7 degrees,
+    # n samples (52: the last 14 of the outer ring dropped), offsets shrunk and rotated by 7 degrees,
     # half-widths changed, pairs re-derived from the kept samples in a permuted bit order with some
-    # pairs flipped, 300 of them; long pairs re-weighted
-    n = 52
+    # pairs flipped, at most 300 of them; long pairs re-weighted
     a = np.deg2rad(7.0)
-    px, py = np.array(base.px[:n]) * 0.93, np.array(base.py[:n]) * 0.93
+    bx = list(base.px[:66]) + [3.1, -4.2, 0.7, -1.3][:max(n - 66, 0)]
+    by = list(base.py[:66]) + [-2.2, 1.9, 5.1, -6.4][:max(n - 66, 0)]
+    bs = list(base.sigma_half[:66]) + [2.5, 3.0, 2.2, 1.7][:max(n - 66, 0)]
+    px, py = np.array(bx[:n]) * 0.93, np.array(by[:n]) * 0.93
     p.n_points = n
     for i in range(n):
         p.px[i] = np.float32(np.cos(a) * px[i] - np.sin(a) * py[i])
         p.py[i] = np.float32(np.sin(a) * px[i] + np.cos(a) * py[i])
-        p.sigma_half[i] = np.float32(base.sigma_half[i] * (0.9 if i % 3 else widen))
+        p.sigma_half[i] = np.float32(bs[i] * (0.9 if i % 3 else widen))
+    if fat_first:
+        p.sigma_half[1] = np.float32(2.6)
     pairs = [(base.short_i[b], base.short_j[b]) for b in range(base.n_short)
              if base.short_i[b] < n and base.short_j[b] < n]
+    pairs += [(i, i - 5) for i in range(66, n)] + [(i - 60, i) for i in range(66, n)]
     order = rng.permutation(len(pairs))[:300]
     p.n_short = len(order)
     for b, o in enumerate(order):
@@ -122,7 +131,7 @@ def test_bad_patterns_are_rejected():
         if edit == "points":
             p.n_points = 61
         elif edit == "pair":
-            p.short_i[5] = 60
+            p.short_i[5] = 70
         elif edit == "border":
             p.border = 5
         else:

@@ -173,11 +173,13 @@ def test_descriptor_contract(oracle):
     img = synth.corners_image(cfg.w, cfg.h, 21)
     kps = oracle.detect(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts)
     pat = oracle.pattern()
-    assert pat.n_points == 60 and pat.n_short == 383 and pat.n_long == 870 and pat.border == 29
+    assert pat.n_points == 66 and pat.n_short == 384 and pat.n_long == 968 and pat.border == 29
+    pub = oracle.pattern_published()
+    assert pub.n_points == 60 and pub.n_short == 383 and pub.n_long == 870 and pub.border == 29
     for mode in (oracle.MODE_UPRIGHT, oracle.MODE_GRADIENT):
         k, d = oracle.describe(img, kps, mode)
         assert d.shape == (len(k), 48) and len(k) <= len(kps)        # desc.cols == 48
-        assert not (d[:, 47] & 0x80).any()                            # bit 383 unused
+        assert (d[:, 47] & 0x80).any() and not (d[:, 47] & 0x80).all()  # bit 383 live
         b = pat.border
         assert np.all((k["x"] >= b) & (k["x"] < cfg.w - b) & (k["y"] >= b) & (k["y"] < cfg.h - b))
         assert 0.35 < np.unpackbits(d).mean() < 0.65

@@ -6,9 +6,9 @@ tools/make_real_image_fixture.py).
    -m gpu twin of this file, test_gpu_real_image.py, holds the HIP path to the same vectors);
  * the oracle's descriptors of REAL content are compared with the only real BRISK2 outputs the
    reference tree holds, the 819 node descriptors of resources/small_voc.yml.gz: nearest-word
-   Hamming distances through the real 9^3 tree and the bit-to-bit correlation structure.  The
-   outcome is recorded as it is (VERDICT r3 item 1b asked for the numbers "either way"): the
-   built-in sampling pattern does NOT reproduce BRISK2's pair set / bit order.
+   Hamming distances through the real 9^3 tree, the bit-to-bit correlation structure, and the exact
+   transitivity check of the pair table (the table was recovered from these descriptors in round 5,
+   tools/pattern/README.md).
 """
 import hashlib
 import os
@@ -73,64 +73,96 @@ def _hamming(A, B):
     return (a @ (1 - b).T + (1 - a) @ b.T).astype(np.int32)
 
 
-def test_oracle_descriptors_against_the_real_brisk2_vocabulary(oracle):
-    """What the 819 real BRISK2 descriptors say about the oracle's descriptor arithmetic.
-
-    Two statistics, each with its "same extractor" and "unrelated bits" reference points:
-     (1) distance from a descriptor to the nearest vocabulary node (brute force and through the
-         real tree's descent): descriptors of one extractor on unrelated scenes lie much closer
-         to each other than random bit strings do, because bits that share a sample point are
-         correlated;
-     (2) the correlation of the two 384x384 bit-correlation matrices: the same pair set in the
-         same bit order gives a value near 1, an unrelated order a value near 0.
-    Measured: (1) 149.6 (random 163.5; the oracle's descriptors of OTHER images among
-    themselves 105); (2) 0.09.  And the vocabulary's bit 383 is live (density 0.46) where the
-    oracle's 383 short pairs leave it zero.  So the restated pattern is distinguishable from
-    real BRISK2: the pattern is data (okvfe_set_pattern), and bit-compatibility with stored BRISK2
-    descriptors (maps, vocabularies) needs the real pattern installed."""
+def _voc_statistics(oracle, d):
     voc = np.fromfile(os.path.join(GOLDEN, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+    bo, bv = _bits(d), _bits(voc)
+    co, cv = np.corrcoef(bo.T), np.corrcoef(bv.T)
+    iu = np.triu_indices(384, 1)
+    return _hamming(d, voc).min(axis=1).mean(), np.corrcoef(co[iu], cv[iu])[0, 1], bo, bv
+
+
+def test_oracle_descriptors_against_the_real_brisk2_vocabulary(oracle):
+    """What the 819 real BRISK2 descriptors (resources/small_voc.yml.gz, FBrisk.hpp:35) say about the oracle's
+    descriptor: the pair table and bit order of the built-in pattern were recovered from them
+    (tools/pattern/README.md), and the oracle's descriptors of the only real image in the tree must now look
+    like BRISK2 -- where rounds 1-4's restated table did not (recorded then: nearest node 149.6, matrix
+    correlation 0.09, bit 383 dead).
+
+     (1) mean distance to the nearest vocabulary node: random strings 163.5, vocabulary nodes among themselves
+         47.7, oracle descriptors of another scene 114 (a blurred copy: 90);
+     (2) correlation of the two 384 x 384 bit-correlation matrices: 0.63 on this image (the statistic also
+         depends on image content and on the smoothing width, which stays an assumption: the forward simulator
+         of tools/pattern reaches 0.88 with wider smoothing);
+     (3) all 384 bits live with densities near one half, as in the vocabulary."""
     fx = RC.load()
     full = fx["image"]
-    k, d = oracle.detect_describe(full, 10.0, 0, 5, 4000, oracle.MODE_GRADIENT)
+    # upright = the gravity-aligned extraction of an upright camera, which is how the vocabulary's bits are
+    # distributed (densities 0.44..0.56); the gradient orientation skews the densities (0.28..0.72)
+    k, d = oracle.detect_describe(full, 10.0, 0, 5, 4000, oracle.MODE_UPRIGHT)
     assert len(k) > 1500
-    # committed camera-aware descriptors of the crops: a second, independent sample
-    d2 = np.concatenate([fx[f"{c.name}/desc_aware"] for c in RC.CASES])
+    near, r, bo, bv = _voc_statistics(oracle, d)
     rng = np.random.default_rng(0)
     rnd = rng.integers(0, 256, (2000, 48), dtype=np.uint8)
-
-    near_oracle = _hamming(d, voc).min(axis=1).mean()
-    near_aware = _hamming(d2, voc).min(axis=1).mean()
+    voc = np.fromfile(os.path.join(GOLDEN, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
     near_random = _hamming(rnd, voc).min(axis=1).mean()
     hv = _hamming(voc, voc)
     np.fill_diagonal(hv, 999)
-    near_voc = hv.min(axis=1).mean()
-    half = len(d) // 2
-    near_self = _hamming(d[:half], d[half:]).min(axis=1).mean()
-    # recorded values (tolerances = a few sigma of the sample means)
-    assert abs(near_voc - 47.7) < 0.5
+    assert abs(hv.min(axis=1).mean() - 47.7) < 0.5
     assert abs(near_random - 163.5) < 1.5
-    assert 140.0 < near_oracle < 158.0, near_oracle
-    assert 140.0 < near_aware < 158.0, near_aware
-    assert near_self < 115.0, near_self
+    assert near < 120.0, near            # measured 114.7 (rounds 1-4: 149.6)
+    assert r > 0.55, r                   # measured 0.630 (rounds 1-4: 0.087)
+    assert 0.40 < bo[:, 383].mean() < 0.52 and 0.40 < bv[:, 383].mean() < 0.52  # the last bit is live in both
+    dens = bo.mean(axis=0)
+    assert 0.40 < dens.min() and dens.max() < 0.60, (dens.min(), dens.max())
+    # the committed camera-aware descriptors of the crops: an independent sample, other orientation rule
+    d2 = np.concatenate([fx[f"{c.name}/desc_aware"] for c in RC.CASES])
+    near2, r2, _, _ = _voc_statistics(oracle, d2)
+    assert near2 < 120.0 and r2 > 0.4, (near2, r2)   # measured 111.9, 0.477 (checkerboard-heavy crops, tilted gravity)
 
-    # the tree descent of the reference's vocabulary reaches words at the same (random-like) distance
+    # the tree descent of the reference's vocabulary lands near the brute-force nearest node
     tree = np.load(os.path.join(GOLDEN, "small_voc_tree.npz"))
     begin, index = oracle.voc_tree_arrays(tree["parent"])
     words, nodes = oracle.voc_transform(d, tree["desc"], begin, index, tree["word"])
     assert words.min() >= 0 and words.max() < 729
     dist_word = np.array([oracle.popcnt_xor(d[i], tree["desc"][nodes[i]]) for i in range(0, len(d), 7)])
-    assert 150.0 < dist_word.mean() < 185.0, dist_word.mean()
+    assert dist_word.mean() < 150.0, dist_word.mean()   # rounds 1-4: 150..185 (random-like)
 
-    # (2) bit-correlation structure
-    bo, bv = _bits(d), _bits(voc)
-    assert bo[:, 383].max() == 0.0          # the oracle's 383 pairs never set the last bit ...
-    assert 0.40 < bv[:, 383].mean() < 0.52  # ... real BRISK2 does
-    dens = bv.mean(axis=0)
-    assert 0.44 < dens.min() and dens.max() < 0.56
-    co = np.corrcoef(bo[:, :383].T)
-    cv = np.corrcoef(bv[:, :383].T)
-    iu = np.triu_indices(383, 1)
-    r = np.corrcoef(co[iu], cv[iu])[0, 1]
-    assert abs(r) < 0.2, r                  # measured 0.087: unrelated pair order
-    # both have the banded structure of "consecutive bits share a sample point"
-    assert np.mean(np.abs(np.diagonal(co, 1))) > 0.3 and np.mean(np.abs(np.diagonal(cv, 1))) > 0.3
+
+def test_pair_table_is_consistent_with_every_vocabulary_descriptor(oracle):
+    """The exact part of the pin: when the comparisons among three sample points are all bits of the
+    descriptor, the cyclic outcome is impossible.  Over the 740 point triangles the built-in table implies,
+    the 819 node descriptors (bit-wise cluster majorities, so not strictly transitive) show 7 cyclic outcomes
+    in total; a table with one pair or one position wrong shows hundreds (three unrelated bits: ~205 each)."""
+    voc = np.fromfile(os.path.join(GOLDEN, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+    B = np.unpackbits(voc, axis=1, bitorder="little").astype(bool)
+    p = oracle.pattern()
+    assert p.n_points == 66 and p.n_short == 384
+    pairs = [(p.short_i[b], p.short_j[b]) for b in range(384)]
+    assert all(i > j for i, j in pairs) and len(set(pairs)) == 384
+    assert pairs == sorted(pairs)  # the generator's loop order: for i: for j < i
+    bit = {q: b for b, q in enumerate(pairs)}
+    below = {}
+    for i, j in pairs:
+        below.setdefault(i, []).append(j)
+    total, n_tri, worst = 0, 0, 0
+    for (z, y), c in bit.items():
+        for x in below.get(y, ()):
+            b = bit.get((z, x))
+            if b is None:
+                continue
+            a = bit[(y, x)]   # a = [y > x], b = [z > x], c = [z > y]: (1,0,1) and (0,1,0) are cycles
+            v = int(np.sum((B[:, a] & ~B[:, b] & B[:, c]) | (~B[:, a] & B[:, b] & ~B[:, c])))
+            total += v
+            n_tri += 1
+            worst = max(worst, v)
+    assert n_tri == 740 and total <= 7 and worst <= 2, (n_tri, total, worst)
+    # and a shifted table (every pair one position late) is rejected by the same count
+    shifted = pairs[-1:] + pairs[:-1]
+    sb = {q: b for b, q in enumerate(shifted)}
+    bad = 0
+    for (z, y), c in sb.items():
+        for x in below.get(y, ()):
+            if (z, x) in sb:
+                a, b = sb[(y, x)], sb[(z, x)]
+                bad += int(np.sum((B[:, a] & ~B[:, b] & B[:, c]) | (~B[:, a] & B[:, b] & ~B[:, c])))
+    assert bad > 20000, bad
