@@ -124,11 +124,16 @@ def cpu_baseline(cfg, base_imgs, fe, grav, poses, budget_s=12.0):
     t0 = time.perf_counter()
     while True:
         i = done % n_distinct
-        ths = [threading.Thread(target=work, args=(c, base_imgs[C * i + c], grav[C * i + c]))
+        # the batch tiles the distinct frames (each replica with its own extraction direction): frame i is
+        # computed -- and, in the checker leg below, compared -- as its replica j from the head, the middle or
+        # the tail of the batch in turn, so the checked rows span the whole address range of the step
+        reps = max(1, fe._bench_frames // n_distinct) if fe is not None else 1
+        j = i + n_distinct * (0, reps // 2, reps - 1)[i % 3]
+        ths = [threading.Thread(target=work, args=(c, base_imgs[C * i + c], grav[C * j + c]))
                for c in range(1, C)]
         for th in ths:
             th.start()
-        work(0, base_imgs[C * i], grav[C * i])
+        work(0, base_imgs[C * i], grav[C * j])
         for th in ths:
             th.join()
         (k0, d0, b0, v0) = out[0]
@@ -140,10 +145,10 @@ def cpu_baseline(cfg, base_imgs, fe, grav, poses, budget_s=12.0):
         elapsed = time.perf_counter() - t0
         if done <= n_distinct and fe is not None:  # checker leg, outside the measured work
             t_chk = time.perf_counter()
-            ok = m is None or np.array_equal(fe._bench_matches[i, :len(k0)].view(np.uint8),
+            ok = m is None or np.array_equal(fe._bench_matches[j, :len(k0)].view(np.uint8),
                                              m.view(np.uint8))
             for c in range(C):
-                g = fe.download(C * i + c)
+                g = fe.download(C * j + c)
                 ok = ok and np.array_equal(g[0].view(np.uint8), out[c][0].view(np.uint8)) \
                     and np.array_equal(g[1], out[c][1]) \
                     and np.array_equal(g[2].view(np.uint64), out[c][2].view(np.uint64))
@@ -959,6 +964,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         fe._bench_matches = m_host
+        fe._bench_frames = B
         cpu = cpu_baseline(cfg, base, fe, grav_v[last_v], pose_variant(cfg, last_v))
     for lane in lanes:
         lane[0].profile_enable(True)

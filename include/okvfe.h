@@ -251,6 +251,20 @@ int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x);
  * scale-space and AGAST contexts always keep theirs. */
 okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep);
 
+/* Order of every 3-term FP64 sum in the matchers' gate chain (dot products, norms, C * v and C^T * v:
+ * stereo_triangulation.cpp:62-76, Frontend.cpp:2027-2073 evaluate them through Eigen):
+ *   OKVFE_SUM3_EIGEN_TREE (default, ABI 6)  x0 + (x1 + x2) -- Eigen's unrolled non-vectorised reduction of a
+ *                                           fixed-size Vector3d (Redux.h, split at Length / 2), which is what a
+ *                                           stock build takes because Vector3d is not packet-aligned;
+ *   OKVFE_SUM3_LEFT_TO_RIGHT                (x0 + x1) + x2 -- the order ABI <= 5 used.
+ * Affects hp_W / quality / back-projection-derived values by <= 1 ulp per sum (decisions rarely flip, bytes do).
+ * Neither order can be confirmed against the reference in this tree (no Eigen); tools/ref_compare decides it
+ * on a machine with the reference built.  The setting lives on the context's DEVICE: it applies to every
+ * context of this process on that device, and the call synchronises the device. */
+#define OKVFE_SUM3_LEFT_TO_RIGHT 0
+#define OKVFE_SUM3_EIGEN_TREE 1
+okvfe_status okvfe_set_fp64_reduction(okvfe_ctx* ctx, int32_t order);
+
 /* Several contexts fed in turn from several host threads / streams on ONE GPU (a camera per context,
  * ThreadedSlam.cpp:434-448): mode 1 runs the score kernels of all contexts of the process on a device
  * one after the other in enqueue order while everything downstream of them overlaps freely, so the

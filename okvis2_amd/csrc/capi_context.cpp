@@ -282,6 +282,17 @@ okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep) {
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_set_fp64_reduction(okvfe_ctx* ctx, int32_t order) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (order != OKVFE_SUM3_LEFT_TO_RIGHT && order != OKVFE_SUM3_EIGEN_TREE)
+    return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_fp64_reduction: order %d", order);
+  if (hipSetDevice(ctx->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+    return fail(ctx, OKVFE_ERR_DEVICE, "okvfe_set_fp64_reduction: device %d", ctx->cfg.device);
+  if (!okvfe::set_fp64_tree_match(order) || !okvfe::set_fp64_tree_map(order))
+    return fail(ctx, OKVFE_ERR_DEVICE, "okvfe_set_fp64_reduction: writing the device flag failed");
+  return OKVFE_OK;
+}
+
 const char* okvfe_last_error(const okvfe_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }

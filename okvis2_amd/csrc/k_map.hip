@@ -6,20 +6,26 @@
 //                              (oracle: orc_prepare_landmarks documents the quirks);
 //   compact_landmarks_kernel   the 3-D landmarks as the packed set the matcher kernel reads
 //                              (projections, <= 2 pooled descriptors each), in landmark order.
-// FP64, left-to-right sums, no FMA; acos / cos through atan_fixed.h resp. host-computed constants.
+// FP64, 3-term sums in the order of okvfe_set_fp64_reduction, no FMA; acos / cos through atan_fixed.h resp. host-computed constants.
 #include "camera_dev.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
 namespace {
 
+// order of the 3-term sums: as in k_match.hip (okvfe_set_fp64_reduction), this translation unit's copy of the flag
+__device__ int g_fp64_tree_map = 1;
+__device__ __forceinline__ double sum3m(double p0, double p1, double p2) {
+  const bool tree = g_fp64_tree_map != 0;
+  const double u = tree ? p1 : p0, v = tree ? p2 : p1, w = tree ? p0 : p2;
+  const double s = u + v;
+  return tree ? w + s : s + w;
+}
 __device__ __forceinline__ double dot3m(const double a[3], const double b[3]) {
-  double s = a[0] * b[0];
-  double t = a[1] * b[1];
-  s = s + t;
-  t = a[2] * b[2];
-  s = s + t;
-  return s;
+  const double p0 = a[0] * b[0];
+  const double p1 = a[1] * b[1];
+  const double p2 = a[2] * b[2];
+  return sum3m(p0, p1, p2);
 }
 __device__ __forceinline__ void normalize3m(const double v[3], double out[3]) {
   const double n = sqrt(dot3m(v, v));
@@ -54,16 +60,8 @@ __global__ __launch_bounds__(128) void prepare_landmarks_kernel(
   // hp_C = T_WC1^-1 * hp_W
   double cr[3], hh[3], hp_C[4];
   for (int i = 0; i < 3; ++i) {
-    double s = T1.C[i] * T1.r[0];
-    double t = T1.C[3 + i] * T1.r[1];
-    s = s + t;
-    t = T1.C[6 + i] * T1.r[2];
-    cr[i] = s + t;
-    s = T1.C[i] * hp[0];
-    t = T1.C[3 + i] * hp[1];
-    s = s + t;
-    t = T1.C[6 + i] * hp[2];
-    hh[i] = s + t;
+    cr[i] = sum3m(T1.C[i] * T1.r[0], T1.C[3 + i] * T1.r[1], T1.C[6 + i] * T1.r[2]);
+    hh[i] = sum3m(T1.C[i] * hp[0], T1.C[3 + i] * hp[1], T1.C[6 + i] * hp[2]);
   }
   for (int i = 0; i < 3; ++i) hp_C[i] = hh[i] + (-cr[i]) * hp[3];
   hp_C[3] = hp[3];
@@ -210,6 +208,11 @@ void launch_compact_landmarks(const int32_t* status, const int32_t* n_desc, cons
                               int32_t* n_out, hipStream_t stream) {
   hipLaunchKernelGGL(compact_landmarks_kernel, dim3(1), dim3(1024), 0, stream, status, n_desc, obs_rows,
                      projection, obs_desc, n_landmarks, want, index_out, proj_out, begin_out, pool_out, n_out);
+}
+
+bool set_fp64_tree_map(int tree) {
+  const int v = tree != 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fp64_tree_map), &v, sizeof(v)) == hipSuccess;
 }
 
 }  // namespace okvfe

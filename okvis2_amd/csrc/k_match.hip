@@ -50,13 +50,20 @@ __device__ __forceinline__ int hamming(const Desc12& a, const uint32_t* __restri
   return c;
 }
 
+// Order of every 3-term FP64 sum (okvfe_set_fp64_reduction; oracle/orc_match.c states the reasoning):
+// 1 = Eigen's unrolled non-vectorised redux x0 + (x1 + x2) (default), 0 = left to right.
+__device__ int g_fp64_tree = 1;
+__device__ __forceinline__ double sum3(double p0, double p1, double p2) {
+  const bool tree = g_fp64_tree != 0;  // scalar load, uniform branch-free select
+  const double u = tree ? p1 : p0, v = tree ? p2 : p1, w = tree ? p0 : p2;
+  const double s = u + v;
+  return tree ? w + s : s + w;  // (addition commutes bit-exactly: one add either way)
+}
 __device__ __forceinline__ double dot3(const double a[3], const double b[3]) {
-  double s = a[0] * b[0];
-  double t = a[1] * b[1];
-  s = s + t;
-  t = a[2] * b[2];
-  s = s + t;
-  return s;
+  const double p0 = a[0] * b[0];
+  const double p1 = a[1] * b[1];
+  const double p2 = a[2] * b[2];
+  return sum3(p0, p1, p2);
 }
 __device__ __forceinline__ void normalize3(const double v[3], double out[3]) {
   const double n = sqrt(dot3(v, v));
@@ -72,12 +79,10 @@ __device__ __forceinline__ void rot(const double C[9], const double v[3], double
 __device__ __forceinline__ void rot_t(const double C[9], const double v[3], double out[3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    double s = C[i] * v[0];
-    double t = C[3 + i] * v[1];
-    s = s + t;
-    t = C[6 + i] * v[2];
-    s = s + t;
-    out[i] = s;
+    const double p0 = C[i] * v[0];
+    const double p1 = C[3 + i] * v[1];
+    const double p2 = C[6 + i] * v[2];
+    out[i] = sum3(p0, p1, p2);
   }
 }
 __device__ __forceinline__ void inv_transform_h(const double C[9], const double r[3],
@@ -1372,6 +1377,12 @@ void launch_hamming_emit(const uint8_t* A, int nA, const uint8_t* B, int nB, int
   if (nA <= 0) return;
   hipLaunchKernelGGL(hamming_emit_kernel, dim3((nA + 63) / 64), dim3(64), 0, stream, A, nA, B, nB,
                      thr, row_offsets, out, cap);
+}
+
+// writes the 3-term-sum order into this translation unit's device flag (current device); synchronous
+bool set_fp64_tree_match(int tree) {
+  const int v = tree != 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fp64_tree), &v, sizeof(v)) == hipSuccess;
 }
 
 }  // namespace okvfe

@@ -169,6 +169,9 @@ __device__ __forceinline__ void xcd_tile(int tiles, int n_images, int* image, in
 // ---- kernel launchers (defined in the .hip files) ----------------------------------------------
 namespace okvfe {
 
+// 3-term FP64 sum order of the matcher / landmark kernels (one device flag per translation unit)
+bool set_fp64_tree_match(int tree);
+bool set_fp64_tree_map(int tree);
 void launch_bow_query_l1(const int32_t* db_begin, const int32_t* db_ids, const double* db_values, int n_entries,
                          const int32_t* q_ids, const double* q_values, int n_q, double* scores,
                          hipStream_t stream);

@@ -84,6 +84,10 @@ typedef struct orc_pattern {
 #define ORC_MODE_GRADIENT 1     /* rotationInvariant=true, not camera aware: long-pair gradient */
 #define ORC_MODE_CAMERA_AWARE 2 /* setCameraProperties + setExtractionDirection given */
 
+/* order of the 3-term FP64 sums of the matchers' gate chain: 1 = Eigen's x0 + (x1 + x2) (default), 0 = left to right */
+void orc_set_reduction(int tree);
+int orc_get_reduction(void);
+
 /* ---- detector (A1) ------------------------------------------------------- */
 void orc_harris_score(const uint8_t* img, int w, int h, int stride, int32_t* score /* h*w */);
 int orc_nms(const int32_t* score, int w, int h, int abs_threshold,

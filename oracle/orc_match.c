@@ -39,13 +39,29 @@ static inline uint32_t popc48(const uint8_t* a, const uint8_t* b) {
   return c;
 }
 
+/* Order of every 3-term FP64 sum of the gate chain (dot products, norms, 3x3 * 3 products).  The reference
+ * evaluates them through Eigen (stereo_triangulation.cpp:62-76, Frontend.cpp:2027-2073): a fixed-size
+ * Vector3d reduction is not packet-aligned, so a stock build takes Eigen's unrolled non-vectorised
+ * redux (Redux.h, redux_novec_unroller: split at Length / 2), which evaluates x0 + (x1 + x2).
+ * tree = 1 (default): that order; tree = 0: left to right, (x0 + x1) + x2 -- what rounds 1-4 assumed.
+ * Neither can be confirmed here (no Eigen in the image); tools/ref_compare picks the winner in one run
+ * on a machine that has the reference built. */
+static int g_reduction_tree = 1;
+void orc_set_reduction(int tree) { g_reduction_tree = tree != 0; }
+int orc_get_reduction(void) { return g_reduction_tree; }
+static inline double sum3(double p0, double p1, double p2) {
+  if (g_reduction_tree) {
+    const double t = p1 + p2;
+    return p0 + t;
+  }
+  const double s = p0 + p1;
+  return s + p2;
+}
 static inline double dot3(const double a[3], const double b[3]) {
-  double s = a[0] * b[0];
-  double t = a[1] * b[1];
-  s = s + t;
-  t = a[2] * b[2];
-  s = s + t;
-  return s;
+  const double p0 = a[0] * b[0];
+  const double p1 = a[1] * b[1];
+  const double p2 = a[2] * b[2];
+  return sum3(p0, p1, p2);
 }
 static inline void normalize3(const double v[3], double out[3]) {
   const double n = sqrt(dot3(v, v));
@@ -60,12 +76,10 @@ static inline void rot(const double C[9], const double v[3], double out[3]) {
 }
 static inline void rot_t(const double C[9], const double v[3], double out[3]) {
   for (int i = 0; i < 3; ++i) {
-    double s = C[i] * v[0];
-    double t = C[3 + i] * v[1];
-    s = s + t;
-    t = C[6 + i] * v[2];
-    s = s + t;
-    out[i] = s;
+    const double p0 = C[i] * v[0];
+    const double p1 = C[3 + i] * v[1];
+    const double p2 = C[6 + i] * v[2];
+    out[i] = sum3(p0, p1, p2);
   }
 }
 /* hp_C = T^-1 * hp_W  (Transformation::operator*(Vector4d), Transformation.hpp:271-278) */

@@ -104,6 +104,11 @@ def pattern() -> Pattern:
     return _PATTERN
 
 
+def set_reduction(eigen_tree: bool = True):
+    """orc_set_reduction: order of the 3-term FP64 sums of the gate chain (default: Eigen's x0 + (x1 + x2))"""
+    lib().orc_set_reduction(1 if eigen_tree else 0)
+
+
 def pattern_published() -> Pattern:
     """the 60-point / 383-pair published-BRISK form (the default until round 5), as a second pattern"""
     p = Pattern()

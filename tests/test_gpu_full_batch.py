@@ -51,15 +51,19 @@ def _digest(res, matches):
     return h.hexdigest()
 
 
-@pytest.mark.parametrize("workload,FRAMES", [("euroc", 768), ("tumvi", 256)])
-def test_full_size_batch_replicas_permutation_idempotence(oracle, workload, FRAMES):
-    """euroc: BASELINE configs[2] at the bench's batch (768 stereo frames of 752x480); tumvi:
-    configs[3] (256 stereo frames of 1024x1024, equidistant cameras: packed last strips of the score
-    kernel, occupancy grid of radius 50, up to 1000 keypoints per image)."""
+@pytest.mark.parametrize("workload,FRAMES,keep_map", [("euroc", 768, False), ("tumvi", 256, False),
+                                                      ("euroc", 3072, False), ("euroc", 3072, True)])
+def test_full_size_batch_replicas_permutation_idempotence(oracle, workload, FRAMES, keep_map):
+    """euroc: BASELINE configs[2], 768 stereo frames of 752x480 and the 3072 of bench.py's default step (image
+    buffer 2.2 GB > 2^31 B, 6144-image XCD streams of the score kernel; with keep_map the 9 GB score map of
+    okvfe_set_keep_score_map as well); tumvi: configs[3] (256 stereo frames of 1024x1024, equidistant cameras:
+    packed last strips of the score kernel, occupancy grid of radius 50, up to 1000 keypoints per image)."""
     import bench
     cfg = synth.euroc_config() if workload == "euroc" else synth.tumvi1024_config()
     imgs, base = bench.make_inputs(cfg, FRAMES, DISTINCT, 4242)
     fe = G.make_frontend(cfg, max_batch=2 * FRAMES, num_cameras=2)
+    if keep_map:
+        fe.set_keep_score_map(True)
     for ci, cam in enumerate(cfg.cams):
         fe.set_camera(ci, cam)
     # one extraction direction per DISTINCT frame and camera, repeated with the frame

@@ -13,7 +13,8 @@ from okvis2_amd import capi, synth
 
 import gpu_common as G
 
-pytestmark = pytest.mark.gpu
+# every test of this module runs under both orders of the 3-term FP64 sums (conftest.fp64_order)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("fp64_order")]
 
 
 def _scene(oracle, cam, n, seed, T):

@@ -150,6 +150,7 @@ def _stereo_inputs(oracle, cfg, seed):
     return L, R, out
 
 
+@pytest.mark.usefixtures("fp64_order")
 def test_match_stereo_host_buffers(oracle):
     cfg = synth.euroc_config()
     fe = G.make_frontend(cfg)
@@ -172,12 +173,16 @@ def test_match_stereo_host_buffers(oracle):
     assert nmatch > 20
 
 
+@pytest.mark.usefixtures("fp64_order")
 def test_match_stereo_lookalike_content(oracle):
     """Exact two-level checker cells: hundreds of near-identical descriptors, half a dozen
     candidates below the threshold per keypoint (up to 15), most of them rejected by the geometric gate -- the regime of
     the matcher's re-scans (six keys each after the first scan's two), also for matchMotionStereo's
     twin loop through the same arrays."""
-    cfg = synth.euroc_config()
+    import dataclasses
+    # threshold 70 (euroc.yaml: 60): with the 384 live bits of the round-5 pattern the checker cells differ a little
+    # more, and the median number of sub-threshold candidates at 60 is 3
+    cfg = dataclasses.replace(synth.euroc_config(), match_threshold=70)
     fe = G.make_frontend(cfg)
     T0, T1 = synth.stereo_poses(cfg.baseline)
     f0 = 0.5 * (cfg.cams[0].fu + cfg.cams[0].fv)
@@ -203,6 +208,7 @@ def test_match_stereo_lookalike_content(oracle):
     assert np.array_equal(got["hp_W"].view(np.uint64), ref["hp_W"].view(np.uint64))
 
 
+@pytest.mark.usefixtures("fp64_order")
 def test_stereo_pipeline_device_resident(oracle):
     """detect+describe of a stereo batch and matchStereo, all outputs resident in HBM."""
     cfg = synth.euroc_config()

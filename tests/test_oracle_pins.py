@@ -283,3 +283,26 @@ def test_descriptor_view_pooling_follows_the_reference_buffer_rules(oracle):
     assert out["n_desc"][2] == 2 and list(out["obs_rows"][2]) == [4, 5, -1]
     assert np.allclose(out["projection"][0], [cam.cu, cam.cv], atol=1.0)
     assert np.allclose(out["r_W"][2, 0], poses[2][1]) and np.allclose(out["r_W"][2, 1], poses[3][1])
+
+
+def test_fp64_reduction_order_is_a_live_switch(oracle):
+    """The 3-term FP64 sums of the gate chain run in Eigen's unrolled-redux order x0 + (x1 + x2) by default
+    (stereo_triangulation.cpp:62-76 evaluates them through fixed-size Eigen vectors) and left to right on request:
+    same decisions on this content, different last bits of the triangulated points."""
+    import real_image_cases as RC
+    fx = RC.load()
+    (k0, d0, b0, v0), (k1, d1, b1, v1) = RC.stereo_sides(oracle, fx["image"])
+    out = {}
+    for tree in (True, False):
+        oracle.set_reduction(tree)
+        try:
+            out[tree] = oracle.match_stereo(d0, k0, b0, v0, d1, k1, b1, v1, *RC.stereo_geometry())
+        finally:
+            oracle.set_reduction(True)
+    a, b = out[True], out[False]
+    assert np.array_equal(a["k1"], b["k1"]) and np.array_equal(a["initialisable"], b["initialisable"])
+    hit = a["k1"] >= 0
+    differ = np.any(a["hp_W"][hit].view(np.uint64) != b["hp_W"][hit].view(np.uint64), axis=1)
+    assert 0 < differ.sum() < hit.sum()
+    assert np.allclose(a["hp_W"][hit], b["hp_W"][hit], rtol=1e-12, atol=0)
+    assert np.array_equal(a["hp_W"].view(np.uint64), fx["stereo/match"]["hp_W"].view(np.uint64))  # committed = default
