@@ -132,7 +132,8 @@ typedef struct okvfe_config {
  * AGAST 9-16 scores on the octaves c_i and intra-octaves d_i, the FAST 5-8 score of c0 as the layer
  * below the first octave, maxima over the 3 x 3 neighbourhood and the +-1 px patches of the layers
  * above and below, 2-D sub-pixel fit, and a parabola over the three layers' scores for the CONTINUOUS
- * scale (keypoint.size = 12 x scale, response = the parabola's maximum, octave = layer index).  No
+ * scale (keypoint.size = 12 x scale, response = the parabola's maximum, octave = layer index; layer nodes
+ * 3/4, 1, 3/2 on octaves, 2/3, 1, 4/3 on intra-octaves, 2/3, 1, 3/2 with the result in [0.7, 1.5] on c0).  No
  * uniformity stage (uniformity_radius is ignored); the strongest max_keypoints maxima per layer are
  * kept, (score desc, y, x).  With octaves == 0 it is OKVFE_SCORE_AGAST_9_16. */
 #define OKVFE_SCORE_BRISK_SCALESPACE 2

@@ -423,7 +423,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     A(d_lut, kLutFloats);
     A(d_pattern, 1);
     if (cfg->scale_invariant && describes) A(d_scales, 1);
-    A(d_kps_det, K * B);
+    A(d_kps_det, K * B + 1);  // + one record: launch_param_copy writes whole 16-byte chunks
     A(d_det_count, B);
     const size_t Kd = describes ? K : 1, Bd = describes ? B : 1;
     A(d_kps_tmp, Kd * Bd);
@@ -561,6 +561,7 @@ void okvfe_destroy(okvfe_ctx* ctx) {
 okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* rays_hw3,
                                    const float* jacobians_hw6, float fu) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  ctx->ahead.valid = false;  // a result computed ahead under the old extraction state must not answer okvfe_compute
   if (cam < 0 || cam >= ctx->cfg.num_cameras || !rays_hw3 || !jacobians_hw6 || !(fu > 0.0f))
     return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_camera_maps: bad argument (cam=%d)", cam);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
@@ -599,6 +600,7 @@ okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* ray
 
 okvfe_status okvfe_set_camera(okvfe_ctx* ctx, int32_t cam, const okvfe_camera* camera) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  ctx->ahead.valid = false;
   if (!camera || cam < 0 || cam >= ctx->cfg.num_cameras || camera->width != ctx->w ||
       camera->height != ctx->h || !(camera->fu > 0.0) || !(camera->fv > 0.0) ||
       camera->distortion < 0 || camera->distortion > 2)
@@ -669,6 +671,7 @@ okvfe_status okvfe_get_pattern(const okvfe_ctx* ctx, okvfe_pattern* out) {
 
 okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* p) {
   if (!ctx || !p) return OKVFE_ERR_INVALID_ARGUMENT;
+  ctx->ahead.valid = false;
   static_assert(OKVFE_PATTERN_POINTS == kPatternPoints && OKVFE_PATTERN_LONG_PAIRS == kMaxLongPairs, "pattern limits");
   if (p->n_points < 1 || p->n_points > kPatternPoints || p->n_short < 0 || p->n_short > OKVFE_PATTERN_SHORT_PAIRS ||
       p->n_long < 0 || p->n_long > kMaxLongPairs)

@@ -304,11 +304,13 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
         if (l > 0) ratio2(l - 1, rb2);
         const int32_t* above = l + 1 < L ? ctx->layers[l + 1]->d_scores : nullptr;
         if (above) ratio2(l + 1, ra2);
-        const double rel_b = (l & 1) ? 2.0 / 3.0 : 0.75, rel_a = (l & 1) ? 4.0 / 3.0 : 1.5;
+        // c_0: the virtual FAST 5-8 layer sits at 2/3 and the result is clamped to [0.7, 1.5] (published refine1D_2)
+        const double rel_b = (l & 1) || l == 0 ? 2.0 / 3.0 : 0.75, rel_a = (l & 1) ? 4.0 / 3.0 : 1.5;
+        const double rel_lo = l == 0 ? 0.7 : rel_b;
         launch_brisk_refine(ch->d_scores, ch->w, ch->h, n_images, ch->cand_cap, ch->d_cand_count, ch->d_sort_ws,
                             ch->cfg.max_keypoints, below, wb, hb, rb2[0], rb2[1], above,
                             above ? ctx->layer_w[l + 1] : 0, above ? ctx->layer_h[l + 1] : 0, ra2[0], ra2[1], rel_b,
-                            rel_a, ch->d_kps_det, ch->kp_cap, ch->d_det_count, s);
+                            rel_a, rel_lo, ch->d_kps_det, ch->kp_cap, ch->d_det_count, s);
       }
       const okvfe_keypoint* kps[8];
       const int32_t* counts[8];
@@ -509,8 +511,9 @@ okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out)
   out->candidate_counts = ctx->d_cand_count;
   // the layout of the LAST batch's map (dense if that call took the unfused score + NMS kernels)
   const ScoreLayout& sl = ctx->n_layers > 1 ? ctx->layers[0]->live_layout : ctx->live_layout;
-  out->score_pitch = sl.pitch;
-  out->score_strips = sl.strips;
+  // no map was written (okvfe_set_keep_score_map): no layout either -- okvfe_harris_score_device is the way to a map
+  out->score_pitch = out->scores ? sl.pitch : 0;
+  out->score_strips = out->scores ? sl.strips : 0;
   return OKVFE_OK;
 }
 
@@ -625,7 +628,8 @@ okvfe_status copy_results_out(okvfe_ctx* ctx, okvfe_keypoint* keypoints, uint8_t
 okvfe_status stage_image(okvfe_ctx* ctx, const uint8_t* image, size_t stride, bool keep_shadow = false) {
   const size_t P = (size_t)ctx->w * ctx->h;
   if (stride < (size_t)ctx->w) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "stride %zu < width %d", stride, ctx->w);
-  okvfe_status st = ensure_pinned(ctx, align_up(P, 256) + 256 + (size_t)ctx->kp_cap * sizeof(okvfe_keypoint));
+  // (+16: launch_param_copy moves whole 16-byte chunks, kp_cap * 28 need not be a multiple of 16)
+  okvfe_status st = ensure_pinned(ctx, align_up(P, 256) + 256 + align_up((size_t)ctx->kp_cap * sizeof(okvfe_keypoint), 16) + 16);
   if (st != OKVFE_OK) return st;
   if (stride == (size_t)ctx->w) {
     std::memcpy(ctx->h_pinned, image, P);

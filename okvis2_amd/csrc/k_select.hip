@@ -20,6 +20,7 @@
 //                         large images): 1024 threads test 1024 candidates per round, the first
 //                         that passes is accepted, 961 threads add its 31x31 stamp.
 // Bound: latency / LDS (no HBM roofline); batches keep all CUs busy with independent images.
+#include <mutex>
 #include "describe_setup_dev.h"
 #include <type_traits>
 
@@ -860,7 +861,7 @@ __device__ int scale_neighbour_max(const ScaleNeighbour& nb, size_t img_off, int
   return best;
 }
 // same operation sequence as orc_scale_refine (oracle/orc_detect.c), FP64, no contraction
-__device__ void scale_refine(double rb, bool have_b, int sb, int s, double ra, bool have_a, int sa, float* rel,
+__device__ void scale_refine(double rb, bool have_b, int sb, int s, double ra, bool have_a, int sa, double lo, float* rel,
                              float* score) {
   *rel = 1.0f;
   *score = (float)s;
@@ -882,7 +883,7 @@ __device__ void scale_refine(double rb, bool have_b, int sb, int s, double ra, b
   double v = -b;
   double a2 = 2.0 * a;
   v = v / a2;
-  v = v < rb ? rb : (v > ra ? ra : v);
+  v = v < lo ? lo : (v > ra ? ra : v);
   double u = v - rb;
   u = a * u;
   u = d10 + u;
@@ -896,7 +897,7 @@ __device__ void scale_refine(double rb, bool have_b, int sb, int s, double ra, b
 __global__ __launch_bounds__(256) void brisk_refine_kernel(
     const int32_t* __restrict__ scores, int w, int h, int cand_cap, const int32_t* __restrict__ cand_count,
     const uint64_t* __restrict__ sort_ws, int ws_stride, int max_kpts, ScaleNeighbour below, ScaleNeighbour above,
-    double rb, double ra, okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
+    double rb, double ra, double lo, okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
   const int img = blockIdx.x;
   int n = cand_count[img];
   n = n > cand_cap ? 0 : n;  // overflowed list: no keypoints (okvfe_check_capacity reports it)
@@ -918,7 +919,7 @@ __global__ __launch_bounds__(256) void brisk_refine_kernel(
     const int sb = below.map ? scale_neighbour_max(below, (size_t)img * below.w * below.h, u, v) : 0;
     const int sa = above.map ? scale_neighbour_max(above, (size_t)img * above.w * above.h, u, v) : 0;
     float rel, resp;
-    scale_refine(rb, below.map != nullptr, sb, score, ra, above.map != nullptr, sa, &rel, &resp);
+    scale_refine(rb, below.map != nullptr, sb, score, ra, above.map != nullptr, sa, lo, &rel, &resp);
     okvfe_keypoint kp;
     kp.x = (float)u + ddx;
     kp.y = (float)v + ddy;
@@ -2220,14 +2221,14 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
 
 void launch_brisk_refine(const int32_t* score, int w, int h, int n_images, int cand_cap, const int32_t* cand_count,
                          const uint64_t* sort_ws, int max_kpts, const int32_t* below, int wb, int hb, int rn_b,
-                         int rd_b, const int32_t* above, int wa, int ha, int rn_a, int rd_a, double rb, double ra,
+                         int rd_b, const int32_t* above, int wa, int ha, int rn_a, int rd_a, double rb, double ra, double lo,
                          okvfe_keypoint* kps, int kp_cap, int32_t* kp_count, hipStream_t stream) {
   if (n_images <= 0) return;
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const ScaleNeighbour nb{below, wb, hb, rn_b, rd_b}, na{above, wa, ha, rn_a, rd_a};
   hipLaunchKernelGGL(brisk_refine_kernel, dim3(n_images), dim3(256), 0, stream, score, w, h, cand_cap, cand_count,
-                     sort_ws, ws_stride, max_kpts, nb, na, rb, ra, kps, kp_cap, kp_count);
+                     sort_ws, ws_stride, max_kpts, nb, na, rb, ra, lo, kps, kp_cap, kp_count);
 }
 
 void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
@@ -2257,13 +2258,12 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   }
   if (two) {  // second launch: 8193..16384 keys in 136 KiB, larger sets in the HBM workspace
     const size_t big_lds = (size_t)rb_slot(2 * kLdsSortKeys) * 8;  // >= the classic 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;  // (several host threads may launch through several contexts)
+    std::call_once(attr_once, [&] {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)big_lds) != hipSuccess)
         (void)hipGetLastError();
-      attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(sort_kernel, dim3(n_images < 256 ? n_images : 256), dim3(kThreads), big_lds, stream, cand,
                        cand_cap, cand_count, sort_ws, ws_stride, kLdsSortKeys, 2 * kLdsSortKeys, legacy ? 0 : 1,
                        n_images);
@@ -2338,13 +2338,12 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   static const bool legacy = lab_env("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
   const LazyPlan lp = lazy_plan(radius, max_kpts, kp_cap, occupancy, occ_image_bytes, occ_rows, occ_cols);
   if (lp.list) {
-    static bool attr_set_l = false;
-    if (!attr_set_l) {
+    static std::once_flag attr_once_l;
+    std::call_once(attr_once_l, [] {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_list_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
         (void)hipGetLastError();
-      attr_set_l = true;
-    }
+    });
     hipLaunchKernelGGL(select_list_kernel, dim3(n_images), dim3(kLazyThreads), lp.lds_list, stream, score, layout, w, h,
                        cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, lp.bins_x, lp.bins_y, lp.cap, kps,
                        kp_cap, kp_count, setup ? *setup : DescribeSetup{}, images);
@@ -2361,16 +2360,15 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
       const int v = e ? atoi(e) : kLazyBlockMax;
       return v < 4 ? 4 : (v > kLazyBlockMax ? kLazyBlockMax : v);
     }();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
         (void)hipGetLastError();  // launches above 64 KiB will then fail loudly on their own
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
         (void)hipGetLastError();
-      attr_set = true;
-    }
+    });
 #define OKVFE_LAZY_LAUNCH(SORTS)                                                                                     \
   hipLaunchKernelGGL(select_lazy_kernel<SORTS>, dim3(n_images), dim3(kLazyThreads), lp.lds, stream, score, layout, w, \
                      h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut, lp.bins_x, lp.bins_y,  \

@@ -190,7 +190,7 @@ hipStream_t pick_stream(okvfe_ctx* ctx, void* stream);
 void layer_size(int w, int h, int l, int* lw, int* lh);
 void layer_scale(int l, int* num, int* den);
 
-// serialisation of the heavy kernels across the contexts of a process (lab builds only: score_token_mode)
+// serialisation of the heavy kernels across the contexts of a process (okvfe_set_heavy_kernel_chaining)
 constexpr int kMaxTokenDevices = 64;
 extern std::mutex g_token_mutex;
 extern hipEvent_t g_score_token[kMaxTokenDevices];

@@ -180,7 +180,7 @@ void launch_agast_score(const uint8_t* img, int w, int h, int n_images, int32_t*
 void launch_fast58_score(const uint8_t* img, int w, int h, int n_images, int32_t* score, hipStream_t stream);
 void launch_brisk_refine(const int32_t* score, int w, int h, int n_images, int cand_cap, const int32_t* cand_count,
                          const uint64_t* sort_ws, int max_kpts, const int32_t* below, int wb, int hb, int rn_b,
-                         int rd_b, const int32_t* above, int wa, int ha, int rn_a, int rd_a, double rb, double ra,
+                         int rd_b, const int32_t* above, int wa, int ha, int rn_a, int rd_a, double rb, double ra, double lo,
                          okvfe_keypoint* kps, int kp_cap, int32_t* kp_count, hipStream_t stream);
 void launch_harris(const uint8_t* img, int w, int h, int n_images, int32_t* score,
                    hipStream_t stream);

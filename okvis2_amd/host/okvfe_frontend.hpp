@@ -70,8 +70,13 @@ class Context {
   // The extractor that shares this context announces what its next compute() will ask for
   // (Frontend.cpp:246-251 sets the direction BEFORE Frame::detect / Frame::describe): the detector
   // then runs okvfe_detect_ahead, and the compute() that follows on the same image costs no GPU work.
+  // ONE pairing per context: a second extractor on another camera slot of the same context would overwrite
+  // these fields behind the first one's back (the detector cannot know which camera an image belongs to), so
+  // it switches the pairing off for good -- both extractors then compute on their own, correct but unpaired.
+  // (One context per camera is the intended set-up: ThreadedSlam.cpp:434-448 runs a thread per camera.)
   struct NextExtraction {
     bool paired = false;  // an extractor is attached and wants pairing
+    bool conflict = false;  // extractors of different camera slots share this context: never pair
     int cam = -1;
     bool aware = false;
     std::array<float, 3> dir{{0.0f, 1.0f, 0.0f}};
@@ -114,25 +119,27 @@ class HipBriskExtractor {
   // ahead of time when both see the same image (okvfe_detect_ahead)
   HipBriskExtractor(std::shared_ptr<Context> ctx, int cameraSlot, bool pairWithDetector = true)
       : ctx_(std::move(ctx)), cam_(cameraSlot) {
-    ctx_->nextExtraction().paired = pairWithDetector;
-    ctx_->nextExtraction().cam = cam_;
+    Context::NextExtraction& nx = ctx_->nextExtraction();
+    if (nx.paired && nx.cam != cam_) nx.conflict = true;
+    nx.paired = pairWithDetector && !nx.conflict;
+    if (nx.paired) nx.cam = cam_;
   }
   bool isCameraAware() const { return aware_; }
   // rays: H*W*3 f32, imageJacobians: H*W*6 f32 (PinholeCamera.hpp:180-208)
   void setCameraProperties(const float* rays, const float* imageJacobians, float fu) {
     ctx_->check(okvfe_set_camera_maps(ctx_->get(), cam_, rays, imageJacobians, fu));
     aware_ = true;
-    ctx_->nextExtraction().aware = true;
+    if (ctx_->nextExtraction().cam == cam_) ctx_->nextExtraction().aware = true;
   }
   // full intrinsics: also enables back-projection of the kept keypoints on the GPU
   void setCamera(const okvfe_camera& camera) {
     ctx_->check(okvfe_set_camera(ctx_->get(), cam_, &camera));
     aware_ = true;
-    ctx_->nextExtraction().aware = true;
+    if (ctx_->nextExtraction().cam == cam_) ctx_->nextExtraction().aware = true;
   }
   void setExtractionDirection(const std::array<float, 3>& dir) {
     dir_ = dir;
-    ctx_->nextExtraction().dir = dir;
+    if (ctx_->nextExtraction().cam == cam_) ctx_->nextExtraction().dir = dir;
   }
   // keypoints in/out: keypoints too close to the rim are removed (Frame.hpp:146)
   void compute(const ImageView& image, std::vector<KeyPoint>& keypoints, Descriptors& descriptors,

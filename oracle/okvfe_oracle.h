@@ -106,7 +106,7 @@ void orc_agast_score(const uint8_t* img, int w, int h, int stride, int32_t* scor
 void orc_fast58_score(const uint8_t* img, int w, int h, int stride, int32_t* score /* h*w */);
 int32_t orc_scale_neighbour_max(const int32_t* other, int wo, int ho, int x, int y, int rn, int rd);
 void orc_scale_refine(double rb, int have_b, int32_t sb, int32_t s, double ra, int have_a, int32_t sa,
-                      float* rel_scale, float* score);
+                      double lo, float* rel_scale, float* score);
 void orc_score_map(int score_type, const uint8_t* img, int w, int h, int stride, int32_t* score);
 int orc_detect_scored(const uint8_t* img, int w, int h, int stride, float uniformity_radius, int octaves,
                       int abs_threshold, int max_kpts, orc_keypoint* kps, int cap, int32_t* score_out,

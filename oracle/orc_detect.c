@@ -152,7 +152,7 @@ void orc_fast58_score(const uint8_t* img, int w, int h, int stride, int32_t* sco
  * vertex, clamped to [r_b, r_a], is the relative scale, the parabola's value there the refined score.
  * A missing neighbour layer, or a parabola that does not open downwards, keeps (1, s). */
 void orc_scale_refine(double rb, int have_b, int32_t sb, int32_t s, double ra, int have_a, int32_t sa,
-                      float* rel_scale, float* score) {
+                      double lo, float* rel_scale, float* score) {
   *rel_scale = 1.0f;
   *score = (float)s;
   if (!have_b || !have_a) return;
@@ -173,7 +173,7 @@ void orc_scale_refine(double rb, int have_b, int32_t sb, int32_t s, double ra, i
   double v = -b;
   double a2 = 2.0 * a;
   v = v / a2;
-  v = v < rb ? rb : (v > ra ? ra : v);
+  v = v < lo ? lo : (v > ra ? ra : v); /* lo = rb except on layer 0 (published: nodes 2/3, 1, 3/2, result in [0.7, 1.5]) */
   /* value at the vertex: y1 + (v - 1) * (d10 + a * (v - rb)) (Newton form) */
   double u = v - rb;
   u = a * u;
@@ -580,6 +580,9 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
       if (score_type == 2) { /* continuous scale from the three layers' scores */
         double rb = 0.75, ra = 1.5; /* octave c_i: d_(i-1) below (3/4), d_i above (3/2) */
         if (l & 1) { rb = 2.0 / 3.0; ra = 4.0 / 3.0; } /* intra-octave d_i: c_i below, c_(i+1) above */
+        double lo = rb;
+        if (l == 0) { rb = 2.0 / 3.0; lo = 0.7; } /* c_0: the virtual FAST 5-8 layer sits at 2/3 (published refine1D_2:
+                                                   * coefficients 18 -30 12 = nodes 2/3, 1, 3/2; result clamped to [0.7, 1.5]) */
         int have_b = 1, have_a = l + 1 < L;
         int32_t sb = 0, sa = 0;
         if (l == 0) {
@@ -601,7 +604,7 @@ static int detect_scale_space(const uint8_t* img, int w, int h, int stride, floa
           sa = orc_scale_neighbour_max(sc[l + 1], lw[l + 1], lh[l + 1], u, v, rn, rd);
         }
         float rel, resp;
-        orc_scale_refine(rb, have_b, sb, pts[l][i].score, ra, have_a, sa, &rel, &resp);
+        orc_scale_refine(rb, have_b, sb, pts[l][i].score, ra, have_a, sa, lo, &rel, &resp);
         float sz = 12.0f * rel; /* basic size 12 at the layer's own scale, times the relative scale ... */
         k->size = sz * scale;   /* ... times the layer scale */
         k->response = resp;

@@ -144,14 +144,16 @@ def test_fast58_and_scale_refine_oracle_known_answers(oracle):
     assert out[5, 5] == 39 and out[4, 4] == 0
     rel, sc = C.c_float(), C.c_float()
     f = oracle.lib().orc_scale_refine
-    f.argtypes = [C.c_double, C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_int32, C.POINTER(C.c_float),
-                  C.POINTER(C.c_float)]
-    f(0.75, 1, 40, 50, 1.5, 1, 40, C.byref(rel), C.byref(sc))  # symmetric in value, not in abscissa
+    f.argtypes = [C.c_double, C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_int, C.c_int32, C.c_double,
+                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    f(0.75, 1, 40, 50, 1.5, 1, 40, 0.75, C.byref(rel), C.byref(sc))  # symmetric in value, not in abscissa
     assert 1.0 < rel.value < 1.5 and sc.value >= 50.0
-    f(0.75, 1, 60, 50, 1.5, 1, 20, C.byref(rel), C.byref(sc))  # rising towards the layer below: clamped there
+    f(0.75, 1, 60, 50, 1.5, 1, 20, 0.75, C.byref(rel), C.byref(sc))  # rising towards the layer below: clamped there
     assert rel.value == pytest.approx(0.75) and sc.value == pytest.approx(60.0)
-    f(0.75, 1, 10, 50, 1.5, 0, 0, C.byref(rel), C.byref(sc))   # top layer: no refinement
+    f(0.75, 1, 10, 50, 1.5, 0, 0, 0.75, C.byref(rel), C.byref(sc))   # top layer: no refinement
     assert rel.value == 1.0 and sc.value == 50.0
+    f(2.0 / 3.0, 1, 60, 50, 1.5, 1, 20, 0.7, C.byref(rel), C.byref(sc))  # layer 0: node at 2/3, clamp at 0.7
+    assert rel.value == pytest.approx(0.7) and 50.0 < sc.value < 60.0
 
 
 def test_agast_batch(oracle):
