@@ -39,12 +39,15 @@ namespace {
 // float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
 constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
+constexpr int kBoxMaskCounts = 10;  // interior byte counts 0 .. 9 (= kMaxBox - 1) per first-byte position 0 .. 3
 constexpr int kSmallBox = 4;  // second pass of the camera-aware-only kernel: boxes of at most 5 x 5 (sigma_half <= 2.0)
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
 constexpr int kZeroRowBytes = 160;  // >= the widest patch row (152 B) + the 3-dword reads past a box
-constexpr int kPatchBufBytes = 6144;
+// LDS per workgroup = 4 patch buffers + values (1152 B) + short pairs (768 B) + box masks (640 B): 26880 B = 21
+// allocation granules of 1280 B, six workgroups per CU (the 6-waves-per-SIMD form)
+constexpr int kPatchBufBytes = 6080;
 #ifndef OKVFE_DESC_WIDE_BUF
-#define OKVFE_DESC_WIDE_BUF 7552  // 4 x 7552 + 1792 B of tables = 32000 B = 25 allocation granules: five workgroups per CU
+#define OKVFE_DESC_WIDE_BUF 7360  // 4 x 7360 + 2560 B of tables = 32000 B = 25 allocation granules: five workgroups per CU
 #endif
 constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
@@ -114,24 +117,19 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
   if constexpr (PX::kFixedTrip) {
   if (FASTONLY || __all(bw <= MAXB && bh <= MAXB)) {
     // Fixed trip counts, no data-dependent selects: the top and the bottom row are read once each,
-    // then kMaxBox - 1 interior slots, where a slot past the box (dy >= bh) reads the all-zero
+    // then MAXB - 1 interior slots, where a slot past the box (dy >= bh) reads the all-zero
     // row of the patch instead, so every accumulation is unconditional.  Interior columns
     // x_left+1 .. x_right-1 (<= 9 bytes) lie in at most 3 aligned dwords of the patch row: one
-    // byte mask per dword, then v_sad_u8(dword & mask, 0, acc) sums 4 pixels per instruction.
+    // byte mask per dword, then one v_msad_u8 per dword sums 4 pixels.
     const int cl = x_left - px.x0, cr = x_right - px.x0;  // patch columns of the rim pixels
     const int xi0 = cl + 1;
     const int q0 = xi0 >> 2;
     const int lo = xi0 & 3, ni = bw - 1;
     constexpr int kDw = (MAXB + 5) / 4;  // interior <= MAXB - 1 bytes from byte 0..3 of the first dword
-    uint32_t m[kDw];
-#pragma unroll
-    for (int j = 0; j < kDw; ++j) {
-      int sb = lo - 4 * j, eb = sb + ni;
-      sb = sb < 0 ? 0 : sb;
-      eb = eb > 4 ? 4 : eb;
-      const int nb = eb - sb;
-      m[j] = nb > 0 ? ((0xFFFFFFFFu >> (8 * (4 - nb))) << (8 * sb)) : 0u;
-    }
+    // byte masks of the interior columns in those dwords: one 16-byte read of the (first byte, count) table in LDS
+    // (kernel prologue: fill_box_masks) instead of ~8 VALU per dword
+    const uint4 mrow = *reinterpret_cast<const uint4*>(px.masks + ((mul24i(lo, kBoxMaskCounts) + ni) << 2));
+    const uint32_t m[3] = {mrow.x, mrow.y, mrow.z};
     // Rows are addressed by 32-bit byte offsets from the first patch row (the zero row lies
     // kZeroRowBytes before it); every product below has both factors under 2^23 (weights <= 2^22,
     // pixel sums <= 81 * 255), so the 24-bit multiplies give the same low 32 bits as the
@@ -145,13 +143,18 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
       pl = px.patch[off + cl];
       pr = px.patch[off + cr];
       const uint32_t* d = reinterpret_cast<const uint32_t*>(px.patch + off) + q0;
+      // v_msad_u8 adds |pixel - 0xFF| = 255 - pixel for the bytes the mask selects and skips the others: one
+      // instruction per dword instead of v_and + v_sad_u8; the row sums come back as 255 * count - accumulator.
+      // A slot past the box reads the zero row and adds 255 per selected byte, which the same identity absorbs:
+      // sum over the real rows = 255 * ni * (slots) - accumulator, whatever the number of real rows.
 #pragma unroll
-      for (int j = 0; j < kDw; ++j) acc = __builtin_amdgcn_sad_u8(d[j] & m[j], 0u, acc);
+      for (int j = 0; j < kDw; ++j) acc = __builtin_amdgcn_msad_u8(d[j], m[j], acc);
       return acc;
     };
-    upper = (int)read_row(run, 0u);
+    const int full = mul24i(ni, 255);
+    upper = full - (int)read_row(run, 0u);
     ret = mul24i(A, pl) + mul24i(B, pr);
-    bottom = (int)read_row(run + mul24i(bh, pitch), 0u);
+    bottom = full - (int)read_row(run + mul24i(bh, pitch), 0u);
     ret += mul24i(D, pl) + mul24i(C, pr);
     uint32_t mid = 0u;
 #pragma unroll
@@ -161,7 +164,7 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
       left += pl;
       right += pr;
     }
-    middle = (int)mid;
+    middle = mul24i(full, MAXB - 1) - (int)mid;
     ret += mul24i(upper, r_y_1_i) + mul24i(middle, scaling) + mul24i(left, r_x_1_i) + mul24i(right, r_x1_i) +
            mul24i(bottom, r_y1_i);
     return div_nonneg(ret + scaling2 / 2, scaling2);
@@ -207,6 +210,22 @@ constexpr int kDescWaves = 4;
 #endif
 constexpr int kDescBlocksPerImage = OKVFE_DESC_BLOCKS;
 
+// table[(first byte 0..3) * kBoxMaskCounts + count][0..2]: 0xFF in every byte of the three consecutive dwords that
+// belongs to the run of `count` interior bytes starting at byte `first byte` of the first dword (4th word: pad)
+__device__ __forceinline__ void fill_box_masks(uint32_t* table, int tid, int nthreads) {
+  for (int e = tid; e < 4 * kBoxMaskCounts; e += nthreads) {
+    const int lo = e / kBoxMaskCounts, ni = e - lo * kBoxMaskCounts;
+    for (int j = 0; j < 4; ++j) {
+      uint32_t mk = 0u;
+      for (int b = 0; b < 4; ++b) {
+        const int pos = 4 * j + b;
+        if (j < 3 && pos >= lo && pos < lo + ni) mk |= 0xFFu << (8 * b);
+      }
+      table[4 * e + j] = mk;
+    }
+  }
+}
+
 struct GlobalPx {  // direct reads from the image (fallback when the patch does not fit in LDS)
   static constexpr bool kFixedTrip = false;
   const uint8_t* img;
@@ -220,6 +239,7 @@ struct PatchPx {   // reads from the keypoint's patch staged in LDS
   static constexpr bool kFixedTrip = true;
   const uint8_t* patch;  // first pixel row; the zero row lies kZeroRowBytes before it
   int x0, y0, pitch;
+  const uint32_t* masks;  // LDS table of fill_box_masks
   __device__ __forceinline__ int operator()(int y, int x) const {
     return patch[(y - y0) * pitch + (x - x0)];
   }
@@ -272,6 +292,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   __shared__ int values[kDescWaves][kPatternPoints];
   // the 383 short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
   // they were a third dependent round trip in every keypoint's chain
+  __shared__ __attribute__((aligned(16))) uint32_t box_masks[4 * kBoxMaskCounts * 4];
+  fill_box_masks(box_masks, threadIdx.x, 64 * kDescWaves);
   __shared__ uint16_t short_pairs[384];
   for (int t = threadIdx.x; t < 384; t += 64 * kDescWaves)
     short_pairs[t] = t < pat->n_short ? (uint16_t)(pat->short_i[t] | (pat->short_j[t] << 8)) : (uint16_t)0;
@@ -332,7 +354,10 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     // instructions for the same pixels.  The staging is bound by the number of vector-memory
     // requests in flight at L2 latency, not by bytes (stage-only 0.43 ms of the kernel's 0.51 with
     // dword requests), so fewer, wider requests are what shortens it.  Rows are padded to 16 B.
-    const int nq = (pw + 15) >> 4;  // 16-byte chunks per patch row
+    int nq = (pw + 15) >> 4;  // 16-byte chunks per patch row
+#ifdef OKVFE_DESC_ODD_PITCH
+    nq |= 1;  // A/B: odd chunk count = rows step through all bank phases (tools/lab: LDS bank conflicts of the box sums)
+#endif
     if (dword_ok && nq >= 1 && nq * 16 <= kZeroRowBytes - 8) {
       const int pitch = nq * 16;
       const uint32_t inv = (65536u + (uint32_t)nq - 1u) / (uint32_t)nq;
@@ -356,6 +381,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         ppx->x0 = px0;
         ppx->y0 = by0;
         ppx->pitch = pitch;
+        ppx->masks = box_masks;
         return true;
       }
     }
@@ -394,6 +420,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     ppx->x0 = px0;
     ppx->y0 = by0;
     ppx->pitch = pitch;
+    ppx->masks = box_masks;
     return true;
   };
   // values of all 60 samples under the current M; false when a box leaves the image
@@ -442,14 +469,16 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     PatchPx ppx;
     int v = 0, v2 = 0;
     if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
-      if (active) v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+      // (no exec-mask change around the box sums: lanes without a sample carry point 0's constants, whose box lies
+      // in the patch, so both passes are straight-line code the scheduler may interleave)
+      v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
       if (extra > 0) {  // wave-uniform; AWARE: the host checked sigma_half <= 2.0 for these points (5 x 5 boxes)
         const int b1 = ladder ? scales->box_scaling[sc2][l2] : pat->box_scaling[l2];
         const int b2 = ladder ? scales->box_scaling2[sc2][l2] : pat->box_scaling2[l2];
         asm volatile("" : "+v"(l2));  // opaque: the position is recomputed, not carried over the first pass
         float xf2, yf2, sg2;
         second_pos(&xf2, &yf2, &sg2);
-        if (active2) v2 = smoothed_intensity<AWARE, AWARE ? kSmallBox : kMaxBox>(ppx, xf2, yf2, sg2, b1, b2);
+        v2 = smoothed_intensity<AWARE, AWARE ? kSmallBox : kMaxBox>(ppx, xf2, yf2, sg2, b1, b2);
       }
     } else {
       if (extra > 0 && active2) {  // rare path (patch larger than the wave's buffer): the few extra samples read the image
