@@ -153,7 +153,7 @@ void build_uniformity_lut(float lut[kLutFloats]) {
       lut[y * 31 + x] = static_cast<float>(v > 0.0 ? v : 0.0);
     }
   // compacted stamp: only the cells with a non-zero weight, raster order, padded to kStampSlots
-  // with weight 0 (k_select.hip, select_wave_kernel: 11 cells per lane instead of 16)
+  // with weight 0 (k_select_grid.hip: 11 cells per lane instead of 16)
   int j = 0;
   for (int t = 0; t < 31 * 31; ++t) {
     if (!(lut[t] > 0.0f)) continue;

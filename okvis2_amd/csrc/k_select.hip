@@ -1,937 +1,26 @@
-// k_select.hip -- K3/K4: score-ordered uniformity enforcement, cap, sub-pixel refinement.
+// k_select.hip -- K3/K4: uniformity enforcement without an occupancy grid, cap, sub-pixel refinement.
 //
 // Replaces the tail of brisk::ScaleSpaceLayer::DetectScaleSpaceMaxima (sort by score,
-// EnforceKeypointUniformity on an occupancy grid, stop at maxNumKpt, Subpixel2D, emit
-// cv::KeyPoint(pt, 12*scale, -1, score, layer)) behind cv::FeatureDetector::detect
-// (okvis_cv/include/okvis/implementation/Frame.hpp:152; parameters
-// okvis_frontend/src/Frontend.cpp:2406-2409 = uniformityRadius, octaves, absoluteThreshold,
+// EnforceKeypointUniformity, stop at maxNumKpt, Subpixel2D, emit cv::KeyPoint(pt, 12*scale, -1, score,
+// layer)) behind cv::FeatureDetector::detect (okvis_cv/include/okvis/implementation/Frame.hpp:152;
+// parameters okvis_frontend/src/Frontend.cpp:2406-2409 = uniformityRadius, octaves, absoluteThreshold,
 // maxNumKpt).
 //
 // Kernels, one workgroup per image:
-//   sort_kernel           bitonic sort of 64-bit keys (score descending, y, x ascending -- a total
-//                         order, so the result does not depend on the append order of K2) in LDS
-//                         (<= 8192 keys; two strides per pass with 4 keys in registers) or in the
-//                         global workspace (larger candidate sets).
-//   select_greedy_kernel  production path (occupancy grid in LDS, two images per CU): the greedy
-//                         is serial in its accepted points only -- occupancy only grows, so a
-//                         candidate that fails its test once is dead for good.  See the comment
-//                         at the kernel: wave 0 decides 64-candidate windows, 4 waves stamp.
-//   select_kernel<>       fallback for grids that do not fit in LDS (small uniformity radius,
-//                         large images): 1024 threads test 1024 candidates per round, the first
-//                         that passes is accepted, 961 threads add its 31x31 stamp.
+//   select_lazy_kernel<SORTS>  production path: accepted points in LDS spatial bins, occupancy summed on
+//                              demand; SORTS = the kernel orders its own candidates (no sort launch)
+//   select_list_kernel         the same over linked lists (fine grids with few keypoints per bin)
+// launch_select picks the form; sorts: k_sort.hip, grid fall-backs: k_select_grid.hip, BRISK scale
+// refinement: k_brisk_refine.hip, shared device helpers: select_common_dev.h.
 // Bound: latency / LDS (no HBM roofline); batches keep all CUs busy with independent images.
 #include <mutex>
 #include "describe_setup_dev.h"
 #include <type_traits>
 
-#include "okvfe_internal.h"
+#include "select_common_dev.h"
 
 namespace okvfe {
 namespace {
-
-constexpr int kThreads = 1024;
-constexpr int kLdsSortKeys = 8192;
-constexpr int kMaxKp = 4096;  // okvfe_create enforces max_keypoints <= 4096
-
-__device__ __forceinline__ uint64_t make_key(const Candidate& c) {
-  return ((uint64_t)(uint32_t)(0x7FFFFFFF - c.score) << 32) | ((uint32_t)c.y << 16) |
-         (uint32_t)c.x;
-}
-
-// Launched twice when the candidate capacity exceeds kLdsSortKeys: first with 64 KiB of LDS for the
-// images whose (padded) candidate count fits 8192 keys -- two workgroups per CU --, then with
-// 128 KiB for the few that need up to 16384 keys; lds_lo_keys / lds_keys bound the range a launch
-// handles, every other image is left to the other launch.  Above 16384 keys the network runs in
-// the HBM workspace.
-__device__ __forceinline__ void sort_classic_body(const Candidate* __restrict__ cand,
-                                                  int cand_cap,
-                                                  const int32_t* __restrict__ cand_count,
-                                                  uint64_t* __restrict__ sort_ws,
-                                                  int ws_stride, int lds_lo_keys,
-                                                  int lds_keys, int img) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw);
-  int n = cand_count[img];
-  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
-  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
-  n = n > cand_cap ? 0 : n;
-  const Candidate* c = cand + (size_t)img * cand_cap;
-  uint64_t* ws = sort_ws + (size_t)img * ws_stride;
-  int np = 1;
-  while (np < n) np <<= 1;
-  const int tid = threadIdx.x;
-  if (np <= lds_lo_keys) return;  // handled by the launch with the smaller LDS allocation
-  if (np > lds_keys && lds_keys < 2 * kLdsSortKeys) return;  // left to the second launch
-  if (np <= lds_keys) {
-    for (int i = tid; i < np; i += kThreads) lds[i] = i < n ? make_key(c[i]) : ~0ull;
-    __syncthreads();
-    // Two consecutive strides (2j, j) of a phase touch the same 4 elements {b, b+j, b+2j, b+3j}
-    // and all 4 lie in one k-block (same direction), so they are done in ONE pass with the keys in
-    // registers: half the LDS traffic and half the barriers of the plain network.
-    auto cswap = [](uint64_t& a, uint64_t& b, bool up) {
-      const bool sw = (a > b) == up;
-      const uint64_t x = sw ? b : a, y = sw ? a : b;
-      a = x;
-      b = y;
-    };
-    for (int k = 2; k <= np; k <<= 1) {
-      int lj = 31 - __builtin_clz(k >> 1);  // largest stride of the phase = 1 << lj
-      for (; lj >= 1; lj -= 2) {            // strides 1 << lj and 1 << (lj - 1)
-        const int j = 1 << (lj - 1);
-        for (int t = tid; t < (np >> 2); t += kThreads) {
-          const int b = ((t >> (lj - 1)) << (lj + 1)) | (t & (j - 1));
-          const bool up = ((b & k) == 0);
-          uint64_t e0 = lds[b], e1 = lds[b + j], e2 = lds[b + 2 * j], e3 = lds[b + 3 * j];
-          cswap(e0, e2, up);
-          cswap(e1, e3, up);
-          cswap(e0, e1, up);
-          cswap(e2, e3, up);
-          lds[b] = e0;
-          lds[b + j] = e1;
-          lds[b + 2 * j] = e2;
-          lds[b + 3 * j] = e3;
-        }
-        __syncthreads();
-      }
-      if (lj == 0) {  // odd number of strides in this phase: the last one (stride 1) alone
-        for (int t = tid; t < (np >> 1); t += kThreads) {
-          const int lo = t << 1;
-          const bool up = ((lo & k) == 0);
-          uint64_t a = lds[lo], b = lds[lo + 1];
-          cswap(a, b, up);
-          lds[lo] = a;
-          lds[lo + 1] = b;
-        }
-        __syncthreads();
-      }
-    }
-    for (int i = tid; i < n; i += kThreads) ws[i] = lds[i];
-  } else {
-    for (int i = tid; i < np; i += kThreads) ws[i] = i < n ? make_key(c[i]) : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= np; k <<= 1) {
-      for (int lj = 31 - __builtin_clz(k >> 1); lj >= 0; --lj) {
-        const int j = 1 << lj;
-        for (int t = tid; t < (np >> 1); t += kThreads) {
-          const int lo = ((t >> lj) << (lj + 1)) | (t & (j - 1));
-          const int hi = lo + j;
-          const bool up = ((lo & k) == 0);
-          const uint64_t a = ws[lo], b = ws[hi];
-          if ((a > b) == up) {
-            ws[lo] = b;
-            ws[hi] = a;
-          }
-        }
-        __syncthreads();
-      }
-    }
-  }
-}
-
-// ---- register-blocked sort (up to 8192 keys), the production path -------------------------------
-// Same total order, different network: the ALL-ASCENDING form of the bitonic sorter (first stride
-// of a phase compares i with its mirror image i ^ (k - 1) inside the block of k, the remaining
-// strides are plain half-cleaners), so the padding keys (~0) never leave the tail [n, np) and every
-// compare-exchange whose lower index is >= n is skipped: the work follows n, not the next power
-// of two (4 450 candidates per EuRoC image used to cost a full 8192 network).  A thread keeps 16
-// keys in registers and runs up to FOUR strides on them between two LDS round trips (24 passes
-// for 8192 keys instead of 49); phases 1..4 run on the 16 keys a thread loads from the candidate
-// list before anything is written to LDS.  LDS index i lives at slot i + (i >> 4): with one pad
-// slot per 16 keys all access patterns of the passes (16 keys per lane at strides 1, 2, 4 ... ) are
-// bank-conflict free.  LDS-bandwidth / VALU bound, two workgroups per CU.
-constexpr int kRbThreads = 512;
-constexpr int kRbKeys = 16;  // per thread and pass
-__host__ __device__ __forceinline__ int rb_slot(int i) { return i + (i >> 4); }
-// Keys travel through the network as FP64 bit patterns: a compare-exchange is then v_min_f64 +
-// v_max_f64 (2 instructions) instead of two 64-bit integer compares and four selects (~14 with the
-// SGPR hazards).  A key K = (0x7FFFFFFF - score) << 32 | y << 16 | x is below 2^63; D = K - 2^62 in
-// sign-magnitude form is a finite double (|D| <= 2^62 < 0x7FF0...: never Inf / NaN) whose IEEE order
-// is the order of K.  Denormal patterns are ordinary values here (FP64 denormals are never flushed
-// on this target) and no arithmetic touches the bits.
-using RbKey = double;
-__device__ __forceinline__ RbKey rb_encode(uint64_t k) {
-  const int64_t d = (int64_t)k - (int64_t)(1ull << 62);
-  const uint64_t bits = d >= 0 ? (uint64_t)d : (0x8000000000000000ull | (uint64_t)(-d));
-  return __longlong_as_double((long long)bits);
-}
-__device__ __forceinline__ uint64_t rb_decode(RbKey v) {
-  const uint64_t bits = (uint64_t)__double_as_longlong(v);
-  const int64_t mag = (int64_t)(bits & 0x7FFFFFFFFFFFFFFFull);
-  const int64_t d = (bits >> 63) ? -mag : mag;
-  return (uint64_t)(d + (int64_t)(1ull << 62));
-}
-constexpr uint64_t kRbPadKey = 0x7FFFFFFFFFFFFFFFull;  // above every real key (score >= 1)
-__device__ __forceinline__ void rb_cswap(RbKey& a, RbKey& b) {  // ascending
-  RbKey lo, hi;
-  asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b));
-  a = lo;
-  b = hi;
-}
-// R strides (bits R-1 .. 0 of the element number m) on 2^R keys; MIRROR: the first one pairs m
-// with its complement (the keys of the upper half were fetched with mirrored low index bits)
-template <int R, bool MIRROR>
-__device__ __forceinline__ void rb_network(RbKey (&key)[kRbKeys]) {
-  constexpr int N = 1 << R;
-  if (MIRROR) {
-#pragma unroll
-    for (int m = 0; m < N / 2; ++m) rb_cswap(key[m], key[(N - 1) ^ m]);
-  }
-#pragma unroll
-  for (int b = MIRROR ? R - 2 : R - 1; b >= 0; --b) {
-#pragma unroll
-    for (int m = 0; m < N; ++m)
-      if ((m & (1 << b)) == 0) rb_cswap(key[m], key[m | (1 << b)]);
-  }
-}
-// one LDS pass: strides 2^(q+R-1) .. 2^q of the network on np keys
-template <int R, bool MIRROR, int THREADS>
-__device__ __forceinline__ void rb_pass(RbKey* lds, int np, int n, int q, int tid) {
-  constexpr int N = 1 << R;
-  const int low_mask = (1 << q) - 1;
-  for (int g = tid; g < (np >> R); g += THREADS) {
-    const int low = g & low_mask;
-    const int base = ((g >> q) << (q + R)) | low;
-    if (base >= n) continue;  // smallest index of the group: all of its keys are padding
-    const int base_hi = MIRROR ? base ^ low_mask : base;  // upper half: mirrored low bits
-    RbKey key[kRbKeys];
-#pragma unroll
-    for (int m = 0; m < N; ++m)
-      key[m] = lds[rb_slot(((MIRROR && m >= N / 2) ? base_hi : base) | (m << q))];
-    rb_network<R, MIRROR>(key);
-#pragma unroll
-    for (int m = 0; m < N; ++m)
-      lds[rb_slot(((MIRROR && m >= N / 2) ? base_hi : base) | (m << q))] = key[m];
-  }
-}
-
-// the network on one image's list of n <= 2^lnp keys, THREADS threads, 2^lnp + 2^(lnp-4) LDS slots
-template <int THREADS>
-__device__ __forceinline__ void sort_rb_body(RbKey* lds, const Candidate* __restrict__ c, int n, int lnp,
-                                             uint64_t* __restrict__ ws) {
-  const int np = 1 << lnp;
-  const int tid = threadIdx.x;
-  // phases 1..4 on 16 consecutive keys straight from the candidate list
-  for (int g = tid; g < (np >> 4); g += THREADS) {
-    RbKey key[kRbKeys];
-#pragma unroll
-    for (int m = 0; m < kRbKeys; ++m) {
-      const int i = g * kRbKeys + m;
-      key[m] = rb_encode(i < n ? make_key(c[i]) : kRbPadKey);
-    }
-    if (g * kRbKeys < n) {
-      // phase k = 2^p inside the thread: mirror within blocks of 2^p keys, then half-cleaners
-#pragma unroll
-      for (int p = 1; p <= 4; ++p) {
-        const int blk = 1 << p;
-#pragma unroll
-        for (int m = 0; m < kRbKeys; ++m)
-          if ((m & (blk - 1)) < blk / 2) rb_cswap(key[m], key[m ^ (blk - 1)]);
-#pragma unroll
-        for (int b = p - 2; b >= 0; --b)
-#pragma unroll
-          for (int m = 0; m < kRbKeys; ++m)
-            if ((m & (1 << b)) == 0) rb_cswap(key[m], key[m | (1 << b)]);
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < kRbKeys; ++m) lds[rb_slot(g * kRbKeys + m)] = key[m];
-  }
-  __syncthreads();
-  for (int lk = 5; lk <= lnp; ++lk) {  // phase: blocks of 2^lk keys
-    int top = lk - 1;                  // highest stride bit still to do
-    bool mirror = true;
-    while (top >= 0) {
-      const int r = top + 1 < 4 ? top + 1 : 4;
-      const int q = top - r + 1;
-      if (mirror) {
-        rb_pass<4, true, THREADS>(lds, np, n, q, tid);  // lk >= 5: the first pass always has 4 strides
-      } else {
-        switch (r) {
-          case 4: rb_pass<4, false, THREADS>(lds, np, n, q, tid); break;
-          case 3: rb_pass<3, false, THREADS>(lds, np, n, q, tid); break;
-          case 2: rb_pass<2, false, THREADS>(lds, np, n, q, tid); break;
-          default: rb_pass<1, false, THREADS>(lds, np, n, q, tid); break;
-        }
-      }
-      __syncthreads();
-      top -= r;
-      mirror = false;
-    }
-  }
-  for (int i = tid; i < n; i += THREADS) ws[i] = rb_decode(lds[rb_slot(i)]);
-}
-
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void sort_rb_kernel(const Candidate* __restrict__ cand,
-                                                             int cand_cap,
-                                                             const int32_t* __restrict__ cand_count,
-                                                             uint64_t* __restrict__ sort_ws,
-                                                             int ws_stride, int max_keys) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int img = blockIdx.x;
-  int n = cand_count[img];
-  n = n > cand_cap ? 0 : n;  // overflowed list: no keypoints (see sort_kernel)
-  if (n == 0) return;
-  int lnp = 4;
-  while ((1 << lnp) < n) ++lnp;
-  if ((1 << lnp) > max_keys) return;  // left to sort_kernel (second launch)
-  sort_rb_body<THREADS>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
-                        sort_ws + (size_t)img * ws_stride);
-}
-
-// The large-list launch (and the legacy path): lists of 8193 .. 16384 keys run the register-blocked
-// network with 1024 threads in 136 KiB of LDS (13.5 k maxima per 1024 x 1024 image: 0.28 -> 0.17 ms per
-// 1024 images with the two-stride network before), everything else the classic bodies above.
-__global__ __launch_bounds__(kThreads) void sort_kernel(const Candidate* __restrict__ cand,
-                                                        int cand_cap,
-                                                        const int32_t* __restrict__ cand_count,
-                                                        uint64_t* __restrict__ sort_ws,
-                                                        int ws_stride, int lds_lo_keys,
-                                                        int lds_keys, int rb_mid, int n_images) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // The large-list launch allocates 136 KiB of LDS per workgroup: one workgroup per CU, so a grid of
-  // one block per image cost ~2.5 us per 256 images even when no image needs it (the usual case: 16 us
-  // per 1536-image step).  The grid is at most one round of workgroups; each walks its images.
-  for (int img = blockIdx.x; img < n_images; img += gridDim.x) {  // block-uniform
-    bool done = false;
-    if (rb_mid) {
-      int n = cand_count[img];
-      n = n > cand_cap ? 0 : n;
-      int lnp = 4;
-      while ((1 << lnp) < n) ++lnp;
-      if ((1 << lnp) > lds_lo_keys && (1 << lnp) <= 2 * kLdsSortKeys) {  // block-uniform
-        sort_rb_body<kThreads>(reinterpret_cast<RbKey*>(smem_raw), cand + (size_t)img * cand_cap, n, lnp,
-                               sort_ws + (size_t)img * ws_stride);
-        done = true;
-      }
-    }
-    if (!done) sort_classic_body(cand, cand_cap, cand_count, sort_ws, ws_stride, lds_lo_keys, lds_keys, img);
-    __syncthreads();  // the LDS is reused by the next image
-  }
-}
-
-// 2-D quadratic sub-pixel refinement; mirrors the published BRISK Subpixel2D with 64-bit
-// coefficients (Harris scores overflow 32-bit products) and double Hessian terms.
-// The nine Harris scores around pixel (u, v), 2 <= u < w - 2, 2 <= v < h - 2, straight from the image: exactly
-// what the score map of harris_kernel holds there (k_harris.hip; HarrisScoreCalculator of the brisk library):
-// Scharr (3, 10, 3) gradients, products >> 14 (zero on the image rim), 3 x 3 binomial, det - (trace / 4)^2.
-// Map-free calls (round 4): the score kernel writes no map -- four of its five bytes per pixel -- and the
-// selection recomputes these nine values for the ~230 keypoints per image it keeps (7 x 7 pixels, ~1 k
-// integer operations each; +18 us on the selection of 1536 EuRoC images against -105 us on the score kernel.
-// A kernel of its own for this -- one thread per keypoint of the batch -- was measured and is slower (111 us:
-// it is all scattered line fetches, which hide behind other images' arithmetic in here).
-// xx | yy << 16 share a register (both < 2^14 after the binomial).
-__device__ __forceinline__ void harris_scores_3x3(const uint8_t* __restrict__ im, int w, int h, int u, int v,
-                                                  int32_t out[9]) {
-  // (requires w % 4 == 0 and a dword-aligned image, like the fused score kernel this stands in for)
-  // Pixels u - 3 .. u + 3 of rows v - 3 .. v + 3 as three aligned dwords per row (one keypoint per lane: every
-  // load instruction of the wave touches 64 different lines, so the count of loads is what this costs); the
-  // dword before the row / past its end is not read -- the pixel it would supply only feeds gradient products
-  // on the image rim, which are zero by definition.
-  const int base = (u - 3) & ~3;  // -4 for u = 2
-  const int sh = (u - 3) - base;  // 0..3
-  uint32_t q0[7], q1[7];          // pixels 0..3 and 4..6 of each row
-#pragma unroll
-  for (int r = 0; r < 7; ++r) {
-    const int y = v - 3 + r;
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(im + (size_t)(y < 0 ? 0 : (y > h - 1 ? h - 1 : y)) * w);
-    const uint32_t d0 = base >= 0 ? row[base >> 2] : 0u;
-    const uint32_t d1 = row[(base >> 2) + 1];
-    const uint32_t d2 = base + 8 < w ? row[(base >> 2) + 2] : 0u;
-    q0[r] = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)sh);
-    q1[r] = __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)sh);
-  }
-  auto px = [&](int r, int k) { return (int)(((k < 4 ? q0[r] : q1[r]) >> (8 * (k & 3))) & 0xFFu); };
-  int acc_p[9], acc_xy[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) acc_p[k] = acc_xy[k] = 0;
-  // The Scharr pair is separable: a = 3 p(y-1) + 10 p(y) + 3 p(y+1), b = p(y+1) - p(y-1) per pixel column,
-  // then gx = a(x+1) - a(x-1), gy = 3 b(x-1) + 10 b(x) + 3 b(x+1).
-#pragma unroll
-  for (int r = -2; r <= 2; ++r) {  // gradient row v + r: pixel rows r + 2, r + 3, r + 4 of the window
-    const bool yin = v + r >= 1 && v + r <= h - 2;
-    int a[7], b[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const int t0 = px(r + 2, k), t1 = px(r + 3, k), t2 = px(r + 4, k);
-      a[k] = 3 * (t0 + t2) + 10 * t1;
-      b[k] = t2 - t0;
-    }
-    int gp[5], gxy[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int x = u - 2 + k;
-      const int gx = a[k + 2] - a[k];
-      const int gy = 3 * (b[k] + b[k + 2]) + 10 * b[k + 1];
-      const bool in = yin && x >= 1 && x <= w - 2;  // gradient products are zero on the image rim
-      gp[k] = in ? ((gx * gx) >> 14) | (((gy * gy) >> 14) << 16) : 0;
-      gxy[k] = in ? (gx * gy) >> 14 : 0;  // arithmetic shift: floor, like the reference's 16-bit products
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int hp = gp[c] + 2 * gp[c + 1] + gp[c + 2];
-      const int hxy = gxy[c] + 2 * gxy[c + 1] + gxy[c + 2];
-#pragma unroll
-      for (int j = -1; j <= 1; ++j) {
-        const int d = j - r;
-        if (d >= -1 && d <= 1) {
-          acc_p[(j + 1) * 3 + c] += d == 0 ? 2 * hp : hp;
-          acc_xy[(j + 1) * 3 + c] += d == 0 ? 2 * hxy : hxy;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int s0 = acc_p[k] & 0xFFFF, s1 = (int)((unsigned)acc_p[k] >> 16), s2 = acc_xy[k];
-    const int tq = ((s0 >> 1) + (s1 >> 1)) >> 1;
-    out[k] = s0 * s1 - s2 * s2 - tq * tq;
-  }
-}
-
-__device__ void subpixel2d(const int32_t s[9], float* delta_x, float* delta_y) {
-  // s_i_j of the published formula = score(x-1+i, y-1+j): first index along x
-  const int64_t s00 = s[0], s01 = s[3], s02 = s[6];
-  const int64_t s10 = s[1], s11 = s[4], s12 = s[7];
-  const int64_t s20 = s[2], s21 = s[5], s22 = s[8];
-  const int64_t tmp1 = s00 + s02 - 2 * s11 + s20 + s22;
-  const int64_t c1 = 3 * (tmp1 + s01 - ((s10 + s12) * 2) + s21);
-  const int64_t c2 = 3 * (tmp1 - ((s01 + s21) * 2) + s10 + s12);
-  const int64_t tmp2 = s02 - s20;
-  const int64_t tmp3 = s00 + tmp2 - s22;
-  const int64_t tmp4 = tmp3 - 2 * tmp2;
-  const int64_t c3 = -3 * (tmp3 + s01 - s21);
-  const int64_t c4 = -3 * (tmp4 + s10 - s12);
-  const int64_t c5 = (s00 - s02 - s20 + s22) * 4;
-  const int64_t c6 = -(s00 + s02 - ((s10 + s01 + s12 + s21) * 2) - 5 * s11 + s20 + s22) * 2;
-  const double d1 = (double)c1, d2 = (double)c2, d3 = (double)c3, d4 = (double)c4, d5 = (double)c5;
-  double ha = 4.0 * d1;
-  ha = ha * d2;
-  double hb = d5 * d5;
-  const double hdet = ha - hb;
-  if (hdet == 0.0) {
-    *delta_x = 0.0f;
-    *delta_y = 0.0f;
-    return;
-  }
-  if (!(hdet > 0.0 && c1 < 0)) {
-    int64_t best = c3 + c4 + c5;
-    float bx = 1.0f, by = 1.0f;
-    int64_t t = -c3 + c4 - c5;
-    if (t > best) { best = t; bx = -1.0f; by = 1.0f; }
-    t = c3 - c4 - c5;
-    if (t > best) { best = t; bx = 1.0f; by = -1.0f; }
-    t = -c3 - c4 + c5;
-    if (t > best) { best = t; bx = -1.0f; by = -1.0f; }
-    *delta_x = bx;
-    *delta_y = by;
-    return;
-  }
-  const float fh = -(float)hdet;
-  double na = 2.0 * d2;
-  na = na * d3;
-  double nb = d4 * d5;
-  const float nx = (float)(na - nb);
-  na = 2.0 * d1;
-  na = na * d4;
-  nb = d3 * d5;
-  const float ny = (float)(na - nb);
-  float dx = nx / fh;
-  float dy = ny / fh;
-  const bool tx = dx > 1.0f, tx_ = dx < -1.0f, ty = dy > 1.0f, ty_ = dy < -1.0f;
-  if (tx || tx_ || ty || ty_) {
-    const float f1 = (float)c1, f2 = (float)c2, f3 = (float)c3, f4 = (float)c4, f5 = (float)c5,
-                f6 = (float)c6;
-    float dx1 = 0.0f, dx2 = 0.0f, dy1 = 0.0f, dy2 = 0.0f;
-    if (tx) {
-      dx1 = 1.0f;
-      dy1 = -(f4 + f5) / (2.0f * f2);
-      if (dy1 > 1.0f) dy1 = 1.0f; else if (dy1 < -1.0f) dy1 = -1.0f;
-    } else if (tx_) {
-      dx1 = -1.0f;
-      dy1 = -(f4 - f5) / (2.0f * f2);
-      if (dy1 > 1.0f) dy1 = 1.0f; else if (dy1 < -1.0f) dy1 = -1.0f;
-    }
-    if (ty) {
-      dy2 = 1.0f;
-      dx2 = -(f3 + f5) / (2.0f * f1);
-      if (dx2 > 1.0f) dx2 = 1.0f; else if (dx2 < -1.0f) dx2 = -1.0f;
-    } else if (ty_) {
-      dy2 = -1.0f;
-      dx2 = -(f3 - f5) / (2.0f * f1);
-      if (dx2 > 1.0f) dx2 = 1.0f; else if (dx2 < -1.0f) dx2 = -1.0f;
-    }
-    float m1 = f1 * dx1; m1 = m1 * dx1;
-    float a = f2 * dy1; a = a * dy1; m1 = m1 + a;
-    a = f3 * dx1; m1 = m1 + a;
-    a = f4 * dy1; m1 = m1 + a;
-    a = f5 * dx1; a = a * dy1; m1 = m1 + a;
-    m1 = m1 + f6;
-    float m2 = f1 * dx2; m2 = m2 * dx2;
-    a = f2 * dy2; a = a * dy2; m2 = m2 + a;
-    a = f3 * dx2; m2 = m2 + a;
-    a = f4 * dy2; m2 = m2 + a;
-    a = f5 * dx2; a = a * dy2; m2 = m2 + a;
-    m2 = m2 + f6;
-    if (m1 > m2) { dx = dx1; dy = dy1; } else { dx = dx2; dy = dy2; }
-  }
-  *delta_x = dx;
-  *delta_y = dy;
-}
-
-template <bool OCC_LDS>
-__global__ __launch_bounds__(kThreads) void select_kernel(
-    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, const Candidate* __restrict__ cand,
-    int cand_cap, const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws,
-    int ws_stride, float radius, int max_kpts, const float* __restrict__ lut,
-    uint8_t* __restrict__ occ_ws, size_t occ_image_bytes, int occ_rows, int occ_cols,
-    okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ int wave_first[16];
-  __shared__ uint32_t accepted_xy[kMaxKp];  // (y << 16) | x of accepted points, <= kp_cap
-  __shared__ int32_t accepted_score[kMaxKp];
-  const int img = blockIdx.x;
-  const int tid = threadIdx.x;
-  int n = cand_count[img];
-  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
-  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
-  n = n > cand_cap ? 0 : n;
-  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
-  okvfe_keypoint* out = kps + (size_t)img * kp_cap;
-  int kept = 0;
-
-  if (!(radius > 0.0f)) {
-    // uniformity disabled: every maximum is a keypoint, in raster order, not capped by max_kpts
-    // (sorted by (y, x) here: keys carry score in the high half, so re-sort is avoided by
-    // ranking each candidate directly -- O(n^2/threads), only for this rarely used mode)
-    const Candidate* c = cand + (size_t)img * cand_cap;
-    for (int i = tid; i < n; i += kThreads) {
-      const uint32_t me = ((uint32_t)c[i].y << 16) | (uint32_t)c[i].x;
-      int rank = 0;
-      for (int j = 0; j < n; ++j) rank += ((((uint32_t)c[j].y << 16) | (uint32_t)c[j].x) < me);
-      if (rank < kp_cap && rank < kMaxKp) {
-        accepted_xy[rank] = me;
-        accepted_score[rank] = c[i].score;
-      }
-    }
-    kept = n < kp_cap ? n : kp_cap;
-    kept = kept < kMaxKp ? kept : kMaxKp;
-    __syncthreads();
-  } else if (n > 0) {
-    uint8_t* occ = OCC_LDS ? smem_raw : occ_ws + (size_t)img * occ_image_bytes;
-    if (OCC_LDS) {
-      uint32_t* z = reinterpret_cast<uint32_t*>(smem_raw);
-      const int nz = (occ_rows * occ_cols + 3) >> 2;
-      for (int i = tid; i < nz; i += kThreads) z[i] = 0u;
-    }
-    const float scaling = (float)(15.0 / (double)radius);
-    const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-    const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
-    __syncthreads();
-    int pos = 0;
-    while (pos < n && kept < limit) {
-      // ---- test the window [pos, pos + 1024) against the current occupancy
-      const int idx = pos + tid;
-      bool pass = false;
-      if (idx < n) {
-        const uint64_t k = keys[idx];
-        const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-        const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
-        const float fy = (float)y * scaling;
-        const float fx = (float)x * scaling;
-        const int cy = (int)(fy + 16.0f);
-        const int cx = (int)(fx + 16.0f);
-        const float s0 = (float)occ[(size_t)cy * occ_cols + cx];
-        const float q = (float)score / max_score;
-        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
-        pass = !(nsc1 < s0);
-      }
-      const unsigned long long b = __ballot(pass);
-      if ((tid & 63) == 0) wave_first[tid >> 6] = b ? (int)__ffsll((long long)b) - 1 : -1;
-      __syncthreads();
-      int first = -1;
-#pragma unroll
-      for (int wv = 15; wv >= 0; --wv)
-        if (wave_first[wv] >= 0) first = wv * 64 + wave_first[wv];
-      if (first < 0) {
-        pos += kThreads;
-        __syncthreads();
-        continue;
-      }
-      // ---- accept candidate pos + first: stamp its 31x31 patch
-      const uint64_t k = keys[pos + first];
-      const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-      const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
-      if (tid < 961) {
-        const float fy = (float)y * scaling;
-        const float fx = (float)x * scaling;
-        const int cy = (int)(fy + 16.0f);
-        const int cx = (int)(fx + 16.0f);
-        const float q = (float)score / max_score;
-        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
-        const float nsc = (float)(0.99 * (double)nsc1);
-        const int ry = tid / 31, rx = tid - ry * 31;
-        const float m = lut[tid] * nsc;
-        const int add = (int)ceilf(m);
-        uint8_t* cell = occ + (size_t)(cy + ry - 15) * occ_cols + (cx + rx - 15);
-        const int v = (int)(*cell) + add;
-        *cell = (uint8_t)(v > 255 ? 255 : v);
-      }
-      if (tid == 0) {
-        accepted_xy[kept] = (uint32_t)(k & 0xFFFFFFFFu);
-        accepted_score[kept] = score;
-      }
-      ++kept;
-      pos += first + 1;
-      __syncthreads();
-    }
-  }
-
-  // ---- K4: sub-pixel refinement and keypoint emission
-  for (int i = tid; i < kept; i += kThreads) {
-    const int u = (int)(accepted_xy[i] & 0xFFFF), v = (int)(accepted_xy[i] >> 16);
-    int32_t patch[9];
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx)
-        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
-    float ddx, ddy;
-    subpixel2d(patch, &ddx, &ddy);
-    okvfe_keypoint kp;
-    kp.x = (float)u + ddx;
-    kp.y = (float)v + ddy;
-    kp.size = 12.0f;
-    kp.angle = -1.0f;
-    kp.response = (float)accepted_score[i];
-    kp.octave = 0;
-    kp.class_id = -1;
-    out[i] = kp;
-  }
-  if (tid == 0) kp_count[img] = kept;
-}
-
-// ---- greedy selection, one workgroup of 4 waves per image (the production path when the
-// occupancy grid fits in LDS) ----------------------------------------------------------------
-// LDS holds the occupancy grid, the indices of the accepted candidates (u16), a sliding chunk of
-// per-candidate records {cell (cy << 16 | cx), level nsc1 (float)} refilled from the sorted keys,
-// and the accept list of the current round -- under half a CU's LDS for EuRoC-sized grids, so two
-// images run per CU.
-//   decide (wave 0): tests 64 consecutive candidates against the occupancy and accepts, in order,
-//     every passing one that is more than 30 cells (on either axis) away from all points accepted
-//     before it in the same round: its occupancy value is then unchanged, so the sequential test
-//     of the reference would pass as well, and its stamp is disjoint from theirs.  The first
-//     passing candidate closer than that ends the round and is re-tested in the next one.
-//     Windows without a passing candidate are skipped without leaving the wave.
-//   stamp (all 4 waves): every thread takes 3 of the 697 non-zero cells of the 31x31 weight table
-//     for each accepted point of the round; the stamps of a round touch disjoint cells, so no
-//     ordering between them is needed.
-// Two workgroup barriers per round; sub-pixel refinement of the accepted points runs at the end.
-constexpr int kSelThreads = 256;
-constexpr int kStampIts = (kStampCells + kSelThreads - 1) / kSelThreads;
-constexpr int kRoundCap = 64;
-
-// OCC_LDS = false: the occupancy grid does not fit in LDS (small uniformity radius or large images)
-// and lives in the context's HBM workspace (zeroed by the launcher); same algorithm, the byte
-// reads / read-modify-writes go to L2 and the workgroup barriers order them.
-// AccT: type of the accepted-candidate indices kept in LDS (u16 while the candidate capacity allows).
-template <bool OCC_LDS, typename AccT>
-__global__ __launch_bounds__(kSelThreads) void select_greedy_kernel(
-    const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, int cand_cap,
-    const int32_t* __restrict__ cand_count, const uint64_t* __restrict__ sort_ws, int ws_stride,
-    float radius, int max_kpts, const float* __restrict__ lut, int occ_cols, int occ_bytes16,
-    int acc_bytes16, int chunk_cap, okvfe_keypoint* __restrict__ kps, int kp_cap,
-    int32_t* __restrict__ kp_count, uint8_t* __restrict__ occ_hbm, size_t occ_hbm_pitch) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __shared__ int2 round_list[kRoundCap];  // {cell, 0.99 * level} of the points accepted this round
-  __shared__ int s_round, s_pos, s_kept;
-  // serial dependency chain: when other streams' kernels share the SIMD, these waves should win
-  // arbitration, the throughput kernels fill the gaps
-  __builtin_amdgcn_s_setprio(3);
-  const int img = blockIdx.x;
-  const int lds_occ = OCC_LDS ? occ_bytes16 : 0;  // LDS bytes taken by the grid
-  uint8_t* occ = OCC_LDS ? smem_raw : occ_hbm + (size_t)img * occ_hbm_pitch;
-  AccT* acc_idx = reinterpret_cast<AccT*>(smem_raw + lds_occ);
-  uint2* recs = reinterpret_cast<uint2*>(smem_raw + lds_occ + acc_bytes16);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const bool decider = tid < 64;  // wave 0
-  int n = cand_count[img];
-  // overflowed candidate list: WHICH maxima were dropped depends on the order of the atomics, so
-  // the image keeps no keypoints at all (deterministic) and okvfe_check_capacity reports it
-  n = n > cand_cap ? 0 : n;
-  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * layout.pitch * h;
-  okvfe_keypoint* out = kps + (size_t)img * kp_cap;
-  int kept = 0;
-  if (n > 0) {  // block-uniform
-    if (OCC_LDS) {
-      uint4* z = reinterpret_cast<uint4*>(smem_raw);
-      const uint4 zero = make_uint4(0, 0, 0, 0);
-      for (int i = tid; i < (occ_bytes16 >> 4); i += kSelThreads) z[i] = zero;
-    }
-    const float scaling = (float)(15.0 / (double)radius);
-    const float max_score = (float)(0x7FFFFFFF - (int32_t)(keys[0] >> 32));
-    // records of candidates [base, base + chunk_cap) -> recs[], by the whole workgroup (a handful
-    // of independent loads per thread, all in flight together)
-    auto fill_chunk = [&](int base) {
-      const int cnt = min(chunk_cap, n - base);
-      for (int i = tid; i < cnt; i += kSelThreads) {
-        const uint64_t k = keys[base + i];
-        const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-        const int y = (int)((k >> 16) & 0xFFFF), x = (int)(k & 0xFFFF);
-        const float fy = (float)y * scaling;
-        const float fx = (float)x * scaling;
-        const int cy = (int)(fy + 16.0f);
-        const int cx = (int)(fx + 16.0f);
-        const float q = (float)score / max_score;
-        const float nsc1 = sqrtf(sqrtf(q)) * 255.0f;
-        recs[i] = make_uint2(((uint32_t)cy << 16) | (uint32_t)cx, __float_as_uint(nsc1));
-      }
-    };
-    int chunk_base = 0;
-    fill_chunk(0);
-    // per-thread stamp geometry: slots j = it*256 + tid of the compacted table
-    float lutv[kStampIts];
-    int off[kStampIts];
-    const uint2* stamp = reinterpret_cast<const uint2*>(lut + kStampTableOffset);
-#pragma unroll
-    for (int it = 0; it < kStampIts; ++it) {
-      const int j = it * kSelThreads + tid;
-      const uint2 e = stamp[j < kStampSlots ? j : kStampSlots - 1];  // padding slots: weight 0
-      lutv[it] = __uint_as_float(e.y);
-      off[it] = ((int)(e.x >> 8) - 15) * occ_cols + ((int)(e.x & 0xFF) - 15);
-    }
-    const bool last_writes = (kStampIts - 1) * kSelThreads + tid < kStampCells;
-    const int limit = max_kpts < kp_cap ? max_kpts : kp_cap;
-    int pos = 0;
-    __syncthreads();
-    while (true) {
-      // the 64-candidate window would run past the resident chunk: slide it (block-uniform)
-      if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
-        chunk_base = pos;
-        fill_chunk(pos);
-        __syncthreads();
-      }
-      if (decider) {
-        int nacc = 0;
-        bool refill = false;
-        while (pos < n && kept < limit) {
-          if (pos + 64 > chunk_base + chunk_cap && chunk_base + chunk_cap < n) {
-            refill = true;  // skipped past the chunk through windows without a passing candidate
-            break;
-          }
-          const int idx = pos + lane;
-          uint2 rec = make_uint2(0, 0);
-          if (idx < n) rec = recs[idx - chunk_base];
-          const int cx = (int)(rec.x & 0xFFFF), cy = (int)(rec.x >> 16);
-          const int cell = cy * occ_cols + cx;
-          const float s0 = (float)occ[cell];  // idx >= n reads cell 0: in range, result unused
-          const bool pass = idx < n && !(__uint_as_float(rec.y) < s0);
-          unsigned long long m = __ballot(pass);
-          if (m == 0) {
-            pos += 64;
-            continue;
-          }
-          // One backward branch per accepted point.  `blocked` collects the candidates whose cell
-          // lies within 30 cells (both axes) of a point accepted in this round: the first such
-          // passing candidate ends the round and is re-tested in the next one.  Inside 15 cells
-          // its occupancy value changes; between 16 and 30 it would still pass, but its stamp
-          // would overlap the other one -- ending the round there keeps all stamps of a round
-          // disjoint, so the four waves can apply them without any ordering between them.
-          unsigned long long blocked = 0, accm = 0, rem = m, cand;
-          int first = (int)__ffsll((long long)rem) - 1;
-          bool go;
-          do {
-            const int wcx = __builtin_amdgcn_readlane(cx, first);
-            const int wcy = __builtin_amdgcn_readlane(cy, first);
-            const int ax = cx - wcx, ay = cy - wcy;
-            blocked |= __ballot((ax < 0 ? -ax : ax) <= 30 && (ay < 0 ? -ay : ay) <= 30);
-            accm |= 1ull << first;
-            ++nacc;
-            rem &= rem - 1;
-            cand = kept + nacc < limit ? rem : 0ull;
-            first = ((int)__ffsll((long long)cand) - 1) & 63;
-            go = cand != 0 && !((blocked >> first) & 1);
-          } while (go);
-          const int adv = cand != 0 ? first : 64;  // limit reached: the outer loop ends anyway
-          // accepted lanes publish themselves in order: rank = accepted lanes below this one
-          if ((accm >> lane) & 1) {
-            const int rank = __popcll(accm & ((1ull << lane) - 1ull));
-            const float nsc = (float)(0.99 * (double)__uint_as_float(rec.y));
-            round_list[rank] = make_int2(cell, __float_as_int(nsc));
-            acc_idx[kept + rank] = (AccT)idx;
-          }
-          kept += nacc;
-          pos += adv;
-          break;
-        }
-        if (lane == 0) {
-          s_round = refill ? -1 : nacc;  // refill is only set with nacc == 0
-          s_pos = pos;
-          s_kept = kept;
-        }
-      }
-      __syncthreads();
-      const int nacc = s_round;
-      pos = s_pos;
-      kept = s_kept;
-      if (nacc == 0) break;  // block-uniform: candidates exhausted or limit reached
-      if (nacc < 0) continue;  // chunk refill requested: back to the top
-      // stamps of one round are disjoint: up to 4 are in flight together (all reads, then the
-      // arithmetic and the writes)
-      for (int a0 = 0; a0 < nacc; a0 += 4) {
-        int2 e[4];
-        int v[4][kStampIts];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = round_list[min(a0 + u, nacc - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int it = 0; it < kStampIts; ++it) v[u][it] = occ[e[u].x + off[it]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (a0 + u >= nacc) break;  // block-uniform
-          const float nsc = __int_as_float(e[u].y);
-#pragma unroll
-          for (int it = 0; it < kStampIts; ++it) {
-            const float mm = lutv[it] * nsc;
-            const int nv = v[u][it] + (int)ceilf(mm);
-            if (it < kStampIts - 1 || last_writes)
-              occ[e[u].x + off[it]] = (uint8_t)(nv > 255 ? 255 : nv);
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = tid; i < kept; i += kSelThreads) {
-    const uint64_t k = keys[acc_idx[i]];
-    const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-    const int v = (int)((k >> 16) & 0xFFFF), u = (int)(k & 0xFFFF);
-    int32_t patch[9];
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx)
-        patch[(dy + 1) * 3 + (dx + 1)] = sc[score_index(layout, u + dx, v + dy)];
-    float ddx, ddy;
-    subpixel2d(patch, &ddx, &ddy);
-    okvfe_keypoint kp;
-    kp.x = (float)u + ddx;
-    kp.y = (float)v + ddy;
-    kp.size = 12.0f;
-    kp.angle = -1.0f;
-    kp.response = (float)score;
-    kp.octave = 0;
-    kp.class_id = -1;
-    out[i] = kp;
-  }
-  if (tid == 0) kp_count[img] = kept;
-}
-
-
-// ---- published BRISK scale-space detector: strongest maxima of a layer + continuous scale ---------
-// (score_type OKVFE_SCORE_BRISK_SCALESPACE = brisk::BriskFeatureDetector(threshold, octaves),
-// okvis_cv/test/TestFrame.cpp:71-72; oracle: detect_scale_space with score_type 2.)  Input: the
-// layer's candidates after the cross-layer maximum test, sorted (score desc, y, x).  Per kept
-// candidate: 2-D sub-pixel fit in the layer, the largest score within +-1 px of the corresponding
-// location in the layer below / above (layer 0: the FAST 5-8 map of c0), and the vertex of the
-// parabola through the three (relative scale, score) points.  Output in LAYER coordinates with
-// size = 12 * relative scale; merge_layers_kernel maps both into the image.
-struct ScaleNeighbour {
-  const int32_t* map;  // dense score map of the neighbouring layer, null = none
-  int w, h, rn, rd;    // its size; scale of this layer / scale of that layer, reduced
-};
-__device__ __forceinline__ int floor_div_i(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
-__device__ int scale_neighbour_max(const ScaleNeighbour& nb, size_t img_off, int x, int y) {
-  const int D = 2 * nb.rd;
-  const int Nx = (2 * x + 1) * nb.rn - nb.rd, Ny = (2 * y + 1) * nb.rn - nb.rd;
-  int u0 = -floor_div_i(-(Nx - D), D), u1 = floor_div_i(Nx + D, D);
-  int v0 = -floor_div_i(-(Ny - D), D), v1 = floor_div_i(Ny + D, D);
-  u0 = max(u0, 0);
-  v0 = max(v0, 0);
-  u1 = min(u1, nb.w - 1);
-  v1 = min(v1, nb.h - 1);
-  const int32_t* m = nb.map + img_off;
-  int best = 0;
-  for (int v = v0; v <= v1; ++v)
-    for (int u = u0; u <= u1; ++u) best = max(best, m[(size_t)v * nb.w + u]);
-  return best;
-}
-// same operation sequence as orc_scale_refine (oracle/orc_detect.c), FP64, no contraction
-__device__ void scale_refine(double rb, bool have_b, int sb, int s, double ra, bool have_a, int sa, double lo, float* rel,
-                             float* score) {
-  *rel = 1.0f;
-  *score = (float)s;
-  if (!have_b || !have_a) return;
-  const double y0 = (double)sb, y1 = (double)s, y2 = (double)sa;
-  double d10 = y1 - y0;
-  double h10 = 1.0 - rb;
-  d10 = d10 / h10;
-  double d21 = y2 - y1;
-  double h21 = ra - 1.0;
-  d21 = d21 / h21;
-  double a = d21 - d10;
-  double h20 = ra - rb;
-  a = a / h20;
-  if (!(a < 0.0)) return;
-  double t = 1.0 + rb;
-  t = a * t;
-  const double b = d10 - t;
-  double v = -b;
-  double a2 = 2.0 * a;
-  v = v / a2;
-  v = v < lo ? lo : (v > ra ? ra : v);
-  double u = v - rb;
-  u = a * u;
-  u = d10 + u;
-  double dv = v - 1.0;
-  u = dv * u;
-  u = y1 + u;
-  *rel = (float)v;
-  *score = (float)u;
-}
-
-__global__ __launch_bounds__(256) void brisk_refine_kernel(
-    const int32_t* __restrict__ scores, int w, int h, int cand_cap, const int32_t* __restrict__ cand_count,
-    const uint64_t* __restrict__ sort_ws, int ws_stride, int max_kpts, ScaleNeighbour below, ScaleNeighbour above,
-    double rb, double ra, double lo, okvfe_keypoint* __restrict__ kps, int kp_cap, int32_t* __restrict__ kp_count) {
-  const int img = blockIdx.x;
-  int n = cand_count[img];
-  n = n > cand_cap ? 0 : n;  // overflowed list: no keypoints (okvfe_check_capacity reports it)
-  const int kept = min(n, min(max_kpts, kp_cap));
-  const uint64_t* keys = sort_ws + (size_t)img * ws_stride;
-  const int32_t* sc = scores + (size_t)img * w * h;
-  okvfe_keypoint* out = kps + (size_t)img * kp_cap;
-  for (int i = threadIdx.x; i < kept; i += 256) {
-    const uint64_t k = keys[i];
-    const int score = 0x7FFFFFFF - (int32_t)(k >> 32);
-    const int v = (int)((k >> 16) & 0xFFFF), u = (int)(k & 0xFFFF);
-    int32_t patch[9];
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) patch[(dy + 1) * 3 + (dx + 1)] = sc[(size_t)(v + dy) * w + (u + dx)];
-    float ddx, ddy;
-    subpixel2d(patch, &ddx, &ddy);
-    const int sb = below.map ? scale_neighbour_max(below, (size_t)img * below.w * below.h, u, v) : 0;
-    const int sa = above.map ? scale_neighbour_max(above, (size_t)img * above.w * above.h, u, v) : 0;
-    float rel, resp;
-    scale_refine(rb, below.map != nullptr, sb, score, ra, above.map != nullptr, sa, lo, &rel, &resp);
-    okvfe_keypoint kp;
-    kp.x = (float)u + ddx;
-    kp.y = (float)v + ddy;
-    kp.size = 12.0f * rel;
-    kp.angle = -1.0f;
-    kp.response = resp;
-    kp.octave = 0;
-    kp.class_id = -1;
-    out[i] = kp;
-  }
-  if (threadIdx.x == 0) kp_count[img] = kept;
-}
 
 // ---- lazy-occupancy selection: no grid, one workgroup of 4 waves per image ----------------------
 // The occupancy grid of the reference is only ever READ at the cells of candidates: a candidate
@@ -2218,58 +1307,6 @@ __global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6,
   if (tid == 0) kp_count[img] = kept;
 }
 
-
-void launch_brisk_refine(const int32_t* score, int w, int h, int n_images, int cand_cap, const int32_t* cand_count,
-                         const uint64_t* sort_ws, int max_kpts, const int32_t* below, int wb, int hb, int rn_b,
-                         int rd_b, const int32_t* above, int wa, int ha, int rn_a, int rd_a, double rb, double ra, double lo,
-                         okvfe_keypoint* kps, int kp_cap, int32_t* kp_count, hipStream_t stream) {
-  if (n_images <= 0) return;
-  int ws_stride = 1;
-  while (ws_stride < cand_cap) ws_stride <<= 1;
-  const ScaleNeighbour nb{below, wb, hb, rn_b, rd_b}, na{above, wa, ha, rn_a, rd_a};
-  hipLaunchKernelGGL(brisk_refine_kernel, dim3(n_images), dim3(256), 0, stream, score, w, h, cand_cap, cand_count,
-                     sort_ws, ws_stride, max_kpts, nb, na, rb, ra, lo, kps, kp_cap, kp_count);
-}
-
-void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count, int n_images,
-                 float radius, uint64_t* sort_ws, hipStream_t stream) {
-  if (n_images <= 0 || !(radius > 0.0f)) return;
-  int ws_stride = 1;
-  while (ws_stride < cand_cap) ws_stride <<= 1;
-  const int sort_keys = ws_stride < kLdsSortKeys ? ws_stride : kLdsSortKeys;
-  const bool two = ws_stride > kLdsSortKeys;
-  static const bool legacy = lab_env("OKVFE_LEGACY_SORT") != nullptr;  // A/B knob
-  if (legacy) {
-    // first launch: up to 8192 keys in 64 KiB (when it is the only launch it also takes the rest)
-    hipLaunchKernelGGL(sort_kernel, dim3(n_images), dim3(kThreads), (size_t)sort_keys * 8, stream,
-                       cand, cand_cap, cand_count, sort_ws, ws_stride, 0,
-                       two ? sort_keys : 2 * kLdsSortKeys, 0, n_images);
-  } else {
-    // up to 8192 keys: register-blocked network in 68 KiB (16 keys minimum: one thread's share)
-    const int keys = sort_keys < kRbKeys ? kRbKeys : sort_keys;
-    // a handful of images (the B = 1 seams) cannot fill the GPU: twice the threads per list shorten the
-    // one chain there is (28 -> ~18 us per 4.4 k keys); batches keep two 512-thread workgroups per CU
-    if (n_images <= 64)
-      hipLaunchKernelGGL(sort_rb_kernel<2 * kRbThreads>, dim3(n_images), dim3(2 * kRbThreads),
-                         (size_t)rb_slot(keys) * 8, stream, cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
-    else
-      hipLaunchKernelGGL(sort_rb_kernel<kRbThreads>, dim3(n_images), dim3(kRbThreads), (size_t)rb_slot(keys) * 8,
-                         stream, cand, cand_cap, cand_count, sort_ws, ws_stride, keys);
-  }
-  if (two) {  // second launch: 8193..16384 keys in 136 KiB, larger sets in the HBM workspace
-    const size_t big_lds = (size_t)rb_slot(2 * kLdsSortKeys) * 8;  // >= the classic 128 KiB
-    static std::once_flag attr_once;  // (several host threads may launch through several contexts)
-    std::call_once(attr_once, [&] {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)big_lds) != hipSuccess)
-        (void)hipGetLastError();
-    });
-    hipLaunchKernelGGL(sort_kernel, dim3(n_images < 256 ? n_images : 256), dim3(kThreads), big_lds, stream, cand,
-                       cand_cap, cand_count, sort_ws, ws_stride, kLdsSortKeys, 2 * kLdsSortKeys, legacy ? 0 : 1,
-                       n_images);
-  }
-}
-
 namespace {
 struct LazyPlan {
   bool list, array;  // which lazy-occupancy kernel runs (neither: the grid kernels)
@@ -2327,15 +1364,6 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   if (n_images <= 0) return false;
   int ws_stride = 1;
   while (ws_stride < cand_cap) ws_stride <<= 1;
-  const size_t occ_bytes = ((size_t)occ_rows * occ_cols + 15) & ~(size_t)15;
-  static const bool force_hbm = lab_env("OKVFE_SELECT_OCC_HBM") != nullptr;  // A/B knob
-  const bool occ_lds = radius > 0.0f && occ_bytes <= 120 * 1024 && !force_hbm;
-  // greedy kernel: occupancy + accepted indices (u16, u32 for capacities above 65536) + a sliding
-  // chunk of candidate records.  Half a CU's LDS (two images per CU) when at least 128 records
-  // fit, else the whole CU; grids that do not fit at all stay in the HBM workspace.
-  const bool wide = cand_cap > 65536;
-  const size_t acc_bytes = ((size_t)kp_cap * (wide ? 4 : 2) + 15) & ~(size_t)15;
-  static const bool legacy = lab_env("OKVFE_LEGACY_SELECT") != nullptr;  // A/B knob
   const LazyPlan lp = lazy_plan(radius, max_kpts, kp_cap, occupancy, occ_image_bytes, occ_rows, occ_cols);
   if (lp.list) {
     static std::once_flag attr_once_l;
@@ -2381,52 +1409,8 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
 #undef OKVFE_LAZY_LAUNCH
     return setup != nullptr;  // the extractor's setup ran with the emission
   }
-  if (occ_lds && !legacy) {
-    const size_t fixed = occ_bytes + acc_bytes;
-    const size_t half = 79 * 1024, full = 152 * 1024;  // + ~0.5 KiB static: two blocks per CU
-    size_t budget = fixed + 128 * 8 <= half ? half : full;
-    if (fixed + 128 * 8 <= budget) {
-      size_t chunk = (budget - fixed) / 8 / 64 * 64;
-      const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
-      if (chunk > need) chunk = need;
-      const size_t lds = fixed + chunk * 8;
-#define OKVFE_SELECT_LAUNCH(LDS, T, BYTES, OCC, PITCH)                                           \
-  hipLaunchKernelGGL((select_greedy_kernel<LDS, T>), dim3(n_images), dim3(kSelThreads), BYTES,   \
-                     stream, score, layout, w, h, cand_cap, cand_count, sort_ws, ws_stride, radius, \
-                     max_kpts, lut, occ_cols, (int)occ_bytes, (int)acc_bytes, (int)chunk, kps,   \
-                     kp_cap, kp_count, OCC, PITCH)
-      if (wide)
-        OKVFE_SELECT_LAUNCH(true, uint32_t, lds, (uint8_t*)nullptr, (size_t)0);
-      else
-        OKVFE_SELECT_LAUNCH(true, uint16_t, lds, (uint8_t*)nullptr, (size_t)0);
-      return false;
-    }
-  }
-  if (radius > 0.0f && occupancy != nullptr && !legacy && acc_bytes + 128 * 8 <= 24 * 1024) {
-    // grid in HBM: LDS only holds the accepted indices and the record chunk (24 KiB: 6 images / CU)
-    size_t chunk = (24 * 1024 - acc_bytes) / 8 / 64 * 64;
-    const size_t need = ((size_t)cand_cap + 63) / 64 * 64;
-    if (chunk > need) chunk = need;
-    (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
-    if (wide)
-      OKVFE_SELECT_LAUNCH(false, uint32_t, acc_bytes + chunk * 8, occupancy, occ_image_bytes);
-    else
-      OKVFE_SELECT_LAUNCH(false, uint16_t, acc_bytes + chunk * 8, occupancy, occ_image_bytes);
-    return false;
-  }
-#undef OKVFE_SELECT_LAUNCH
-  if (occ_lds) {
-    hipLaunchKernelGGL(select_kernel<true>, dim3(n_images), dim3(kThreads), occ_bytes, stream,
-                       score, layout, w, h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius,
-                       max_kpts, lut, occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap,
-                       kp_count);
-  } else {
-    if (radius > 0.0f)
-      (void)hipMemsetAsync(occupancy, 0, occ_image_bytes * (size_t)n_images, stream);
-    hipLaunchKernelGGL(select_kernel<false>, dim3(n_images), dim3(kThreads), 0, stream, score, layout, w,
-                       h, cand, cand_cap, cand_count, sort_ws, ws_stride, radius, max_kpts, lut,
-                       occupancy, occ_image_bytes, occ_rows, occ_cols, kps, kp_cap, kp_count);
-  }
+  launch_select_grid(score, layout, w, h, n_images, cand, cand_cap, cand_count, radius, max_kpts, lut, occupancy,
+                     occ_image_bytes, occ_rows, occ_cols, kps, kp_cap, kp_count, sort_ws, stream);
   return false;
 }
 

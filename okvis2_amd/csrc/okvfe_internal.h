@@ -236,6 +236,11 @@ struct DescribeSetup {  // pat == nullptr: not requested
 // caller launches no sort before it
 bool select_sorts_candidates(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
                              int occ_rows, int occ_cols);
+// grid fall-backs of launch_select (k_select_grid.hip)
+void launch_select_grid(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
+                        int cand_cap, const int32_t* cand_count, float radius, int max_kpts, const float* lut,
+                        uint8_t* occupancy, size_t occ_image_bytes, int occ_rows, int occ_cols, okvfe_keypoint* kps,
+                        int kp_cap, int32_t* kp_count, uint64_t* sort_ws, hipStream_t stream);
 bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n_images, Candidate* cand,
                    int cand_cap, const int32_t* cand_count, float radius, int max_kpts,
                    const float* lut, uint8_t* occupancy, size_t occ_pitch_bytes, int occ_rows,
