@@ -30,7 +30,7 @@ MIN_TIMED_S = 0.5
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def make_inputs(cfg, n_frames, n_distinct, seed0, content="corners"):
+def make_inputs(cfg, n_frames, n_distinct, seed0, content="corners", tile=True):
     """Multiframes of C = len(cfg.cams) images: cameras 0/1 are a synthetic stereo pair, further
     cameras (Hilti-shaped rig without extrinsics) look elsewhere and get independent images.
     content: "corners" = jittered random-gray cells of 12 px + noise (about 320 keypoints per 752x480
@@ -48,8 +48,19 @@ def make_inputs(cfg, n_frames, n_distinct, seed0, content="corners"):
         for c in range(2, C):
             base.append(synth.corners_image(cfg.w, cfg.h, seed0 + 7919 * c + i, **kw))
     base = np.stack(base)  # [C*n_distinct, H, W]
+    if not tile:  # (bench: the batch is tiled ON THE DEVICE from the distinct frames -- tile_on_device)
+        return None, base
     reps = (n_frames + n_distinct - 1) // n_distinct
     return np.concatenate([base] * reps)[: C * n_frames], base
+
+
+def tile_on_device(base, n_images, dev):
+    """The batch = the distinct frames repeated, built on the GPU: a rank uploads C * distinct images instead of
+    tiling gigabytes in host memory first (8 ranks x 2.2 GB at the default step)."""
+    import torch
+    d_base = torch.from_numpy(base).to(dev)
+    reps = (n_images + len(base) - 1) // len(base)
+    return d_base.repeat(reps, 1, 1)[:n_images].contiguous()
 
 
 def real_inputs(cfg, n_frames, n_distinct):
@@ -72,9 +83,7 @@ def real_inputs(cfg, n_frames, n_distinct):
         y0 = (i * 41) % max(1, H - cfg.h + 1)
         base.append(full[y0:y0 + cfg.h, x0:x0 + cfg.w])
         base.append(full[y0:y0 + cfg.h, x0 + disp:x0 + disp + cfg.w])
-    base = np.ascontiguousarray(np.stack(base))
-    reps = (n_frames + n_distinct - 1) // n_distinct
-    return np.concatenate([base] * reps)[: 2 * n_frames]
+    return np.ascontiguousarray(np.stack(base))  # the distinct frames; the caller tiles them (tile_on_device)
 
 
 N_VARIANTS = 4  # distinct per-step host parameter sets (gravity directions, poses)
@@ -804,8 +813,8 @@ def main():
     C = len(cfg.cams)  # images per multiframe
     n_img = C * B
     distinct = min(args.distinct, B)
-    imgs, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank, args.content)
-    d_img = torch.from_numpy(imgs).to(dev)
+    _, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank, args.content, tile=False)
+    d_img = tile_on_device(base, n_img, dev)
     # `--lanes` independent contexts, each with its own HIP stream and B / lanes stereo frames of
     # the batch.  Frames are independent units, so this is the same sharding as across GPUs.
     S = max(1, min(args.lanes, B))
@@ -847,8 +856,9 @@ def main():
 
     def ensure_pinned():
         nonlocal h_img
-        if h_img is None:
-            h_img = torch.from_numpy(imgs).pin_memory()
+        if h_img is None:  # host-fed legs only: the tiled batch in pinned memory, copied back from the device
+            h_img = torch.empty(d_img.shape, dtype=torch.uint8, pin_memory=True)
+            h_img.copy_(d_img)
         return h_img
 
     def step(feed="device"):
@@ -1141,8 +1151,8 @@ def main():
         # (2) dense content: tied checker corners that all pass the uniformity stage (~700
         # keypoints per image): the matcher's 700 x 700 regime
         if args.content == "corners" and C > 1:
-            imgs_d, _ = make_inputs(cfg, B, distinct, 5000 + 977 * rank, "checker")
-            d_img.copy_(torch.from_numpy(imgs_d).to(dev))
+            _, base_d = make_inputs(cfg, B, distinct, 5000 + 977 * rank, "checker", tile=False)
+            d_img.copy_(tile_on_device(base_d, n_img, dev))
             for _ in range(4):
                 step("device")
             n_d = max(3, min(args.steps, 60))
@@ -1161,7 +1171,7 @@ def main():
         if args.content == "corners" and C == 2:
             imgs_r = real_inputs(cfg, B, distinct)
             if imgs_r is not None:
-                d_img.copy_(torch.from_numpy(imgs_r).to(dev))
+                d_img.copy_(tile_on_device(imgs_r, n_img, dev))
                 for _ in range(2):
                     step("device")
                 n_r = max(3, min(args.steps, 60))
