@@ -43,11 +43,12 @@ constexpr int kBoxMaskCounts = 10;  // interior byte counts 0 .. 9 (= kMaxBox - 
 constexpr int kSmallBox = 4;  // second pass of the camera-aware-only kernel: boxes of at most 5 x 5 (sigma_half <= 2.0)
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
 constexpr int kZeroRowBytes = 160;  // >= the widest patch row (152 B) + the 3-dword reads past a box
-// LDS per workgroup = 4 patch buffers + values (1152 B) + short pairs (768 B) + box masks (640 B): 26880 B = 21
+// LDS per workgroup = 4 patch buffers + values (1152 B) + short pairs (768 B) + box masks (640 B) + second-pass
+// constants (160 B): <= 26880 B = 21
 // allocation granules of 1280 B, six workgroups per CU (the 6-waves-per-SIMD form)
-constexpr int kPatchBufBytes = 6080;
+constexpr int kPatchBufBytes = 6032;
 #ifndef OKVFE_DESC_WIDE_BUF
-#define OKVFE_DESC_WIDE_BUF 7360  // 4 x 7360 + 2560 B of tables = 32000 B = 25 allocation granules: five workgroups per CU
+#define OKVFE_DESC_WIDE_BUF 7312  // 4 x 7312 + 2720 B of tables <= 32000 B = 25 allocation granules: five workgroups per CU
 #endif
 constexpr int kPatchDataBytes = kPatchBufBytes - kZeroRowBytes - 16;  // 16 B slack: 3-dword row reads
 // floor(num / den) for 0 <= num < 2^31, den >= 1 and a quotient below 2^22 (here: 1024 * mean
@@ -294,6 +295,17 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   // they were a third dependent round trip in every keypoint's chain
   __shared__ __attribute__((aligned(16))) uint32_t box_masks[4 * kBoxMaskCounts * 4];
   fill_box_masks(box_masks, threadIdx.x, 64 * kDescWaves);
+  // constants of the second-pass samples (points 0 .. kPatternPoints - 65) at the base scale: read from LDS per
+  // keypoint (global loads here were a second memory round trip in every keypoint's chain)
+  __shared__ float second_f[3][kPatternPoints - 64];
+  __shared__ int second_i[2][kPatternPoints - 64];
+  if (threadIdx.x < kPatternPoints - 64) {
+    second_f[0][threadIdx.x] = pat->px[threadIdx.x];
+    second_f[1][threadIdx.x] = pat->py[threadIdx.x];
+    second_f[2][threadIdx.x] = pat->sigma_half[threadIdx.x];
+    second_i[0][threadIdx.x] = pat->box_scaling[threadIdx.x];
+    second_i[1][threadIdx.x] = pat->box_scaling2[threadIdx.x];
+  }
   __shared__ uint16_t short_pairs[384];
   for (int t = threadIdx.x; t < 384; t += 64 * kDescWaves)
     short_pairs[t] = t < pat->n_short ? (uint16_t)(pat->short_i[t] | (pat->short_j[t] << 8)) : (uint16_t)0;
@@ -434,9 +446,9 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     const int sc2 = ladder ? scale_idx : 0;
     bool ok2 = true;
     auto second_pos = [&](float* x2, float* y2, float* s2) -> bool {
-      const float px2 = ladder ? scales->px[sc2][l2] : pat->px[l2];
-      const float py2 = ladder ? scales->py[sc2][l2] : pat->py[l2];
-      *s2 = ladder ? scales->sigma_half[sc2][l2] : pat->sigma_half[l2];
+      const float px2 = ladder ? scales->px[sc2][l2] : second_f[0][l2];
+      const float py2 = ladder ? scales->py[sc2][l2] : second_f[1][l2];
+      *s2 = ladder ? scales->sigma_half[sc2][l2] : second_f[2][l2];
       return sample_pos(M, kp.x, kp.y, px2, py2, *s2, w, h, x2, y2);
     };
     if (extra > 0) {  // wave-uniform
@@ -473,8 +485,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       // in the patch, so both passes are straight-line code the scheduler may interleave)
       v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
       if (extra > 0) {  // wave-uniform; AWARE: the host checked sigma_half <= 2.0 for these points (5 x 5 boxes)
-        const int b1 = ladder ? scales->box_scaling[sc2][l2] : pat->box_scaling[l2];
-        const int b2 = ladder ? scales->box_scaling2[sc2][l2] : pat->box_scaling2[l2];
+        const int b1 = ladder ? scales->box_scaling[sc2][l2] : second_i[0][l2];
+        const int b2 = ladder ? scales->box_scaling2[sc2][l2] : second_i[1][l2];
         asm volatile("" : "+v"(l2));  // opaque: the position is recomputed, not carried over the first pass
         float xf2, yf2, sg2;
         second_pos(&xf2, &yf2, &sg2);
@@ -485,8 +497,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         const GlobalPx gpx2{im, w};
         float xf2, yf2, sg2;
         second_pos(&xf2, &yf2, &sg2);
-        const int b1 = ladder ? scales->box_scaling[sc2][l2] : pat->box_scaling[l2];
-        const int b2 = ladder ? scales->box_scaling2[sc2][l2] : pat->box_scaling2[l2];
+        const int b1 = ladder ? scales->box_scaling[sc2][l2] : second_i[0][l2];
+        const int b2 = ladder ? scales->box_scaling2[sc2][l2] : second_i[1][l2];
         v2 = smoothed_intensity(gpx2, xf2, yf2, sg2, b1, b2);
       }
       // The patch does not fit in the wave's LDS buffer (wide-angle cameras stretch the camera-aware
@@ -550,14 +562,25 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   // tables in LDS the chain of a keypoint is then a single global round trip (the patch) instead of
   // three.  The loads are wave-uniform; their values move to SGPRs when the keypoint's turn comes.
   const int k_step = tiles * kDescWaves;
-  float2 nxt_xy = make_float2(0.f, 0.f);
-  float4 nxt_M = make_float4(0.f, 0.f, 0.f, 0.f);
+  // scalar loads (the constant address space forces s_load): the prefetched values of the NEXT keypoint then wait in
+  // SGPRs instead of seven VGPRs across this keypoint's box sums (that was what spilled at 80 registers).  Safe on
+  // the scalar cache: a slot's position / M / valid byte are written before this kernel starts and read here before
+  // this wave -- the only writer of the slot -- overwrites them.
+  typedef const float __attribute__((address_space(4))) * cfloat_p;
+  typedef const uint8_t __attribute__((address_space(4))) * cbyte_p;
+  float nxt_x = 0.f, nxt_y = 0.f, nxt_M0 = 0.f, nxt_M1 = 0.f, nxt_M2 = 0.f, nxt_M3 = 0.f;
   int nxt_valid = 0;
   auto fetch = [&](int kk) {
     const size_t sl = (size_t)img * kp_cap + kk;
-    nxt_xy = *reinterpret_cast<const float2*>(&kps_in[sl].x);
-    nxt_M = *reinterpret_cast<const float4*>(desc_tmp + sl * OKVFE_DESC_BYTES);
-    nxt_valid = (int)valid_tmp[sl];
+    const cfloat_p pxy = (cfloat_p)(uintptr_t)(&kps_in[sl].x);
+    const cfloat_p pm = (cfloat_p)(uintptr_t)(desc_tmp + sl * OKVFE_DESC_BYTES);
+    nxt_x = pxy[0];
+    nxt_y = pxy[1];
+    nxt_M0 = pm[0];
+    nxt_M1 = pm[1];
+    nxt_M2 = pm[2];
+    nxt_M3 = pm[3];
+    nxt_valid = (int)((cbyte_p)(uintptr_t)valid_tmp)[sl];
   };
   fetch(tile * kDescWaves + wv);
   for (int k = tile * kDescWaves + wv; k < n; k += k_step) {
@@ -566,8 +589,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(lane));
   const size_t slot = (size_t)img * kp_cap + k;
   auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-  kp.x = uni(nxt_xy.x);
-  kp.y = uni(nxt_xy.y);
+  kp.x = uni(nxt_x);
+  kp.y = uni(nxt_y);
   // border test and (camera-aware mode) the matrix M come from describe_setup_kernel
   const int vbyte = __builtin_amdgcn_readfirstlane(nxt_valid);  // valid | scale index << 1
   bool valid = (vbyte & 1) != 0;
@@ -581,7 +604,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     bsc2 = scales->box_scaling2[sc][li];
     border = scales->border[sc];
   }
-  M[0] = uni(nxt_M.x); M[1] = uni(nxt_M.y); M[2] = uni(nxt_M.z); M[3] = uni(nxt_M.w);
+  M[0] = uni(nxt_M0); M[1] = uni(nxt_M1); M[2] = uni(nxt_M2); M[3] = uni(nxt_M3);
   if (k + k_step < n) fetch(k + k_step);  // scalar branch
   bool new_angle = false;
   const int mode = AWARE ? (int)kCameraAware : (int)ip.mode;
