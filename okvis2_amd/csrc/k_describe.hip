@@ -38,7 +38,7 @@ namespace {
 // Box of half-side sigma_half centred at (xf, yf); returns 1024 * mean intensity.  Same integer /
 // float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
-constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
+[[maybe_unused]] constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
 constexpr int kBoxMaskCounts = 10;  // interior byte counts 0 .. 9 (= kMaxBox - 1) per first-byte position 0 .. 3
 constexpr int kSmallBox = 4;  // second pass of the camera-aware-only kernel: boxes of at most 5 x 5 (sigma_half <= 2.0)
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         asm volatile("" : "+v"(l2));  // opaque: the position is recomputed, not carried over the first pass
         float xf2, yf2, sg2;
         second_pos(&xf2, &yf2, &sg2);
-        v2 = smoothed_intensity<AWARE, AWARE ? kSmallBox : kMaxBox>(ppx, xf2, yf2, sg2, b1, b2);
+        v2 = smoothed_intensity<AWARE, kSmallBox>(ppx, xf2, yf2, sg2, b1, b2);  // (generic form: run-time check, plain loops beyond 5 x 5)
       }
     } else {
       if (extra > 0 && active2) {  // rare path (patch larger than the wave's buffer): the few extra samples read the image
