@@ -1,5 +1,5 @@
 """GPU box: timeline of one steady-state bench step from a rocprofv3 --kernel-trace csv.
-usage: python tools/gaps.py <dir with *kernel_trace.csv> [step index, default 10]"""
+usage: python tools/lab/gaps.py <dir with *kernel_trace.csv> [step index, default 10]"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # K1 experiment helper (GPU box): SQ counters of the fused score kernel for the env settings given
-# as arguments ("-" = defaults).  usage: bash tools/k1pmc.sh "-" "OKVFE_K1_TH=31" ...
+# as arguments ("-" = defaults).  usage: bash tools/lab/k1pmc.sh "-" "OKVFE_K1_TH=31" ...
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 i=0

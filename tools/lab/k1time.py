@@ -1,9 +1,9 @@
 """GPU box: time of the fused score+NMS kernel alone (HIP events of the harris stage) for A/B
 variants whose score-map LAYOUT is experimental (the rest of the pipeline would read garbage):
-only okvfe_detect_batch_device is called.   OKVFE_LIB=... python tools/k1time.py [n_images]"""
+only okvfe_detect_batch_device is called.   OKVFE_LIB=... python tools/lab/k1time.py [n_images]"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 from okvis2_amd import capi, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1536

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds A/B variants of libokvfe.so that differ only in k_harris.hip macros:
-#   bash tools/k1variants.sh name1 "-DFOO=1 -DBAR" name2 "..."   -> okvis2_amd/libokvfe_<name>.so
+#   bash tools/lab/k1variants.sh name1 "-DFOO=1 -DBAR" name2 "..."   -> okvis2_amd/libokvfe_<name>.so
 set -e
 cd $(dirname $0)/../okvis2_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"

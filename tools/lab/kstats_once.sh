@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: rocprofv3 kernel stats of the default bench command, top kernels only.  usage: bash tools/kstats_once.sh [repeats]
+# GPU box: rocprofv3 kernel stats of the default bench command, top kernels only.  usage: bash tools/lab/kstats_once.sh [repeats]
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 for i in $(seq 1 ${1:-1}); do
   rm -rf /tmp/ks$i

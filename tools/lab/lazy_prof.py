@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lab build only: phase times of select_lazy_kernel for image 0 (s_memrealtime, 10-ns ticks), B = 1 and batch."""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["OKVFE_LIB"] = os.path.join(ROOT, "okvis2_amd", "libokvfe_lab.so")
 sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds an A/B variant of libokvfe.so that differs in ONE kernel source:
-#   bash tools/variant.sh <name> <k_file.hip> "<extra hipcc flags / -D...>" [sed-expression on the source]
+#   bash tools/lab/variant.sh <name> <k_file.hip> "<extra hipcc flags / -D...>" [sed-expression on the source]
 #   -> okvis2_amd/libokvfe_<name>.so   (use with OKVFE_LIB=$PWD/okvis2_amd/libokvfe_<name>.so)
 set -e
 name=$1; file=$2; defs=$3; sedx=${4:-}
