@@ -642,9 +642,9 @@ typedef struct okvfe_map_device {
 } okvfe_map_device;
 /* = Frontend::matchToMapByThread (Frontend.cpp:1552-1589) for n_frames frames.  use_dev: device
  * n_frames x K flags or NULL (every keypoint).  Outputs (device, n_frames x K): landmark index
- * (-1 = none) and distance (match_threshold if none).  * The call keeps the frames' keypoint order in ONE workspace of the context: two calls of this entry
- * point on the same context must not be in flight on different streams at the same time (every other
- * entry point of the batch API may be). */
+ * (-1 = none) and distance (match_threshold if none).  The call keeps the frames' keypoint order in a workspace
+ * of its own per stream (ABI 6), so calls on different streams of one context may be in flight together, like
+ * every other entry point of the batch API (the host side of a context is still one thread at a time). */
 okvfe_status okvfe_match_to_map_blocks_device(okvfe_ctx* ctx, const void* blocks_dev, int32_t n_frames,
                                               const uint8_t* use_dev, const okvfe_map_device* map,
                                               double reprojection_threshold, int32_t* best_landmark_dev,

@@ -523,7 +523,8 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   for (uint8_t* p : ctx->d_layer_img)
     if (p) (void)hipFree(p);
   if (ctx->d_virtual) (void)hipFree(ctx->d_virtual);
-  if (ctx->d_map_perm) (void)hipFree(ctx->d_map_perm);
+  for (auto& m : ctx->map_perm)
+    if (m.d) (void)hipFree(m.d);
   for (void* p : ctx->allocs) (void)hipFree(p);
   for (float* p : ctx->cam_rays)
     if (p) (void)hipFree(p);

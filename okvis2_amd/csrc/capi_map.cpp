@@ -428,21 +428,30 @@ okvfe_status okvfe_match_to_map_blocks_device(okvfe_ctx* ctx, const void* blocks
   hipStream_t s = pick_stream(ctx, stream);
   const BlockLayout L = block_layout(ctx->kp_cap);
   const int offs[6] = {(int)L.o_count, (int)L.o_kps, (int)L.o_desc, (int)L.o_bp, (int)L.o_bpv, (int)L.total};
-  if ((size_t)n_frames > ctx->map_perm_frames) {  // workspace of the region order: grown on demand (synchronises once)
-    if (ctx->d_map_perm) HIP_TRY(ctx, hipFree(ctx->d_map_perm));
-    ctx->d_map_perm = nullptr;
-    ctx->map_perm_frames = 0;
+  // workspace of the region order: one per stream, grown on demand (growing frees the old buffer, which
+  // synchronises the device once)
+  okvfe_ctx::MapPerm* mp = nullptr;
+  for (auto& m : ctx->map_perm)
+    if (m.stream == s) mp = &m;
+  if (!mp) {
+    ctx->map_perm.push_back(okvfe_ctx::MapPerm{s, nullptr, 0});
+    mp = &ctx->map_perm.back();
+  }
+  if ((size_t)n_frames > mp->frames) {
+    if (mp->d) HIP_TRY(ctx, hipFree(mp->d));
+    mp->d = nullptr;
+    mp->frames = 0;
     void* q = nullptr;
     HIP_TRY(ctx, hipMalloc(&q, (size_t)n_frames * ctx->kp_cap * sizeof(int32_t)));
-    ctx->d_map_perm = static_cast<int32_t*>(q);
-    ctx->map_perm_frames = (size_t)n_frames;
+    mp->d = static_cast<int32_t*>(q);
+    mp->frames = (size_t)n_frames;
   }
   {
     StageTimer t(ctx, OKVFE_STAGE_MAP, s);
     launch_match_to_map_blocks(offs, static_cast<const uint8_t*>(blocks_dev), n_frames, ctx->kp_cap, use_dev,
                                map->projections, (size_t)map->n_landmarks * 2, map->desc_begin, map->n_landmarks,
                                map->pool, reprojection_threshold * reprojection_threshold, ctx->cfg.match_threshold,
-                               best_landmark_dev, best_dist_dev, ctx->d_map_perm, s);
+                               best_landmark_dev, best_dist_dev, mp->d, s);
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;

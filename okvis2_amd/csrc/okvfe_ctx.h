@@ -32,10 +32,14 @@ struct okvfe_ctx {
   std::vector<void*> allocs;
   int32_t* d_scores = nullptr;
   int32_t* d_virtual = nullptr;   // scale-space parent, OKVFE_SCORE_BRISK_SCALESPACE: FAST 5-8 map of layer 0
-  // okvfe_match_to_map_blocks_device: keypoint order per frame [frames][kp_cap].  ONE workspace per
-  // context: calls of that entry point on different streams must not overlap (okvfe.h says so)
-  int32_t* d_map_perm = nullptr;
-  size_t map_perm_frames = 0;     // frames d_map_perm holds
+  // okvfe_match_to_map_blocks_device: keypoint order per frame [frames][kp_cap], ONE workspace PER STREAM the entry
+  // point was called on (calls on one stream are ordered; calls on different streams no longer share a buffer)
+  struct MapPerm {
+    hipStream_t stream = nullptr;
+    int32_t* d = nullptr;
+    size_t frames = 0;  // frames d holds
+  };
+  std::vector<MapPerm> map_perm;
   ScoreLayout score_layout{0, 0};  // of d_scores: slotted where the fused score+NMS kernel applies
   ScoreLayout live_layout{0, 0};   // the layout the LAST score launch actually wrote (dense when the fused kernel refused the call)
   // Map-free detection (round 4): single-scale Harris calls whose selection kernel can recompute the nine
