@@ -13,10 +13,14 @@ import bench  # noqa: E402
 def test_newest_pmc_collection_is_found_by_numeric_tag():
     pmc, name = bench.k1_pmc_for(752, 480, True)
     assert pmc is not None and pmc["map_free"] and pmc["width"] == 752
-    tags = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("round4_v") and f.endswith("_k1_pmc.json")
-            and f.count("_") == 3]
-    newest = max(int(f.split("_")[1][1:]) for f in tags)
-    assert name == f"round4_v{newest}_k1_pmc.json"  # v12 after v5, not before it
+    import re
+    tags = []  # (round, collection) of every un-suffixed EuRoC collection: round4_v12 after round4_v5, round5_v1 after both
+    for f in os.listdir(os.path.join(ROOT, "profiles")):
+        m = re.fullmatch(r"round(\d+)_v(\d+)_k1_pmc\.json", f)
+        if m:
+            tags.append((int(m.group(1)), int(m.group(2))))
+    r, v = max(tags)
+    assert name == f"round{r}_v{v}_k1_pmc.json"
     with_map, name_m = bench.k1_pmc_for(752, 480, False)
     assert with_map is not None and not with_map.get("map_free", False) and "withmap" in name_m
     assert bench.k1_pmc_for(123, 45, True) == (None, None)
