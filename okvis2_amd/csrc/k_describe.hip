@@ -80,7 +80,10 @@ __device__ __forceinline__ int div_nonneg(int num, int den) {
 // form and the test for it are compiled out.
 // MAXB: largest box side minus one the fixed-trip form serves (kMaxBox; the second-pass samples of a pattern
 // with more than 64 points are its innermost, smallest boxes and take kSmallBox: 4 row slots, 2 dwords).
-template <bool FASTONLY = false, int MAXB = 10, typename PX>
+// LATE_WAIT: the patch loads (buffer_load ... lds) are still in flight when the function is entered; it waits for
+// them just before its first pixel read, so the ~80 instructions of per-sample set-up run under the loads' latency
+// (only with FASTONLY: the one code path then reaches the wait in every lane).
+template <bool FASTONLY = false, int MAXB = 10, bool LATE_WAIT = false, typename PX>
 __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
                                                   float sigma_half, int scaling, int scaling2) {
   if (sigma_half < 0.5f) {
@@ -153,6 +156,11 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
       return acc;
     };
     const int full = mul24i(ni, 255);
+    if constexpr (LATE_WAIT) {
+      static_assert(!LATE_WAIT || FASTONLY, "late wait needs the single code path");
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the staged rows have landed in LDS
+      __builtin_amdgcn_wave_barrier();
+    }
     upper = full - (int)read_row(run, 0u);
     ret = mul24i(A, pl) + mul24i(B, pr);
     bottom = full - (int)read_row(run + mul24i(bh, pitch), 0u);
@@ -205,6 +213,16 @@ __device__ __forceinline__ bool sample_pos(const float M[4], float kx, float ky,
   return (x_1 >= 0.0f && y_1 >= 0.0f && x1 < (float)(w - 1) && y1 < (float)(h - 1));
 }
 
+// A/B switches of the round-5 latency experiments (tools/lab/descab5.sh; defaults = the kept forms)
+#ifndef OKVFE_DESC_LATE_WAIT
+#define OKVFE_DESC_LATE_WAIT 1   // per-sample set-up runs under the patch loads' latency
+#endif
+#ifndef OKVFE_DESC_PAIRS_REG
+#define OKVFE_DESC_PAIRS_REG 1   // the lane's six pair entries live in registers (0: read from the LDS table per keypoint)
+#endif
+#ifndef OKVFE_DESC_PAIRS_OPAQUE
+#define OKVFE_DESC_PAIRS_OPAQUE 0  // 1: the gather addresses derived from them are recomputed per keypoint (no hoisting)
+#endif
 constexpr int kDescWaves = 4;
 #ifndef OKVFE_DESC_BLOCKS
 #define OKVFE_DESC_BLOCKS 16
@@ -345,6 +363,10 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   float M[4];
   float xf, yf;
   int scale_idx = 0;  // this keypoint's rung of the scale ladder (wave-uniform)
+  uint32_t my_pairs[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    my_pairs[j] = (uint32_t)short_pairs[(2 * j) * 64 + lane] | ((uint32_t)short_pairs[(2 * j + 1) * 64 + lane] << 16);
   int* vals = values[wv];
   uint8_t* patch = patches[wv] + kZeroRowBytes;
   if (lane < kZeroRowBytes / 4) reinterpret_cast<uint32_t*>(patches[wv])[lane] = 0u;
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
 
   // stages the pixels [bx0..bx1] x [by0..by1] (inside the image) into LDS; false if too large
-  auto stage_patch = [&](int bx0, int bx1, int by0, int by1, PatchPx* ppx) -> bool {
+  auto stage_patch = [&](int bx0, int bx1, int by0, int by1, PatchPx* ppx, bool* in_flight = nullptr) -> bool {
     // the bounds derive from the keypoint (same in every lane): tell the compiler they are scalar
     bx0 = __builtin_amdgcn_readfirstlane(bx0);
     bx1 = __builtin_amdgcn_readfirstlane(bx1);
@@ -387,8 +409,12 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
                 img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * R * pitch), 16,
                 (int)src_lane, src0 + it * R * w, 0, 0);
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        if (AWARE && in_flight && OKVFE_DESC_LATE_WAIT) {
+          *in_flight = true;  // the caller's first box sum waits (smoothed_intensity<.., LATE_WAIT>)
+        } else {
+          __builtin_amdgcn_s_waitcnt(0);
+          __builtin_amdgcn_wave_barrier();
+        }
         ppx->patch = patch;
         ppx->x0 = px0;
         ppx->y0 = by0;
@@ -480,10 +506,14 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     }
     PatchPx ppx;
     int v = 0, v2 = 0;
-    if (stage_patch(bx0, bx1, by0, by1, &ppx)) {
+    bool in_flight = false;
+    if (stage_patch(bx0, bx1, by0, by1, &ppx, &in_flight)) {
       // (no exec-mask change around the box sums: lanes without a sample carry point 0's constants, whose box lies
       // in the patch, so both passes are straight-line code the scheduler may interleave)
-      v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+      if (AWARE && in_flight)  // wave-uniform
+        v = smoothed_intensity<AWARE, kMaxBox, AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+      else
+        v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
       if (extra > 0) {  // wave-uniform; AWARE: the host checked sigma_half <= 2.0 for these points (5 x 5 boxes)
         const int b1 = ladder ? scales->box_scaling[sc2][l2] : second_i[0][l2];
         const int b2 = ladder ? scales->box_scaling2[sc2][l2] : second_i[1][l2];
@@ -587,6 +617,9 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   // opaque to the optimiser: expressions of the lane constants are NOT hoisted out of the loop
   // (they would cost ~25 more live VGPRs and push the kernel below 6 waves/SIMD)
   asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(lane));
+#if OKVFE_DESC_PAIRS_OPAQUE
+  asm volatile("" : "+v"(my_pairs[0]), "+v"(my_pairs[1]), "+v"(my_pairs[2]));  // (nor the 12 gather addresses derived from these)
+#endif
   const size_t slot = (size_t)img * kp_cap + k;
   auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
   kp.x = uni(nxt_x);
@@ -657,7 +690,13 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     unsigned long long words[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const uint32_t pr = short_pairs[j * 64 + lane];  // slots past n_short hold 0 | 0: bit 0
+      // this lane's pair of word j, held in registers for the whole wave (two pairs per dword): no table read in a
+      // keypoint's chain, only the two value gathers
+#if OKVFE_DESC_PAIRS_REG
+      const uint32_t pr = (j & 1) ? my_pairs[j >> 1] >> 16 : my_pairs[j >> 1] & 0xFFFFu;  // slots past n_short: 0 | 0
+#else
+      const uint32_t pr = short_pairs[j * 64 + lane];
+#endif
       const bool bit = vals[pr & 255u] > vals[pr >> 8];
       words[j] = __ballot(bit);
     }

@@ -4,7 +4,7 @@
 #   -> okvis2_amd/libokvfe_<name>.so   (use with OKVFE_LIB=$PWD/okvis2_amd/libokvfe_<name>.so)
 set -e
 name=$1; file=$2; defs=$3; sedx=${4:-}
-cd $(dirname $0)/../okvis2_amd/csrc
+cd $(dirname $0)/../../okvis2_amd/csrc
 make -s
 src=$file
 if [ -n "$sedx" ]; then sed "$sedx" $file > /tmp/variant_$name.hip; src=/tmp/variant_$name.hip; fi
