@@ -305,6 +305,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images, int tiles,
     uint32_t inv_tiles, const PatternScales* __restrict__ scales) {
   // (the 96-register instantiation leaves LDS for five workgroups of 32 KB: its waves get 7.5 KB buffers)
+  // (the generic form runs four workgroups per CU: 4 x 7312 + 2720 + 8800 B of long pairs = 40768 B, 128 registers)
   constexpr int kBufBytes = kWavesPerSimd >= 6 ? kPatchBufBytes : OKVFE_DESC_WIDE_BUF;
   constexpr int kDataBytes = kBufBytes - kZeroRowBytes - 16;
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kBufBytes];
@@ -323,6 +324,20 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     second_f[2][threadIdx.x] = pat->sigma_half[threadIdx.x];
     second_i[0][threadIdx.x] = pat->box_scaling[threadIdx.x];
     second_i[1][threadIdx.x] = pat->box_scaling2[threadIdx.x];
+  }
+  // generic form: the long pairs of the gradient orientation as {i | j << 8, wdx | wdy << 16} in LDS (their four
+  // global tables were ~64 loads per lane in every keypoint's chain); weights beyond 16 bits keep the global path
+  __shared__ uint2 long_tab[AWARE ? 1 : kMaxLongPairs];
+  __shared__ int long_wide;
+  if constexpr (!AWARE) {
+    if (threadIdx.x == 0) long_wide = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < pat->n_long; t += 64 * kDescWaves) {
+      const int wx = pat->long_wdx[t], wy = pat->long_wdy[t];
+      if (wx < -32768 || wx > 32767 || wy < -32768 || wy > 32767) long_wide = 1;
+      long_tab[t] = make_uint2((uint32_t)pat->long_i[t] | ((uint32_t)pat->long_j[t] << 8),
+                               ((uint32_t)wx & 0xFFFFu) | ((uint32_t)wy << 16));
+    }
   }
   __shared__ uint16_t short_pairs[384];
   for (int t = threadIdx.x; t < 384; t += 64 * kDescWaves)
@@ -462,7 +477,11 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     return true;
   };
   // values of all 60 samples under the current M; false when a box leaves the image
-  auto sample_all = [&](bool fixed_box) -> bool {
+  // gradient mode samples twice under the same fixed box (unrotated for the orientation, then rotated): the patch
+  // staged for the first call serves the second one
+  PatchPx kept_patch{};
+  bool have_kept = false;
+  auto sample_all = [&](bool fixed_box, bool reuse = false) -> bool {
     const bool ok = sample_pos(M, kp.x, kp.y, px, py, sg, w, h, &xf, &yf);
     // second-pass sample of lanes < extra: its constants are re-read per keypoint and its position is computed
     // twice (here for the inside-the-image test, again after the first pass) so that nothing of it stays in
@@ -507,7 +526,13 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     PatchPx ppx;
     int v = 0, v2 = 0;
     bool in_flight = false;
-    if (stage_patch(bx0, bx1, by0, by1, &ppx, &in_flight)) {
+    const bool reused = !AWARE && reuse && have_kept;  // wave-uniform
+    if (reused) ppx = kept_patch;
+    if (reused || stage_patch(bx0, bx1, by0, by1, &ppx, &in_flight)) {
+      if (!AWARE && fixed_box) {
+        kept_patch = ppx;
+        have_kept = true;
+      }
       // (no exec-mask change around the box sums: lanes without a sample carry point 0's constants, whose box lies
       // in the patch, so both passes are straight-line code the scheduler may interleave)
       if (AWARE && in_flight)  // wave-uniform
@@ -645,10 +670,22 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     valid = sample_all(true);
     if (valid) {
       int d0 = 0, d1 = 0;
-      for (int l = lane; l < pat->n_long; l += 64) {
-        const int delta_t = vals[pat->long_i[l]] - vals[pat->long_j[l]];
-        d0 += delta_t * pat->long_wdx[l] / 1024;
-        d1 += delta_t * pat->long_wdy[l] / 1024;
+      if constexpr (!AWARE) {
+        if (long_wide == 0) {  // block-uniform
+          const int nl = pat->n_long;
+          for (int l = lane; l < nl; l += 64) {
+            const uint2 e = long_tab[l];
+            const int delta_t = vals[e.x & 255u] - vals[(e.x >> 8) & 255u];
+            d0 += delta_t * (int)(short)(e.y & 0xFFFFu) / 1024;
+            d1 += delta_t * ((int)e.y >> 16) / 1024;
+          }
+        } else {
+          for (int l = lane; l < pat->n_long; l += 64) {
+            const int delta_t = vals[pat->long_i[l]] - vals[pat->long_j[l]];
+            d0 += delta_t * pat->long_wdx[l] / 1024;
+            d1 += delta_t * pat->long_wdy[l] / 1024;
+          }
+        }
       }
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) {
@@ -657,15 +694,14 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       }
       int best_k = 0;
       if (d0 != 0 || d1 != 0) {
-        long long best = LLONG_MIN;
-        int bk = 0;
-        for (int r = lane * 16; r < lane * 16 + 16; ++r) {
-          const long long dot = (long long)d0 * pat->rot_cos[r] + (long long)d1 * pat->rot_sin[r];
-          if (dot > best) {
-            best = dot;
-            bk = r;
-          }
-        }
+        // exact arg-max over the 1024 directions (smallest index among equal maxima, as the serial scan of the
+        // published code finds it), evaluated only where it can lie: the dot product is a sampled sinusoid, 32 steps
+        // from its peak it has dropped by 632 |d| while the rounding of the tables moves any sample by < |d|, and the
+        // float estimate of the peak is good to a millionth of a step -- so lane l tests step k_est - 32 + l
+        const float ang = atan2f((float)d1, (float)d0);
+        const int k_est = (int)lrintf(ang * (1024.0f / 6.2831853071795864769f));
+        int bk = (k_est - 32 + lane) & 1023;
+        long long best = (long long)d0 * pat->rot_cos[bk] + (long long)d1 * pat->rot_sin[bk];
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
           const long long ob = __shfl_xor(best, d);
@@ -685,7 +721,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       M[3] = pat->rot_cosf[best_k];
     }
   }
-  if (valid) valid = sample_all(mode != kCameraAware);
+  if (valid) valid = sample_all(mode != kCameraAware, /*reuse=*/new_angle);
+  have_kept = false;
   if (valid) {
     unsigned long long words[6];
 #pragma unroll
@@ -792,10 +829,15 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   static const bool no_aware = lab_env("OKVFE_DESC_GENERIC") != nullptr;  // A/B knob: the all-modes kernel
   if (no_aware || scales != nullptr || w % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3) != 0)
     all_camera_aware = false;  // (scale-invariant extraction, unaligned images: generic form)
-  if (wide_patches) {
-    if (all_camera_aware) OKVFE_DESC_LAUNCH(5, true); else OKVFE_DESC_LAUNCH(5, false);
+  if (!all_camera_aware) {
+    // the all-modes form: 128 registers, the long pairs in LDS: four workgroups per CU (measured on the BRISK
+    // scale-space path, 512 images x 2780 keypoints in gradient mode: 5.5 ms with 80 registers and the long-pair /
+    // rotation tables in global memory, 4.3 ms in this form; the 5- and 6-wave forms of it 4.7 ms)
+    OKVFE_DESC_LAUNCH(4, false);
+  } else if (wide_patches) {
+    OKVFE_DESC_LAUNCH(5, true);
   } else {
-    if (all_camera_aware) OKVFE_DESC_LAUNCH(6, true); else OKVFE_DESC_LAUNCH(6, false);
+    OKVFE_DESC_LAUNCH(6, true);
   }
 #undef OKVFE_DESC_LAUNCH
 }

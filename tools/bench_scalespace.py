@@ -11,7 +11,8 @@ octaves = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 score_type = int(sys.argv[3]) if len(sys.argv) > 3 else capi.SCORE_BRISK_SCALESPACE
 w, h = 752, 480
 fe = capi.Frontend(w, h, 0.0 if score_type == capi.SCORE_BRISK_SCALESPACE else 20.0, octaves, 34, 800, max_batch=n,
-                   score_type=score_type, max_candidates=1 << 15)
+                   score_type=score_type, max_candidates=1 << 15,
+                   rotation_invariant=os.environ.get("SS_UPRIGHT") is None)
 base = np.stack([synth.corners_image(w, h, i) for i in range(8)])
 imgs = torch.from_numpy(np.concatenate([base] * (n // 8))).cuda()
 st = torch.cuda.Stream()
