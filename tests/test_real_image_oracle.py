@@ -92,7 +92,7 @@ def test_oracle_descriptors_against_the_real_brisk2_vocabulary(oracle):
          47.7, oracle descriptors of another scene 114 (a blurred copy: 90);
      (2) correlation of the two 384 x 384 bit-correlation matrices: 0.63 on this image (the statistic also
          depends on image content and on the smoothing width, which stays an assumption: the forward simulator
-         of tools/pattern reaches 0.88 with wider smoothing);
+         of tools/pattern reaches 0.87 when its descriptors are clustered like a vocabulary and smoothed with one published sigma);
      (3) all 384 bits live with densities near one half, as in the vocabulary."""
     fx = RC.load()
     full = fx["image"]
