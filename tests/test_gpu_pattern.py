@@ -138,3 +138,35 @@ def test_bad_patterns_are_rejected():
             p.sigma_half[3] = 0.0
         with pytest.raises(capi.OkvfeError):
             fe.set_pattern(p)
+
+
+def test_widened_builtin_pattern_stays_bit_exact(oracle, monkeypatch):
+    """The built-in pattern with every box 1.73 x wider (what the vocabulary's statistics
+    favour): boxes up to 17 x 17 -> the generic descriptor kernel's plain box loops, larger patches, a wider rim."""
+    import math
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, rotation_invariant=True)
+    fe.set_camera(0, cam)
+    p = fe.get_pattern()
+    reach = 0.0
+    for i in range(p.n_points):
+        p.sigma_half[i] = np.float32(p.sigma_half[i] * 1.73)
+        reach = max(reach, math.hypot(p.px[i], p.py[i]) + p.sigma_half[i])
+    p.border = int(math.ceil(reach)) + 1
+    assert p.border > 29 and max(p.sigma_half[:p.n_points]) > 7.5
+    fe.set_pattern(p)
+    q = _to_orc(oracle, p)
+    monkeypatch.setattr(oracle, "pattern", lambda: q)
+    rays, jac = oracle.awareness_maps(cam)
+    for seed in (41, 42):
+        img = synth.corners_image(cfg.w, cfg.h, seed)
+        k, d, _, _ = fe.detect_describe(img, cam=0, gravity=(0.05, 0.99, -0.1))
+        rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                        oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.05, 0.99, -0.1))
+        G.assert_keypoints_equal(k, rk)
+        assert np.array_equal(d, rd) and len(k) > 100
+        k, d, _, _ = fe.detect_describe(img)  # gradient orientation
+        rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, oracle.MODE_GRADIENT)
+        G.assert_keypoints_equal(k, rk)
+        assert np.array_equal(d, rd)
