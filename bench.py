@@ -86,6 +86,28 @@ def real_inputs(cfg, n_frames, n_distinct):
     return np.ascontiguousarray(np.stack(base))  # the distinct frames; the caller tiles them (tile_on_device)
 
 
+def widen_pattern(fe, factor):
+    """--box-widen: the context's pattern with every box `factor` times wider (border follows), also installed in the
+    oracle that the cpu_baseline leg checks against"""
+    import ctypes as C
+    p = fe.get_pattern()
+    reach = 0.0
+    for i in range(p.n_points):
+        p.sigma_half[i] = np.float32(p.sigma_half[i] * factor)
+        reach = max(reach, math.hypot(p.px[i], p.py[i]) + p.sigma_half[i])
+    p.border = int(math.ceil(reach)) + 1
+    fe.set_pattern(p)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    q = type(O.pattern())()
+    C.memmove(C.byref(q), C.byref(O.pattern()), C.sizeof(q))
+    for f in ("n_points", "n_short", "n_long", "border"):
+        setattr(q, f, getattr(p, f))
+    for f in ("px", "py", "sigma_half", "short_i", "short_j", "long_i", "long_j", "long_wdx", "long_wdy"):
+        C.memmove(getattr(q, f), getattr(p, f), C.sizeof(getattr(p, f)))
+    O._PATTERN = q
+
+
 N_VARIANTS = 4  # distinct per-step host parameter sets (gravity directions, poses)
 
 
@@ -743,6 +765,10 @@ def main():
                          "overlapped with the previous step's kernels).  The device-fed run also "
                          "reports a short host-fed measurement as `host_fed`")
     ap.add_argument("--content", choices=("corners", "checker"), default="corners")
+    ap.add_argument("--box-widen", type=float, default=1.0,
+                    help="informational: install the built-in pattern with every smoothing box widened by this factor "
+                         "(1.73 = what the vocabulary's statistics favour, tools/pattern/README.md); the oracle of the "
+                         "cpu_baseline leg gets the same pattern")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed / dense-content legs")
     ap.add_argument("--exact-steps", action="store_true",
@@ -847,6 +873,8 @@ def main():
                             num_cameras=C, device=local_rank, max_candidates=args.max_candidates)
         for ci, cam in enumerate(cfg.cams):
             lfe.set_camera(ci, cam)
+        if args.box_widen != 1.0:
+            widen_pattern(lfe, args.box_widen)
         st = torch.cuda.Stream(device=dev)
         lanes.append((lfe, st, d_img[C * l * Bl:].data_ptr(), d_match[l * Bl:].data_ptr()))
     fe = lanes[0][0]
