@@ -8,21 +8,23 @@
 // cameras/implementation/PinholeCamera.hpp:574-593).
 //
 //   describe_setup_kernel  one thread per keypoint: border test, camera-aware matrix M.
-//   describe_kernel  one wave per keypoint at a time, lane i = pattern point i (60 of 64 lanes),
-//                    6 waves per SIMD; 16 workgroups of 4 waves per image, each wave walks the
-//                    image's keypoints with stride 64 (per-lane pattern constants, image
-//                    parameters and the buffer resource are set up once per wave; wave-uniform
-//                    values -- keypoint, M -- live in SGPRs).  The pixels under the keypoint's pattern go straight from the image
-//                    into a dense LDS patch (buffer_load ... lds, whole rows per instruction);
-//                    every sample is a box sum with sub-pixel rim weights read from LDS
-//                    (fixed trip counts, v_sad_u8 over masked dwords); 383 pair comparisons
-//                    become 6 wave ballots -> 6 x u64 = 48 bytes.  All blocks of an image run
-//                    on one XCD.  No integral image: the 4 B/px integral pass of the classic
-//                    CPU formulation (5 B/px of HBM traffic) is gone.
-//                    Latency / LDS bound (~340 VALU per keypoint; ONE global round trip per
-//                    keypoint: its patch, 16 B per lane; the short-pair table sits in LDS, the next
-//                    keypoint's position / M / valid flag are requested a keypoint ahead);
-//                    ~4.2 KB in + 48 B out per keypoint, 0.19 GB of HBM reads per 512 EuRoC images.
+//   describe_kernel  one wave per keypoint at a time, lane l = pattern point extra + l: the built-in pattern has 66
+//                    points, its first two (centre, first hexagon point) are a second, 5 x 5-slot pass of lanes
+//                    0..1 over the same patch.  <6, AWARE> / <5, AWARE>: camera-aware extraction only (the
+//                    production mode), 6 / 5 waves per SIMD; <4, generic>: every mode (gradient orientation with
+//                    its long pairs in LDS, upright, scale ladder, unaligned images, boxes beyond 11 x 11).  16
+//                    workgroups of 4 waves per image, each wave walks the image's keypoints with stride 64
+//                    (per-lane pattern constants, the lane's six pair entries, image parameters and the buffer
+//                    resource are set up once per wave; wave-uniform values -- keypoint, M -- live in SGPRs, the next
+//                    keypoint's arrive through scalar loads).  The pixels under the keypoint's pattern go straight
+//                    from the image into a dense LDS patch (buffer_load ... lds, whole rows per instruction) while
+//                    the per-sample set-up runs; every sample is a box sum with sub-pixel rim weights read from LDS
+//                    (fixed trip counts, v_msad_u8 over dwords masked from an LDS table); 384 pair comparisons
+//                    become 6 wave ballots -> 6 x u64 = 48 bytes.  All blocks of an image run on one XCD.  No
+//                    integral image: the 4 B/px integral pass of the classic CPU formulation is gone.
+//                    Bound by vector-ALU issue, the LDS gather and the latency of each keypoint's dependent chain
+//                    together (540 VALU + 82 LDS wave-instructions per keypoint; ONE global round trip per
+//                    keypoint: its patch); ~4.2 KB in + 48 B out per keypoint.
 //   compact_kernel   removes the keypoints the extractor dropped (order preserved) and
 //                    back-projects the survivors in FP64 (Gauss-Newton undistortion).
 #include <limits.h>
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
   constexpr int kDataBytes = kBufBytes - kZeroRowBytes - 16;
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kBufBytes];
   __shared__ int values[kDescWaves][kPatternPoints];
-  // the 383 short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
+  // the short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
   // they were a third dependent round trip in every keypoint's chain
   __shared__ __attribute__((aligned(16))) uint32_t box_masks[4 * kBoxMaskCounts * 4];
   fill_box_masks(box_masks, threadIdx.x, 64 * kDescWaves);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     ppx->masks = box_masks;
     return true;
   };
-  // values of all 60 samples under the current M; false when a box leaves the image
+  // values of all samples under the current M; false when a box leaves the image
   // gradient mode samples twice under the same fixed box (unrotated for the orientation, then rotated): the patch
   // staged for the first call serves the second one
   PatchPx kept_patch{};
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
       bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
     } else {
-      // superset of all 60 boxes under M: |M p|_x <= |row_x(M)| * |p| and |p| + sigma_half stays
+      // superset of all boxes under M: |M p|_x <= |row_x(M)| * |p| and |p| + sigma_half stays
       // below border - 1 for this pattern; the boxes themselves were checked to lie in the image
       // (only a superset is needed: hardware sqrt estimate, rounded up by the 1.001 factor)
       float nx = M[0] * M[0], t = M[1] * M[1];
