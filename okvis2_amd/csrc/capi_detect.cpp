@@ -96,13 +96,19 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
 // The camera-aware-only descriptor kernel carries the fixed-trip box sum alone: every box of the installed pattern has
 // to fit its 11 x 11 slots (sigma_half <= 4.75: the built-in pattern; okvfe_set_pattern may install wider samples,
 // which take the all-modes kernel).
-static bool pattern_small_boxes(const okvfe::Pattern& P) {
-  // first-pass samples (points extra ..): 11 x 11 slots; second-pass samples (points 0 .. extra-1 of a pattern with
-  // more than 64 points): 5 x 5 slots (k_describe.hip: kMaxBox, kSmallBox)
+// 0: every box of the installed pattern fits the fixed-trip slots of the fast descriptor kernels (first-pass samples
+// 11 x 11: sigma_half <= 4.75; second-pass samples = points 0 .. n - 65 of a pattern with more than 64 points, 5 x 5:
+// sigma_half <= 2.0); 1: the slots of the WIDE instantiations (21 x 21: <= 9.75, 10 x 10: <= 4.25); 2: wider still
+// (k_describe.hip: kMaxBox / kSmallBox / kWideBox / kWideSmallBox)
+static int pattern_box_class(const okvfe::Pattern& P) {
   const int extra = P.n_points > 64 ? P.n_points - 64 : 0;
-  for (int i = 0; i < P.n_points && i < okvfe::kPatternPoints; ++i)
-    if (!(P.sigma_half[i] <= (i < extra ? 2.0f : 4.75f))) return false;
-  return true;
+  int cls = 0;
+  for (int i = 0; i < P.n_points && i < okvfe::kPatternPoints; ++i) {
+    const float s = P.sigma_half[i];
+    if (!(s <= (i < extra ? 2.0f : 4.75f))) cls = cls < 1 ? 1 : cls;
+    if (!(s <= (i < extra ? 4.25f : 9.75f))) cls = 2;
+  }
+  return cls;
 }
 
 namespace {
@@ -367,7 +373,7 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
-                    ctx->all_aware && pattern_small_boxes(ctx->host_pattern));
+                    ctx->all_aware, pattern_box_class(ctx->host_pattern));
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -795,7 +801,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
                   ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false,
-                  ctx->all_aware && pattern_small_boxes(ctx->host_pattern));
+                  ctx->all_aware, pattern_box_class(ctx->host_pattern));
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

@@ -41,8 +41,18 @@ namespace {
 // float operation sequence as the published BRISK smoothedIntensity (sub-pixel rim weights); the
 // interior / edge sums are taken directly over the pixels (identical to integral-image sums).
 [[maybe_unused]] constexpr int kMaxBox = 10;  // fast path: boxes of at most 11 x 11 pixels (sigma_half <= 4.75)
-constexpr int kBoxMaskCounts = 10;  // interior byte counts 0 .. 9 (= kMaxBox - 1) per first-byte position 0 .. 3
 constexpr int kSmallBox = 4;  // second pass of the camera-aware-only kernel: boxes of at most 5 x 5 (sigma_half <= 2.0)
+// WIDE-box instantiations (round 5: a pattern with wider smoothing -- what the vocabulary's statistics favour,
+// tools/pattern/README.md -- must not fall off the fast path): boxes up to 21 x 21 (sigma_half <= 9.75) in the
+// first pass, up to 10 x 10 (sigma_half <= 4.25) in the second
+constexpr int kWideBox = 20;
+constexpr int kWideSmallBox = 9;
+// mask table geometry per kernel: counts = interior byte counts 0 .. MAXB - 1, row = dwords per entry
+template <bool WIDE> struct BoxTab {
+  static constexpr int kCounts = WIDE ? kWideBox : 10;
+  static constexpr int kRowDw = WIDE ? 8 : 4;   // (MAXB + 5) / 4 mask dwords, padded to whole 16-byte reads
+  static constexpr int kMaskDw = WIDE ? 6 : 3;
+};
 // LDS patch of one wave: [kZeroRowBytes of zeros][pixel rows, dense: pitch = 4 * dwords per row]
 constexpr int kZeroRowBytes = 160;  // >= the widest patch row (152 B) + the 3-dword reads past a box
 // LDS per workgroup = 4 patch buffers + values (1152 B) + short pairs (768 B) + box masks (640 B) + second-pass
@@ -85,7 +95,7 @@ __device__ __forceinline__ int div_nonneg(int num, int den) {
 // LATE_WAIT: the patch loads (buffer_load ... lds) are still in flight when the function is entered; it waits for
 // them just before its first pixel read, so the ~80 instructions of per-sample set-up run under the loads' latency
 // (only with FASTONLY: the one code path then reaches the wait in every lane).
-template <bool FASTONLY = false, int MAXB = 10, bool LATE_WAIT = false, typename PX>
+template <bool FASTONLY = false, int MAXB = 10, bool LATE_WAIT = false, bool WIDETAB = false, typename PX>
 __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float yf,
                                                   float sigma_half, int scaling, int scaling2) {
   if (sigma_half < 0.5f) {
@@ -134,8 +144,19 @@ __device__ __forceinline__ int smoothed_intensity(const PX& px, float xf, float 
     constexpr int kDw = (MAXB + 5) / 4;  // interior <= MAXB - 1 bytes from byte 0..3 of the first dword
     // byte masks of the interior columns in those dwords: one 16-byte read of the (first byte, count) table in LDS
     // (kernel prologue: fill_box_masks) instead of ~8 VALU per dword
-    const uint4 mrow = *reinterpret_cast<const uint4*>(px.masks + ((mul24i(lo, kBoxMaskCounts) + ni) << 2));
-    const uint32_t m[3] = {mrow.x, mrow.y, mrow.z};
+    static_assert(kDw <= BoxTab<WIDETAB>::kMaskDw && MAXB <= BoxTab<WIDETAB>::kCounts, "mask table of the kernel");
+    const uint32_t* mp = px.masks + ((mul24i(lo, BoxTab<WIDETAB>::kCounts) + ni) << (BoxTab<WIDETAB>::kRowDw == 8 ? 3 : 2));
+    const uint4 mrow = *reinterpret_cast<const uint4*>(mp);
+    uint32_t m[kDw];
+    m[0] = mrow.x;
+    if constexpr (kDw > 1) m[1] = mrow.y;
+    if constexpr (kDw > 2) m[2] = mrow.z;
+    if constexpr (kDw > 3) m[3] = mrow.w;
+    if constexpr (kDw > 4) {
+      const uint2 mhi = *reinterpret_cast<const uint2*>(mp + 4);
+      m[4] = mhi.x;
+      if constexpr (kDw > 5) m[5] = mhi.y;
+    }
     // Rows are addressed by 32-bit byte offsets from the first patch row (the zero row lies
     // kZeroRowBytes before it); every product below has both factors under 2^23 (weights <= 2^22,
     // pixel sums <= 81 * 255), so the 24-bit multiplies give the same low 32 bits as the
@@ -231,18 +252,20 @@ constexpr int kDescWaves = 4;
 #endif
 constexpr int kDescBlocksPerImage = OKVFE_DESC_BLOCKS;
 
-// table[(first byte 0..3) * kBoxMaskCounts + count][0..2]: 0xFF in every byte of the three consecutive dwords that
-// belongs to the run of `count` interior bytes starting at byte `first byte` of the first dword (4th word: pad)
+// table[((first byte 0..3) * kCounts + count) * kRowDw + j]: 0xFF in every byte of dword j (j < kMaskDw) that belongs
+// to the run of `count` interior bytes starting at byte `first byte` of the first dword (the rest of a row: 0)
+template <bool WIDE>
 __device__ __forceinline__ void fill_box_masks(uint32_t* table, int tid, int nthreads) {
-  for (int e = tid; e < 4 * kBoxMaskCounts; e += nthreads) {
-    const int lo = e / kBoxMaskCounts, ni = e - lo * kBoxMaskCounts;
-    for (int j = 0; j < 4; ++j) {
+  using T = BoxTab<WIDE>;
+  for (int e = tid; e < 4 * T::kCounts; e += nthreads) {
+    const int lo = e / T::kCounts, ni = e - lo * T::kCounts;
+    for (int j = 0; j < T::kRowDw; ++j) {
       uint32_t mk = 0u;
-      for (int b = 0; b < 4; ++b) {
-        const int pos = 4 * j + b;
-        if (j < 3 && pos >= lo && pos < lo + ni) mk |= 0xFFu << (8 * b);
+      for (int b2 = 0; b2 < 4; ++b2) {
+        const int pos = 4 * j + b2;
+        if (j < T::kMaskDw && pos >= lo && pos < lo + ni) mk |= 0xFFu << (8 * b2);
       }
-      table[4 * e + j] = mk;
+      table[T::kRowDw * e + j] = mk;
     }
   }
 }
@@ -298,7 +321,9 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
 // setExtractionDirection): the gradient-orientation pass and the fixed-box staging are compiled out -- a
 // third of the kernel's code and the registers that had to live across it.  It is launched for patterns whose boxes
 // all fit the fixed-trip box sum only (sigma_half <= 4.75: capi_detect.cpp), so the plain-loop form is compiled out too.
-template <int kWavesPerSimd, bool AWARE = false>
+// WIDE: the pattern's boxes go up to 21 x 21 (first pass) / 9 x 9 (second pass): same code with more row slots and a
+// wider mask table, four workgroups per CU.
+template <int kWavesPerSimd, bool AWARE = false, bool WIDE = false>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(kWavesPerSimd, 8))) void describe_kernel(
     const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
     const ImageParams* __restrict__ prm, const float* const* __restrict__ rays,
@@ -308,14 +333,16 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     uint32_t inv_tiles, const PatternScales* __restrict__ scales) {
   // (the 96-register instantiation leaves LDS for five workgroups of 32 KB: its waves get 7.5 KB buffers)
   // (the generic form runs four workgroups per CU: 4 x 7312 + 2720 + 8800 B of long pairs = 40768 B, 128 registers)
-  constexpr int kBufBytes = kWavesPerSimd >= 6 ? kPatchBufBytes : OKVFE_DESC_WIDE_BUF;
-  constexpr int kDataBytes = kBufBytes - kZeroRowBytes - 16;
+  // (WIDE: 4 x 9072 + 4640 B of tables, resp. 4 x 6864 + 13444 with the long pairs: <= 40960 B, four workgroups per CU)
+  constexpr int kBufBytes = WIDE ? (AWARE ? 9072 : 6864) : (kWavesPerSimd >= 6 ? kPatchBufBytes : OKVFE_DESC_WIDE_BUF);
+  constexpr int kDataBytes = kBufBytes - kZeroRowBytes - (WIDE ? 32 : 16);  // slack: the row reads past a box (3 / 6 dwords)
+  constexpr int kFirstBox = WIDE ? kWideBox : kMaxBox, kSecondBox = WIDE ? kWideSmallBox : kSmallBox;
   __shared__ __attribute__((aligned(16))) uint8_t patches[kDescWaves][kBufBytes];
   __shared__ int values[kDescWaves][kPatternPoints];
   // the short pairs (i | j << 8), once per workgroup: read 12 x per keypoint from global memory
   // they were a third dependent round trip in every keypoint's chain
-  __shared__ __attribute__((aligned(16))) uint32_t box_masks[4 * kBoxMaskCounts * 4];
-  fill_box_masks(box_masks, threadIdx.x, 64 * kDescWaves);
+  __shared__ __attribute__((aligned(16))) uint32_t box_masks[4 * BoxTab<WIDE>::kCounts * BoxTab<WIDE>::kRowDw];
+  fill_box_masks<WIDE>(box_masks, threadIdx.x, 64 * kDescWaves);
   // constants of the second-pass samples (points 0 .. kPatternPoints - 65) at the base scale: read from LDS per
   // keypoint (global loads here were a second memory round trip in every keypoint's chain)
   __shared__ float second_f[3][kPatternPoints - 64];
@@ -538,16 +565,16 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
       // (no exec-mask change around the box sums: lanes without a sample carry point 0's constants, whose box lies
       // in the patch, so both passes are straight-line code the scheduler may interleave)
       if (AWARE && in_flight)  // wave-uniform
-        v = smoothed_intensity<AWARE, kMaxBox, AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+        v = smoothed_intensity<AWARE, kFirstBox, AWARE, WIDE>(ppx, xf, yf, sg, bsc, bsc2);
       else
-        v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+        v = smoothed_intensity<AWARE, kFirstBox, false, WIDE>(ppx, xf, yf, sg, bsc, bsc2);
       if (extra > 0) {  // wave-uniform; AWARE: the host checked sigma_half <= 2.0 for these points (5 x 5 boxes)
         const int b1 = ladder ? scales->box_scaling[sc2][l2] : second_i[0][l2];
         const int b2 = ladder ? scales->box_scaling2[sc2][l2] : second_i[1][l2];
         asm volatile("" : "+v"(l2));  // opaque: the position is recomputed, not carried over the first pass
         float xf2, yf2, sg2;
         second_pos(&xf2, &yf2, &sg2);
-        v2 = smoothed_intensity<AWARE, kSmallBox>(ppx, xf2, yf2, sg2, b1, b2);  // (generic form: run-time check, plain loops beyond 5 x 5)
+        v2 = smoothed_intensity<AWARE, kSecondBox, false, WIDE>(ppx, xf2, yf2, sg2, b1, b2);  // (generic form: run-time check, plain loops beyond 5 x 5)
       }
     } else {
       if (extra > 0 && active2) {  // rare path (patch larger than the wave's buffer): the few extra samples read the image
@@ -588,7 +615,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         }
         const bool mine = !done && ly0 >= band0 && ly1 <= band1;
         if (mine) {
-          v = smoothed_intensity<AWARE>(ppx, xf, yf, sg, bsc, bsc2);
+          v = smoothed_intensity<AWARE, kFirstBox, false, WIDE>(ppx, xf, yf, sg, bsc, bsc2);
           done = true;
         }
         if (band1 >= by1) break;
@@ -811,7 +838,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done,
-                     bool all_camera_aware) {
+                     bool all_camera_aware, int box_class) {
   if (n_images <= 0) return;
   static const char* force = lab_env("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
@@ -824,22 +851,26 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
   if (tiles > kDescBlocksPerImage) tiles = kDescBlocksPerImage;
   const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
-#define OKVFE_DESC_LAUNCH(WAVES, AWARE)                                                                          \
-  hipLaunchKernelGGL((describe_kernel<WAVES, AWARE>), dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, img, \
-                     w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images, \
-                     tiles, inv_tiles, scales)
+#define OKVFE_DESC_LAUNCH(WAVES, AWARE, WIDE)                                                                    \
+  hipLaunchKernelGGL((describe_kernel<WAVES, AWARE, WIDE>), dim3(tiles * n_images), dim3(64 * kDescWaves), 0, stream, \
+                     img, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp,        \
+                     n_images, tiles, inv_tiles, scales)
   static const bool no_aware = lab_env("OKVFE_DESC_GENERIC") != nullptr;  // A/B knob: the all-modes kernel
   if (no_aware || scales != nullptr || w % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3) != 0)
     all_camera_aware = false;  // (scale-invariant extraction, unaligned images: generic form)
-  if (!all_camera_aware) {
+  // box_class (capi_detect.cpp: pattern_box_class): 0 = every box fits the 11 x 11 / 5 x 5 slots, 1 = the 21 x 21 /
+  // 9 x 9 slots of the WIDE instantiations, 2 = wider still: the all-modes form's plain box loops
+  if (box_class == 1 && scales == nullptr) {
+    if (all_camera_aware) OKVFE_DESC_LAUNCH(4, true, true); else OKVFE_DESC_LAUNCH(4, false, true);
+  } else if (!all_camera_aware || box_class != 0) {
     // the all-modes form: 128 registers, the long pairs in LDS: four workgroups per CU (measured on the BRISK
     // scale-space path, 512 images x 2780 keypoints in gradient mode: 5.5 ms with 80 registers and the long-pair /
     // rotation tables in global memory, 4.3 ms in this form; the 5- and 6-wave forms of it 4.7 ms)
-    OKVFE_DESC_LAUNCH(4, false);
+    OKVFE_DESC_LAUNCH(4, false, false);
   } else if (wide_patches) {
-    OKVFE_DESC_LAUNCH(5, true);
+    OKVFE_DESC_LAUNCH(5, true, false);
   } else {
-    OKVFE_DESC_LAUNCH(6, true);
+    OKVFE_DESC_LAUNCH(6, true, false);
   }
 #undef OKVFE_DESC_LAUNCH
 }

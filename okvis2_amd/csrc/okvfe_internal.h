@@ -254,7 +254,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done = false,
-                     bool all_camera_aware = false);  // (every image of the call has mode kCameraAware)
+                     bool all_camera_aware = false, int box_class = 0);  // (every image of the call has mode kCameraAware)
 bool describe_patch_fits(float nx, float ny, int border);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,

@@ -140,9 +140,11 @@ def test_bad_patterns_are_rejected():
             fe.set_pattern(p)
 
 
-def test_widened_builtin_pattern_stays_bit_exact(oracle, monkeypatch):
-    """The built-in pattern with every box 1.73 x wider (what the vocabulary's statistics
-    favour): boxes up to 17 x 17 -> the generic descriptor kernel's plain box loops, larger patches, a wider rim."""
+@pytest.mark.parametrize("factor", [1.3, 1.73, 2.0, 2.3])
+def test_widened_builtin_pattern_stays_bit_exact(oracle, monkeypatch, factor):
+    """The built-in pattern with every box wider (the vocabulary's statistics favour
+    1.7 - 2 x): boxes up to 21 x 21 take the WIDE instantiations of the descriptor kernel (21 x 21 / 10 x 10 row
+    slots, six-dword masks), 2.3 x is beyond them (plain box loops); larger patches, a wider rim."""
     import math
     cfg = synth.euroc_config()
     cam = cfg.cams[0]
@@ -151,10 +153,10 @@ def test_widened_builtin_pattern_stays_bit_exact(oracle, monkeypatch):
     p = fe.get_pattern()
     reach = 0.0
     for i in range(p.n_points):
-        p.sigma_half[i] = np.float32(p.sigma_half[i] * 1.73)
+        p.sigma_half[i] = np.float32(p.sigma_half[i] * factor)
         reach = max(reach, math.hypot(p.px[i], p.py[i]) + p.sigma_half[i])
     p.border = int(math.ceil(reach)) + 1
-    assert p.border > 29 and max(p.sigma_half[:p.n_points]) > 7.5
+    assert p.border > 29 and max(p.sigma_half[:p.n_points]) > 4.75
     fe.set_pattern(p)
     q = _to_orc(oracle, p)
     monkeypatch.setattr(oracle, "pattern", lambda: q)
