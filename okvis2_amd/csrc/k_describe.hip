@@ -246,7 +246,10 @@ __device__ __forceinline__ bool sample_pos(const float M[4], float kx, float ky,
 #ifndef OKVFE_DESC_PAIRS_OPAQUE
 #define OKVFE_DESC_PAIRS_OPAQUE 0  // 1: the gather addresses derived from them are recomputed per keypoint (no hoisting)
 #endif
-constexpr int kDescWaves = 4;
+#ifndef OKVFE_DESC_WG_WAVES
+#define OKVFE_DESC_WG_WAVES 4
+#endif
+constexpr int kDescWaves = OKVFE_DESC_WG_WAVES;
 #ifndef OKVFE_DESC_BLOCKS
 #define OKVFE_DESC_BLOCKS 16
 #endif
