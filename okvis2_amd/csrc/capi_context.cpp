@@ -462,6 +462,8 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     c->cam_jac.assign(cfg->num_cameras, nullptr);
     c->cam_fu.assign(cfg->num_cameras, 0.0f);
     c->cam_wide.assign(cfg->num_cameras, 0);
+    c->cam_norms.assign(cfg->num_cameras, {});
+    c->cam_aware_slow.assign(cfg->num_cameras, 0);
     c->h_cams.assign(cfg->num_cameras, DeviceCamera{});
     c->cam_has_intrinsics.assign(cfg->num_cameras, false);
     if (n_layers > 1) {
@@ -559,6 +561,22 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   delete ctx;
 }
 
+// which descriptor kernel suits camera `cam` under the installed pattern (re-run by okvfe_set_pattern)
+static void refresh_camera_patch_stats(okvfe_ctx* ctx, int cam) {
+  const std::vector<float>& norms = ctx->cam_norms[cam];
+  size_t seen = 0, large = 0, slow = 0;
+  for (size_t i = 0; i + 1 < norms.size(); i += 2) {
+    ++seen;
+    if (!describe_patch_fits(norms[i], norms[i + 1], ctx->host_pattern.border)) ++large;
+    if (describe_aware_patch_class(norms[i], norms[i + 1], ctx->host_pattern.reach) > 1) ++slow;
+  }
+  // (the 96-register instantiation with its 7.5 KB buffers pays when MANY patches need bands: measured with the
+  // camera-aware-only six-wave form as the alternative -- 57 % / 60 % of the pixels (640x480 at fu 350, RealSense
+  // D455): 1.13 against 1.33 ms, 0.53 against 0.58; 30 % (TUM-VI 512 / 1024): 0.27 against 0.22 ms, 0.26 against 0.27)
+  ctx->cam_wide[cam] = seen > 0 && large * 5 > seen * 2;  // more than 40 %
+  ctx->cam_aware_slow[cam] = seen == 0 || slow * 10 > seen;
+}
+
 okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* rays_hw3,
                                    const float* jacobians_hw6, float fu) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
@@ -582,20 +600,18 @@ okvfe_status okvfe_set_camera_maps(okvfe_ctx* ctx, int32_t cam, const float* ray
   ctx->cam_fu[cam] = fu;
   // how often does a keypoint's warped pattern exceed the one-piece LDS patch?  (row norms of the
   // image Jacobian bound the row norms of M = J [e_x e_y] / fu; every 8th pixel)
-  size_t seen = 0, large = 0;
+  std::vector<float>& norms = ctx->cam_norms[cam];
+  norms.clear();
   for (int y = 0; y < ctx->h; y += 8)
     for (int x = 0; x < ctx->w; x += 8) {
       const float* J = jacobians_hw6 + ((size_t)y * ctx->w + x) * 6;
       const float nx = std::sqrt(J[0] * J[0] + J[1] * J[1] + J[2] * J[2]) / fu;
       const float ny = std::sqrt(J[3] * J[3] + J[4] * J[4] + J[5] * J[5]) / fu;
       if (!(nx == nx) || !(ny == ny)) continue;  // pixels without a ray
-      ++seen;
-      if (!describe_patch_fits(nx, ny, ctx->host_pattern.border)) ++large;
+      norms.push_back(nx);
+      norms.push_back(ny);
     }
-  // (the 96-register instantiation with its 7.5 KB buffers pays when MANY patches need bands: measured with the
-  // camera-aware-only six-wave form as the alternative -- 57 % / 60 % of the pixels (640x480 at fu 350, RealSense
-  // D455): 1.13 against 1.33 ms, 0.53 against 0.58; 30 % (TUM-VI 512 / 1024): 0.27 against 0.22 ms, 0.26 against 0.27)
-  ctx->cam_wide[cam] = seen > 0 && large * 5 > seen * 2;  // more than 40 %
+  refresh_camera_patch_stats(ctx, cam);
   return OKVFE_OK;
 }
 
@@ -708,6 +724,8 @@ okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* p) {
   std::memcpy(P.long_wdx, p->long_wdx, sizeof(P.long_wdx));
   std::memcpy(P.long_wdy, p->long_wdy, sizeof(P.long_wdy));
   P.border = p->border;
+  P.reach = pattern_reach(P);
+  for (int c = 0; c < ctx->cfg.num_cameras; ++c) refresh_camera_patch_stats(ctx, c);
   for (int i = 0; i < kPatternPoints; ++i) {  // same float sequence as build_pattern (host_tables.cpp)
     const float sg = i < P.n_points ? P.sigma_half[i] : 1.0f;
     float area = 4.0f * sg;

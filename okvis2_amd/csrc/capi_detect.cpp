@@ -52,6 +52,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
                                         const float* gravity, hipStream_t s, bool before_detect = false) {
   std::vector<ImageParams> prm(n_images);
   ctx->wide_patches = false;
+  ctx->aware_fast = true;
   ctx->all_aware = n_images > 0;
   for (int i = 0; i < n_images; ++i) {
     ImageParams& p = prm[i];
@@ -69,6 +70,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
       p.dir[2] = gravity[3 * i + 2];
       p.fu = ctx->cam_fu[p.cam];
       if (ctx->cam_wide[p.cam]) ctx->wide_patches = true;
+      if (ctx->cam_aware_slow[p.cam]) ctx->aware_fast = false;
     } else {
       p.mode = ctx->mode_default;
       ctx->all_aware = false;
@@ -107,6 +109,9 @@ static int pattern_box_class(const okvfe::Pattern& P) {
     const float s = P.sigma_half[i];
     if (!(s <= (i < extra ? 2.0f : 4.75f))) cls = cls < 1 ? 1 : cls;
     if (!(s <= (i < extra ? 4.25f : 9.75f))) cls = 2;
+    // half-widths below 0.5 are bilinear point samples: only the all-modes kernel carries that branch (and waits for
+    // its patch before it: ADVICE r5)
+    if (!(s >= 0.5f)) cls = 2;
   }
   return cls;
 }
@@ -373,7 +378,7 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
-                    ctx->all_aware, pattern_box_class(ctx->host_pattern));
+                    ctx->all_aware, pattern_box_class(ctx->host_pattern), ctx->aware_fast);
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -801,7 +806,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
                   ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false,
-                  ctx->all_aware, pattern_box_class(ctx->host_pattern));
+                  ctx->all_aware, pattern_box_class(ctx->host_pattern), ctx->aware_fast);
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

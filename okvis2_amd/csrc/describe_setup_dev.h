@@ -74,6 +74,37 @@ __device__ __forceinline__ void describe_setup_one(const DescribeSetup& ds, int 
     valid = camera_aware_matrix(ds.rays[ip.cam], ds.jac[ip.cam], w, ip.fu, dir, kp.x, kp.y, M);
   }
   *reinterpret_cast<float4*>(ds.desc_tmp + slot * OKVFE_DESC_BYTES) = make_float4(M[0], M[1], M[2], M[3]);
+  if (ip.mode == kCameraAware && !ds.scales) {
+    // patch geometry for describe_aware_kernel (k_describe_aware.hip), bytes 16..23 of the slot: a superset of every
+    // sample box under M -- |M p|_x <= |row_x(M)| |p|, boxes are not scaled by M, a box spans at most half a pixel
+    // beyond x -+ sigma_half (the 0.75 leaves a quarter pixel for the float rounding of the positions) -- clipped to
+    // the image (boxes that leave it drop the keypoint).  Class 0 / 1: rows of 64 / 80 bytes in LDS; 3: neither.
+    int g0 = 0, g1 = 3 << 29;
+    if (valid) {
+      const float reach = ds.pat->reach;
+      float nx = M[0] * M[0], t = M[1] * M[1];
+      nx = sqrtf(nx + t) * 1.001f;
+      float ny = M[2] * M[2];
+      t = M[3] * M[3];
+      ny = sqrtf(ny + t) * 1.001f;
+      const float ex = fmaxf(nx, 1.0f) * reach + 0.75f, ey = fmaxf(ny, 1.0f) * reach + 0.75f;
+      if (ex < 1024.0f && ey < 1024.0f) {  // (false for NaN)
+        int bx0 = (int)floorf(kp.x - ex), bx1 = (int)ceilf(kp.x + ex);
+        int by0 = (int)floorf(kp.y - ey), by1 = (int)ceilf(kp.y + ey);
+        bx0 = bx0 < 0 ? 0 : bx0;
+        by0 = by0 < 0 ? 0 : by0;
+        bx1 = bx1 > w - 1 ? w - 1 : bx1;
+        by1 = by1 > h - 1 ? h - 1 : by1;
+        const int px0 = bx0 & ~3, pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
+        const int cls = (pw <= 64 && ph <= 64) ? 0 : ((pw <= 80 && ph <= 72) ? 1 : 3);
+        if (pw >= 1 && ph >= 1 && px0 < 4096 && by0 < 4096) {
+          g0 = by0 * w + px0;
+          g1 = (px0 >> 2) | (by0 << 10) | ((cls == 3 ? 0 : ph) << 22) | (cls << 29);
+        }
+      }
+    }
+    *reinterpret_cast<int2*>(ds.desc_tmp + slot * OKVFE_DESC_BYTES + 16) = make_int2(g0, g1);
+  }
   ds.valid_tmp[slot] = (uint8_t)((valid ? 1 : 0) | (scale << 1));
   ds.kps_tmp[slot] = kp;  // the record travels on from here; describe_kernel only rewrites the angle
 }

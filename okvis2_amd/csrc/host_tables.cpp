@@ -26,6 +26,14 @@
 
 namespace okvfe {
 
+float pattern_reach(const Pattern& p) {
+  double reach = 0.0;
+  for (int i = 0; i < p.n_points && i < kPatternPoints; ++i)
+    reach = std::fmax(reach, std::sqrt(static_cast<double>(p.px[i]) * p.px[i] + static_cast<double>(p.py[i]) * p.py[i]) +
+                                 static_cast<double>(p.sigma_half[i]));
+  return static_cast<float>(reach * 1.0001 + 1.0e-3);  // (rounded up: only ever used for a superset)
+}
+
 void build_pattern(Pattern* p) {
   // The BRISK2 pattern as recovered from the 819 real node descriptors of the reference's vocabulary
   // (resources/small_voc.yml.gz; tools/pattern/README.md): 66 sample points -- centre, hexagon, rings of
@@ -59,6 +67,7 @@ void build_pattern(Pattern* p) {
   }
   p->n_points = n;
   p->border = static_cast<int>(std::ceil(reach)) + 1;
+  p->reach = pattern_reach(*p);
   for (int i = 0; i < kPatternPoints; ++i) {
     const float sg = i < n ? p->sigma_half[i] : 1.0f;
     float area = 4.0f * sg;

@@ -841,7 +841,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done,
-                     bool all_camera_aware, int box_class) {
+                     bool all_camera_aware, int box_class, bool aware_fast) {
   if (n_images <= 0) return;
   static const char* force = lab_env("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
@@ -861,6 +861,14 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   static const bool no_aware = lab_env("OKVFE_DESC_GENERIC") != nullptr;  // A/B knob: the all-modes kernel
   if (no_aware || scales != nullptr || w % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3) != 0)
     all_camera_aware = false;  // (scale-invariant extraction, unaligned images: generic form)
+  // round 6: the production mode on cameras whose patches fit the two LDS classes -> k_describe_aware.hip (extra
+  // samples in batches, patch geometry from the set-up thread, compile-time row pitches)
+  static const bool old_aware = lab_env("OKVFE_DESC_R5") != nullptr;  // A/B knob: the round-5 kernels
+  if (all_camera_aware && aware_fast && box_class <= 1 && !old_aware && w < 4096 && h < 4096) {
+    launch_describe_aware(img, w, h, n_images, pat, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp, box_class == 1,
+                          stream);
+    return;
+  }
   // box_class (capi_detect.cpp: pattern_box_class): 0 = every box fits the 11 x 11 / 5 x 5 slots, 1 = the 21 x 21 /
   // 9 x 9 slots of the WIDE instantiations, 2 = wider still: the all-modes form's plain box loops
   if (box_class == 1 && scales == nullptr) {

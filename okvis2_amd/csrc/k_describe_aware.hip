@@ -1,0 +1,566 @@
+// k_describe_aware.hip -- K6, the production form: BRISK2 descriptors under camera-aware extraction.
+//
+// Replaces brisk::BriskDescriptorExtractor::compute (behind cv::DescriptorExtractor::compute,
+// okvis_cv/include/okvis/implementation/Frame.hpp:167; extractor built at okvis_frontend/src/Frontend.cpp:2410-2412,
+// configured by setCameraProperties / setExtractionDirection at :239-251) for calls in which EVERY image is extracted
+// camera-aware with the fixed-scale pattern -- what OKVIS2 runs.  Everything else (gradient orientation, upright,
+// scale ladder, unaligned images, boxes beyond the fixed-trip slots, cameras whose warped patterns mostly exceed the
+// LDS patch classes below) stays with describe_kernel (k_describe.hip).
+//
+// Round 6.  The round-5 kernel spent 518 wave64 VALU + 83 LDS instructions per keypoint; a third of both was a SECOND
+// pass of the whole wave for the two samples (of 66) that do not fit 64 lanes, another fifth was wave-uniform patch
+// geometry recomputed by 64 lanes, and two thirds of the first pass's row loop was address arithmetic.  This kernel:
+//
+//   * EXTRA SAMPLES IN BATCHES.  A wave walks up to 64 / extra keypoints per round; before the walk, lane
+//     j * extra + e computes extra sample e of the round's keypoint j straight from the image (aligned dword loads,
+//     the same fixed-trip box sum), so the second pass runs once per ROUND instead of once per keypoint; its lines are
+//     the ones the patches of the same keypoints pull into the XCD's L2 a moment later.
+//   * PATCH GEOMETRY FROM THE SET-UP THREAD.  describe_setup_one (one THREAD per keypoint, in the tail of the
+//     selection kernel) leaves {first byte offset, x0 / y0 / rows / class} next to M in the keypoint's descriptor
+//     slot; they arrive here through the scalar prefetch of the next keypoint.
+//   * TWO COMPILE-TIME ROW PITCHES (64 and 80 bytes: |M| up to ~1.05 / ~1.25) so that every row read of the box sum
+//     is base + immediate; rows past a lane's box are masked off by exec instead of being redirected to a zero row.
+//     Patches of neither class (wide-angle rims) are sampled straight from the image by plain loops -- correct, slow,
+//     and rare on the cameras this kernel is launched for (capi_context.cpp: cam_slow).
+//
+// Bit-exact to describe_kernel and to the oracle: the float set-up and the integer sums are the same operation
+// sequences (published BRISK smoothedIntensity with sub-pixel rim weights).
+#include "okvfe_internal.h"
+
+namespace okvfe {
+namespace {
+
+#ifdef OKVFE_LAB
+__device__ unsigned long long g_aware_prof[16];
+#define AW_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#else
+#define AW_T(x)
+#endif
+constexpr int kAwWaves = 4;
+constexpr int kAwBufRows1 = 72, kAwPitch0 = 64, kAwPitch1 = 80;
+constexpr int kAwBufBytes = kAwBufRows1 * kAwPitch1 + 32;  // 5792: class 0 needs 64 x 64 = 4096; 32 B slack: row reads past a box
+
+template <bool WIDE> struct AwCfg {
+  static constexpr int kMaxB = WIDE ? 20 : 10;   // first-pass samples: box side - 1 (21 x 21 / 11 x 11 pixels)
+  static constexpr int kMaxB2 = WIDE ? 9 : 4;    // extra samples (10 x 10 / 5 x 5)
+  static constexpr int kCounts = WIDE ? 20 : 10; // mask table: interior byte counts 0 .. kCounts - 1
+  static constexpr int kRowDw = WIDE ? 8 : 4;    // dwords per table entry (whole 16-byte reads)
+  static constexpr int kMaskDw = WIDE ? 6 : 4;
+  // row windows start at a multiple of kAlign bytes.  11 x 11 boxes: 8, so that a row's interior (<= 9 bytes from
+  // byte 0..7) is one or two ALIGNED 8-byte reads -- ds_read_b64 serves 32 lanes per cycle on 64 banks where
+  // ds_read2_b32 + ds_read_b32 took three dword slots on 32, and the LDS gather is what bounds the kernel; the second
+  // read is skipped (exec) by the lanes whose interior ends in the first.  21 x 21: dword windows of six.
+  static constexpr int kAlign = WIDE ? 4 : 8;
+};
+
+__device__ __forceinline__ int mul24i(int a, int b) {
+  int d;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ int mad24i(int a, int b, int c) {  // low 32 bits of a[23:0] * b[23:0] + c
+  int d;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// floor(num / den) for 0 <= num < 2^31, 1 <= den < 2^24, quotient < 2^22: float estimate (rcp = v_rcp_f32 of
+// (float)den, off by at most one either way -- relative error of the product < 2^-22) + one exact correction
+__device__ __forceinline__ int div_nonneg_rcp(int num, int den, float rcp) {
+  int q = (int)((float)num * rcp);
+  const int r = num - mul24i(q, den);
+  q += r >= den ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
+
+// table[((first byte 0..kAlign-1) * kCounts + count) * kRowDw + j]: 0xFF in every byte of dword j that belongs to the
+// run of `count` interior bytes starting at byte `first byte` of the window
+template <bool WIDE>
+__device__ __forceinline__ void fill_box_masks(uint32_t* table, int tid, int nthreads) {
+  using T = AwCfg<WIDE>;
+  for (int e = tid; e < T::kAlign * T::kCounts; e += nthreads) {
+    const int lo = e / T::kCounts, ni = e - lo * T::kCounts;
+    for (int j = 0; j < T::kRowDw; ++j) {
+      uint32_t mk = 0u;
+      for (int b2 = 0; b2 < 4; ++b2) {
+        const int pos = 4 * j + b2;
+        if (j < T::kMaskDw && pos >= lo && pos < lo + ni) mk |= 0xFFu << (8 * b2);
+      }
+      table[T::kRowDw * e + j] = mk;
+    }
+  }
+}
+
+// ---- pixel readers of the box sum ---------------------------------------------------------------------------------
+// byte(off) / dwords(off, d[]) at byte offset `off` from the reader's origin; kPitch > 0: compile-time row pitch
+template <int PITCH>
+struct LdsReader {  // the keypoint's patch in LDS, row pitch PITCH
+  static constexpr int kPitch = PITCH;
+  const uint8_t* base;  // LDS
+  static constexpr int pitch = PITCH;
+  __device__ __forceinline__ int byte(int off) const { return base[off]; }
+  template <int N>
+  __device__ __forceinline__ void dwords(int off, uint32_t (&d)[N]) const {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + off);
+#pragma unroll
+    for (int j = 0; j < N; ++j) d[j] = p[j];
+  }
+  __device__ __forceinline__ uint2 qword(int off) const { return *reinterpret_cast<const uint2*>(base + off); }  // 8-aligned
+};
+struct ImageReader {  // straight from the image: aligned dword loads through the bounds-checked buffer resource
+  static constexpr int kPitch = 0;
+  __amdgpu_buffer_rsrc_t rsrc;
+  int pitch;
+  __device__ __forceinline__ int byte(int off) const {
+    return (int)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, off, 0, 0);
+  }
+  template <int N>
+  __device__ __forceinline__ void dwords(int off, uint32_t (&d)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4 * j, 0, 0);
+  }
+  __device__ __forceinline__ uint2 qword(int off) const {
+    return make_uint2((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0),
+                      (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
+  }
+};
+
+// Box of half-side sigma_half centred at (xf, yf), 1024 * mean intensity: the published BRISK smoothedIntensity with
+// sub-pixel rim weights, fixed trip counts.  `x0`, `y0`: image coordinates of the reader's origin; MAXB: largest box
+// side minus one served.  Same float / integer sequence as smoothed_intensity (k_describe.hip).
+template <int MAXB, bool WIDE, typename RD>
+__device__ __forceinline__ int box_mean(const RD& rd, const uint32_t* __restrict__ masks, int x0, int y0, float xf,
+                                        float yf, float sigma_half, int scaling, int scaling2, float rcp2) {
+  using T = AwCfg<WIDE>;
+  const float x_1 = xf - sigma_half, x1 = xf + sigma_half;
+  const float y_1 = yf - sigma_half, y1 = yf + sigma_half;
+  const int x_left = (int)(x_1 + 0.5f), y_top = (int)(y_1 + 0.5f);
+  const int x_right = (int)(x1 + 0.5f), y_bottom = (int)(y1 + 0.5f);
+  float r_x_1 = (float)x_left - x_1;  r_x_1 = r_x_1 + 0.5f;
+  float r_y_1 = (float)y_top - y_1;   r_y_1 = r_y_1 + 0.5f;
+  float r_x1 = x1 - (float)x_right;   r_x1 = r_x1 + 0.5f;
+  float r_y1 = y1 - (float)y_bottom;  r_y1 = r_y1 + 0.5f;
+  const float fs = (float)scaling;
+  float t;
+  t = r_x_1 * r_y_1; const int A = (int)(t * fs);
+  t = r_x1 * r_y_1;  const int B = (int)(t * fs);
+  t = r_x1 * r_y1;   const int C = (int)(t * fs);
+  t = r_x_1 * r_y1;  const int D = (int)(t * fs);
+  const int r_x_1_i = (int)(r_x_1 * fs), r_y_1_i = (int)(r_y_1 * fs);
+  const int r_x1_i = (int)(r_x1 * fs), r_y1_i = (int)(r_y1 * fs);
+  const int bw = x_right - x_left, bh = y_bottom - y_top;  // 1 .. MAXB
+  constexpr int kAl = T::kAlign;
+  constexpr int kDw = WIDE ? (MAXB + 5) / 4 : 4;  // interior <= MAXB - 1 bytes from byte 0..kAl-1 of the window
+  static_assert(kDw <= T::kMaskDw && MAXB <= T::kCounts && (WIDE || MAXB + kAl - 2 <= 16), "mask table of the kernel");
+  const int cl = x_left - x0;
+  const int xi0 = cl + 1, lo = xi0 & (kAl - 1), ni = bw - 1;
+  uint32_t m[kDw];
+  {
+    const uint32_t* mp = masks + ((mul24i(lo, T::kCounts) + ni) << (T::kRowDw == 8 ? 3 : 2));
+    const uint4 mrow = *reinterpret_cast<const uint4*>(mp);
+    m[0] = mrow.x;
+    if constexpr (kDw > 1) m[1] = mrow.y;
+    if constexpr (kDw > 2) m[2] = mrow.z;
+    if constexpr (kDw > 3) m[3] = mrow.w;
+    if constexpr (kDw > 4) {
+      const uint2 mhi = *reinterpret_cast<const uint2*>(mp + 4);
+      m[4] = mhi.x;
+      if constexpr (kDw > 5) m[5] = mhi.y;
+    }
+  }
+  const int pitch = RD::kPitch > 0 ? RD::kPitch : rd.pitch;
+  const int row0 = mul24i(y_top - y0, pitch);
+  const int aL = row0 + cl, aR = aL + bw, aQ = row0 + (xi0 & ~(kAl - 1));
+  const bool two = lo + ni > 8;  // (8-byte windows: the interior reaches into the second)
+  // v_msad_u8 adds 255 - pixel for the bytes the mask selects and skips the others: a row's interior sum comes back
+  // as 255 * ni - accumulator
+  auto row_sum = [&](int off, uint32_t acc) -> uint32_t {
+    if constexpr (WIDE) {
+      uint32_t d[kDw];
+      rd.template dwords<kDw>(aQ + off, d);
+#pragma unroll
+      for (int j = 0; j < kDw; ++j) acc = __builtin_amdgcn_msad_u8(d[j], m[j], acc);
+    } else {
+      // (both reads are issued before the first sum; a lane without a second window keeps zeros, and its masks
+      // m[2], m[3] are zero anyway)
+      const uint2 a = rd.qword(aQ + off);
+      uint2 b = make_uint2(0u, 0u);
+      if (two) b = rd.qword(aQ + off + 8);
+      acc = __builtin_amdgcn_msad_u8(a.x, m[0], acc);
+      acc = __builtin_amdgcn_msad_u8(a.y, m[1], acc);
+      acc = __builtin_amdgcn_msad_u8(b.x, m[2], acc);
+      acc = __builtin_amdgcn_msad_u8(b.y, m[3], acc);
+    }
+    return acc;
+  };
+  const int full = mul24i(ni, 255);
+  // top and bottom row
+  const int ob = mul24i(bh, pitch);
+  const int pl_t = rd.byte(aL), pr_t = rd.byte(aR);
+  const uint32_t up = row_sum(0, 0u);
+  const int pl_b = rd.byte(aL + ob), pr_b = rd.byte(aR + ob);
+  const uint32_t bot = row_sum(ob, 0u);
+  int ret = mad24i(A, pl_t, scaling2 / 2);
+  ret = mad24i(B, pr_t, ret);
+  ret = mad24i(C, pr_b, ret);
+  ret = mad24i(D, pl_b, ret);
+  // interior rows 1 .. bh - 1: fixed trip count, rows past the lane's box masked off by exec -- the LDS pipe is this
+  // kernel's bound (bank conflicts of the gather), so a lane that has no row left must not read.  (Measured against
+  // it: the reads of three rows issued together for every lane and the sums selected afterwards, 1.45 vs 1.36 ms.)
+  uint32_t mid = 0u;
+  int left = 0, right = 0;
+#pragma unroll
+  for (int dy = 1; dy < MAXB; ++dy) {
+    if (dy < bh) {
+      const int off = RD::kPitch > 0 ? dy * RD::kPitch : mul24i(dy, pitch);
+      const int pl = rd.byte(aL + off), pr = rd.byte(aR + off);
+      mid = row_sum(off, mid);
+      left += pl;
+      right += pr;
+    }
+  }
+  const int upper = full - (int)up, bottom = full - (int)bot;
+  const int middle = mul24i(full, bh - 1) - (int)mid;
+  ret = mad24i(upper, r_y_1_i, ret);
+  ret = mad24i(middle, scaling, ret);
+  ret = mad24i(left, r_x_1_i, ret);
+  ret = mad24i(right, r_x1_i, ret);
+  ret = mad24i(bottom, r_y1_i, ret);
+  return div_nonneg_rcp(ret, scaling2, rcp2);
+}
+
+// any box size, straight from the image (patches of neither LDS class): plain loops
+__device__ __forceinline__ int box_mean_plain(const uint8_t* __restrict__ im, int w, float xf, float yf, float sigma_half,
+                                              int scaling, int scaling2, float rcp2) {
+  const float x_1 = xf - sigma_half, x1 = xf + sigma_half;
+  const float y_1 = yf - sigma_half, y1 = yf + sigma_half;
+  const int x_left = (int)(x_1 + 0.5f), y_top = (int)(y_1 + 0.5f);
+  const int x_right = (int)(x1 + 0.5f), y_bottom = (int)(y1 + 0.5f);
+  float r_x_1 = (float)x_left - x_1;  r_x_1 = r_x_1 + 0.5f;
+  float r_y_1 = (float)y_top - y_1;   r_y_1 = r_y_1 + 0.5f;
+  float r_x1 = x1 - (float)x_right;   r_x1 = r_x1 + 0.5f;
+  float r_y1 = y1 - (float)y_bottom;  r_y1 = r_y1 + 0.5f;
+  const float fs = (float)scaling;
+  float t;
+  t = r_x_1 * r_y_1; const int A = (int)(t * fs);
+  t = r_x1 * r_y_1;  const int B = (int)(t * fs);
+  t = r_x1 * r_y1;   const int C = (int)(t * fs);
+  t = r_x_1 * r_y1;  const int D = (int)(t * fs);
+  const int r_x_1_i = (int)(r_x_1 * fs), r_y_1_i = (int)(r_y_1 * fs);
+  const int r_x1_i = (int)(r_x1 * fs), r_y1_i = (int)(r_y1 * fs);
+  auto px = [&](int y, int x) -> int { return im[(size_t)y * w + x]; };
+  int ret = A * px(y_top, x_left);
+  ret += B * px(y_top, x_right);
+  ret += C * px(y_bottom, x_right);
+  ret += D * px(y_bottom, x_left);
+  int upper = 0, middle = 0, left = 0, right = 0, bottom = 0;
+  for (int x = x_left + 1; x < x_right; ++x) {
+    upper += px(y_top, x);
+    bottom += px(y_bottom, x);
+  }
+  for (int y = y_top + 1; y < y_bottom; ++y) {
+    left += px(y, x_left);
+    right += px(y, x_right);
+    for (int x = x_left + 1; x < x_right; ++x) middle += px(y, x);
+  }
+  ret += upper * r_y_1_i + middle * scaling + left * r_x_1_i + right * r_x1_i + bottom * r_y1_i;
+  return div_nonneg_rcp(ret + scaling2 / 2, scaling2, rcp2);
+}
+
+// sample position of a pattern point under M; ok = box inside the image (NaN-safe)
+__device__ __forceinline__ bool sample_pos(float M0, float M1, float M2, float M3, float kx, float ky, float px,
+                                           float py, float sg, int w, int h, float* xf, float* yf) {
+  float a = M0 * px;
+  float b = M1 * py;
+  a = a + b;
+  *xf = kx + a;
+  float c = M2 * px;
+  float d = M3 * py;
+  c = c + d;
+  *yf = ky + c;
+  const float x_1 = *xf - sg, x1 = *xf + sg, y_1 = *yf - sg, y1 = *yf + sg;
+  return (x_1 >= 0.0f && y_1 >= 0.0f && x1 < (float)(w - 1) && y1 < (float)(h - 1));
+}
+
+// One wave per keypoint at a time, lane l = pattern point extra + l; 4 waves per workgroup, `tiles` workgroups per
+// image (all on one XCD), a wave walks the image's keypoints wave, wave + 4 * tiles, ...
+template <bool WIDE>
+__global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(WIDE ? 5 : 6, 8))) void describe_aware_kernel(
+    const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat,
+    const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
+    uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images, int tiles, uint32_t inv_tiles) {
+  using T = AwCfg<WIDE>;
+  AW_T(t_entry);
+  __shared__ __attribute__((aligned(16))) uint8_t patches[kAwWaves][kAwBufBytes];
+  __shared__ int values[kAwWaves][kPatternPoints];
+  __shared__ __attribute__((aligned(16))) uint32_t box_masks[T::kAlign * T::kCounts * T::kRowDw];
+  __shared__ float second_f[3][kPatternPoints - 64];
+  __shared__ int second_i[2][kPatternPoints - 64];
+  __shared__ uint16_t short_pairs[384];
+  fill_box_masks<WIDE>(box_masks, threadIdx.x, 64 * kAwWaves);
+  if (threadIdx.x < kPatternPoints - 64) {
+    second_f[0][threadIdx.x] = pat->px[threadIdx.x];
+    second_f[1][threadIdx.x] = pat->py[threadIdx.x];
+    second_f[2][threadIdx.x] = pat->sigma_half[threadIdx.x];
+    second_i[0][threadIdx.x] = pat->box_scaling[threadIdx.x];
+    second_i[1][threadIdx.x] = pat->box_scaling2[threadIdx.x];
+  }
+  for (int t = threadIdx.x; t < 384; t += 64 * kAwWaves)
+    short_pairs[t] = t < pat->n_short ? (uint16_t)(pat->short_i[t] | (pat->short_j[t] << 8)) : (uint16_t)0;
+  __syncthreads();
+  // all keypoint blocks of an image run on the same XCD (block L -> XCD L % 8): its pixels are fetched into ONE L2
+  int img, tile;
+  {
+    const uint32_t L = blockIdx.x, n8 = (uint32_t)n_images & ~7u, full = n8 * (uint32_t)tiles;
+    const uint32_t slot = L < full ? L >> 3 : L - full;
+    uint32_t g = (uint32_t)(((uint64_t)slot * inv_tiles) >> 32);  // slot / tiles, off by <= 1
+    if (g * (uint32_t)tiles > slot) --g;
+    if ((g + 1) * (uint32_t)tiles <= slot) ++g;
+    img = L < full ? (int)(g * 8u + (L & 7u)) : (int)(n8 + g);
+    tile = (int)(slot - g * (uint32_t)tiles);
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  const int n = kp_count_in[img];
+  const int k_first = tile * kAwWaves + wv, k_step = tiles * kAwWaves;
+  if (k_first >= n) return;  // whole wave exits; no block-wide barriers below
+  const uint8_t* im = images + (size_t)img * w * h;
+  const size_t slot0 = (size_t)img * kp_cap;
+  const int extra = __builtin_amdgcn_readfirstlane(pat->n_points > 64 ? pat->n_points - 64 : 0);
+  const bool active = extra + lane < pat->n_points;
+  const int li = active ? extra + lane : 0;
+  float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
+  int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];
+  float rcp2 = __builtin_amdgcn_rcpf((float)bsc2);
+  uint32_t my_pairs[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    my_pairs[j] = (uint32_t)short_pairs[(2 * j) * 64 + lane] | ((uint32_t)short_pairs[(2 * j + 1) * 64 + lane] << 16);
+  int* vals = values[wv];
+  uint8_t* patch = patches[wv];
+  const __amdgpu_buffer_rsrc_t img_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
+  // per-lane source offsets of the two patch classes: lane = row * chunks + 16-byte chunk
+  const int src_lane0 = (lane >> 2) * w + (lane & 3) * 16;                  // pitch 64: 16 rows per trip
+  const int rr1 = (int)(((uint32_t)lane * 13108u) >> 16);                   // lane / 5
+  const int src_lane1 = rr1 * w + (lane - rr1 * 5) * 16;                    // pitch 80: 12 rows per trip (lanes 0..59)
+
+  // ---- extra samples of a round of keypoints: lane j * extra + e ---------------------------------------------------
+  const int per_round = extra > 0 ? 64 / extra : 64;  // keypoints per round
+  const uint32_t inv_extra = extra > 0 ? (65536u + (uint32_t)extra - 1u) / (uint32_t)extra : 0u;
+  const int ej = extra > 0 ? (int)(((uint32_t)lane * inv_extra) >> 16) : 0;  // lane / extra
+  const int ee = lane - ej * extra;
+  int v2_all = 0;
+  unsigned long long ok2_bits = ~0ull;
+
+  typedef const float __attribute__((address_space(4))) * cfloat_p;
+  typedef const int __attribute__((address_space(4))) * cint_p;
+  typedef const uint8_t __attribute__((address_space(4))) * cbyte_p;
+  float nxt_x = 0.f, nxt_y = 0.f, nxt_M0 = 0.f, nxt_M1 = 0.f, nxt_M2 = 0.f, nxt_M3 = 0.f;
+  int nxt_g0 = 0, nxt_g1 = 0, nxt_valid = 0;
+  // scalar loads (the constant address space forces s_load): the NEXT keypoint's values wait in SGPRs.  Safe on the
+  // scalar cache: a slot's position / M / geometry / valid byte are written before this kernel starts and read here
+  // before this wave -- the only writer of the slot -- overwrites them.
+  auto fetch = [&](int kk) {
+    const size_t sl = slot0 + kk;
+    const cfloat_p pxy = (cfloat_p)(uintptr_t)(&kps_in[sl].x);
+    const cfloat_p pm = (cfloat_p)(uintptr_t)(desc_tmp + sl * OKVFE_DESC_BYTES);
+    nxt_x = pxy[0];
+    nxt_y = pxy[1];
+    nxt_M0 = pm[0];
+    nxt_M1 = pm[1];
+    nxt_M2 = pm[2];
+    nxt_M3 = pm[3];
+    nxt_g0 = ((cint_p)pm)[4];
+    nxt_g1 = ((cint_p)pm)[5];
+    nxt_valid = (int)((cbyte_p)(uintptr_t)valid_tmp)[sl];
+  };
+  fetch(k_first);
+  AW_T(t_pro);
+#ifdef OKVFE_LAB
+  unsigned long long a_extras = 0, a_dma = 0, a_box = 0, a_bits = 0, a_kp = 0;
+#endif
+  for (int kb = k_first; kb < n; kb += per_round * k_step) {
+    AW_T(t_r0);
+    if (extra > 0) {  // wave-uniform
+      const int kk = kb + ej * k_step;
+      const bool has = ej < per_round && kk < n;
+      const size_t sl = slot0 + (has ? kk : kb);
+      const float2 xy = *reinterpret_cast<const float2*>(&kps_in[sl].x);
+      const float4 Mv = *reinterpret_cast<const float4*>(desc_tmp + sl * OKVFE_DESC_BYTES);
+      const bool need = has && (valid_tmp[sl] & 1) != 0;
+      const float px2 = second_f[0][ee], py2 = second_f[1][ee], s2 = second_f[2][ee];
+      const int b1 = second_i[0][ee], b2 = second_i[1][ee];
+      float xf2, yf2;
+      const bool ok2 = sample_pos(Mv.x, Mv.y, Mv.z, Mv.w, xy.x, xy.y, px2, py2, s2, w, h, &xf2, &yf2);
+      ok2_bits = __ballot(ok2 || !need);
+      v2_all = 0;
+      if (need && ok2) {
+        const ImageReader rd{img_rsrc, w};
+        v2_all = box_mean<T::kMaxB2, WIDE>(rd, box_masks, 0, 0, xf2, yf2, s2, b1, b2, __builtin_amdgcn_rcpf((float)b2));
+      }
+    }
+#ifdef OKVFE_LAB
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" :: "v"(v2_all));
+      AW_T(t_r1);
+      a_extras += t_r1 - t_r0;
+    }
+#endif
+    for (int jj = 0; jj < per_round; ++jj) {
+      const int k = kb + jj * k_step;  // wave-uniform
+      if (k >= n) break;
+      AW_T(t_a);
+      // opaque to the optimiser: expressions of the lane constants are NOT hoisted out of the loop
+      asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(rcp2), "+v"(lane));
+      const size_t slot = slot0 + k;
+      auto unif = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+      const float kx = unif(nxt_x), ky = unif(nxt_y);
+      const float M0 = unif(nxt_M0), M1 = unif(nxt_M1), M2 = unif(nxt_M2), M3 = unif(nxt_M3);
+      const int g0 = __builtin_amdgcn_readfirstlane(nxt_g0), g1 = __builtin_amdgcn_readfirstlane(nxt_g1);
+      bool valid = (__builtin_amdgcn_readfirstlane(nxt_valid) & 1) != 0;
+      if (k + k_step < n) fetch(k + k_step);  // scalar branch
+      if (valid) {
+        const int x0 = (g1 & 0x3FF) << 2, y0 = (g1 >> 10) & 0xFFF, ph = (g1 >> 22) & 0x7F, cls = (g1 >> 29) & 3;
+        // the patch goes straight from the image into LDS (buffer_load ... lds, 16 bytes per lane, whole rows per
+        // instruction) while the per-sample set-up runs
+        __builtin_amdgcn_wave_barrier();
+        if (cls == 0) {
+          const int trips = (ph + 15) >> 4;
+          for (int it = 0; it < trips; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * 1024),
+                                                     16, src_lane0, g0 + it * 16 * w, 0, 0);
+        } else if (cls == 1) {
+          const int trips = (ph + 11) / 12;
+          if (lane < 60)
+            for (int it = 0; it < trips; ++it)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * 960),
+                                                       16, src_lane1, g0 + it * 12 * w, 0, 0);
+        }
+        float xf, yf;
+        const bool ok = sample_pos(M0, M1, M2, M3, kx, ky, px, py, sg, w, h, &xf, &yf);
+        const unsigned long long emask = extra > 0 ? ((1ull << extra) - 1ull) << (jj * extra) : 0ull;
+        valid = __all(ok || !active) && (ok2_bits & emask) == emask;
+        // (the loads are waited for even when the keypoint is dropped: the next keypoint's may not overtake them)
+        int v = 0;
+#ifdef OKVFE_LAB
+        unsigned long long t_b = 0, t_c = 0;
+#endif
+        if (cls == 0) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the staged rows have landed in LDS
+          __builtin_amdgcn_wave_barrier();
+#ifdef OKVFE_LAB
+          t_b = __builtin_amdgcn_s_memtime();
+#endif
+          if (valid) {
+            const LdsReader<kAwPitch0> rd{patch};
+            v = box_mean<T::kMaxB, WIDE>(rd, box_masks, x0, y0, xf, yf, sg, bsc, bsc2, rcp2);
+          }
+        } else if (cls == 1) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          __builtin_amdgcn_wave_barrier();
+          if (valid) {
+            const LdsReader<kAwPitch1> rd{patch};
+            v = box_mean<T::kMaxB, WIDE>(rd, box_masks, x0, y0, xf, yf, sg, bsc, bsc2, rcp2);
+          }
+        } else if (valid) {
+          v = box_mean_plain(im, w, xf, yf, sg, bsc, bsc2, rcp2);
+        }
+#ifdef OKVFE_LAB
+        asm volatile("" :: "v"(v));
+        t_c = __builtin_amdgcn_s_memtime();
+        if (t_b) { a_dma += t_b - t_a; a_box += t_c - t_b; }
+#endif
+        if (valid) {
+          __builtin_amdgcn_wave_barrier();
+          vals[extra + lane] = v;  // extra + 63 < kPatternPoints
+          if (extra > 0) {
+            const int t2 = __builtin_amdgcn_ds_bpermute(4 * (jj * extra + lane), v2_all);
+            if (lane < extra) vals[lane] = t2;
+          }
+          __builtin_amdgcn_wave_barrier();
+          unsigned long long words[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const uint32_t pr = (j & 1) ? my_pairs[j >> 1] >> 16 : my_pairs[j >> 1] & 0xFFFFu;  // slots past n_short: 0 | 0
+            const bool bit = vals[pr & 255u] > vals[pr >> 8];
+            words[j] = __ballot(bit);
+          }
+          if (lane < 6) {
+            unsigned long long wsel = words[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j)
+              if (lane == j) wsel = words[j];
+            reinterpret_cast<unsigned long long*>(desc_tmp + slot * OKVFE_DESC_BYTES)[lane] = wsel;
+          }
+        }
+      }
+      if (lane == 0) valid_tmp[slot] = valid ? 1 : 0;
+      __builtin_amdgcn_wave_barrier();  // vals[] / the patch are rewritten for the next keypoint
+#ifdef OKVFE_LAB
+      {
+        AW_T(t_d);
+        a_bits += t_d - t_a;
+        a_kp += 1;
+      }
+#endif
+    }
+  }
+#ifdef OKVFE_LAB
+  if (lane == 0 && wv == 0 && (blockIdx.x & 63) == 5) {
+    AW_T(t_end);
+    atomicAdd(&g_aware_prof[0], 1ull);
+    atomicAdd(&g_aware_prof[1], t_pro - t_entry);
+    atomicAdd(&g_aware_prof[2], a_extras);
+    atomicAdd(&g_aware_prof[3], a_dma);
+    atomicAdd(&g_aware_prof[4], a_box);
+    atomicAdd(&g_aware_prof[5], a_bits);
+    atomicAdd(&g_aware_prof[6], a_kp);
+    atomicAdd(&g_aware_prof[7], t_end - t_entry);
+  }
+#endif
+}
+
+}  // namespace
+
+// Patch class of a camera-aware keypoint (describe_setup_dev.h computes the same on the device): 0 / 1 = LDS patch of
+// pitch 64 / 80, 3 = neither.  Host copy for the cameras' statistics (capi_context.cpp).
+int describe_aware_patch_class(float nx, float ny, float reach) {
+  const float ex = fmaxf(nx * 1.001f, 1.0f) * reach + 0.75f;
+  const float ey = fmaxf(ny * 1.001f, 1.0f) * reach + 0.75f;
+  const int pw = 2 * (int)ceilf(ex) + 1 + 3, ph = 2 * (int)ceilf(ey) + 1;  // + 3: the row start is aligned down to a dword
+  if (pw <= kAwPitch0 && ph <= 64) return 0;
+  if (pw <= kAwPitch1 && ph <= kAwBufRows1) return 1;
+  return 3;
+}
+
+#ifdef OKVFE_LAB
+extern "C" int okvfe_lab_aware_prof(unsigned long long out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_aware_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_aware_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
+void launch_describe_aware(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
+                           const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in, uint8_t* desc_tmp,
+                           uint8_t* valid_tmp, bool wide_boxes, hipStream_t stream) {
+  if (n_images <= 0) return;
+  static const char* tiles_env = lab_env("OKVFE_DESC_TILES");  // A/B knob: workgroups per image
+  int tiles = (kp_cap + kAwWaves - 1) / kAwWaves;
+  const int want = tiles_env ? atoi(tiles_env) : 16;
+  if (tiles > want) tiles = want;
+  const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
+  if (wide_boxes)
+    hipLaunchKernelGGL((describe_aware_kernel<true>), dim3(tiles * n_images), dim3(64 * kAwWaves), 0, stream, img, w, h,
+                       pat, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp, n_images, tiles, inv_tiles);
+  else
+    hipLaunchKernelGGL((describe_aware_kernel<false>), dim3(tiles * n_images), dim3(64 * kAwWaves), 0, stream, img, w, h,
+                       pat, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp, n_images, tiles, inv_tiles);
+}
+
+}  // namespace okvfe

@@ -109,6 +109,12 @@ struct okvfe_ctx {
   std::vector<float*> cam_rays, cam_jac;  // device maps per camera slot (nullptr = not set)
   std::vector<float> cam_fu;
   std::vector<uint8_t> cam_wide;  // camera-aware patches of this camera often exceed the LDS buffer (describe_kernel<5>)
+  // row norms (nx, ny) of the image Jacobian / fu at every 8th pixel, kept so that okvfe_set_pattern can re-derive
+  // the two statistics; cam_aware_slow: more than a tenth of the camera's keypoints would have a patch of neither LDS
+  // class of describe_aware_kernel (k_describe_aware.hip) -> such a camera keeps describe_kernel
+  std::vector<std::vector<float>> cam_norms;
+  std::vector<uint8_t> cam_aware_slow;
+  bool aware_fast = false;        // of the images of the current batch: none from a cam_aware_slow camera
   bool wide_patches = false;      // of the images of the current batch
   bool all_aware = false;         // every image of the current batch is extracted camera-aware
   bool counters_cleared = false;  // upload_image_params zeroed d_cand_count on the call's stream

@@ -46,8 +46,11 @@ struct Pattern {
   // (int)(4194304 / (4 sigma^2)), scaling2 = (int)(scaling * 4 sigma^2 / 1024) (same float
   // sequence as the device code used per keypoint before they were tabulated)
   int32_t box_scaling[kPatternPoints], box_scaling2[kPatternPoints];
+  // max_i |p_i| + sigma_half_i, rounded up: the patch geometry of describe_setup_one (describe_setup_dev.h)
+  float reach;
 };
 void build_pattern(Pattern* p);
+float pattern_reach(const Pattern& p);
 // scale_invariant = true (Frontend.hpp:235-237): the published BRISK extractor keeps the pattern at 64
 // scales spanning a factor of 30 and picks index max(int(64 / lb(30) * lb(size / 7.2) + 0.5), 0)
 // (<= 63) from the keypoint's diameter; the fixed-scale extractor is index 17 of the same ladder.
@@ -254,8 +257,14 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done = false,
-                     bool all_camera_aware = false, int box_class = 0);  // (every image of the call has mode kCameraAware)
+                     bool all_camera_aware = false, int box_class = 0,  // (every image of the call has mode kCameraAware)
+                     bool aware_fast = false);  // (and none comes from a camera whose patches mostly miss the LDS classes)
 bool describe_patch_fits(float nx, float ny, int border);
+// k_describe_aware.hip: the camera-aware-only extractor with batched extra samples (round 6)
+int describe_aware_patch_class(float nx, float ny, float reach);
+void launch_describe_aware(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
+                           const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in, uint8_t* desc_tmp,
+                           uint8_t* valid_tmp, bool wide_boxes, hipStream_t stream);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
                     const uint8_t* valid_tmp, const int32_t* kp_count_in, int kp_cap,
