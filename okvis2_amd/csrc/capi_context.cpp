@@ -735,6 +735,7 @@ okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* p) {
     P.box_scaling[i] = scaling;
     P.box_scaling2[i] = static_cast<int>(s2 / 1024.0f);
   }
+  fill_aware_lanes(&P);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

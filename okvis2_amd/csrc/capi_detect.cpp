@@ -116,6 +116,22 @@ static int pattern_box_class(const okvfe::Pattern& P) {
   return cls;
 }
 
+// Does describe_aware_kernel (k_describe_aware.hip) serve this call?  -1: no (describe_kernel does); otherwise the
+// largest box side minus one of the pattern's samples beyond 64, which the set-up threads evaluate (0: none).
+// Every image camera-aware on a camera whose patches fit the kernel's LDS classes, the fixed-scale pattern with boxes
+// inside the fixed-trip slots, dword-aligned images.
+static int aware_box_for_call(const okvfe_ctx* ctx, const uint8_t* images_dev) {
+  static const bool old_aware = lab_env("OKVFE_DESC_R5") != nullptr;  // A/B knob: the round-5 kernels
+  const okvfe::Pattern& P = ctx->host_pattern;
+  const int cls = pattern_box_class(P);
+  const int extra = P.n_points > 64 ? P.n_points - 64 : 0;
+  if (old_aware || !ctx->all_aware || !ctx->aware_fast || cls > 1 || extra > okvfe::kAwareMaxExtra || ctx->d_scales ||
+      ctx->n_layers != 1 || ctx->w % 4 != 0 || (reinterpret_cast<uintptr_t>(images_dev) & 3) != 0 || ctx->w >= 4096 ||
+      ctx->h >= 4096)
+    return -1;
+  return extra == 0 ? 0 : (cls == 0 ? 4 : 9);
+}
+
 namespace {
 // The token mutex is held from the wait on the previous holder's event to the record of this
 // launch's event, so two host threads can never chain on the same predecessor.
@@ -187,8 +203,9 @@ void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
 void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
   // detection + description in one call (single scale): the selection kernel also prepares the
   // extractor's per-keypoint inputs (describe_setup_dev.h)
+  L->aware_extra_box = aware_box_for_call(L, L->live_images);
   const DescribeSetup setup{L->d_pattern, L->d_prm, L->d_rays_ptrs, L->d_jac_ptrs, L->d_kps_tmp, L->d_desc_tmp,
-                            L->d_valid_tmp, L->d_scales};
+                            L->d_valid_tmp, L->d_scales, L->live_images, L->aware_extra_box > 0 ? L->aware_extra_box : 0};
   const bool fuse = L->fuse_setup && L->n_layers == 1 && L->d_pattern && L->d_kps_tmp && L->d_prm;
   L->setup_done = launch_select(L->d_scores, L->live_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
                                 L->d_cand_count, L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ,
@@ -378,7 +395,8 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
-                    ctx->all_aware, pattern_box_class(ctx->host_pattern), ctx->aware_fast);
+                    ctx->all_aware, pattern_box_class(ctx->host_pattern),
+                    setup_done ? ctx->aware_extra_box : aware_box_for_call(ctx, images_dev));
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -806,7 +824,7 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
                   ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false,
-                  ctx->all_aware, pattern_box_class(ctx->host_pattern), ctx->aware_fast);
+                  ctx->all_aware, pattern_box_class(ctx->host_pattern), aware_box_for_call(ctx, ctx->d_img_stage));
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

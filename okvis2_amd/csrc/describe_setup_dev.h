@@ -55,6 +55,100 @@ __device__ __forceinline__ bool camera_aware_matrix(const float* __restrict__ ra
   return true;
 }
 
+// Extra sample e (a pattern point beyond the 64 lanes of describe_aware_kernel) of one keypoint, by ONE THREAD and
+// straight from the image: the published BRISK smoothedIntensity with sub-pixel rim weights (same float / integer
+// sequence as box_mean, k_describe_aware.hip), boxes of at most MAXB2 + 1 pixels a side.  All rows are loaded up
+// front (aligned dword windows, one memory round trip); false = the box leaves the image (the keypoint is dropped).
+template <int MAXB2>
+__device__ __forceinline__ bool extra_sample_value(const uint8_t* __restrict__ im, int w, int h, float xf, float yf,
+                                                   float sigma_half, int scaling, int scaling2, int* value) {
+  const float x_1 = xf - sigma_half, x1 = xf + sigma_half;
+  const float y_1 = yf - sigma_half, y1 = yf + sigma_half;
+  if (!(x_1 >= 0.0f && y_1 >= 0.0f && x1 < (float)(w - 1) && y1 < (float)(h - 1))) return false;
+  const int x_left = (int)(x_1 + 0.5f), y_top = (int)(y_1 + 0.5f);
+  const int x_right = (int)(x1 + 0.5f), y_bottom = (int)(y1 + 0.5f);
+  float r_x_1 = (float)x_left - x_1;  r_x_1 = r_x_1 + 0.5f;
+  float r_y_1 = (float)y_top - y_1;   r_y_1 = r_y_1 + 0.5f;
+  float r_x1 = x1 - (float)x_right;   r_x1 = r_x1 + 0.5f;
+  float r_y1 = y1 - (float)y_bottom;  r_y1 = r_y1 + 0.5f;
+  const float fs = (float)scaling;
+  float t;
+  t = r_x_1 * r_y_1; const int A = (int)(t * fs);
+  t = r_x1 * r_y_1;  const int B = (int)(t * fs);
+  t = r_x1 * r_y1;   const int C = (int)(t * fs);
+  t = r_x_1 * r_y1;  const int D = (int)(t * fs);
+  const int r_x_1_i = (int)(r_x_1 * fs), r_y_1_i = (int)(r_y_1 * fs);
+  const int r_x1_i = (int)(r_x1 * fs), r_y1_i = (int)(r_y1 * fs);
+  const int bw = x_right - x_left, bh = y_bottom - y_top;
+  if (bw > MAXB2 || bh > MAXB2) return false;  // (cannot happen: the host checked the pattern's half-widths)
+  // row window: NDW dwords from the dword that holds x_left (byte b of it); x_right is byte b + bw <= 3 + MAXB2
+  constexpr int NDW = (3 + MAXB2) / 4 + 1;
+  const int b = x_left & 3;
+  const uint8_t* p0 = im + (size_t)y_top * w + (x_left & ~3);
+  auto byte_at = [&](const uint32_t (&r)[NDW], int pos) -> int {  // byte `pos` of a row window
+    uint32_t v = r[0];
+#pragma unroll
+    for (int j = 1; j < NDW; ++j) v = (pos >> 2) == j ? r[j] : v;
+    return (int)((v >> (8 * (pos & 3))) & 0xFFu);
+  };
+  uint32_t msk[NDW];  // bytes b + 1 .. b + bw - 1 of a row window
+#pragma unroll
+  for (int j = 0; j < NDW; ++j) {
+    int lo = b + 1 - 4 * j, hi = b + bw - 4 * j;
+    lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+    hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+    const uint32_t mlo = lo >= 4 ? 0xFFFFFFFFu : ((1u << (8 * lo)) - 1u);
+    const uint32_t mhi = hi >= 4 ? 0xFFFFFFFFu : ((1u << (8 * hi)) - 1u);
+    msk[j] = mhi & ~mlo;
+  }
+  int upper = 0, middle = 0, left = 0, right = 0, bottom = 0, pl_t = 0, pr_t = 0, pl_b = 0, pr_b = 0;
+  // five rows per memory round trip (registers: the selection kernel's tail has 80)
+  constexpr int kChunk = 5;
+#pragma unroll
+  for (int c0 = 0; c0 <= MAXB2; c0 += kChunk) {
+    uint32_t d[kChunk][NDW];
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) {
+      const int dy = c0 + r;
+      if (dy <= MAXB2) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p0 + (size_t)(dy < bh ? dy : bh) * w);
+#pragma unroll
+        for (int j = 0; j < NDW; ++j) d[r][j] = q[j];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) {
+      const int dy = c0 + r;
+      if (dy <= MAXB2) {
+        const int pl = byte_at(d[r], b), pr = byte_at(d[r], b + bw);
+        int in = 0;
+#pragma unroll
+        for (int j = 0; j < NDW; ++j) in += (int)__builtin_amdgcn_sad_u8(d[r][j] & msk[j], 0u, 0u);
+        if (dy == 0) {
+          pl_t = pl;
+          pr_t = pr;
+          upper = in;
+        } else if (dy < bh) {
+          left += pl;
+          right += pr;
+          middle += in;
+        } else if (dy == bh) {
+          pl_b = pl;
+          pr_b = pr;
+          bottom = in;
+        }
+      }
+    }
+  }
+  int ret = A * pl_t;
+  ret += B * pr_t;
+  ret += C * pr_b;
+  ret += D * pl_b;
+  ret += upper * r_y_1_i + middle * scaling + left * r_x_1_i + right * r_x1_i + bottom * r_y1_i;
+  *value = (ret + scaling2 / 2) / scaling2;  // (non-negative: floor)
+  return true;
+}
+
 // One keypoint: valid byte (bit 0 = inside the rim and a usable ray, bits 1..6 = scale index of the
 // scale-invariant extractor), M into the first 16 bytes of the (not yet written) descriptor slot, the
 // record into kps_tmp.
@@ -104,6 +198,25 @@ __device__ __forceinline__ void describe_setup_one(const DescribeSetup& ds, int 
       }
     }
     *reinterpret_cast<int2*>(ds.desc_tmp + slot * OKVFE_DESC_BYTES + 16) = make_int2(g0, g1);
+    // ... and the samples beyond its 64 lanes, bytes 24.. of the slot
+    if (valid && ds.extra_box > 0) {
+      const int extra = ds.pat->n_points - 64;  // 1 .. kAwareMaxExtra (host-checked)
+      const uint8_t* im = ds.images + (size_t)img * w * h;
+      for (int e = 0; e < extra && valid; ++e) {
+        const float px = ds.pat->px[e], py = ds.pat->py[e], sg = ds.pat->sigma_half[e];
+        float a = M[0] * px, b2 = M[1] * py;  // (the sequence of sample_pos, k_describe_aware.hip)
+        a = a + b2;
+        const float xf = kp.x + a;
+        float c = M[2] * px, d2 = M[3] * py;
+        c = c + d2;
+        const float yf = kp.y + c;
+        int v = 0;
+        valid = ds.extra_box <= 4
+                    ? extra_sample_value<4>(im, w, h, xf, yf, sg, ds.pat->box_scaling[e], ds.pat->box_scaling2[e], &v)
+                    : extra_sample_value<9>(im, w, h, xf, yf, sg, ds.pat->box_scaling[e], ds.pat->box_scaling2[e], &v);
+        *reinterpret_cast<int*>(ds.desc_tmp + slot * OKVFE_DESC_BYTES + 24 + 4 * e) = v;
+      }
+    }
   }
   ds.valid_tmp[slot] = (uint8_t)((valid ? 1 : 0) | (scale << 1));
   ds.kps_tmp[slot] = kp;  // the record travels on from here; describe_kernel only rewrites the angle

@@ -34,6 +34,28 @@ float pattern_reach(const Pattern& p) {
   return static_cast<float>(reach * 1.0001 + 1.0e-3);  // (rounded up: only ever used for a superset)
 }
 
+void fill_aware_lanes(Pattern* p) {
+  const int extra = p->n_points > 64 ? p->n_points - 64 : 0;
+  for (int l = 0; l < 64; ++l) {
+    const int li = extra + l < p->n_points ? extra + l : 0;
+    int32_t* r = p->aware_lane[l];
+    std::memcpy(&r[0], &p->px[li], 4);
+    std::memcpy(&r[1], &p->py[li], 4);
+    std::memcpy(&r[2], &p->sigma_half[li], 4);
+    r[3] = p->box_scaling[li];
+    r[4] = p->box_scaling2[li];
+    for (int j = 0; j < 3; ++j) {
+      uint32_t v = 0;
+      for (int half = 0; half < 2; ++half) {
+        const int t = (2 * j + half) * 64 + l;  // bit t of the descriptor: word 2 j + half, lane l
+        const uint32_t e = t < p->n_short ? (uint32_t)p->short_i[t] | ((uint32_t)p->short_j[t] << 8) : 0u;
+        v |= e << (16 * half);
+      }
+      r[5 + j] = (int32_t)v;
+    }
+  }
+}
+
 void build_pattern(Pattern* p) {
   // The BRISK2 pattern as recovered from the 819 real node descriptors of the reference's vocabulary
   // (resources/small_voc.yml.gz; tools/pattern/README.md): 66 sample points -- centre, hexagon, rings of
@@ -103,6 +125,7 @@ void build_pattern(Pattern* p) {
     p->rot_cosf[k] = static_cast<float>(std::cos(a));
     p->rot_sinf[k] = static_cast<float>(std::sin(a));
   }
+  fill_aware_lanes(p);
 }
 
 int pattern_scale_index(float size) {

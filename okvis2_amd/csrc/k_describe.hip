@@ -306,12 +306,12 @@ __global__ __launch_bounds__(256) void describe_setup_kernel(
     const float* const* __restrict__ rays, const float* const* __restrict__ jac,
     const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
     okvfe_keypoint* __restrict__ kps_tmp, uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp,
-    const PatternScales* __restrict__ scales) {
+    const PatternScales* __restrict__ scales, const uint8_t* __restrict__ images, int extra_box) {
   const int img = blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= kp_count_in[img]) return;
   const size_t slot = (size_t)img * kp_cap + k;
-  const DescribeSetup ds{pat, prm, rays, jac, kps_tmp, desc_tmp, valid_tmp, scales};
+  const DescribeSetup ds{pat, prm, rays, jac, kps_tmp, desc_tmp, valid_tmp, scales, images, extra_box};
   describe_setup_one(ds, w, h, img, slot, kps_in[slot]);
 }
 
@@ -841,14 +841,14 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done,
-                     bool all_camera_aware, int box_class, bool aware_fast) {
+                     bool all_camera_aware, int box_class, int aware_extra_box) {
   if (n_images <= 0) return;
   static const char* force = lab_env("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
   if (!setup_done)  // (done by select_lazy_kernel when detection and description were one call)
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                     valid_tmp, scales);
+                     valid_tmp, scales, img, aware_extra_box > 0 ? aware_extra_box : 0);
   // blocks per image: enough waves to fill the machine with one image's ~300 keypoints spread
   // over them (a wave then describes ~9 keypoints of its image in a row)
   int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
@@ -863,8 +863,9 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
     all_camera_aware = false;  // (scale-invariant extraction, unaligned images: generic form)
   // round 6: the production mode on cameras whose patches fit the two LDS classes -> k_describe_aware.hip (extra
   // samples in batches, patch geometry from the set-up thread, compile-time row pitches)
-  static const bool old_aware = lab_env("OKVFE_DESC_R5") != nullptr;  // A/B knob: the round-5 kernels
-  if (all_camera_aware && aware_fast && box_class <= 1 && !old_aware && w < 4096 && h < 4096) {
+  // (aware_extra_box >= 0: capi_detect.cpp decided for it -- cameras, pattern, alignment -- and the set-up threads
+  // have left the extra samples in the slots)
+  if (all_camera_aware && aware_extra_box >= 0 && box_class <= 1) {
     launch_describe_aware(img, w, h, n_images, pat, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp, box_class == 1,
                           stream);
     return;

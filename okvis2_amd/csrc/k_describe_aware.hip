@@ -11,10 +11,12 @@
 // pass of the whole wave for the two samples (of 66) that do not fit 64 lanes, another fifth was wave-uniform patch
 // geometry recomputed by 64 lanes, and two thirds of the first pass's row loop was address arithmetic.  This kernel:
 //
-//   * EXTRA SAMPLES IN BATCHES.  A wave walks up to 64 / extra keypoints per round; before the walk, lane
-//     j * extra + e computes extra sample e of the round's keypoint j straight from the image (aligned dword loads,
-//     the same fixed-trip box sum), so the second pass runs once per ROUND instead of once per keypoint; its lines are
-//     the ones the patches of the same keypoints pull into the XCD's L2 a moment later.
+//   * EXTRA SAMPLES FROM THE SET-UP THREAD.  describe_setup_one (describe_setup_dev.h: one THREAD per keypoint, in
+//     the tail of the selection kernel, where the keypoint's pixels are still in the L2) evaluates the samples beyond
+//     64 with the same box sum and leaves them in the keypoint's descriptor slot; the wave that owns the keypoint
+//     loads them with the patch.  (First form of this round: lane j * extra + e of the wave computed them for a round
+//     of its keypoints before walking them -- 8.8 k of a wave's 41 k cycles, latency of two dependent global round
+//     trips: tools/lab/aware_prof.py.)
 //   * PATCH GEOMETRY FROM THE SET-UP THREAD.  describe_setup_one (one THREAD per keypoint, in the tail of the
 //     selection kernel) leaves {first byte offset, x0 / y0 / rows / class} next to M in the keypoint's descriptor
 //     slot; they arrive here through the scalar prefetch of the next keypoint.
@@ -92,7 +94,7 @@ __device__ __forceinline__ void fill_box_masks(uint32_t* table, int tid, int nth
 }
 
 // ---- pixel readers of the box sum ---------------------------------------------------------------------------------
-// byte(off) / dwords(off, d[]) at byte offset `off` from the reader's origin; kPitch > 0: compile-time row pitch
+// byte(off) / dwords(off, d[]) / qword(off) at byte offset `off` from the patch's first byte; compile-time row pitch
 template <int PITCH>
 struct LdsReader {  // the keypoint's patch in LDS, row pitch PITCH
   static constexpr int kPitch = PITCH;
@@ -107,24 +109,6 @@ struct LdsReader {  // the keypoint's patch in LDS, row pitch PITCH
   }
   __device__ __forceinline__ uint2 qword(int off) const { return *reinterpret_cast<const uint2*>(base + off); }  // 8-aligned
 };
-struct ImageReader {  // straight from the image: aligned dword loads through the bounds-checked buffer resource
-  static constexpr int kPitch = 0;
-  __amdgpu_buffer_rsrc_t rsrc;
-  int pitch;
-  __device__ __forceinline__ int byte(int off) const {
-    return (int)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, off, 0, 0);
-  }
-  template <int N>
-  __device__ __forceinline__ void dwords(int off, uint32_t (&d)[N]) const {
-#pragma unroll
-    for (int j = 0; j < N; ++j) d[j] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4 * j, 0, 0);
-  }
-  __device__ __forceinline__ uint2 qword(int off) const {
-    return make_uint2((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0),
-                      (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0));
-  }
-};
-
 // Box of half-side sigma_half centred at (xf, yf), 1024 * mean intensity: the published BRISK smoothedIntensity with
 // sub-pixel rim weights, fixed trip counts.  `x0`, `y0`: image coordinates of the reader's origin; MAXB: largest box
 // side minus one served.  Same float / integer sequence as smoothed_intensity (k_describe.hip).
@@ -205,18 +189,51 @@ __device__ __forceinline__ int box_mean(const RD& rd, const uint32_t* __restrict
   ret = mad24i(C, pr_b, ret);
   ret = mad24i(D, pl_b, ret);
   // interior rows 1 .. bh - 1: fixed trip count, rows past the lane's box masked off by exec -- the LDS pipe is this
-  // kernel's bound (bank conflicts of the gather), so a lane that has no row left must not read.  (Measured against
-  // it: the reads of three rows issued together for every lane and the sums selected afterwards, 1.45 vs 1.36 ms.)
+  // kernel's bound (bank conflicts of the gather), so a lane that has no row left must not read.  Rows go in groups of
+  // three nested tests (dy < bh is monotone): the reads of a group are all issued on the way in and summed on the way
+  // out, one LDS round trip per group instead of one per row.  (Measured against it: the reads of three rows issued
+  // for every lane and the sums selected afterwards, 1.45 vs 1.36 ms.)
   uint32_t mid = 0u;
   int left = 0, right = 0;
+  struct Row {
+    uint32_t d[kDw];
+    int pl, pr;
+  };
+  auto issue = [&](int dy, Row& r) {
+    const int off = RD::kPitch > 0 ? dy * RD::kPitch : mul24i(dy, pitch);
+    r.pl = rd.byte(aL + off);
+    r.pr = rd.byte(aR + off);
+    if constexpr (WIDE) {
+      rd.template dwords<kDw>(aQ + off, r.d);
+    } else {
+      const uint2 a = rd.qword(aQ + off);
+      uint2 b = make_uint2(0u, 0u);
+      if (two) b = rd.qword(aQ + off + 8);
+      r.d[0] = a.x; r.d[1] = a.y; r.d[2] = b.x; r.d[3] = b.y;
+    }
+  };
+  auto consume = [&](const Row& r) {
 #pragma unroll
-  for (int dy = 1; dy < MAXB; ++dy) {
-    if (dy < bh) {
-      const int off = RD::kPitch > 0 ? dy * RD::kPitch : mul24i(dy, pitch);
-      const int pl = rd.byte(aL + off), pr = rd.byte(aR + off);
-      mid = row_sum(off, mid);
-      left += pl;
-      right += pr;
+    for (int j = 0; j < kDw; ++j) mid = __builtin_amdgcn_msad_u8(r.d[j], m[j], mid);
+    left += r.pl;
+    right += r.pr;
+  };
+#pragma unroll
+  for (int d0 = 1; d0 < MAXB; d0 += 3) {
+    if (d0 < bh) {
+      Row r0;
+      issue(d0, r0);
+      if (d0 + 1 < MAXB && d0 + 1 < bh) {
+        Row r1;
+        issue(d0 + 1, r1);
+        if (d0 + 2 < MAXB && d0 + 2 < bh) {
+          Row r2;
+          issue(d0 + 2, r2);
+          consume(r2);
+        }
+        consume(r1);
+      }
+      consume(r0);
     }
   }
   const int upper = full - (int)up, bottom = full - (int)bot;
@@ -294,21 +311,9 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
   __shared__ __attribute__((aligned(16))) uint8_t patches[kAwWaves][kAwBufBytes];
   __shared__ int values[kAwWaves][kPatternPoints];
   __shared__ __attribute__((aligned(16))) uint32_t box_masks[T::kAlign * T::kCounts * T::kRowDw];
-  __shared__ float second_f[3][kPatternPoints - 64];
-  __shared__ int second_i[2][kPatternPoints - 64];
-  __shared__ uint16_t short_pairs[384];
-  fill_box_masks<WIDE>(box_masks, threadIdx.x, 64 * kAwWaves);
-  if (threadIdx.x < kPatternPoints - 64) {
-    second_f[0][threadIdx.x] = pat->px[threadIdx.x];
-    second_f[1][threadIdx.x] = pat->py[threadIdx.x];
-    second_f[2][threadIdx.x] = pat->sigma_half[threadIdx.x];
-    second_i[0][threadIdx.x] = pat->box_scaling[threadIdx.x];
-    second_i[1][threadIdx.x] = pat->box_scaling2[threadIdx.x];
-  }
-  for (int t = threadIdx.x; t < 384; t += 64 * kAwWaves)
-    short_pairs[t] = t < pat->n_short ? (uint16_t)(pat->short_i[t] | (pat->short_j[t] << 8)) : (uint16_t)0;
-  __syncthreads();
-  // all keypoint blocks of an image run on the same XCD (block L -> XCD L % 8): its pixels are fetched into ONE L2
+  // everything a wave needs before its first keypoint is requested up front -- the image's keypoint count, the lane's
+  // constants (one 32-byte record, Pattern::aware_lane), the first keypoint's scalars -- so that the prologue is ONE
+  // global round trip (it was five dependent ones: 7.6 k of a wave's 41 k cycles, tools/lab/aware_prof.py)
   int img, tile;
   {
     const uint32_t L = blockIdx.x, n8 = (uint32_t)n_images & ~7u, full = n8 * (uint32_t)tiles;
@@ -316,43 +321,18 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
     uint32_t g = (uint32_t)(((uint64_t)slot * inv_tiles) >> 32);  // slot / tiles, off by <= 1
     if (g * (uint32_t)tiles > slot) --g;
     if ((g + 1) * (uint32_t)tiles <= slot) ++g;
+    // all keypoint blocks of an image run on the same XCD (block L -> XCD L % 8): its pixels are fetched into ONE L2
     img = L < full ? (int)(g * 8u + (L & 7u)) : (int)(n8 + g);
     tile = (int)(slot - g * (uint32_t)tiles);
   }
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
-  const int n = kp_count_in[img];
-  const int k_first = tile * kAwWaves + wv, k_step = tiles * kAwWaves;
-  if (k_first >= n) return;  // whole wave exits; no block-wide barriers below
-  const uint8_t* im = images + (size_t)img * w * h;
+  const int k_first = tile * kAwWaves + wv, k_step = tiles * kAwWaves;  // (k_first < kp_cap: launch_describe_aware)
   const size_t slot0 = (size_t)img * kp_cap;
-  const int extra = __builtin_amdgcn_readfirstlane(pat->n_points > 64 ? pat->n_points - 64 : 0);
-  const bool active = extra + lane < pat->n_points;
-  const int li = active ? extra + lane : 0;
-  float px = pat->px[li], py = pat->py[li], sg = pat->sigma_half[li];
-  int bsc = pat->box_scaling[li], bsc2 = pat->box_scaling2[li];
-  float rcp2 = __builtin_amdgcn_rcpf((float)bsc2);
-  uint32_t my_pairs[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-    my_pairs[j] = (uint32_t)short_pairs[(2 * j) * 64 + lane] | ((uint32_t)short_pairs[(2 * j + 1) * 64 + lane] << 16);
-  int* vals = values[wv];
-  uint8_t* patch = patches[wv];
-  const __amdgpu_buffer_rsrc_t img_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
-  // per-lane source offsets of the two patch classes: lane = row * chunks + 16-byte chunk
-  const int src_lane0 = (lane >> 2) * w + (lane & 3) * 16;                  // pitch 64: 16 rows per trip
-  const int rr1 = (int)(((uint32_t)lane * 13108u) >> 16);                   // lane / 5
-  const int src_lane1 = rr1 * w + (lane - rr1 * 5) * 16;                    // pitch 80: 12 rows per trip (lanes 0..59)
-
-  // ---- extra samples of a round of keypoints: lane j * extra + e ---------------------------------------------------
-  const int per_round = extra > 0 ? 64 / extra : 64;  // keypoints per round
-  const uint32_t inv_extra = extra > 0 ? (65536u + (uint32_t)extra - 1u) / (uint32_t)extra : 0u;
-  const int ej = extra > 0 ? (int)(((uint32_t)lane * inv_extra) >> 16) : 0;  // lane / extra
-  const int ee = lane - ej * extra;
-  int v2_all = 0;
-  unsigned long long ok2_bits = ~0ull;
-
+  const int n_raw = kp_count_in[img];
+  const int n_points = pat->n_points;
+  const int4 lc0 = *reinterpret_cast<const int4*>(&pat->aware_lane[lane][0]);
+  const int4 lc1 = *reinterpret_cast<const int4*>(&pat->aware_lane[lane][4]);
   typedef const float __attribute__((address_space(4))) * cfloat_p;
   typedef const int __attribute__((address_space(4))) * cint_p;
   typedef const uint8_t __attribute__((address_space(4))) * cbyte_p;
@@ -375,42 +355,32 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
     nxt_g1 = ((cint_p)pm)[5];
     nxt_valid = (int)((cbyte_p)(uintptr_t)valid_tmp)[sl];
   };
-  fetch(k_first);
+  fetch(k_first < kp_cap ? k_first : kp_cap - 1);  // (a slot past the image's count holds stale bytes: read, never used)
+  fill_box_masks<WIDE>(box_masks, threadIdx.x, 64 * kAwWaves);
+  __syncthreads();
+  const int n = __builtin_amdgcn_readfirstlane(n_raw);
+  if (k_first >= n) return;  // whole wave exits; no block-wide barriers below
+  const uint8_t* im = images + (size_t)img * w * h;
+  const int extra = __builtin_amdgcn_readfirstlane(n_points > 64 ? n_points - 64 : 0);
+  const bool active = extra + lane < n_points;
+  float px = __int_as_float(lc0.x), py = __int_as_float(lc0.y), sg = __int_as_float(lc0.z);
+  int bsc = lc0.w, bsc2 = lc1.x;
+  float rcp2 = __builtin_amdgcn_rcpf((float)bsc2);
+  const uint32_t my_pairs[3] = {(uint32_t)lc1.y, (uint32_t)lc1.z, (uint32_t)lc1.w};
+  int* vals = values[wv];
+  uint8_t* patch = patches[wv];
+  const __amdgpu_buffer_rsrc_t img_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
+  // per-lane source offsets of the two patch classes: lane = row * chunks + 16-byte chunk
+  const int src_lane0 = (lane >> 2) * w + (lane & 3) * 16;                  // pitch 64: 16 rows per trip
+  const int rr1 = (int)(((uint32_t)lane * 13108u) >> 16);                   // lane / 5
+  const int src_lane1 = rr1 * w + (lane - rr1 * 5) * 16;                    // pitch 80: 12 rows per trip (lanes 0..59)
   AW_T(t_pro);
 #ifdef OKVFE_LAB
-  unsigned long long a_extras = 0, a_dma = 0, a_box = 0, a_bits = 0, a_kp = 0;
+  unsigned long long a_dma = 0, a_box = 0, a_bits = 0, a_kp = 0;
 #endif
-  for (int kb = k_first; kb < n; kb += per_round * k_step) {
-    AW_T(t_r0);
-    if (extra > 0) {  // wave-uniform
-      const int kk = kb + ej * k_step;
-      const bool has = ej < per_round && kk < n;
-      const size_t sl = slot0 + (has ? kk : kb);
-      const float2 xy = *reinterpret_cast<const float2*>(&kps_in[sl].x);
-      const float4 Mv = *reinterpret_cast<const float4*>(desc_tmp + sl * OKVFE_DESC_BYTES);
-      const bool need = has && (valid_tmp[sl] & 1) != 0;
-      const float px2 = second_f[0][ee], py2 = second_f[1][ee], s2 = second_f[2][ee];
-      const int b1 = second_i[0][ee], b2 = second_i[1][ee];
-      float xf2, yf2;
-      const bool ok2 = sample_pos(Mv.x, Mv.y, Mv.z, Mv.w, xy.x, xy.y, px2, py2, s2, w, h, &xf2, &yf2);
-      ok2_bits = __ballot(ok2 || !need);
-      v2_all = 0;
-      if (need && ok2) {
-        const ImageReader rd{img_rsrc, w};
-        v2_all = box_mean<T::kMaxB2, WIDE>(rd, box_masks, 0, 0, xf2, yf2, s2, b1, b2, __builtin_amdgcn_rcpf((float)b2));
-      }
-    }
-#ifdef OKVFE_LAB
+  for (int k = k_first; k < n; k += k_step) {  // (k: wave-uniform)
     {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("" :: "v"(v2_all));
-      AW_T(t_r1);
-      a_extras += t_r1 - t_r0;
-    }
-#endif
-    for (int jj = 0; jj < per_round; ++jj) {
-      const int k = kb + jj * k_step;  // wave-uniform
-      if (k >= n) break;
       AW_T(t_a);
       // opaque to the optimiser: expressions of the lane constants are NOT hoisted out of the loop
       asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(rcp2), "+v"(lane));
@@ -438,10 +408,13 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
               __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * 960),
                                                        16, src_lane1, g0 + it * 12 * w, 0, 0);
         }
+        // the samples beyond 64, evaluated by the set-up thread (which also dropped the keypoint if one of their boxes
+        // left the image): lanes 0 .. extra - 1 pick them up with the patch
+        int xv = 0;
+        if (lane < extra) xv = *reinterpret_cast<const int*>(desc_tmp + slot * OKVFE_DESC_BYTES + 24 + 4 * lane);
         float xf, yf;
         const bool ok = sample_pos(M0, M1, M2, M3, kx, ky, px, py, sg, w, h, &xf, &yf);
-        const unsigned long long emask = extra > 0 ? ((1ull << extra) - 1ull) << (jj * extra) : 0ull;
-        valid = __all(ok || !active) && (ok2_bits & emask) == emask;
+        valid = __all(ok || !active);
         // (the loads are waited for even when the keypoint is dropped: the next keypoint's may not overtake them)
         int v = 0;
 #ifdef OKVFE_LAB
@@ -475,10 +448,7 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
         if (valid) {
           __builtin_amdgcn_wave_barrier();
           vals[extra + lane] = v;  // extra + 63 < kPatternPoints
-          if (extra > 0) {
-            const int t2 = __builtin_amdgcn_ds_bpermute(4 * (jj * extra + lane), v2_all);
-            if (lane < extra) vals[lane] = t2;
-          }
+          if (lane < extra) vals[lane] = xv;
           __builtin_amdgcn_wave_barrier();
           unsigned long long words[6];
 #pragma unroll
@@ -512,7 +482,7 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
     AW_T(t_end);
     atomicAdd(&g_aware_prof[0], 1ull);
     atomicAdd(&g_aware_prof[1], t_pro - t_entry);
-    atomicAdd(&g_aware_prof[2], a_extras);
+    atomicAdd(&g_aware_prof[2], 0ull);
     atomicAdd(&g_aware_prof[3], a_dma);
     atomicAdd(&g_aware_prof[4], a_box);
     atomicAdd(&g_aware_prof[5], a_bits);

@@ -115,6 +115,7 @@ struct okvfe_ctx {
   std::vector<std::vector<float>> cam_norms;
   std::vector<uint8_t> cam_aware_slow;
   bool aware_fast = false;        // of the images of the current batch: none from a cam_aware_slow camera
+  int aware_extra_box = -1;       // of the running call (aware_box_for_call): >= 0 = describe_aware_kernel serves it
   bool wide_patches = false;      // of the images of the current batch
   bool all_aware = false;         // every image of the current batch is extracted camera-aware
   bool counters_cleared = false;  // upload_image_params zeroed d_cand_count on the call's stream

@@ -48,7 +48,12 @@ struct Pattern {
   int32_t box_scaling[kPatternPoints], box_scaling2[kPatternPoints];
   // max_i |p_i| + sigma_half_i, rounded up: the patch geometry of describe_setup_one (describe_setup_dev.h)
   float reach;
+  // describe_aware_kernel's per-lane constants in ONE 32-byte record (two 16-byte loads, no dependent look-ups in a
+  // wave's prologue): lane l samples point extra + l (a lane without a point: point 0) -- {px, py, sigma_half (float
+  // bits), box_scaling, box_scaling2, short pairs of words 0|1, 2|3, 4|5 (i | j << 8 each, two per dword)}
+  int32_t aware_lane[64][8];
 };
+void fill_aware_lanes(Pattern* p);
 void build_pattern(Pattern* p);
 float pattern_reach(const Pattern& p);
 // scale_invariant = true (Frontend.hpp:235-237): the published BRISK extractor keeps the pattern at 64
@@ -234,7 +239,13 @@ struct DescribeSetup {  // pat == nullptr: not requested
   uint8_t* desc_tmp;
   uint8_t* valid_tmp;
   const PatternScales* scales;
+  // describe_aware_kernel's inputs (k_describe_aware.hip): the set-up thread also evaluates the pattern's samples
+  // beyond 64 ("extra", <= kAwareMaxExtra of them) from `images` -- boxes of at most extra_box + 1 pixels a side
+  // (4 or 9); 0 = not wanted (the call will run describe_kernel)
+  const uint8_t* images = nullptr;
+  int extra_box = 0;
 };
+constexpr int kAwareMaxExtra = 6;  // ints that fit the descriptor slot behind M (16 B) and the patch geometry (8 B)
 // true: launch_select orders the candidates itself for this configuration (array-bin lazy selection): the
 // caller launches no sort before it
 bool select_sorts_candidates(float radius, int max_kpts, int kp_cap, const uint8_t* occupancy, size_t occ_image_bytes,
@@ -258,7 +269,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done = false,
                      bool all_camera_aware = false, int box_class = 0,  // (every image of the call has mode kCameraAware)
-                     bool aware_fast = false);  // (and none comes from a camera whose patches mostly miss the LDS classes)
+                     int aware_extra_box = -1);  // >= 0: describe_aware_kernel serves the call (capi_detect.cpp: aware_box_for_call)
 bool describe_patch_fits(float nx, float ny, int border);
 // k_describe_aware.hip: the camera-aware-only extractor with batched extra samples (round 6)
 int describe_aware_patch_class(float nx, float ny, float reach);
