@@ -116,8 +116,8 @@ static int pattern_box_class(const okvfe::Pattern& P) {
   return cls;
 }
 
-// Does describe_aware_kernel (k_describe_aware.hip) serve this call?  -1: no (describe_kernel does); otherwise the
-// largest box side minus one of the pattern's samples beyond 64, which the set-up threads evaluate (0: none).
+// Does describe_aware_kernel (k_describe_aware.hip) serve this call?  -1: no (describe_kernel does); otherwise
+// (samples beyond 64) << 8 | their largest box side minus one (0: the pattern has no such samples).
 // Every image camera-aware on a camera whose patches fit the kernel's LDS classes, the fixed-scale pattern with boxes
 // inside the fixed-trip slots, dword-aligned images.
 static int aware_box_for_call(const okvfe_ctx* ctx, const uint8_t* images_dev) {
@@ -129,7 +129,7 @@ static int aware_box_for_call(const okvfe_ctx* ctx, const uint8_t* images_dev) {
       ctx->n_layers != 1 || ctx->w % 4 != 0 || (reinterpret_cast<uintptr_t>(images_dev) & 3) != 0 || ctx->w >= 4096 ||
       ctx->h >= 4096)
     return -1;
-  return extra == 0 ? 0 : (cls == 0 ? 4 : 9);
+  return extra == 0 ? 0 : ((extra << 8) | (cls == 0 ? 4 : 9));  // (samples beyond 64) << 8 | box side - 1
 }
 
 namespace {
@@ -205,7 +205,8 @@ void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
   // extractor's per-keypoint inputs (describe_setup_dev.h)
   L->aware_extra_box = aware_box_for_call(L, L->live_images);
   const DescribeSetup setup{L->d_pattern, L->d_prm, L->d_rays_ptrs, L->d_jac_ptrs, L->d_kps_tmp, L->d_desc_tmp,
-                            L->d_valid_tmp, L->d_scales, L->live_images, L->aware_extra_box > 0 ? L->aware_extra_box : 0};
+                            L->d_valid_tmp, L->d_scales, L->live_images,
+                            L->aware_extra_box > 0 && okvfe::aware_extras_in_setup() ? (L->aware_extra_box & 0xFF) : 0};
   const bool fuse = L->fuse_setup && L->n_layers == 1 && L->d_pattern && L->d_kps_tmp && L->d_prm;
   L->setup_done = launch_select(L->d_scores, L->live_layout, L->w, L->h, n_images, L->d_cand, L->cand_cap,
                                 L->d_cand_count, L->cfg.uniformity_radius, L->cfg.max_keypoints, L->d_lut, L->d_occ,

@@ -149,6 +149,25 @@ __device__ __forceinline__ bool extra_sample_value(const uint8_t* __restrict__ i
   return true;
 }
 
+// extra sample e of the keypoint at (kx, ky) under M -> bytes 24 + 4 e of its descriptor slot; false: box outside the image
+__device__ __forceinline__ bool extra_sample_one(const Pattern* __restrict__ pat, const uint8_t* __restrict__ im, int w,
+                                                 int h, int extra_box, int e, const float M[4], float kx, float ky,
+                                                 uint8_t* __restrict__ slot_bytes) {
+  const float px = pat->px[e], py = pat->py[e], sg = pat->sigma_half[e];
+  float a = M[0] * px, b2 = M[1] * py;  // (the sequence of sample_pos, k_describe_aware.hip)
+  a = a + b2;
+  const float xf = kx + a;
+  float c = M[2] * px, d2 = M[3] * py;
+  c = c + d2;
+  const float yf = ky + c;
+  int v = 0;
+  const bool ok = extra_box <= 4
+                      ? extra_sample_value<4>(im, w, h, xf, yf, sg, pat->box_scaling[e], pat->box_scaling2[e], &v)
+                      : extra_sample_value<9>(im, w, h, xf, yf, sg, pat->box_scaling[e], pat->box_scaling2[e], &v);
+  *reinterpret_cast<int*>(slot_bytes + 24 + 4 * e) = v;
+  return ok;
+}
+
 // One keypoint: valid byte (bit 0 = inside the rim and a usable ray, bits 1..6 = scale index of the
 // scale-invariant extractor), M into the first 16 bytes of the (not yet written) descriptor slot, the
 // record into kps_tmp.
@@ -198,24 +217,12 @@ __device__ __forceinline__ void describe_setup_one(const DescribeSetup& ds, int 
       }
     }
     *reinterpret_cast<int2*>(ds.desc_tmp + slot * OKVFE_DESC_BYTES + 16) = make_int2(g0, g1);
-    // ... and the samples beyond its 64 lanes, bytes 24.. of the slot
+    // ... and the samples beyond its 64 lanes, bytes 24.. of the slot (extra_box == 0: describe_extras_kernel does it)
     if (valid && ds.extra_box > 0) {
       const int extra = ds.pat->n_points - 64;  // 1 .. kAwareMaxExtra (host-checked)
-      const uint8_t* im = ds.images + (size_t)img * w * h;
-      for (int e = 0; e < extra && valid; ++e) {
-        const float px = ds.pat->px[e], py = ds.pat->py[e], sg = ds.pat->sigma_half[e];
-        float a = M[0] * px, b2 = M[1] * py;  // (the sequence of sample_pos, k_describe_aware.hip)
-        a = a + b2;
-        const float xf = kp.x + a;
-        float c = M[2] * px, d2 = M[3] * py;
-        c = c + d2;
-        const float yf = kp.y + c;
-        int v = 0;
-        valid = ds.extra_box <= 4
-                    ? extra_sample_value<4>(im, w, h, xf, yf, sg, ds.pat->box_scaling[e], ds.pat->box_scaling2[e], &v)
-                    : extra_sample_value<9>(im, w, h, xf, yf, sg, ds.pat->box_scaling[e], ds.pat->box_scaling2[e], &v);
-        *reinterpret_cast<int*>(ds.desc_tmp + slot * OKVFE_DESC_BYTES + 24 + 4 * e) = v;
-      }
+      for (int e = 0; e < extra && valid; ++e)
+        valid = extra_sample_one(ds.pat, ds.images + (size_t)img * w * h, w, h, ds.extra_box, e, M, kp.x, kp.y,
+                                 ds.desc_tmp + slot * OKVFE_DESC_BYTES);
     }
   }
   ds.valid_tmp[slot] = (uint8_t)((valid ? 1 : 0) | (scale << 1));

@@ -848,7 +848,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   if (!setup_done)  // (done by select_lazy_kernel when detection and description were one call)
   hipLaunchKernelGGL(describe_setup_kernel, dim3((kp_cap + 255) / 256, n_images), dim3(256), 0,
                      stream, w, h, pat, prm, rays, jac, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp,
-                     valid_tmp, scales, img, aware_extra_box > 0 ? aware_extra_box : 0);
+                     valid_tmp, scales, img, aware_extra_box > 0 && aware_extras_in_setup() ? (aware_extra_box & 0xFF) : 0);
   // blocks per image: enough waves to fill the machine with one image's ~300 keypoints spread
   // over them (a wave then describes ~9 keypoints of its image in a row)
   int tiles = (kp_cap + kDescWaves - 1) / kDescWaves;
@@ -867,7 +867,8 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
   // have left the extra samples in the slots)
   if (all_camera_aware && aware_extra_box >= 0 && box_class <= 1) {
     launch_describe_aware(img, w, h, n_images, pat, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp, box_class == 1,
-                          stream);
+                          stream, aware_extra_box > 0 && !aware_extras_in_setup() ? (aware_extra_box >> 8) : 0,
+                          aware_extra_box & 0xFF);
     return;
   }
   // box_class (capi_detect.cpp: pattern_box_class): 0 = every box fits the 11 x 11 / 5 x 5 slots, 1 = the 21 x 21 /

@@ -27,6 +27,7 @@
 //
 // Bit-exact to describe_kernel and to the oracle: the float set-up and the integer sums are the same operation
 // sequences (published BRISK smoothedIntensity with sub-pixel rim weights).
+#include "describe_setup_dev.h"
 #include "okvfe_internal.h"
 
 namespace okvfe {
@@ -299,6 +300,29 @@ __device__ __forceinline__ bool sample_pos(float M0, float M1, float M2, float M
   return (x_1 >= 0.0f && y_1 >= 0.0f && x1 < (float)(w - 1) && y1 < (float)(h - 1));
 }
 
+// The samples beyond the 64 lanes, one THREAD per (keypoint, extra sample): M and the valid byte come from the set-up
+// (describe_setup_one), the value goes to bytes 24.. of the keypoint's slot, a box outside the image drops the keypoint.
+// (Alternative home: the tail of the selection kernel, where the pixels are still in the L2 -- okvfe_internal.h
+// DescribeSetup::extra_box; it costs that kernel its register allocation: scratch 68 -> 160 bytes, + 0.08-0.1 ms.)
+__global__ __launch_bounds__(256) void describe_extras_kernel(const uint8_t* __restrict__ images, int w, int h,
+                                                              const Pattern* __restrict__ pat, int extra, int extra_box,
+                                                              const okvfe_keypoint* __restrict__ kps_in, int kp_cap,
+                                                              const int32_t* __restrict__ kp_count_in,
+                                                              uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp) {
+  const int img = blockIdx.y;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  const int k = item / extra, e = item - k * extra;
+  if (k >= kp_count_in[img]) return;
+  const size_t slot = (size_t)img * kp_cap + k;
+  if ((valid_tmp[slot] & 1) == 0) return;
+  const float4 Mv = *reinterpret_cast<const float4*>(desc_tmp + slot * OKVFE_DESC_BYTES);
+  const float M[4] = {Mv.x, Mv.y, Mv.z, Mv.w};
+  const float2 xy = *reinterpret_cast<const float2*>(&kps_in[slot].x);
+  if (!extra_sample_one(pat, images + (size_t)img * w * h, w, h, extra_box, e, M, xy.x, xy.y,
+                        desc_tmp + slot * OKVFE_DESC_BYTES))
+    valid_tmp[slot] = 0;  // (only ever cleared, by any of the keypoint's threads)
+}
+
 // One wave per keypoint at a time, lane l = pattern point extra + l; 4 waves per workgroup, `tiles` workgroups per
 // image (all on one XCD), a wave walks the image's keypoints wave, wave + 4 * tiles, ...
 template <bool WIDE>
@@ -516,10 +540,20 @@ extern "C" int okvfe_lab_aware_prof(unsigned long long out[16], int reset) {
 }
 #endif
 
+bool aware_extras_in_setup() {
+  // A/B knob: a kernel of their own instead (describe_extras_kernel: 0.18 ms per 6144 EuRoC images where the selection
+  // kernel's tail takes 0.085 for the same work -- 688 k vs 705 k stereo-frames/s)
+  static const bool own_kernel = lab_env("OKVFE_EXTRAS_KERNEL") != nullptr;
+  return !own_kernel;
+}
+
 void launch_describe_aware(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
                            const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in, uint8_t* desc_tmp,
-                           uint8_t* valid_tmp, bool wide_boxes, hipStream_t stream) {
+                           uint8_t* valid_tmp, bool wide_boxes, hipStream_t stream, int extras_now, int extra_box) {
   if (n_images <= 0) return;
+  if (extras_now > 0)  // (not done by the set-up threads)
+    hipLaunchKernelGGL(describe_extras_kernel, dim3((kp_cap * extras_now + 255) / 256, n_images), dim3(256), 0, stream, img,
+                       w, h, pat, extras_now, extra_box, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp);
   static const char* tiles_env = lab_env("OKVFE_DESC_TILES");  // A/B knob: workgroups per image
   int tiles = (kp_cap + kAwWaves - 1) / kAwWaves;
   const int want = tiles_env ? atoi(tiles_env) : 16;

@@ -275,7 +275,10 @@ bool describe_patch_fits(float nx, float ny, int border);
 int describe_aware_patch_class(float nx, float ny, float reach);
 void launch_describe_aware(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,
                            const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in, uint8_t* desc_tmp,
-                           uint8_t* valid_tmp, bool wide_boxes, hipStream_t stream);
+                           uint8_t* valid_tmp, bool wide_boxes, hipStream_t stream, int extras_now, int extra_box);
+// true: the set-up threads (selection kernel's tail / describe_setup_kernel) evaluate the extra samples; false: a
+// kernel of their own does (describe_extras_kernel)
+bool aware_extras_in_setup();
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
                     const uint8_t* valid_tmp, const int32_t* kp_count_in, int kp_cap,
