@@ -47,13 +47,14 @@ template <bool WIDE> struct AwCfg {
   static constexpr int kMaxB = WIDE ? 20 : 10;   // first-pass samples: box side - 1 (21 x 21 / 11 x 11 pixels)
   static constexpr int kMaxB2 = WIDE ? 9 : 4;    // extra samples (10 x 10 / 5 x 5)
   static constexpr int kCounts = WIDE ? 20 : 10; // mask table: interior byte counts 0 .. kCounts - 1
-  static constexpr int kRowDw = WIDE ? 8 : 4;    // dwords per table entry (whole 16-byte reads)
-  static constexpr int kMaskDw = WIDE ? 6 : 4;
-  // row windows start at a multiple of kAlign bytes.  11 x 11 boxes: 8, so that a row's interior (<= 9 bytes from
-  // byte 0..7) is one or two ALIGNED 8-byte reads -- ds_read_b64 serves 32 lanes per cycle on 64 banks where
-  // ds_read2_b32 + ds_read_b32 took three dword slots on 32, and the LDS gather is what bounds the kernel; the second
-  // read is skipped (exec) by the lanes whose interior ends in the first.  21 x 21: dword windows of six.
-  static constexpr int kAlign = WIDE ? 4 : 8;
+  // A row's interior (<= 9 / 19 bytes) is read as ALIGNED 8-byte windows from the multiple of 8 at or below its first
+  // byte: ds_read_b64 serves 32 lanes per cycle on 64 banks where ds_read2_b32 + ds_read_b32 took three dword slots
+  // on 32, and the LDS gather is what bounds the kernel.  Window q >= 1 is skipped (exec) by the lanes whose interior
+  // ends before it.
+  static constexpr int kAlign = 8;
+  static constexpr int kQ = WIDE ? 4 : 2;        // windows per row: 7 + 9 <= 16, 7 + 19 <= 32 bytes
+  static constexpr int kRowDw = 2 * kQ;          // dwords per table entry
+  static constexpr int kMaskDw = 2 * kQ;
 };
 
 __device__ __forceinline__ int mul24i(int a, int b) {
@@ -95,19 +96,13 @@ __device__ __forceinline__ void fill_box_masks(uint32_t* table, int tid, int nth
 }
 
 // ---- pixel readers of the box sum ---------------------------------------------------------------------------------
-// byte(off) / dwords(off, d[]) / qword(off) at byte offset `off` from the patch's first byte; compile-time row pitch
+// byte(off) / qword(off) at byte offset `off` from the patch's first byte; compile-time row pitch
 template <int PITCH>
 struct LdsReader {  // the keypoint's patch in LDS, row pitch PITCH
   static constexpr int kPitch = PITCH;
   const uint8_t* base;  // LDS
   static constexpr int pitch = PITCH;
   __device__ __forceinline__ int byte(int off) const { return base[off]; }
-  template <int N>
-  __device__ __forceinline__ void dwords(int off, uint32_t (&d)[N]) const {
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + off);
-#pragma unroll
-    for (int j = 0; j < N; ++j) d[j] = p[j];
-  }
   __device__ __forceinline__ uint2 qword(int off) const { return *reinterpret_cast<const uint2*>(base + off); }  // 8-aligned
 };
 // Box of half-side sigma_half centred at (xf, yf), 1024 * mean intensity: the published BRISK smoothedIntensity with
@@ -134,57 +129,60 @@ __device__ __forceinline__ int box_mean(const RD& rd, const uint32_t* __restrict
   const int r_x_1_i = (int)(r_x_1 * fs), r_y_1_i = (int)(r_y_1 * fs);
   const int r_x1_i = (int)(r_x1 * fs), r_y1_i = (int)(r_y1 * fs);
   const int bw = x_right - x_left, bh = y_bottom - y_top;  // 1 .. MAXB
-  constexpr int kAl = T::kAlign;
-  constexpr int kDw = WIDE ? (MAXB + 5) / 4 : 4;  // interior <= MAXB - 1 bytes from byte 0..kAl-1 of the window
-  static_assert(kDw <= T::kMaskDw && MAXB <= T::kCounts && (WIDE || MAXB + kAl - 2 <= 16), "mask table of the kernel");
+  constexpr int kAl = T::kAlign, kQ = T::kQ, kDw = 2 * kQ;
+  static_assert(MAXB <= T::kCounts && MAXB + kAl - 2 <= 8 * kQ, "mask table of the kernel");
   const int cl = x_left - x0;
   const int xi0 = cl + 1, lo = xi0 & (kAl - 1), ni = bw - 1;
   uint32_t m[kDw];
   {
-    const uint32_t* mp = masks + ((mul24i(lo, T::kCounts) + ni) << (T::kRowDw == 8 ? 3 : 2));
-    const uint4 mrow = *reinterpret_cast<const uint4*>(mp);
-    m[0] = mrow.x;
-    if constexpr (kDw > 1) m[1] = mrow.y;
-    if constexpr (kDw > 2) m[2] = mrow.z;
-    if constexpr (kDw > 3) m[3] = mrow.w;
-    if constexpr (kDw > 4) {
-      const uint2 mhi = *reinterpret_cast<const uint2*>(mp + 4);
-      m[4] = mhi.x;
-      if constexpr (kDw > 5) m[5] = mhi.y;
+    const uint4* mp = reinterpret_cast<const uint4*>(masks + ((mul24i(lo, T::kCounts) + ni) * T::kRowDw));
+#pragma unroll
+    for (int q = 0; q < kQ; q += 2) {
+      const uint4 mrow = mp[q >> 1];
+      m[2 * q] = mrow.x;
+      m[2 * q + 1] = mrow.y;
+      m[2 * q + 2] = mrow.z;
+      m[2 * q + 3] = mrow.w;
     }
   }
   const int pitch = RD::kPitch > 0 ? RD::kPitch : rd.pitch;
   const int row0 = mul24i(y_top - y0, pitch);
   const int aL = row0 + cl, aR = aL + bw, aQ = row0 + (xi0 & ~(kAl - 1));
-  const bool two = lo + ni > 8;  // (8-byte windows: the interior reaches into the second)
+  const int nq = (lo + ni + 7) >> 3;  // windows the interior reaches (0 for an empty interior: window 0 is read anyway)
   // v_msad_u8 adds 255 - pixel for the bytes the mask selects and skips the others: a row's interior sum comes back
   // as 255 * ni - accumulator
-  auto row_sum = [&](int off, uint32_t acc) -> uint32_t {
-    if constexpr (WIDE) {
-      uint32_t d[kDw];
-      rd.template dwords<kDw>(aQ + off, d);
+  struct Row {
+    uint32_t d[kDw];
+    int pl, pr;
+  };
+  // all reads of a row are issued before its first sum; a window the lane skips keeps zeros (its masks are zero anyway)
+  auto issue = [&](int off, Row& r) {
+    r.pl = rd.byte(aL + off);
+    r.pr = rd.byte(aR + off);
+    const uint2 a = rd.qword(aQ + off);
+    r.d[0] = a.x;
+    r.d[1] = a.y;
 #pragma unroll
-      for (int j = 0; j < kDw; ++j) acc = __builtin_amdgcn_msad_u8(d[j], m[j], acc);
-    } else {
-      // (both reads are issued before the first sum; a lane without a second window keeps zeros, and its masks
-      // m[2], m[3] are zero anyway)
-      const uint2 a = rd.qword(aQ + off);
+    for (int q = 1; q < kQ; ++q) {
       uint2 b = make_uint2(0u, 0u);
-      if (two) b = rd.qword(aQ + off + 8);
-      acc = __builtin_amdgcn_msad_u8(a.x, m[0], acc);
-      acc = __builtin_amdgcn_msad_u8(a.y, m[1], acc);
-      acc = __builtin_amdgcn_msad_u8(b.x, m[2], acc);
-      acc = __builtin_amdgcn_msad_u8(b.y, m[3], acc);
+      if (nq > q) b = rd.qword(aQ + off + 8 * q);
+      r.d[2 * q] = b.x;
+      r.d[2 * q + 1] = b.y;
     }
+  };
+  auto row_sum = [&](const Row& r, uint32_t acc) -> uint32_t {
+#pragma unroll
+    for (int j = 0; j < kDw; ++j) acc = __builtin_amdgcn_msad_u8(r.d[j], m[j], acc);
     return acc;
   };
   const int full = mul24i(ni, 255);
   // top and bottom row
   const int ob = mul24i(bh, pitch);
-  const int pl_t = rd.byte(aL), pr_t = rd.byte(aR);
-  const uint32_t up = row_sum(0, 0u);
-  const int pl_b = rd.byte(aL + ob), pr_b = rd.byte(aR + ob);
-  const uint32_t bot = row_sum(ob, 0u);
+  Row rt, rb;
+  issue(0, rt);
+  issue(ob, rb);
+  const int pl_t = rt.pl, pr_t = rt.pr, pl_b = rb.pl, pr_b = rb.pr;
+  const uint32_t up = row_sum(rt, 0u), bot = row_sum(rb, 0u);
   int ret = mad24i(A, pl_t, scaling2 / 2);
   ret = mad24i(B, pr_t, ret);
   ret = mad24i(C, pr_b, ret);
@@ -196,26 +194,9 @@ __device__ __forceinline__ int box_mean(const RD& rd, const uint32_t* __restrict
   // for every lane and the sums selected afterwards, 1.45 vs 1.36 ms.)
   uint32_t mid = 0u;
   int left = 0, right = 0;
-  struct Row {
-    uint32_t d[kDw];
-    int pl, pr;
-  };
-  auto issue = [&](int dy, Row& r) {
-    const int off = RD::kPitch > 0 ? dy * RD::kPitch : mul24i(dy, pitch);
-    r.pl = rd.byte(aL + off);
-    r.pr = rd.byte(aR + off);
-    if constexpr (WIDE) {
-      rd.template dwords<kDw>(aQ + off, r.d);
-    } else {
-      const uint2 a = rd.qword(aQ + off);
-      uint2 b = make_uint2(0u, 0u);
-      if (two) b = rd.qword(aQ + off + 8);
-      r.d[0] = a.x; r.d[1] = a.y; r.d[2] = b.x; r.d[3] = b.y;
-    }
-  };
+  auto row_off = [&](int dy) -> int { return RD::kPitch > 0 ? dy * RD::kPitch : mul24i(dy, pitch); };
   auto consume = [&](const Row& r) {
-#pragma unroll
-    for (int j = 0; j < kDw; ++j) mid = __builtin_amdgcn_msad_u8(r.d[j], m[j], mid);
+    mid = row_sum(r, mid);
     left += r.pl;
     right += r.pr;
   };
@@ -223,13 +204,13 @@ __device__ __forceinline__ int box_mean(const RD& rd, const uint32_t* __restrict
   for (int d0 = 1; d0 < MAXB; d0 += 3) {
     if (d0 < bh) {
       Row r0;
-      issue(d0, r0);
+      issue(row_off(d0), r0);
       if (d0 + 1 < MAXB && d0 + 1 < bh) {
         Row r1;
-        issue(d0 + 1, r1);
+        issue(row_off(d0 + 1), r1);
         if (d0 + 2 < MAXB && d0 + 2 < bh) {
           Row r2;
-          issue(d0 + 2, r2);
+          issue(row_off(d0 + 2), r2);
           consume(r2);
         }
         consume(r1);
