@@ -251,6 +251,17 @@ int32_t okvfe_score_column(const okvfe_ctx* ctx, int32_t x);
  * makes the following detect calls of this context write the map again (okvfe_device_outputs.scores);
  * scale-space and AGAST contexts always keep theirs. */
 okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep);
+/* Lanes inside one call (ABI 7).  okvfe_detect_describe_batch_device / _host cut a batch into `lanes` slices of whole
+ * stereo pairs and run each slice's kernel chain on a stream of the context's own, joined back onto the caller's
+ * stream before the call returns (still without a host synchronisation): the vector-ALU-bound score kernel of one
+ * slice runs under the LDS- and latency-bound selection / descriptor kernels of another -- what a caller used to get
+ * only by splitting the batch over several contexts and streams (the camera-parallel shape of
+ * okvis_multisensor_processing/src/ThreadedSlam.cpp:434-448, inside the call).  Results are those of the unsplit
+ * call, byte for byte (every kernel works per image).  lanes = 0: the library's choice -- at present not to cut: with
+ * ONE caller stream every call ends in a join, the slices run in phase and measure 1-5 % slower than the unsplit call,
+ * while several contexts on several streams (lanes that drift out of phase across calls) gain 8 %: DESIGN.md (e); 1: off;
+ * 2..8: that many.  Single-scale contexts only; others ignore it. */
+okvfe_status okvfe_set_internal_lanes(okvfe_ctx* ctx, int32_t lanes);
 
 /* Order of every 3-term FP64 sum in the matchers' gate chain (dot products, norms, C * v and C^T * v:
  * stereo_triangulation.cpp:62-76, Frontend.cpp:2027-2073 evaluate them through Eigen):

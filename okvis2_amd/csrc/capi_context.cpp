@@ -282,6 +282,13 @@ okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep) {
   return OKVFE_OK;
 }
 
+okvfe_status okvfe_set_internal_lanes(okvfe_ctx* ctx, int32_t lanes) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  if (lanes < 0 || lanes > 8) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_internal_lanes: %d (0 .. 8)", lanes);
+  ctx->internal_lanes = lanes;
+  return OKVFE_OK;
+}
+
 okvfe_status okvfe_set_fp64_reduction(okvfe_ctx* ctx, int32_t order) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
   if (order != OKVFE_SUM3_LEFT_TO_RIGHT && order != OKVFE_SUM3_EIGEN_TREE)
@@ -417,6 +424,8 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
       A(d_scores, (size_t)c->score_layout.pitch * c->h * B);
       A(d_cand, (size_t)c->cand_cap * B);
       A(d_cand_count, 2 * B + (size_t)kFixListCap * B);  // candidate counts, fix-up counts, fix-up lists
+      c->d_fix_count = c->d_cand_count + B;
+      c->d_fix_list = c->d_cand_count + 2 * B;
       A(d_sort_ws, (size_t)c->ws_stride * B);
       A(d_occ, c->occ_image_bytes * B);
     }
@@ -522,6 +531,24 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
   for (okvfe_ctx* ch : ctx->layers) okvfe_destroy(ch);
+  for (okvfe_ctx* v : ctx->lane_ctx) {  // views: a stream and two chaining events each, no memory
+    if (v->stream) {
+      (void)hipStreamSynchronize(v->stream);
+      (void)hipStreamDestroy(v->stream);
+    }
+    for (hipEvent_t ev : v->heavy_done) {
+      if (!ev) continue;
+      std::lock_guard<std::mutex> lock(g_token_mutex);
+      for (auto& t : g_score_token)
+        if (t == ev) t = nullptr;
+      (void)hipEventDestroy(ev);
+    }
+    if (v->k1_done) (void)hipEventDestroy(v->k1_done);
+    delete v;
+  }
+  for (hipEvent_t ev : ctx->lane_done)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
   for (uint8_t* p : ctx->d_layer_img)
     if (p) (void)hipFree(p);
   if (ctx->d_virtual) (void)hipFree(ctx->d_virtual);

@@ -159,7 +159,7 @@ okvfe_status heavy_end(okvfe_ctx* ctx, hipStream_t s, int which, TokenScope* t) 
 
 // K1 + K2 of one layer context `L` (score map + NMS candidates), launched for `owner`
 void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipStream_t s, bool* fused) {
-  int32_t* d_fix_count = L->d_cand_count + L->B;  // [0, B) candidate counts, [B, 2B) flagged counts
+  int32_t* d_fix_count = L->d_fix_count;
   if (L->cfg.score_type != OKVFE_SCORE_HARRIS) {  // AGAST score map only; the stand-alone NMS follows
     launch_agast_score(images_dev, L->w, L->h, n_images, L->d_scores, s);
     *fused = false;
@@ -176,7 +176,7 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
   *fused = L->score_layout.strips >= 1 &&
            launch_harris_nms(images_dev, L->w, L->h, n_images, L->d_scores, L->score_layout,
                              L->cfg.absolute_threshold, L->d_cand, L->cand_cap, L->d_cand_count, d_fix_count,
-                             L->d_cand_count + 2 * (size_t)L->B, s, !map_free);
+                             L->d_fix_list, s, !map_free);
   L->map_free_live = *fused && map_free;
   L->live_images = images_dev;
   if (!*fused) launch_harris(images_dev, L->w, L->h, n_images, L->d_scores, s);
@@ -185,10 +185,10 @@ void layer_score_nms(okvfe_ctx* L, const uint8_t* images_dev, int n_images, hipS
   L->live_layout = *fused ? L->score_layout : ScoreLayout{L->w, 0};
 }
 void layer_nms_finish(okvfe_ctx* L, int n_images, hipStream_t s, bool fused) {
-  int32_t* d_fix_count = L->d_cand_count + L->B;
+  int32_t* d_fix_count = L->d_fix_count;
   if (fused)
     launch_nms_fixup(L->d_scores, L->live_layout, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
-                     L->d_cand_count, d_fix_count, L->d_cand_count + 2 * (size_t)L->B, s, L->map_free_live, L->d_scores);
+                     L->d_cand_count, d_fix_count, L->d_fix_list, s, L->map_free_live, L->d_scores);
   else
     launch_nms(L->d_scores, L->w, L->h, n_images, L->cfg.absolute_threshold, L->d_cand, L->cand_cap,
                L->d_cand_count, s);
@@ -203,7 +203,7 @@ void layer_sort(okvfe_ctx* L, int n_images, hipStream_t s) {
 void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
   // detection + description in one call (single scale): the selection kernel also prepares the
   // extractor's per-keypoint inputs (describe_setup_dev.h)
-  L->aware_extra_box = aware_box_for_call(L, L->live_images);
+  if (!L->lane_view) L->aware_extra_box = aware_box_for_call(L, L->live_images);  // (a view: its owner decided)
   const DescribeSetup setup{L->d_pattern, L->d_prm, L->d_rays_ptrs, L->d_jac_ptrs, L->d_kps_tmp, L->d_desc_tmp,
                             L->d_valid_tmp, L->d_scales, L->live_images,
                             L->aware_extra_box > 0 && okvfe::aware_extras_in_setup() ? (L->aware_extra_box & 0xFF) : 0};
@@ -222,15 +222,25 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
   okvfe_status st;
   ctx->setup_done = false;  // set by this call's selection launch only (a failed earlier call must not leak it)
   if (ctx->n_layers == 1) {
-    if (!ctx->counters_cleared)  // (cleared together with the parameter upload of the same call otherwise)
-      HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+    if (!ctx->counters_cleared) {  // (cleared together with the parameter upload of the same call otherwise)
+      if (ctx->lane_view) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, (size_t)ctx->B * sizeof(int32_t), s));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_fix_count, 0, (size_t)ctx->B * sizeof(int32_t), s));
+      } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
+      }
+    }
     ctx->counters_cleared = false;
     if ((st = heavy_begin(ctx, s, 0, &token)) != OKVFE_OK) return st;
     bool fused;
+    // lanes inside one call: the score kernels run one after the other, so that the lanes proceed OUT OF PHASE -- the
+    // (vector-ALU-bound) score kernel of lane l beside the selection / descriptor kernels of the lanes before it
+    if (ctx->k1_wait) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->k1_wait, 0));
     {
       StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
       layer_score_nms(ctx, images_dev, n_images, s, &fused);
     }
+    if (ctx->k1_done) HIP_TRY(ctx, hipEventRecord(ctx->k1_done, s));
     if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
     {
       StageTimer t(ctx, OKVFE_STAGE_NMS, s);
@@ -396,8 +406,8 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
     launch_describe(images_dev, w, h, n_images, ctx->d_pattern, ctx->d_prm,
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
-                    ctx->all_aware, pattern_box_class(ctx->host_pattern),
-                    setup_done ? ctx->aware_extra_box : aware_box_for_call(ctx, images_dev));
+                    ctx->all_aware, ctx->lane_view ? ctx->box_class_call : pattern_box_class(ctx->host_pattern),
+                    ctx->lane_view || setup_done ? ctx->aware_extra_box : aware_box_for_call(ctx, images_dev));
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -408,9 +418,153 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->last_stream = s;
+  if (ctx->lane_view) return OKVFE_OK;  // (the owner releases the parameter slot behind the join)
   const int slot = ctx->prm_slot;
   ctx->prm_slot = -1;
   return ring_release(ctx, &ctx->prm_ring, slot, s);  // the ImageParams slot has no reader after this
+}
+
+// ---- lanes inside one call (okvfe_ctx::internal_lanes) ---------------------------------------------------------------
+int lanes_for_call(const okvfe_ctx* ctx, int n_images) {
+  static const char* force = lab_env("OKVFE_INTERNAL_LANES");  // A/B knob
+  int k = force ? atoi(force) : ctx->internal_lanes;
+  if (ctx->n_layers != 1 || ctx->lane_view || ctx->child || !ctx->d_cand) return 1;
+  // 0 = the library's choice, which is NOT to cut (measured, round 6, 3072 EuRoC stereo frames per call, one caller
+  // stream): 1 / 2 / 3 / 4 / 6 lanes = 710 / 688 / 702 / 700 / 677 k stereo-frames/s, with the score kernels chained
+  // 710 / 685 / 673 / 684 / 659 k -- every call ends in a join, so the lanes start each call in phase and the slices'
+  // kernels are the unsplit kernels in quarters; the +8 % of several CONTEXTS on several streams (766 k at three) comes
+  // from lanes that drift out of phase across calls, which one caller stream cannot have
+  if (k == 0) k = 1;
+  if (k > 8) k = 8;
+  while (k > 1 && n_images / k < 64) --k;
+  return k < 1 ? 1 : k;
+}
+
+okvfe_status ensure_lanes(okvfe_ctx* ctx, int k) {
+  if (!ctx->lane_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
+  while ((int)ctx->lane_ctx.size() < k) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));  // (streams live on the context's device, whatever the caller's current one)
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipStreamDestroy(st);
+      HIP_TRY(ctx, e);
+    }
+    hipEvent_t k1 = nullptr;
+    e = hipEventCreateWithFlags(&k1, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipStreamDestroy(st);
+      (void)hipEventDestroy(ev);
+      HIP_TRY(ctx, e);
+    }
+    okvfe_ctx* v = new okvfe_ctx();
+    v->k1_done = k1;
+    v->lane_view = true;
+    v->prof_owner = ctx;
+    v->stream = st;
+    ctx->lane_ctx.push_back(v);
+    ctx->lane_done.push_back(ev);
+  }
+  return OKVFE_OK;
+}
+
+// view `v` = images [first, first + n) of `p`'s buffers, with the state of the running call
+void bind_lane(okvfe_ctx* v, okvfe_ctx* p, int first, int n) {
+  const size_t f = (size_t)first, K = (size_t)p->kp_cap;
+  v->cfg = p->cfg;
+  v->w = p->w; v->h = p->h; v->B = n; v->kp_cap = p->kp_cap; v->cand_cap = p->cand_cap; v->ws_stride = p->ws_stride;
+  v->occ_rows = p->occ_rows; v->occ_cols = p->occ_cols; v->occ_image_bytes = p->occ_image_bytes;
+  v->mode_default = p->mode_default;
+  v->score_layout = p->score_layout; v->live_layout = p->live_layout; v->keep_score_map = p->keep_score_map;
+  v->n_layers = 1;
+  v->d_scores = p->d_scores + f * (size_t)p->score_layout.pitch * p->h;
+  v->d_cand = p->d_cand + f * p->cand_cap;
+  v->d_cand_count = p->d_cand_count + f;
+  v->d_fix_count = p->d_fix_count + f;
+  v->d_fix_list = p->d_fix_list + f * kFixListCap;
+  v->d_sort_ws = p->d_sort_ws + f * p->ws_stride;
+  v->d_occ = p->d_occ ? p->d_occ + f * p->occ_image_bytes : nullptr;
+  v->d_lut = p->d_lut; v->d_pattern = p->d_pattern; v->d_scales = p->d_scales;
+  v->d_kps_det = p->d_kps_det + f * K; v->d_det_count = p->d_det_count + f;
+  v->d_kps_tmp = p->d_kps_tmp + f * K; v->d_desc_tmp = p->d_desc_tmp + f * K * OKVFE_DESC_BYTES;
+  v->d_valid_tmp = p->d_valid_tmp + f * K;
+  v->d_kps = p->d_kps + f * K; v->d_desc = p->d_desc + f * K * OKVFE_DESC_BYTES;
+  v->d_bp = p->d_bp + f * K * 3; v->d_bpv = p->d_bpv + f * K; v->d_count = p->d_count + f;
+  v->d_prm = p->d_prm + f;
+  v->d_cams = p->d_cams; v->d_rays_ptrs = p->d_rays_ptrs; v->d_jac_ptrs = p->d_jac_ptrs;
+  v->wide_patches = p->wide_patches; v->all_aware = p->all_aware; v->aware_fast = p->aware_fast;
+  v->aware_extra_box = p->aware_extra_box; v->box_class_call = p->box_class_call;
+  v->fuse_setup = p->fuse_setup;
+  v->counters_cleared = p->counters_cleared;
+  v->prof_mask = p->prof_mask;
+  v->prm_slot = -1;
+}
+
+// detect + describe of a device-resident batch, in lanes when the call is large enough
+okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
+  const int k = lanes_for_call(ctx, n_images);
+  okvfe_status st;
+  if (k <= 1) {
+    st = detect_stage(ctx, images_dev, n_images, s);
+    ctx->fuse_setup = false;
+    if (st != OKVFE_OK) {
+      ctx->setup_done = false;
+      ctx->detected_images = 0;
+      return st;
+    }
+    ctx->detected_images = n_images;
+    return describe_stage(ctx, images_dev, n_images, s);
+  }
+  if ((st = ensure_lanes(ctx, k)) != OKVFE_OK) return st;
+  // slices of whole stereo pairs, multiples of 8 images (the kernels' image -> XCD striping)
+  int chunk = (n_images + k - 1) / k;
+  chunk = (chunk + 7) & ~7;
+  const size_t P = (size_t)ctx->w * ctx->h;
+  ctx->box_class_call = pattern_box_class(ctx->host_pattern);
+  ctx->aware_extra_box = aware_box_for_call(ctx, images_dev);
+  HIP_TRY(ctx, hipEventRecord(ctx->lane_fork, s));  // behind the parameter upload (and whatever the caller queued)
+  okvfe_status first_err = OKVFE_OK;
+  int used = 0;
+  for (int l = 0; l < k; ++l) {
+    const int first = l * chunk;
+    const int n = std::min(chunk, n_images - first);
+    if (n <= 0) break;
+    okvfe_ctx* v = ctx->lane_ctx[l];
+    bind_lane(v, ctx, first, n);
+    static const bool no_chain = lab_env("OKVFE_LANES_NOCHAIN") != nullptr;  // A/B knob
+    v->k1_wait = l > 0 && !no_chain ? ctx->lane_ctx[l - 1]->k1_done : nullptr;
+    HIP_TRY(ctx, hipStreamWaitEvent(v->stream, ctx->lane_fork, 0));
+    st = detect_stage(v, images_dev + first * P, n, v->stream);
+    v->fuse_setup = false;
+    if (st == OKVFE_OK) st = describe_stage(v, images_dev + first * P, n, v->stream);
+    if (st != OKVFE_OK && first_err == OKVFE_OK) {
+      first_err = st;
+      ctx->err = v->err;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->lane_done[l], v->stream));
+    used = l + 1;
+  }
+  for (int l = 0; l < used; ++l) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lane_done[l], 0));
+  ctx->fuse_setup = false;
+  ctx->setup_done = false;
+  ctx->counters_cleared = false;
+  okvfe_ctx* v0 = ctx->lane_ctx[0];
+  ctx->map_free_live = v0->map_free_live;
+  ctx->live_layout = v0->live_layout;
+  ctx->live_images = images_dev;
+  ctx->last_stream = s;
+  ctx->last_n_images = n_images;
+  const int slot = ctx->prm_slot;
+  ctx->prm_slot = -1;
+  st = ring_release(ctx, &ctx->prm_ring, slot, s);  // behind the join: every lane has read its parameters
+  if (first_err != OKVFE_OK) {
+    ctx->detected_images = 0;
+    return first_err;
+  }
+  ctx->detected_images = n_images;
+  return st;
 }
 }  // namespace
 
@@ -454,15 +608,7 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
   if (st != OKVFE_OK) return st;
   static const bool no_fuse = lab_env("OKVFE_NO_FUSED_SETUP") != nullptr;  // A/B knob
   ctx->fuse_setup = !no_fuse;
-  st = detect_stage(ctx, images_dev, n_images, s);
-  ctx->fuse_setup = false;
-  if (st != OKVFE_OK) {
-    ctx->setup_done = false;
-    ctx->detected_images = 0;
-    return st;
-  }
-  ctx->detected_images = n_images;
-  return describe_stage(ctx, images_dev, n_images, s);
+  return detect_describe_split(ctx, images_dev, n_images, s);
 }
 
 okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* images_host, int32_t n_images,
@@ -513,15 +659,7 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
   okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
   if (st != OKVFE_OK) return st;
   ctx->fuse_setup = lab_env("OKVFE_NO_FUSED_SETUP") == nullptr;
-  st = detect_stage(ctx, ctx->d_feed[slot], n_images, s);
-  ctx->fuse_setup = false;
-  if (st != OKVFE_OK) {
-    ctx->setup_done = false;
-    ctx->detected_images = 0;
-    return st;
-  }
-  ctx->detected_images = n_images;
-  if ((st = describe_stage(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
+  if ((st = detect_describe_split(ctx, ctx->d_feed[slot], n_images, s)) != OKVFE_OK) return st;
   HIP_TRY(ctx, hipEventRecord(ctx->feed_consumed[slot], s));
   ctx->feed_busy[slot] = true;
   return OKVFE_OK;

@@ -50,6 +50,8 @@ struct okvfe_ctx {
   const uint8_t* live_images = nullptr;  // images of the running detect call (map-free: read again by the selection)
   Candidate* d_cand = nullptr;
   int32_t* d_cand_count = nullptr;
+  int32_t* d_fix_count = nullptr;  // flagged-record counts [B] and their lists [B][kFixListCap]: inside d_cand_count's
+  int32_t* d_fix_list = nullptr;   // allocation (creation) -- separate names so that a lane view can offset them
   uint64_t* d_sort_ws = nullptr;
   uint8_t* d_occ = nullptr;
   float* d_lut = nullptr;
@@ -90,6 +92,21 @@ struct okvfe_ctx {
   ParamRing prm_ring, pair_ring, cls_ring;
   int prm_slot = -1;  // slot d_prm points into
 
+  // Lanes inside one call (round 6; okvfe_set_internal_lanes): a device-resident batch is cut into `internal_lanes`
+  // slices, each run on a stream of the context's own -- the VALU-bound score kernel of one slice under the LDS- and
+  // latency-bound selection / descriptor / matcher kernels of another (the camera-parallel shape of
+  // okvis_multisensor_processing/src/ThreadedSlam.cpp:434-448, inside the call).  A lane is a VIEW: an okvfe_ctx
+  // whose per-image pointers are this context's, offset to the slice (bind_lane, capi_detect.cpp); it owns a stream
+  // and two events, nothing else.
+  int internal_lanes = 0;  // 0 = automatic (4 from 512 images per call), 1 = off
+  bool lane_view = false;
+  okvfe_ctx* prof_owner = nullptr;  // lane view: stage timers record into the owning context
+  hipEvent_t k1_wait = nullptr;     // lane view: its score kernel starts behind this event (the previous lane's k1_done)
+  hipEvent_t k1_done = nullptr;     // ... and records this one behind itself
+  std::vector<okvfe_ctx*> lane_ctx;
+  std::vector<hipEvent_t> lane_done;
+  hipEvent_t lane_fork = nullptr;
+
   // scale space (octaves > 0): one detect-only child context per layer (K1..K4 at the layer's
   // size), layer images for l >= 1 owned here; this (parent) context keeps the merged keypoints
   // and everything from the descriptor stage on
@@ -115,6 +132,7 @@ struct okvfe_ctx {
   std::vector<std::vector<float>> cam_norms;
   std::vector<uint8_t> cam_aware_slow;
   bool aware_fast = false;        // of the images of the current batch: none from a cam_aware_slow camera
+  int box_class_call = 0;         // lane view: pattern_box_class of the owner's pattern
   int aware_extra_box = -1;       // of the running call (aware_box_for_call): >= 0 = describe_aware_kernel serves it
   bool wide_patches = false;      // of the images of the current batch
   bool all_aware = false;         // every image of the current batch is extracted camera-aware
@@ -212,7 +230,8 @@ struct StageTimer {
   okvfe_ctx* ctx;
   hipStream_t s;
   int idx = -1;
-  StageTimer(okvfe_ctx* c, int stage, hipStream_t st) : ctx(c), s(st) {
+  StageTimer(okvfe_ctx* c0, int stage, hipStream_t st) : ctx(c0->prof_owner ? c0->prof_owner : c0), s(st) {
+    okvfe_ctx* c = ctx;
     if (!((c->prof_mask >> stage) & 1u) || c->prof_events.size() >= 65536) return;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {

@@ -127,6 +127,15 @@ def test_full_size_batch_replicas_permutation_idempotence(oracle, workload, FRAM
     assert _digest(res2, matches2) == first
     del res2, matches2
 
+    # ---- lanes inside the call (okvfe_set_internal_lanes): slices on the context's own streams, same bytes
+    if FRAMES == 768:
+        for lanes in (4, 3):
+            fe.set_internal_lanes(lanes)
+            res3, matches3 = _run(fe, cfg, d_img, FRAMES, grav, pairs, d_match)
+            assert _digest(res3, matches3) == first, lanes
+            del res3, matches3
+        fe.set_internal_lanes(0)
+
     # ---- permutation: multiframes in reversed order
     order = np.arange(FRAMES)[::-1].copy()
     idx = np.stack([2 * order, 2 * order + 1], axis=1).reshape(-1)
