@@ -631,7 +631,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     const int l = from_left(sc[3]), r2 = from_right(sc[0]);
     const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
                        max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
-    if (test && r >= r_lo && r < r_hi) {
+#ifndef OKVFE_K1_SKIP
+#define OKVFE_K1_SKIP 1
+#endif
+    // (OKVFE_K1_SKIP, round 6 A/B: a wave whose centre row has no score at the threshold skips its four tests -- the
+    // row's maximum is at hand in the 3-maxima of the previous step)
+    if (test && r >= r_lo && r < r_hi &&
+        (!OKVFE_K1_SKIP || __builtin_amdgcn_ballot_w64(max(nh[q ^ 1][1], nh[q ^ 1][2]) >= nms.thr) != 0ull)) {
       const int lft[4] = {nl, nc[0], nc[1], nc[2]};
       const int rgt[4] = {nc[1], nc[2], nc[3], nr};
       uint64_t mk[4], ovf[4];
