@@ -86,17 +86,11 @@ def real_inputs(cfg, n_frames, n_distinct):
     return np.ascontiguousarray(np.stack(base))  # the distinct frames; the caller tiles them (tile_on_device)
 
 
-def widen_pattern(fe, factor):
-    """--box-widen: the context's pattern with every box `factor` times wider (border follows), also installed in the
-    oracle that the cpu_baseline leg checks against"""
+def oracle_follows_pattern(fe):
+    """--box-widen: the context was created with okvfe_config.box_scale; the oracle that the cpu_baseline leg checks
+    against gets the same pattern (the pattern is data on both sides)"""
     import ctypes as C
     p = fe.get_pattern()
-    reach = 0.0
-    for i in range(p.n_points):
-        p.sigma_half[i] = np.float32(p.sigma_half[i] * factor)
-        reach = max(reach, math.hypot(p.px[i], p.py[i]) + p.sigma_half[i])
-    p.border = int(math.ceil(reach)) + 1
-    fe.set_pattern(p)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     q = type(O.pattern())()
@@ -870,11 +864,12 @@ def main():
     for l in range(S):
         lfe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, cfg.octaves, cfg.abs_threshold,
                             cfg.max_kpts, match_threshold=cfg.match_threshold, max_batch=C * Bl,
-                            num_cameras=C, device=local_rank, max_candidates=args.max_candidates)
+                            num_cameras=C, device=local_rank, max_candidates=args.max_candidates,
+                            box_scale=args.box_widen)
         for ci, cam in enumerate(cfg.cams):
             lfe.set_camera(ci, cam)
-        if args.box_widen != 1.0:
-            widen_pattern(lfe, args.box_widen)
+        if args.box_widen != 1.0 and l == 0:
+            oracle_follows_pattern(lfe)
         st = torch.cuda.Stream(device=dev)
         lanes.append((lfe, st, d_img[C * l * Bl:].data_ptr(), d_match[l * Bl:].data_ptr()))
     fe = lanes[0][0]

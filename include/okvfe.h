@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define OKVFE_ABI_VERSION 6
+#define OKVFE_ABI_VERSION 7
 #define OKVFE_STREAM_LEGACY_DEFAULT ((void*)(uintptr_t)1) /* = hipStreamLegacy */
 #define OKVFE_DESC_BYTES 48 /* okvis_frontend/include/DBoW2/FBrisk.hpp:35 */
 
@@ -124,6 +124,14 @@ typedef struct okvfe_config {
                                * brisk::BriskFeatureDetector, the reference's ARM branch
                                * (okvis_cv/test/TestFrame.cpp:71-72), absolute_threshold = its
                                * threshold (34 there); the rest of the detector is shared */
+  float box_scale;            /* ABI 7.  Smoothing width of the built-in BRISK2 pattern: every sample's box half-side
+                               * = the published one (sigma = 1.3 x the ring's sample spacing) x box_scale; 0 and 1.0 =
+                               * the published boxes.  The one parameter of the descriptor that no file of the reference
+                               * tree pins (the boxes live in the un-vendored brisk submodule; the vocabulary's statistics
+                               * sit best at 1.7 - 2.0 x, tools/pattern/README.md): a named knob instead of an
+                               * okvfe_get_pattern / okvfe_set_pattern edit.  Range (0.25, 2.5]; up to 2.05 stays on the
+                               * fast descriptor kernels (21 x 21 / 10 x 10 row slots from 1.03 x on).  okvfe_set_pattern
+                               * afterwards replaces the whole pattern, this scaling included. */
 } okvfe_config;
 #define OKVFE_SCORE_HARRIS 0
 #define OKVFE_SCORE_AGAST_9_16 1
@@ -614,9 +622,17 @@ okvfe_status okvfe_match_stereo_blocks_device(okvfe_ctx* ctx, const void* block0
  * confirm (its `brisk` submodule is empty).  A pattern dumped from a real brisk build -- sample
  * offsets, smoothing half-widths, the short pairs IN BIT ORDER, the long pairs of the orientation
  * estimate -- is installed with okvfe_set_pattern and replaces it without touching a kernel.
- * Limits of the kernels: <= 72 sample points (lane i; points 64.. take a second pass), <= 384 short pairs (bit b of
- * the 48-byte row = value[short_i[b]] > value[short_j[b]]; unused bits stay 0), <= 1100 long pairs,
- * border >= the farthest sample + its half-width + 1.  okvfe_set_pattern synchronises the context. */
+ * Limits of the kernels: <= 72 sample points, <= 384 short pairs (bit b of the 48-byte row =
+ * value[short_i[b]] > value[short_j[b]]; unused bits stay 0), <= 1100 long pairs, border >= the farthest
+ * sample + its half-width + 1.  okvfe_set_pattern synchronises the context.
+ * Which descriptor kernel serves a pattern (okvfe_pattern_kernel_class): a wave has 64 lanes, and lane l samples
+ * point (n_points - 64) + l; the FIRST n_points - 64 points of a pattern with more than 64 are the extra samples
+ * (evaluated beside the wave), so put the smallest boxes first -- the built-in pattern has the centre and one
+ * hexagon point there.
+ *   class 0: extra samples' half-width <= 2.0 (5 x 5 row slots), all others <= 4.75 (11 x 11): the fast kernels;
+ *   class 1: <= 4.25 / <= 9.75 (10 x 10 / 21 x 21 row slots): the WIDE instantiations of the same kernels;
+ *   class 2: wider still, or any half-width below 0.5 (bilinear point samples): the all-modes kernel with plain
+ *            box loops -- correct for every pattern, several times slower. */
 #define OKVFE_PATTERN_POINTS 72
 #define OKVFE_PATTERN_SHORT_PAIRS 384
 #define OKVFE_PATTERN_LONG_PAIRS 1100
@@ -633,6 +649,8 @@ typedef struct okvfe_pattern {
 } okvfe_pattern;
 okvfe_status okvfe_get_pattern(const okvfe_ctx* ctx, okvfe_pattern* out);
 okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* pattern);
+/* 0 / 1 / 2 as above for the pattern installed now (after okvfe_create's box_scale or okvfe_set_pattern); -1: ctx NULL */
+int32_t okvfe_pattern_kernel_class(const okvfe_ctx* ctx);
 
 /* ---- device-resident, batched map matchers ---------------------------------- */
 /* The map-side loops of the front-end on data that never leaves the GPU: frame f of the batch is

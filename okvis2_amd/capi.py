@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("OKVFE_LIB") or os.path.join(_HERE, "libokvfe.so")  # 
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_DEVICE, \
     ERR_NOT_READY = 1, 2, 3, 4, 5, 6, 7
-ABI_VERSION = 6
+ABI_VERSION = 7
 SCORE_HARRIS, SCORE_AGAST_9_16, SCORE_BRISK_SCALESPACE = 0, 1, 2
 DESC_BYTES = 48
 
@@ -37,7 +37,7 @@ class Config(C.Structure):
                 ("absolute_threshold", C.c_int32), ("max_keypoints", C.c_int32),
                 ("rotation_invariant", C.c_int32), ("scale_invariant", C.c_int32),
                 ("match_threshold", C.c_int32), ("max_candidates", C.c_int32),
-                ("score_type", C.c_int32)]
+                ("score_type", C.c_int32), ("box_scale", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -94,7 +94,7 @@ EXPORTS = [
     "okvfe_match_stereo_blocks_batch_device", "okvfe_check_capacity",
     "okvfe_detect_describe_batch_host", "okvfe_verify_place_match", "okvfe_fbrisk_transform",
     "okvfe_match_to_map_landmarks", "okvfe_bow_vector", "okvfe_bow_query_l1",
-    "okvfe_get_pattern", "okvfe_set_pattern",
+    "okvfe_get_pattern", "okvfe_set_pattern", "okvfe_pattern_kernel_class",
     "okvfe_match_to_map_blocks_device", "okvfe_match_to_map_uninitialised_blocks_device",
     "okvfe_verify_place_blocks_device",
     "okvfe_comm_unique_id", "okvfe_comm_create", "okvfe_comm_wrap", "okvfe_comm_destroy",
@@ -360,11 +360,11 @@ class Frontend:
     def __init__(self, width, height, uniformity_radius, octaves, absolute_threshold,
                  max_keypoints, rotation_invariant=True, scale_invariant=False,
                  match_threshold=60, max_batch=1, num_cameras=1, device=0, max_candidates=0,
-                 score_type=SCORE_HARRIS):
+                 score_type=SCORE_HARRIS, box_scale=1.0):
         cfg = Config(ABI_VERSION, device, width, height, max_batch, num_cameras,
                      float(uniformity_radius), int(octaves), int(absolute_threshold),
                      int(max_keypoints), int(bool(rotation_invariant)), int(bool(scale_invariant)),
-                     int(match_threshold), int(max_candidates), int(score_type))
+                     int(match_threshold), int(max_candidates), int(score_type), float(box_scale))
         self._h = C.c_void_p()
         # row capacity per image: a scale space (octaves > 0) has 2 * octaves layers and every layer
         # may deliver max_keypoints (okvfe_device_outputs.max_keypoints reports the same number)
@@ -709,6 +709,10 @@ class Frontend:
 
     def set_pattern(self, pattern: PatternData):
         self._check(lib().okvfe_set_pattern(self._h, C.byref(pattern)))
+
+    def pattern_kernel_class(self) -> int:
+        """0 / 1: the fast descriptor kernels (11 x 11 / 21 x 21 row slots); 2: the all-modes kernel (include/okvfe.h)"""
+        return int(lib().okvfe_pattern_kernel_class(self._h))
 
     # -- device-resident, batched map matchers (frame f = gather block f) -----------------
     @staticmethod

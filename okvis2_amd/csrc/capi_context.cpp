@@ -359,6 +359,9 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
                 "okvfe_create: score_type %d (0 = Harris, 1 = AGAST 9-16, 2 = BRISK scale space)", cfg->score_type);
   if (cfg->match_threshold < 0 || cfg->match_threshold > 385)
     return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: match_threshold out of range");
+  if (cfg->box_scale != 0.0f && !(cfg->box_scale > 0.25f && cfg->box_scale <= 2.5f))
+    return fail(nullptr, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_create: box_scale %g (0 or 1 = the published boxes; range (0.25, 2.5])",
+                (double)cfg->box_scale);
   if (cfg->octaves < 0 || cfg->octaves > 4)
     return fail(nullptr, OKVFE_ERR_UNSUPPORTED, "okvfe_create: octaves=%d out of range (0..4)", cfg->octaves);
   const int n_layers = cfg->octaves > 0 ? 2 * cfg->octaves : 1;
@@ -454,6 +457,7 @@ okvfe_status create_impl(const okvfe_config* cfg, bool child, okvfe_ctx** out) {
     float lut[kLutFloats];
     build_uniformity_lut(lut);
     build_pattern(&c->host_pattern);
+    if (cfg->box_scale != 0.0f && cfg->box_scale != 1.0f) scale_pattern_boxes(&c->host_pattern, cfg->box_scale);
     HIP_TRY(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_pattern, &c->host_pattern, sizeof(Pattern), hipMemcpyHostToDevice));
     if (c->d_scales) {
@@ -549,6 +553,10 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   for (hipEvent_t ev : ctx->lane_done)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
+  if (ctx->score_stream && !ctx->lane_view) {
+    (void)hipStreamSynchronize(ctx->score_stream);
+    (void)hipStreamDestroy(ctx->score_stream);
+  }
   for (uint8_t* p : ctx->d_layer_img)
     if (p) (void)hipFree(p);
   if (ctx->d_virtual) (void)hipFree(ctx->d_virtual);

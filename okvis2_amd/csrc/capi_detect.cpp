@@ -116,6 +116,8 @@ static int pattern_box_class(const okvfe::Pattern& P) {
   return cls;
 }
 
+extern "C" int32_t okvfe_pattern_kernel_class(const okvfe_ctx* ctx) { return ctx ? pattern_box_class(ctx->host_pattern) : -1; }
+
 // Does describe_aware_kernel (k_describe_aware.hip) serve this call?  -1: no (describe_kernel does); otherwise
 // (samples beyond 64) << 8 | their largest box side minus one (0: the pattern has no such samples).
 // Every image camera-aware on a camera whose patches fit the kernel's LDS classes, the fixed-scale pattern with boxes
@@ -222,10 +224,13 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
   okvfe_status st;
   ctx->setup_done = false;  // set by this call's selection launch only (a failed earlier call must not leak it)
   if (ctx->n_layers == 1) {
+    // priority lanes: the score kernel (and the clears in front of it) go to the owner's low-priority score stream,
+    // which runs the slices' score kernels back to back; this lane's stream picks up behind its k1_done
+    hipStream_t ks = ctx->lane_view && ctx->score_stream ? ctx->score_stream : s;
     if (!ctx->counters_cleared) {  // (cleared together with the parameter upload of the same call otherwise)
       if (ctx->lane_view) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, (size_t)ctx->B * sizeof(int32_t), s));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_fix_count, 0, (size_t)ctx->B * sizeof(int32_t), s));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, (size_t)ctx->B * sizeof(int32_t), ks));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_fix_count, 0, (size_t)ctx->B * sizeof(int32_t), ks));
       } else {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_cand_count, 0, 2 * (size_t)ctx->B * sizeof(int32_t), s));
       }
@@ -235,12 +240,13 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
     bool fused;
     // lanes inside one call: the score kernels run one after the other, so that the lanes proceed OUT OF PHASE -- the
     // (vector-ALU-bound) score kernel of lane l beside the selection / descriptor kernels of the lanes before it
-    if (ctx->k1_wait) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->k1_wait, 0));
+    if (ctx->k1_wait && ks == s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->k1_wait, 0));
     {
-      StageTimer t(ctx, OKVFE_STAGE_HARRIS, s);
-      layer_score_nms(ctx, images_dev, n_images, s, &fused);
+      StageTimer t(ctx, OKVFE_STAGE_HARRIS, ks);
+      layer_score_nms(ctx, images_dev, n_images, ks, &fused);
     }
-    if (ctx->k1_done) HIP_TRY(ctx, hipEventRecord(ctx->k1_done, s));
+    if (ctx->k1_done) HIP_TRY(ctx, hipEventRecord(ctx->k1_done, ks));
+    if (ks != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->k1_done, 0));
     if ((st = heavy_end(ctx, s, 0, &token)) != OKVFE_OK) return st;
     {
       StageTimer t(ctx, OKVFE_STAGE_NMS, s);
@@ -442,11 +448,23 @@ int lanes_for_call(const okvfe_ctx* ctx, int n_images) {
 
 okvfe_status ensure_lanes(okvfe_ctx* ctx, int k) {
   if (!ctx->lane_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
+  static const bool prio_env = lab_env("OKVFE_LANES_PRIO") != nullptr;  // A/B knob
+  const bool prio = prio_env || ctx->lanes_prio;
+  int p_low = 0, p_high = 0;
+  if (prio) {
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&p_low, &p_high));  // (numerically: low >= high)
+    if (!ctx->score_stream) HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->score_stream, hipStreamNonBlocking, p_low));
+    ctx->lanes_prio = true;
+  }
   while ((int)ctx->lane_ctx.size() < k) {
     hipStream_t st = nullptr;
     hipEvent_t ev = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));  // (streams live on the context's device, whatever the caller's current one)
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (prio)
+      HIP_TRY(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, p_high));
+    else
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e != hipSuccess) {
       (void)hipStreamDestroy(st);
@@ -535,7 +553,9 @@ okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, in
     bind_lane(v, ctx, first, n);
     static const bool no_chain = lab_env("OKVFE_LANES_NOCHAIN") != nullptr;  // A/B knob
     v->k1_wait = l > 0 && !no_chain ? ctx->lane_ctx[l - 1]->k1_done : nullptr;
+    v->score_stream = ctx->score_stream;
     HIP_TRY(ctx, hipStreamWaitEvent(v->stream, ctx->lane_fork, 0));
+    if (ctx->score_stream && l == 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->score_stream, ctx->lane_fork, 0));
     st = detect_stage(v, images_dev + first * P, n, v->stream);
     v->fuse_setup = false;
     if (st == OKVFE_OK) st = describe_stage(v, images_dev + first * P, n, v->stream);

@@ -128,6 +128,29 @@ void build_pattern(Pattern* p) {
   fill_aware_lanes(p);
 }
 
+// okvfe_config.box_scale: every smoothing box of the pattern `s` times wider (half-side in double, rounded once);
+// the rim a keypoint must keep from the image border follows the farthest box
+void scale_pattern_boxes(Pattern* p, float s) {
+  double reach = 0.0;
+  for (int i = 0; i < p->n_points; ++i) {
+    p->sigma_half[i] = static_cast<float>(static_cast<double>(p->sigma_half[i]) * static_cast<double>(s));
+    reach = std::fmax(reach, std::sqrt(static_cast<double>(p->px[i]) * p->px[i] + static_cast<double>(p->py[i]) * p->py[i]) +
+                                 static_cast<double>(p->sigma_half[i]));
+  }
+  p->border = static_cast<int>(std::ceil(reach)) + 1;
+  p->reach = pattern_reach(*p);
+  for (int i = 0; i < kPatternPoints; ++i) {  // same float sequence as build_pattern
+    const float sg = i < p->n_points ? p->sigma_half[i] : 1.0f;
+    float area = 4.0f * sg;
+    area = area * sg;
+    const int scaling = static_cast<int>(4194304.0f / area);
+    const float s2 = static_cast<float>(scaling) * area;
+    p->box_scaling[i] = scaling;
+    p->box_scaling2[i] = static_cast<int>(s2 / 1024.0f);
+  }
+  fill_aware_lanes(p);
+}
+
 int pattern_scale_index(float size) {
   const double lb_range = std::log(30.0) / std::log(2.0);
   if (!(size > 0.0f)) return 0;

@@ -106,6 +106,10 @@ struct okvfe_ctx {
   std::vector<okvfe_ctx*> lane_ctx;
   std::vector<hipEvent_t> lane_done;
   hipEvent_t lane_fork = nullptr;
+  // priority form of the lanes (lab knob OKVFE_LANES_PRIO / okvfe_set_internal_lanes(-k)): ONE low-priority stream runs the
+  // score kernels of all slices back to back, the slices' tails (fix-up .. compaction) run on high-priority lane streams
+  hipStream_t score_stream = nullptr;  // owner: the low-priority stream; lane view: where its score kernel goes (or null)
+  bool lanes_prio = false;             // owner: lane streams were created with priorities
 
   // scale space (octaves > 0): one detect-only child context per layer (K1..K4 at the layer's
   // size), layer images for l >= 1 owned here; this (parent) context keeps the merged keypoints

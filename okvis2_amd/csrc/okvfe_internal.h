@@ -55,6 +55,7 @@ struct Pattern {
 };
 void fill_aware_lanes(Pattern* p);
 void build_pattern(Pattern* p);
+void scale_pattern_boxes(Pattern* p, float s);
 float pattern_reach(const Pattern& p);
 // scale_invariant = true (Frontend.hpp:235-237): the published BRISK extractor keeps the pattern at 64
 // scales spanning a factor of 30 and picks index max(int(64 / lb(30) * lb(size / 7.2) + 0.5), 0)

@@ -113,6 +113,7 @@ class CrossCameraMatcher {
       cfg.rotation_invariant = p.rotation_invariance;
       cfg.scale_invariant = p.scale_invariance;
       cfg.match_threshold = p.matching_threshold;
+      cfg.box_scale = p.box_scale;
       auto ctx = std::make_shared<Context>(cfg);
       ctx->check(okvfe_set_camera(ctx->get(), 0, &cameras[size_t(c)]));
       local_[c] = ctx;

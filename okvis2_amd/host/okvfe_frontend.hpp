@@ -188,6 +188,7 @@ struct FrontendParameters {  // okvis_common/include/okvis/Parameters.hpp:123-13
   int max_num_keypoints = 450;
   bool rotation_invariance = true;
   bool scale_invariance = false;
+  float box_scale = 1.0f;  // okvfe_config.box_scale: smoothing width of the built-in pattern (not a reference parameter)
 };
 
 // = the detect/describe/matchStereo part of okvis::Frontend (one GPU, all cameras of one rig)
@@ -211,6 +212,7 @@ class HipFrontend {
       cfg.rotation_invariant = p.rotation_invariance;
       cfg.scale_invariant = p.scale_invariance;
       cfg.match_threshold = p.matching_threshold;
+      cfg.box_scale = p.box_scale;
       auto ctx = std::make_shared<Context>(cfg);
       contexts_.push_back(ctx);
       detectors_.emplace_back(ctx);

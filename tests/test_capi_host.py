@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_struct_layouts():
     lib = capi.lib()
     assert lib.okvfe_abi_version() == capi.ABI_VERSION
-    assert C.sizeof(capi.Config) == 15 * 4
+    assert C.sizeof(capi.Config) == 16 * 4
     assert capi.KEYPOINT_DTYPE.itemsize == 28            # cv::KeyPoint: 5 floats + 2 ints
     assert capi.STEREO_MATCH_DTYPE.itemsize == 48
     assert C.sizeof(capi.Pose) == 96 and C.sizeof(capi.Camera) == 80

@@ -172,3 +172,81 @@ def test_widened_builtin_pattern_stays_bit_exact(oracle, monkeypatch, factor):
         rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, oracle.MODE_GRADIENT)
         G.assert_keypoints_equal(k, rk)
         assert np.array_equal(d, rd)
+
+
+@pytest.mark.parametrize("which", ["all", "mixed", "second_pass_only"])
+def test_point_sample_pattern_stays_bit_exact(oracle, monkeypatch, which):
+    """Half-widths below 0.5 are bilinear point samples (the published smoothedIntensity's first branch).  The fast
+    camera-aware kernels carry the box sum alone, so such a pattern has to take the all-modes kernel, whose bilinear
+    read must come AFTER the patch has landed in LDS (the late-wait form read it early).  Twice per image:
+    a stale patch would differ between runs."""
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, rotation_invariant=True)
+    fe.set_camera(0, cam)
+    p = fe.get_pattern()
+    extra = p.n_points - 64
+    for i in range(p.n_points):
+        if which == "all" or (which == "mixed" and i % 3 == 0) or (which == "second_pass_only" and i < extra):
+            p.sigma_half[i] = np.float32(0.3 + 0.01 * (i % 17))
+    fe.set_pattern(p)
+    q = _to_orc(oracle, p)
+    monkeypatch.setattr(oracle, "pattern", lambda: q)
+    rays, jac = oracle.awareness_maps(cam)
+    for seed in (51, 52):
+        img = synth.corners_image(cfg.w, cfg.h, seed)
+        rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                        oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.05, 0.99, -0.1))
+        for _ in range(2):
+            k, d, _, _ = fe.detect_describe(img, cam=0, gravity=(0.05, 0.99, -0.1))
+            G.assert_keypoints_equal(k, rk)
+            assert np.array_equal(d, rd) and len(k) > 100
+        k, d, _, _ = fe.detect_describe(img)  # gradient orientation
+        rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, oracle.MODE_GRADIENT)
+        G.assert_keypoints_equal(k, rk)
+        assert np.array_equal(d, rd)
+
+
+@pytest.mark.parametrize("box_scale,kernel_class", [(1.0, 0), (1.73, 1), (0.8, 0), (2.3, 2)])
+def test_box_scale_config_field(oracle, monkeypatch, box_scale, kernel_class):
+    """okvfe_config.box_scale (ABI 7): the built-in pattern with every smoothing box `box_scale` times wider, as a named
+    parameter -- the one open parity parameter of the descriptor with evidence on both sides (tools/pattern/README.md).
+    The expected pattern is computed HERE (half-side in double x the float factor, rounded once; border follows) and must
+    equal what the context installed; 1.73 runs on the WIDE instantiations of the fast kernels."""
+    import math
+    cfg = synth.euroc_config()
+    cam = cfg.cams[0]
+    base = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts).get_pattern()
+    fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, rotation_invariant=True,
+                       box_scale=box_scale)
+    fe.set_camera(0, cam)
+    p = fe.get_pattern()
+    assert fe.pattern_kernel_class() == kernel_class
+    f = float(np.float32(box_scale))
+    reach = 0.0
+    for i in range(base.n_points):
+        want = np.float32(float(base.sigma_half[i]) * f) if box_scale != 1.0 else np.float32(base.sigma_half[i])
+        assert np.float32(p.sigma_half[i]).view(np.uint32) == want.view(np.uint32), i
+        reach = max(reach, math.hypot(float(p.px[i]), float(p.py[i])) + float(want))
+    assert p.border == (int(math.ceil(reach)) + 1 if box_scale != 1.0 else base.border)
+    assert bytes(p.short_i) == bytes(base.short_i) and bytes(p.px) == bytes(base.px)
+    q = _to_orc(oracle, p)
+    monkeypatch.setattr(oracle, "pattern", lambda: q)
+    rays, jac = oracle.awareness_maps(cam)
+    img = synth.corners_image(cfg.w, cfg.h, 61)
+    k, d, _, _ = fe.detect_describe(img, cam=0, gravity=(0.05, 0.99, -0.1))
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts,
+                                    oracle.MODE_CAMERA_AWARE, rays, jac, np.float32(cam.fu), (0.05, 0.99, -0.1))
+    G.assert_keypoints_equal(k, rk)
+    assert np.array_equal(d, rd) and len(k) > 100
+    k, d, _, _ = fe.detect_describe(img)  # gradient orientation
+    rk, rd = oracle.detect_describe(img, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, oracle.MODE_GRADIENT)
+    G.assert_keypoints_equal(k, rk)
+    assert np.array_equal(d, rd)
+
+
+def test_box_scale_out_of_range_is_rejected():
+    cfg = synth.euroc_config()
+    for bad in (0.1, 3.0, -1.0, float("nan")):
+        with pytest.raises(capi.OkvfeError):
+            capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, box_scale=bad)
