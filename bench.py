@@ -17,6 +17,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import threading
 import time
@@ -257,15 +258,16 @@ def alu_rooflines(stage_ms, pair_evals_per_launch, kp_described_per_launch, patc
                                        "measured issue rates; the rest of the launch is the FP64 gate rounds"}
     if stage_ms.get("describe") and kp_described_per_launch:
         a = kp_described_per_launch * patch_bytes_per_kp / (stage_ms["describe"] * 1e-3) / 1e9
-        out["describe"] = {"kernel": "describe_kernel (K6)", "bound": "l2_to_lds (buffer_load ... lds)",
+        out["describe"] = {"kernel": "describe_aware_kernel (K6, camera-aware; describe_kernel for the other modes)",
+                           "bound": "l2_to_lds (buffer_load ... lds)",
                            "achieved": a, "peak": LDS_DMA_PEAK_GBPS, "unit": "GB/s staged into LDS",
                            "frac": a / LDS_DMA_PEAK_GBPS,
                            "patch_bytes_per_keypoint": patch_bytes_per_kp,
                            "keypoints_per_launch": kp_described_per_launch,
                            "note": "a keypoint's pattern patch (64 rows x 64..80 B) goes L2 -> LDS once; the box "
-                                   "sums (~420 VALU per keypoint, profiles/round3 SQ counters) overlap with it; "
-                                   "stage time includes describe_setup_kernel; since round 4 the tighter bound is vector-ALU "
-                                   "issue (valu_issue block, when the counters of this workload are committed)"}
+                                   "sums (round 6: ~285 VALU + ~63 LDS wave instructions per keypoint, the LDS gather of "
+                                   "the row windows is the busiest unit) overlap with it; a bookkeeping ratio, see the "
+                                   "valu_issue block for the instruction side"}
     if stage_ms.get("select"):
         out["select"] = {"kernel": "select_lazy_kernel (K3 uniformity + K4 sub-pixel)", "bound": "latency",
                          "achieved": n_img_launch / (stage_ms["select"] * 1e-3), "peak": None, "unit": "images/s",
@@ -288,12 +290,14 @@ def valu_issue_blocks(rooflines, stage_ms, n_img_launch, workload, content):
     import glob
     if workload != "euroc" or content != "corners":
         return
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round4_*_pmc_sq.json")), reverse=True)
-    files = [f for f in files if "_pmc_sq" in f and "withmap" not in f]
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "round*_pmc_sq.json")) if "withmap" not in f]
     if not files:
         return
-    # numeric order of the collection tags (v10 after v9)
-    files.sort(key=lambda f: int("".join(c for c in os.path.basename(f).split("_")[1] if c.isdigit()) or 0), reverse=True)
+
+    def tag(path):  # (round, collection) in numeric order: round6_v2 after round5_v10 (profiles/INDEX.md names the authoritative one)
+        m = re.match(r"round(\d+)(?:_v(\d+))?_", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
+    files.sort(key=tag, reverse=True)
     try:
         sq = json.load(open(files[0]))
     except Exception:
@@ -305,9 +309,10 @@ def valu_issue_blocks(rooflines, stage_ms, n_img_launch, workload, content):
         sq_images = float(line["config"]["stereo_frames_per_launch"] * line["config"].get("cameras_per_multiframe", 2))
     except Exception:
         pass
-    for key, prefix, stage in (("describe", "describe_kernel", "describe"), ("select", "select_lazy_kernel", "select"),
-                               ("match_stereo", "match_stereo_kernel", "match")):
-        hit = [v for k, v in sq.items() if k.startswith(prefix)]
+    for key, prefix, stage in (("describe", ("describe_aware_kernel", "describe_kernel"), "describe"),
+                               ("select", ("select_lazy_kernel",), "select"),
+                               ("match_stereo", ("match_stereo_kernel",), "match")):
+        hit = [v for pf in prefix for k, v in sq.items() if k.startswith(pf)]
         if key not in rooflines or not hit or not stage_ms.get(stage):
             continue
         insts = hit[0]["mean_per_dispatch"].get("SQ_INSTS_VALU")
@@ -733,7 +738,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
                     help="stereo frames per step per GPU (default: 3072 EuRoC frames; per workload otherwise, see below)")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic stereo pairs")
+    ap.add_argument("--distinct", type=int, default=256,
+                    help="distinct synthetic stereo pairs in the batch (tiled on the device up to the step's size); rounds 1-5 "
+                         "ran 16, which the default line still reports as value_16_distinct")
     ap.add_argument("--max-candidates", type=int, default=16384)
     ap.add_argument("--lanes", type=int, default=1,
                     help="independent contexts/streams the batch is split over on each GPU.  With 3-4 lanes the "
@@ -832,9 +839,10 @@ def main():
     B = args.batch
     C = len(cfg.cams)  # images per multiframe
     n_img = C * B
-    distinct = min(args.distinct, B)
-    _, base = make_inputs(cfg, B, distinct, 1000 + 977 * rank, args.content, tile=False)
+    n_content = min(args.distinct, B)  # distinct stereo pairs of the batch's content
+    _, base = make_inputs(cfg, B, n_content, 1000 + 977 * rank, args.content, tile=False)
     d_img = tile_on_device(base, n_img, dev)
+    distinct = min(n_content, 16)  # frames whose results are downloaded for statistics and the parity legs
     # `--lanes` independent contexts, each with its own HIP stream and B / lanes stereo frames of
     # the batch.  Frames are independent units, so this is the same sharding as across GPUs.
     S = max(1, min(args.lanes, B))
@@ -1171,6 +1179,18 @@ def main():
             for lane in lanes4:
                 lane[0].close()
             del lanes4
+        # (1d) the content of rounds 1-5: 16 distinct stereo pairs tiled over the batch (selection and matcher then see
+        # 32 different images per step instead of 2 x --distinct)
+        if args.content == "corners" and n_content > 16:
+            d_img.copy_(tile_on_device(base[:C * 16], n_img, dev))
+            for _ in range(2):
+                step("device")
+            n_16 = max(3, min(args.steps, 60))
+            el_16, _ = timed(n_16, "device")
+            extras["sixteen_distinct"] = {
+                "value": world * B * n_16 / el_16, "steps": n_16, "ms_per_step": 1e3 * el_16 / n_16,
+                "note": "the same step on the first 16 of the %d distinct stereo pairs, tiled: the content of the "
+                        "round 1-5 lines" % n_content}
         # (2) dense content: tied checker corners that all pass the uniformity stage (~700
         # keypoints per image): the matcher's 700 x 700 regime
         if args.content == "corners" and C > 1:
@@ -1246,7 +1266,7 @@ def main():
             "config": {"workload": text,
                        "stereo_frames_per_step_per_gpu": B, "lanes_per_gpu": S,
                        "score_kernels_serialised_across_lanes": bool(S > 1 and args.stagger),
-                       "stereo_frames_per_launch": Bl, "distinct_frames": distinct,
+                       "stereo_frames_per_launch": Bl, "distinct_frames": n_content,
                        "content": args.content, "feed": args.feed,
                        "host_parameter_variants": N_VARIANTS,
                        "mean_keypoints_per_image": kp_total / max(1, min(n_img, C * distinct)),
@@ -1299,6 +1319,7 @@ def main():
         if long_region is not None:
             result["long_region"] = long_region
         # the less favourable legs next to `value`, at the top level
+        result["value_16_distinct"] = extras.get("sixteen_distinct", {}).get("value")
         result["value_dense"] = extras.get("dense_content", {}).get("value")
         result["value_real_content"] = extras.get("real_content", {}).get("value")
         result["value_score_map_kept"] = extras.get("score_map_kept", {}).get("value")

@@ -8,14 +8,15 @@ import numpy as np, torch
 from okvis2_amd import capi, synth
 import bench
 cfg = synth.euroc_config()
-imgs, base = bench.make_inputs(cfg, 768, 16, 1000, os.environ.get("LAZY_PROF_CONTENT", "corners"))
+BS = [int(v) for v in os.environ.get("LAZY_PROF_B", "1,1536").split(",")]
+imgs, base = bench.make_inputs(cfg, max(max(BS) // 2, 1), 16, 1000, os.environ.get("LAZY_PROF_CONTENT", "corners"))
 def prof(reset=True):
     out = (C.c_ulonglong * 16)()
     assert capi.lib().okvfe_lab_lazy_prof(out, int(reset)) == 0
     v = list(out); n = max(v[0], 1)
     return {"launches": v[0], "init_us": v[1] / n / 100, "blocks_us": v[2] / n / 100, "tail_us": v[3] / n / 100,
             "total_us": v[4] / n / 100, "prefilter_us": v[5] / n / 100, "survivors": v[6] / n, "win_walk_us": v[8] / n / 100, "win_accept_us": v[9] / n / 100, "win_insert_us": v[10] / n / 100, "rounds": v[11] / n, "candidates": v[7] / n, "tables_us": v[12] / n / 100, "count_us": v[13] / n / 100, "sched_us": v[14] / n / 100, "scatter_us": v[15] / n / 100}
-for B in (1, 1536):
+for B in BS:
     fe = capi.Frontend(cfg.w, cfg.h, cfg.uniformity_radius, 0, cfg.abs_threshold, cfg.max_kpts, max_batch=B, num_cameras=2,
                        max_candidates=16384)
     for ci, cam in enumerate(cfg.cams): fe.set_camera(ci, cam)
