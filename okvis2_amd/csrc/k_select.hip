@@ -69,7 +69,13 @@ namespace {
 constexpr int kLazyTabBytes = 32 * 32 * 4;  // weight(|dx|, |dy|), zero beyond 15
 constexpr int kLazyThreads = 256;
 constexpr int kLazyBinCap = 4;
-constexpr int kLazyBlockMax = 1024;
+#ifndef OKVFE_LAZY_BLOCKMAX
+#define OKVFE_LAZY_BLOCKMAX 1024
+#endif
+#ifndef OKVFE_LAZY_WAVES
+#define OKVFE_LAZY_WAVES 6
+#endif
+constexpr int kLazyBlockMax = OKVFE_LAZY_BLOCKMAX;  // (A/B: 512 + seven waves per SIMD = seven images per CU, tools/lab)
 constexpr int kLazySurvPerWave = kLazyBlockMax / 4;  // surviving KEYS, one list per wave (the ordered windows read no HBM)
 __host__ __device__ inline size_t lazy_align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // table | counts of the bordered bin grid | bin slots | survivor lists | partial sums
@@ -112,7 +118,7 @@ __device__ __forceinline__ int fuse_bin(int32_t score) {
 // SORTS = true (round 4, default): the kernel takes the UNSORTED candidate records and orders only what the
 // greedy pass consumes -- see "chunks" below; false: `sort_ws` holds the keys already sorted (launch_sort).
 template <bool SORTS>
-__global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(6, 8))) void select_lazy_kernel(
+__global__ __launch_bounds__(kLazyThreads) __attribute__((amdgpu_waves_per_eu(OKVFE_LAZY_WAVES, 8))) void select_lazy_kernel(
     const int32_t* __restrict__ scores, ScoreLayout layout, int w, int h, const Candidate* __restrict__ cand, int cand_cap,
     const int32_t* __restrict__ cand_count, uint64_t* sort_ws, int ws_stride,
     float radius, int max_kpts, const float* __restrict__ lut, int bins_x, int bins_y, int cap,

@@ -241,3 +241,46 @@ def test_a_vocabulary_of_oracle_descriptors_has_the_real_vocabularys_bit_structu
     r_raw = np.corrcoef(np.corrcoef(bits.T.astype(np.float64))[iu], cv)[0, 1]
     assert r_nodes > 0.78, r_nodes   # measured 0.814
     assert r_raw > 0.70, r_raw       # measured 0.747
+
+
+def test_box_width_statistics_on_the_real_image_are_recorded(oracle, monkeypatch):
+    """The one open parameter of the descriptor with evidence on both sides is the smoothing WIDTH (okvfe_config.box_scale,
+    ABI 7).  Recorded here, on the reference's own camera image, so that the numbers cannot drift unnoticed
+    (tools/pattern/README.md holds the table and the decision rule): for boxes 1.0 / 1.3 / 1.73 / 2.0 / 2.4 x the
+    published half-side,
+      * mean Hamming distance to the nearest vocabulary node:           114.7 / 106.8 / 96.7 / 91.6 / 86.1
+      * correlation of the bit-correlation matrices, raw descriptors:   0.630 / 0.689 / 0.767 / 0.794 / 0.806
+      * the same with the image's descriptors (uniformity radius 3: 3.1 k of them) clustered into a k-majority tree
+        like a vocabulary:                                              0.670 / 0.736 / 0.781 / 0.825 / 0.810
+    All monotone towards wide up to 2.0 -- and all BIASED towards wide: the vocabulary's nodes are cluster centres,
+    i.e. denoised descriptors, and wider boxes denoise.  They cannot choose the width alone; nothing here favours 1.0."""
+    import ctypes as C
+    import math
+    fx = RC.load()
+    full = fx["image"]
+    voc = np.fromfile(os.path.join(GOLDEN, "small_voc_desc.bin"), dtype=np.uint8).reshape(-1, 48)
+    iu = np.triu_indices(384, 1)
+    cv = np.corrcoef(_bits(voc).T)[iu]
+    base = oracle.pattern()
+    want = {1.0: (114.7, 0.630, 0.670), 1.3: (106.8, 0.689, 0.736), 1.73: (96.7, 0.767, 0.781), 2.0: (91.6, 0.794, 0.825),
+            2.4: (86.1, 0.806, 0.810)}
+    got = {}
+    for m in want:
+        p = type(base)()
+        C.memmove(C.byref(p), C.byref(base), C.sizeof(p))
+        f, reach = float(np.float32(m)), 0.0
+        for i in range(p.n_points):  # = scale_pattern_boxes (host_tables.cpp): half-side in double x the float factor
+            p.sigma_half[i] = np.float32(float(base.sigma_half[i]) * f)
+            reach = max(reach, math.hypot(p.px[i], p.py[i]) + p.sigma_half[i])
+        p.border = int(math.ceil(reach)) + 1
+        monkeypatch.setattr(oracle, "pattern", lambda p=p: p)
+        k, d = oracle.detect_describe(full, 10.0, 0, 5, 4000, oracle.MODE_UPRIGHT)
+        near, r, _, _ = _voc_statistics(oracle, d)
+        _, d2 = oracle.detect_describe(full, 3.0, 0, 5, 30000, oracle.MODE_UPRIGHT)
+        bits = np.unpackbits(d2, axis=1, bitorder="little")
+        nodes = _k_majority_tree(bits)
+        r_nodes = np.corrcoef(np.corrcoef(nodes.T.astype(np.float64))[iu], cv)[0, 1]
+        got[m] = (near, r, r_nodes)
+        assert abs(near - want[m][0]) < 0.6 and abs(r - want[m][1]) < 0.01 and abs(r_nodes - want[m][2]) < 0.03, (m, got[m])
+    ms = sorted(want)
+    assert all(got[a][0] > got[b][0] and got[a][1] < got[b][1] for a, b in zip(ms, ms[1:]))
