@@ -143,7 +143,15 @@ typedef struct okvfe_config {
  * scale (keypoint.size = 12 x scale, response = the parabola's maximum, octave = layer index; layer nodes
  * 3/4, 1, 3/2 on octaves, 2/3, 1, 4/3 on intra-octaves, 2/3, 1, 3/2 with the result in [0.7, 1.5] on c0).  No
  * uniformity stage (uniformity_radius is ignored); the strongest max_keypoints maxima per layer are
- * kept, (score desc, y, x).  With octaves == 0 it is OKVFE_SCORE_AGAST_9_16. */
+ * kept, (score desc, y, x).  With octaves == 0 it is OKVFE_SCORE_AGAST_9_16.
+ * CAVEATS (the brisk sources are not in the reference tree; tools/ref_compare is the check):
+ *  - the keypoint POSITION is the 2-D sub-pixel fit on the keypoint's own layer, scaled to image coordinates; the
+ *    published detector additionally re-interpolates the position between the fits of the layers above and below
+ *    along the fitted scale -- NOT restated here, so x / y may differ from a brisk build by a fraction of a pixel
+ *    times the layer's scale while size / response / octave follow the parabola described above;
+ *  - the c0 node 2/3 (and the [0.7, 1.5] clamp) is taken from the coefficient matrix quoted in the published
+ *    refine1D_2's comment, not from verified code: if the executable coefficients there fit nodes 1/2, 1, 3/2,
+ *    sizes and responses of layer-0 keypoints differ. */
 #define OKVFE_SCORE_BRISK_SCALESPACE 2
 
 typedef struct okvfe_ctx okvfe_ctx;

@@ -434,6 +434,15 @@ okvfe_status okvfe_match_to_map_blocks_device(okvfe_ctx* ctx, const void* blocks
   for (auto& m : ctx->map_perm)
     if (m.stream == s) mp = &m;
   if (!mp) {
+    // at most eight streams keep a workspace: an application that creates a stream per frame would otherwise leave one
+    // behind per handle; the oldest entry is recycled (its stream is drained first: a launch may still read it)
+    constexpr size_t kMaxPermStreams = 8;
+    if (ctx->map_perm.size() >= kMaxPermStreams) {
+      okvfe_ctx::MapPerm old = ctx->map_perm.front();
+      ctx->map_perm.erase(ctx->map_perm.begin());
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      if (old.d) HIP_TRY(ctx, hipFree(old.d));
+    }
     ctx->map_perm.push_back(okvfe_ctx::MapPerm{s, nullptr, 0});
     mp = &ctx->map_perm.back();
   }

@@ -188,13 +188,22 @@ __device__ __forceinline__ void gate_cos(const PairParams& P, const okvfe_keypoi
 // rule of the reference (first k1 reaching the smallest gated distance) is a pure function of the
 // candidate set, so merging the segments by (dist, segment) reproduces it exactly.
 constexpr int kStereoSegs = 4;
-constexpr int kStereoChunk = 128;  // descriptors of one segment staged in LDS at a time (6 KiB)
+#ifndef OKVFE_MATCH_CHUNK
+#define OKVFE_MATCH_CHUNK 64   // (round 6: 128 -> 64 and five waves per SIMD: 262 -> 249 us per 3072 EuRoC pairs; six waves: 277)
+#endif
+#ifndef OKVFE_MATCH_WAVES
+#define OKVFE_MATCH_WAVES 5
+#endif
+constexpr int kStereoChunk = OKVFE_MATCH_CHUNK;  // descriptors of one segment staged in LDS at a time (6 KiB)
 struct SegBest {
   double hp[4];
   int best, k1, init, pad;
 };
 
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+#ifndef OKVFE_MATCH_HALF_REJECT
+#define OKVFE_MATCH_HALF_REJECT 0  // measured SLOWER (280 vs 263 us: the scan is bound by LDS latency at four waves per SIMD, not by its 24 xor / bcnt; the branch stops the loads of the next descriptors from overlapping): A/B only
+#endif
 #ifndef OKVFE_MATCH_MORE
 #define OKVFE_MATCH_MORE 6  // keys per re-scan of the gated matchers (the first scan keeps two)
 #endif
@@ -229,17 +238,46 @@ __device__ __forceinline__ void scan_top(const Desc12& d0, const ScanChunk& C,
   for (int c0 = k1_lo; c0 < k1_hi; c0 += kStereoChunk) {
     const int cnt = min(kStereoChunk, k1_hi - c0);
     if (!resident) load_scan_chunk(C, desc1, HAS_SKIP ? skip1 : nullptr, c0, cnt);
-#pragma unroll 4
-    for (int j = 0; j < cnt; ++j) {
-      const uint32_t dist = (uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(C.desc + 3 * j));
-      uint32_t key = ((dist << 22) | (uint32_t)(c0 + j)) + 1u;
+    auto insert = [&](uint32_t dist, int jj) {
+      uint32_t key = ((dist << 22) | (uint32_t)(c0 + jj)) + 1u;
       bool ok = key > floor_key && dist < threshold;
-      if (HAS_SKIP) ok = ok && C.skip[j] == 0;
+      if (HAS_SKIP) ok = ok && C.skip[jj] == 0;
       key = ok ? key : kNoKey;
 #pragma unroll
       for (int t = K - 1; t > 0; --t) c[t] = min(c[t], max(c[t - 1], key));  // insertion into the sorted K
       c[0] = min(c[0], key);
+    };
+    int j = 0;
+#if OKVFE_MATCH_HALF_REJECT
+    // Round 6: the first 192 bits decide for almost every descriptor of the other side -- unrelated BRISK2 descriptors
+    // differ in 96 +- 7 of them -- so four descriptors at a time are compared on six words first, and when NO lane of the
+    // wave is below the threshold on any of the four (one v_min3 pair, one compare, a scalar branch) the other six
+    // words cannot bring a lane below it either: the insertions would be no-ops and are skipped with the arithmetic
+    for (; j + 4 <= cnt; j += 4) {
+      uint32_t part[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t* bj = reinterpret_cast<const uint32_t*>(C.desc + 3 * (j + u));
+        uint32_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d += __popc(d0.w[i] ^ bj[i]);
+        part[u] = d;
+      }
+      const uint32_t pm = min(min(part[0], part[1]), min(part[2], part[3]));
+      if (__builtin_amdgcn_ballot_w64(pm < threshold) == 0ull) continue;  // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t* bj = reinterpret_cast<const uint32_t*>(C.desc + 3 * (j + u));
+        uint32_t d = part[u];
+#pragma unroll
+        for (int i = 6; i < 12; ++i) d += __popc(d0.w[i] ^ bj[i]);
+        insert(d, j + u);
+      }
     }
+#endif
+#pragma unroll 4
+    for (; j < cnt; ++j)
+      insert((uint32_t)hamming(d0, reinterpret_cast<const uint32_t*>(C.desc + 3 * j)), j);
   }
 }
 template <bool HAS_SKIP>
@@ -254,7 +292,7 @@ __device__ __forceinline__ void scan_top2(const Desc12& d0, const ScanChunk& C,
   *c2_out = c[1];
 }
 
-__device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
+__device__ void match_stereo_rows_r5(const PairParams& P, const BlockView& I0, const BlockView& I1,
                                   int threshold, okvfe_stereo_match* __restrict__ out) {
   __shared__ SegBest seg_best[kStereoSegs - 1][64];
   __shared__ uint4 seg_desc[kStereoSegs][kStereoChunk * 3];
@@ -382,7 +420,522 @@ __device__ void match_stereo_rows(const PairParams& P, const BlockView& I0, cons
   }
 }
 
-__global__ __launch_bounds__(64 * kStereoSegs) __attribute__((amdgpu_waves_per_eu(4, 8))) void match_stereo_kernel(
+__device__ void match_stereo_rows_bound(const PairParams& P, const BlockView& I0, const BlockView& I1,
+                                  int threshold, okvfe_stereo_match* __restrict__ out) {
+  __shared__ SegBest seg_best[kStereoSegs - 1][64];
+  __shared__ uint4 seg_desc[kStereoSegs][kStereoChunk * 3];
+  __shared__ uint32_t best_key[64];  // smallest key any segment has found VALID so far (kNoKey: none): larger keys cannot win
+  __shared__ double e0_lds[3][64];
+  const int seg = threadIdx.y;
+  const int per_seg = (I1.n + kStereoSegs - 1) / kStereoSegs;
+  const int k1_lo = min(seg * per_seg, I1.n), k1_hi = min(k1_lo + per_seg, I1.n);
+  if ((int)blockIdx.x * 64 >= I0.n) return;  // whole block past the last keypoint
+  const int k0 = blockIdx.x * 64 + threadIdx.x;
+  const bool active = k0 < I0.n;
+  Desc12 d0 = {};
+  if (active) d0 = load_desc(I0.desc + (size_t)k0 * OKVFE_DESC_BYTES);
+  double e0_W[3] = {0, 0, 0};
+  const bool v0 = active && I0.bpv[k0] != 0;
+  if (seg == 0) {  // the query rays once per block, not once per segment wave
+    if (v0) {
+      double v[3];
+      rot(P.C0, I0.bp + 3 * (size_t)k0, v);
+      normalize3(v, e0_W);
+    }
+    e0_lds[0][threadIdx.x] = e0_W[0]; e0_lds[1][threadIdx.x] = e0_W[1]; e0_lds[2][threadIdx.x] = e0_W[2];
+    best_key[threadIdx.x] = kNoKey;
+  }
+  __syncthreads();
+  if (seg != 0) {
+    e0_W[0] = e0_lds[0][threadIdx.x]; e0_W[1] = e0_lds[1][threadIdx.x]; e0_W[2] = e0_lds[2][threadIdx.x];
+  }
+  int best = threshold;  // running "distances"
+  int k1_match = 0;
+  bool initialisable = false;
+  double hps[4] = {0, 0, 0, 0};
+  // The reference walks k1 upwards and runs the geometric gate whenever dist < best; as the gate
+  // does not depend on `best`, its outcome is the gated candidate with the smallest (dist, k1).
+  // Each round therefore scans the segment branch-free for the smallest key above the last
+  // rejected one (wave-uniform descriptor loads, 24 VALU per k1) and runs the FP64 gate ONCE for
+  // all lanes together, instead of once per k1 for the one or two lanes that improved there.
+  uint32_t floor_key = 0;  // keys are ((dist << 22) | k1) + 1, so 0 admits everything
+  bool done = !v0;         // without a back-projection the gate rejects every candidate
+  const ScanChunk chunk{seg_desc[seg], nullptr};
+  const bool resident = k1_hi - k1_lo <= kStereoChunk;
+  if (resident) load_scan_chunk(chunk, I1.desc, nullptr, k1_lo, k1_hi - k1_lo);
+  int n_scans = 0;
+  while (__any(!done)) {
+    // the two smallest admissible keys of the segment in one scan: a rejected best candidate
+    // usually has its successor at hand, so the tail of the kernel is not set by re-scans.  A lane
+    // that is still undecided after them sits in look-alike content (repetitive texture: 5-15
+    // candidates below the threshold, most of them rejected by the gate): every further scan then
+    // brings SIX keys (insertion costs 5 min/max pairs more per descriptor, a re-scan 24 + 7)
+    constexpr int kMore = OKVFE_MATCH_MORE;
+#ifndef OKVFE_MATCH_NARROW_SCANS
+#define OKVFE_MATCH_NARROW_SCANS 1
+#endif
+    constexpr int kNarrowScans = OKVFE_MATCH_NARROW_SCANS;
+    uint32_t cs[kMore];
+#pragma unroll
+    for (int u = 0; u < kMore; ++u) cs[u] = kNoKey;
+    int n_c = 2;
+    if (n_scans < kNarrowScans) {
+      scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key,
+                       (uint32_t)threshold, &cs[0], &cs[1]);
+    } else {
+      scan_top<kMore, false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key, (uint32_t)threshold, cs);
+      n_c = kMore;
+    }
+    ++n_scans;
+#pragma unroll 1
+    for (int t = 0; t < n_c; ++t) {
+      uint32_t cand = cs[0];  // cs[t] without a dynamically indexed register array
+#pragma unroll
+      for (int u = 1; u < kMore; ++u) cand = t == u ? cs[u] : cand;
+      bool pending = !done;
+      if (pending && cand == kNoKey) {  // nothing (more) above the floor in this segment
+        done = true;
+        pending = false;
+      }
+      // a candidate above a key that another segment has already found valid cannot win, nor can its successors
+      // (a stale bound only costs work: the merge below decides)
+      if (pending && cand > *reinterpret_cast<volatile uint32_t*>(&best_key[threadIdx.x])) {
+        done = true;
+        pending = false;
+      }
+      if (!__any(pending)) break;  // wave-uniform
+      if (!pending) continue;
+      floor_key = cand;
+      const int k1 = (int)((cand - 1u) & 0x3FFFFFu);
+      const int dist = (int)((cand - 1u) >> 22);
+      if (!I1.bpv[k1]) continue;
+      double v[3], e1_W[3], hp_W[4], hp_C0[4], hp_C1[4];
+      rot(P.C1, I1.bp + 3 * (size_t)k1, v);
+      normalize3(v, e1_W);
+      bool is_valid, is_parallel;
+      double c26, c6;
+      gate_cos(P, I0.kps, k0, I1.kps, k1, &c26, &c6);
+      triangulate_fast(P.r0, e0_W, P.r1, e1_W, c26, c6, hp_W, &is_valid, &is_parallel);
+      inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+      inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+      if (!is_parallel) {
+        const double w4 = hp_W[3];
+        hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+        if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
+        if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
+        if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
+      }
+      if (is_valid) {
+        best = dist;
+        hps[0] = hp_W[0]; hps[1] = hp_W[1]; hps[2] = hp_W[2]; hps[3] = hp_W[3];
+        k1_match = k1;
+        initialisable = !is_parallel;
+        done = true;
+        atomicMin(&best_key[threadIdx.x], cand);
+      }
+    }
+  }
+  if (seg > 0) {
+    SegBest& sb = seg_best[seg - 1][threadIdx.x];
+    sb.best = best; sb.k1 = k1_match; sb.init = initialisable ? 1 : 0;
+    sb.hp[0] = hps[0]; sb.hp[1] = hps[1]; sb.hp[2] = hps[2]; sb.hp[3] = hps[3];
+  }
+  __syncthreads();
+  if (seg > 0) return;
+#pragma unroll
+  for (int s = 0; s < kStereoSegs - 1; ++s) {
+    const SegBest& sb = seg_best[s][threadIdx.x];
+    if (sb.best < best) {  // strict: ties stay with the lower segment = lower k1
+      best = sb.best; k1_match = sb.k1; initialisable = sb.init != 0;
+      hps[0] = sb.hp[0]; hps[1] = sb.hp[1]; hps[2] = sb.hp[2]; hps[3] = sb.hp[3];
+    }
+  }
+  if (active) {
+    okvfe_stereo_match m;
+    const bool hit = best < threshold;
+    m.k1 = hit ? k1_match : -1;
+    m.dist = hit ? best : threshold;
+    m.initialisable = hit ? (initialisable ? 1 : 0) : 0;
+    m.pad = 0;
+    m.hp_W[0] = hit ? hps[0] : 0.0;
+    m.hp_W[1] = hit ? hps[1] : 0.0;
+    m.hp_W[2] = hit ? hps[2] : 0.0;
+    m.hp_W[3] = hit ? hps[3] : 0.0;
+    out[k0] = m;
+  }
+}
+
+// Round 6, the kept form: POOLED gates.  The FP64 gate is ~700 instructions and runs wave-wide for whichever lanes hold a
+// candidate -- a dozen of 64 in a typical segment wave, so the four waves of a block each paid a whole gate for a
+// quarter-full wave, round after round.  Here every (segment, query) that holds a candidate pushes a job {segment, query,
+// key} into one LDS queue per block; the jobs are gated DENSELY by the first ceil(J / 64) waves (one gate invocation
+// for the block in the common case), results go back through LDS, and every (segment, query) carries on with its own
+// sequence of keys exactly as before.  The segments also share, per query, the smallest key found valid so far: larger
+// candidates cannot win and are not gated.  The query rays are rotated once per block.  Same decisions, same bytes.
+__device__ void match_stereo_rows_pooled(const PairParams& P, const BlockView& I0, const BlockView& I1,
+                                         int threshold, okvfe_stereo_match* __restrict__ out) {
+  constexpr int kMore = OKVFE_MATCH_MORE;
+  __shared__ uint4 seg_desc[kStereoSegs][kStereoChunk * 3];
+  __shared__ uint32_t best_key[64];
+  __shared__ double e0_lds[3][64];
+  __shared__ uint32_t job_key[64 * kStereoSegs];
+  __shared__ uint8_t job_who[64 * kStereoSegs];   // segment << 6 | query lane
+  __shared__ uint8_t job_res[kStereoSegs][64];    // bit 0: valid, bit 1: parallel
+  __shared__ double hp_lds[kStereoSegs][4][64];
+  __shared__ int seg_out[kStereoSegs][3][64];     // best distance, k1, initialisable
+  __shared__ int job_n[2];
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int lane = threadIdx.x;
+  const int tid = seg * 64 + lane;
+  const int per_seg = (I1.n + kStereoSegs - 1) / kStereoSegs;
+  const int k1_lo = min(seg * per_seg, I1.n), k1_hi = min(k1_lo + per_seg, I1.n);
+  if ((int)blockIdx.x * 64 >= I0.n) return;  // whole block past the last keypoint
+  const int k0 = blockIdx.x * 64 + lane;
+  const bool active = k0 < I0.n;
+  Desc12 d0 = {};
+  if (active) d0 = load_desc(I0.desc + (size_t)k0 * OKVFE_DESC_BYTES);
+  const bool v0 = active && I0.bpv[k0] != 0;
+  if (seg == 0) {
+    double e[3] = {0, 0, 0};
+    if (v0) {
+      double v[3];
+      rot(P.C0, I0.bp + 3 * (size_t)k0, v);
+      normalize3(v, e);
+    }
+    e0_lds[0][lane] = e[0]; e0_lds[1][lane] = e[1]; e0_lds[2][lane] = e[2];
+    best_key[lane] = kNoKey;
+    if (lane < 2) job_n[lane] = 0;
+  }
+  const ScanChunk chunk{seg_desc[seg], nullptr};
+  const bool resident = k1_hi - k1_lo <= kStereoChunk;
+  if (resident) load_scan_chunk(chunk, I1.desc, nullptr, k1_lo, k1_hi - k1_lo);
+  enum { kDone = 0, kHave = 1, kNeedScan = 2 };
+  int state = v0 ? kNeedScan : kDone;  // without a back-projection the gate rejects every candidate
+  uint32_t cs[kMore];
+#pragma unroll
+  for (int u = 0; u < kMore; ++u) cs[u] = kNoKey;
+  int t = 0, n_c = 2, n_scans = 0;
+  uint32_t floor_key = 0;  // keys are ((dist << 22) | k1) + 1, so 0 admits everything
+  int best = threshold, k1_match = 0, initialisable = 0;
+  int par = 0;
+  __syncthreads();  // rays, bounds and counters are in place
+  while (true) {
+    // ---- scan: a wave scans when none of its lanes still holds a key (the lanes of a wave advance in step)
+    if (!__any(state == kHave) && __any(state == kNeedScan)) {  // wave-uniform
+      if (n_scans < OKVFE_MATCH_NARROW_SCANS) {
+        scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key, (uint32_t)threshold, &cs[0], &cs[1]);
+#pragma unroll
+        for (int u = 2; u < kMore; ++u) cs[u] = kNoKey;
+        n_c = 2;
+      } else {
+        scan_top<kMore, false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, floor_key, (uint32_t)threshold, cs);
+        n_c = kMore;
+      }
+      ++n_scans;
+      t = 0;
+      if (state == kNeedScan) state = kHave;
+    }
+    // ---- this (segment, query)'s next key
+    uint32_t cand = cs[0];
+#pragma unroll
+    for (int u = 1; u < kMore; ++u) cand = t == u ? cs[u] : cand;
+    if (state == kHave && cand == kNoKey) state = kDone;  // nothing (more) above the floor in this segment
+    // a candidate above a key that another segment has found valid cannot win, nor can its successors (a stale bound
+    // only costs work: the merge at the end decides)
+    if (state == kHave && cand > *reinterpret_cast<volatile uint32_t*>(&best_key[lane])) state = kDone;
+    const bool pending = state == kHave;
+    {
+      const unsigned long long m = __ballot(pending);
+      if (m != 0ull) {  // one counter update per wave
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&job_n[par], __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (pending) {
+          const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+          job_key[at] = cand;
+          job_who[at] = (uint8_t)(seg << 6 | lane);
+        }
+      }
+    }
+    if (!__syncthreads_or(state != kDone)) break;  // (the jobs are published)
+    const int J = job_n[par];
+    if (J > 0) {  // block-uniform
+      if (tid == 0) job_n[par ^ 1] = 0;  // next round's counter: nobody reads or pushes it before the barrier below
+      if (seg * 64 < J) {  // the gates, densely: wave-uniform
+        const bool on = tid < J;
+        const uint32_t key = on ? job_key[tid] : 1u;
+        const int who = on ? job_who[tid] : 0;
+        const int jl = who & 63, js = who >> 6;
+        const int k1 = (int)((key - 1u) & 0x3FFFFFu);
+        bool is_valid = false, is_parallel = false;
+        double hp_W[4] = {0, 0, 0, 0};
+        if (on && I1.bpv[k1]) {
+          const int jk0 = blockIdx.x * 64 + jl;
+          const double e0_W[3] = {e0_lds[0][jl], e0_lds[1][jl], e0_lds[2][jl]};
+          double v[3], e1_W[3], hp_C0[4], hp_C1[4];
+          rot(P.C1, I1.bp + 3 * (size_t)k1, v);
+          normalize3(v, e1_W);
+          double c26, c6;
+          gate_cos(P, I0.kps, jk0, I1.kps, k1, &c26, &c6);
+          triangulate_fast(P.r0, e0_W, P.r1, e1_W, c26, c6, hp_W, &is_valid, &is_parallel);
+          inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+          inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+          if (!is_parallel) {
+            const double w4 = hp_W[3];
+            hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+            if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
+            if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
+            if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
+          }
+        }
+        if (on) {
+          job_res[js][jl] = (uint8_t)((is_valid ? 1 : 0) | (is_parallel ? 2 : 0));
+          if (is_valid) {
+            hp_lds[js][0][jl] = hp_W[0]; hp_lds[js][1][jl] = hp_W[1];
+            hp_lds[js][2][jl] = hp_W[2]; hp_lds[js][3][jl] = hp_W[3];
+            atomicMin(&best_key[jl], key);
+          }
+        }
+      }
+      __syncthreads();  // results are back
+      if (pending) {
+        const int r = job_res[seg][lane];
+        floor_key = cand;
+        if (r & 1) {
+          best = (int)((cand - 1u) >> 22);
+          k1_match = (int)((cand - 1u) & 0x3FFFFFu);
+          initialisable = (r & 2) ? 0 : 1;
+          state = kDone;
+        } else {
+          ++t;
+          if (t >= n_c) state = kNeedScan;
+        }
+      }
+      par ^= 1;
+    }
+  }
+  seg_out[seg][0][lane] = best;
+  seg_out[seg][1][lane] = k1_match;
+  seg_out[seg][2][lane] = initialisable;
+  __syncthreads();
+  if (seg > 0 || !active) return;
+  int win = 0;
+#pragma unroll
+  for (int s2 = 1; s2 < kStereoSegs; ++s2) {
+    const int b2 = seg_out[s2][0][lane];
+    if (b2 < best) {  // strict: ties stay with the lower segment = lower k1
+      best = b2; k1_match = seg_out[s2][1][lane]; initialisable = seg_out[s2][2][lane];
+      win = s2;
+    }
+  }
+  okvfe_stereo_match m;
+  const bool hit = best < threshold;
+  m.k1 = hit ? k1_match : -1;
+  m.dist = hit ? best : threshold;
+  m.initialisable = hit ? initialisable : 0;
+  m.pad = 0;
+  m.hp_W[0] = hit ? hp_lds[win][0][lane] : 0.0;
+  m.hp_W[1] = hit ? hp_lds[win][1][lane] : 0.0;
+  m.hp_W[2] = hit ? hp_lds[win][2][lane] : 0.0;
+  m.hp_W[3] = hit ? hp_lds[win][3][lane] : 0.0;
+  out[k0] = m;
+}
+
+#ifndef OKVFE_MATCH_MERGED
+#define OKVFE_MATCH_MERGED 3  // 0: per-segment gates (rounds 2-5), 1: one global candidate order (measured slower: LAB_NOTES), 2: per-segment + shared bound, 3: pooled gates (kept)
+#endif
+// Round 6: ONE candidate order per query.  The four segment waves of a query used to run the whole scheme each --
+// the FP64 set-up of the query's ray, and a gate for the best candidates of THEIR segment even when another segment
+// held a better, valid one (look-alike content: 5-15 candidates per query, most of them rejected).  Now:
+//   * wave 0 rotates and normalises the query rays once, the others pick them up from LDS behind the first barrier;
+//   * every wave scans its segment for its K smallest admissible keys above the query's floor (K = 2, then 6: as
+//     before) and publishes them; all keys up to the HORIZON H = min over the segments of their K-th key are then
+//     known to be complete (a segment that returned fewer than K keys is exhausted);
+//   * the known keys are gated in GLOBAL (dist, k1) order, four per round, one per wave; the first valid one in that
+//     order is the reference's match (the gate does not depend on the running best, Frontend.cpp:2027-2073) and the
+//     wave that gated it writes the row from its registers; if all known keys are rejected the floor moves to H and
+//     the segments are scanned again.
+// Every wave derives the same per-query state from the same LDS words, so the loop conditions are block-uniform.
+__device__ void match_stereo_rows_merged(const PairParams& P, const BlockView& I0, const BlockView& I1,
+                                         int threshold, okvfe_stereo_match* __restrict__ out) {
+  constexpr int kMore = OKVFE_MATCH_MORE;
+  __shared__ uint4 seg_desc[kStereoSegs][kStereoChunk * 3];
+  __shared__ uint32_t seg_keys[kStereoSegs][kMore][64];
+  __shared__ double e0_lds[3][64];
+  __shared__ uint8_t gate_flags[kStereoSegs][64];  // bit 0: valid, bit 1: initialisable
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int lane = threadIdx.x;
+  const int per_seg = (I1.n + kStereoSegs - 1) / kStereoSegs;
+  const int k1_lo = min(seg * per_seg, I1.n), k1_hi = min(k1_lo + per_seg, I1.n);
+  if ((int)blockIdx.x * 64 >= I0.n) return;  // whole block past the last keypoint
+  const int k0 = blockIdx.x * 64 + lane;
+  const bool active = k0 < I0.n;
+  Desc12 d0 = {};
+  if (active) d0 = load_desc(I0.desc + (size_t)k0 * OKVFE_DESC_BYTES);
+  const bool v0 = active && I0.bpv[k0] != 0;
+  if (seg == 0) {
+    double e[3] = {0, 0, 0};
+    if (v0) {
+      double v[3];
+      rot(P.C0, I0.bp + 3 * (size_t)k0, v);
+      normalize3(v, e);
+    }
+    e0_lds[0][lane] = e[0]; e0_lds[1][lane] = e[1]; e0_lds[2][lane] = e[2];
+  }
+  const ScanChunk chunk{seg_desc[seg], nullptr};
+  const bool resident = k1_hi - k1_lo <= kStereoChunk;
+  if (resident) load_scan_chunk(chunk, I1.desc, nullptr, k1_lo, k1_hi - k1_lo);
+  double e0_W[3] = {0, 0, 0};
+  bool have_e0 = false;
+  uint32_t floor_key = 0;     // keys are ((dist << 22) | k1) + 1, so 0 admits everything
+  uint32_t prev = 0;          // every known key <= prev has been gated and rejected
+  uint32_t horizon = 0;       // keys <= horizon are known (kNoKey: every segment is exhausted)
+  bool done = !v0;            // without a back-projection the gate rejects every candidate
+  bool need_scan = !done;
+  int n_keys = 2;             // keys per segment of the last scan (block-uniform)
+  int n_scans = 0;
+  bool wrote = false;         // this lane's row has been written by the wave that gated the winner
+  while (true) {
+    // ---- scan (block-uniform decision: every wave holds the same per-lane flags)
+    const bool any_scan = __any(need_scan);
+    if (any_scan) {
+      uint32_t cs[kMore];
+#pragma unroll
+      for (int u = 0; u < kMore; ++u) cs[u] = kNoKey;
+      // (lanes that need no scan ride along with a floor that admits nothing: their published keys stay)
+      const uint32_t fl = need_scan ? floor_key : kNoKey - 1u;
+      if (n_scans < OKVFE_MATCH_NARROW_SCANS) {
+        scan_top2<false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, fl, (uint32_t)threshold, &cs[0], &cs[1]);
+        n_keys = 2;
+      } else {
+        scan_top<kMore, false>(d0, chunk, I1.desc, nullptr, k1_lo, k1_hi, resident, fl, (uint32_t)threshold, cs);
+        n_keys = kMore;
+      }
+      ++n_scans;
+      if (need_scan) {
+#pragma unroll
+        for (int u = 0; u < kMore; ++u) seg_keys[seg][u][lane] = cs[u];
+      }
+    }
+    __syncthreads();  // keys (and, the first time, the query rays) are published; last round's flags have been read
+    if (!have_e0) {
+      e0_W[0] = e0_lds[0][lane]; e0_W[1] = e0_lds[1][lane]; e0_W[2] = e0_lds[2][lane];
+      have_e0 = true;
+    }
+    if (need_scan) {
+      uint32_t hz = kNoKey;
+#pragma unroll
+      for (int s2 = 0; s2 < kStereoSegs; ++s2) hz = min(hz, seg_keys[s2][n_keys - 1][lane]);
+      horizon = hz;
+      prev = floor_key;
+      need_scan = false;
+    }
+    // ---- the next four known keys above prev, ascending (all waves compute the same four)
+    uint32_t sel[kStereoSegs];
+    {
+      uint32_t lo = prev;
+#pragma unroll
+      for (int r = 0; r < kStereoSegs; ++r) {
+        uint32_t m = kNoKey;
+        if (!done) {
+          for (int u = 0; u < n_keys; ++u) {  // block-uniform trip count
+#pragma unroll
+            for (int s2 = 0; s2 < kStereoSegs; ++s2) {
+              const uint32_t k = seg_keys[s2][u][lane];
+              m = (k > lo && k <= horizon && k < m) ? k : m;
+            }
+          }
+        }
+        sel[r] = m;
+        lo = m == kNoKey ? lo : m;
+      }
+    }
+    // ---- this wave gates candidate `seg` of the four
+    uint32_t mine = sel[0];
+#pragma unroll
+    for (int r = 1; r < kStereoSegs; ++r) mine = seg == r ? sel[r] : mine;
+    const bool pending = !done && mine != kNoKey;
+    bool is_valid = false, is_parallel = false;
+    double hp_W[4] = {0, 0, 0, 0};
+    int k1 = 0, dist = 0;
+    if (__any(pending)) {  // wave-uniform
+      k1 = pending ? (int)((mine - 1u) & 0x3FFFFFu) : 0;
+      dist = (int)((mine - 1u) >> 22);
+      if (pending && I1.bpv[k1]) {
+        double v[3], e1_W[3], hp_C0[4], hp_C1[4];
+        rot(P.C1, I1.bp + 3 * (size_t)k1, v);
+        normalize3(v, e1_W);
+        double c26, c6;
+        gate_cos(P, I0.kps, k0, I1.kps, k1, &c26, &c6);
+        triangulate_fast(P.r0, e0_W, P.r1, e1_W, c26, c6, hp_W, &is_valid, &is_parallel);
+        inv_transform_h(P.C0, P.r0, hp_W, hp_C0);
+        inv_transform_h(P.C1, P.r1, hp_W, hp_C1);
+        if (!is_parallel) {
+          const double w4 = hp_W[3];
+          hp_W[0] /= w4; hp_W[1] /= w4; hp_W[2] /= w4; hp_W[3] /= w4;
+          if (hp_C0[2] / hp_C0[3] < 0.05) is_valid = false;
+          if (hp_C1[2] / hp_C1[3] < 0.05) is_valid = false;
+          if (dot3(e0_W, e1_W) < 0.8) is_valid = false;
+        }
+      }
+    }
+    gate_flags[seg][lane] = (uint8_t)((pending && is_valid) ? 1 : 0);
+    __syncthreads();
+    // ---- the first valid candidate in order wins (every wave reads the same four flags)
+    int win = -1;
+#pragma unroll
+    for (int r = kStereoSegs - 1; r >= 0; --r) win = (!done && gate_flags[r][lane] != 0) ? r : win;
+    if (win >= 0) {
+      if (win == seg && active) {
+        okvfe_stereo_match m;
+        m.k1 = k1;
+        m.dist = dist;
+        m.initialisable = is_parallel ? 0 : 1;
+        m.pad = 0;
+        m.hp_W[0] = hp_W[0]; m.hp_W[1] = hp_W[1]; m.hp_W[2] = hp_W[2]; m.hp_W[3] = hp_W[3];
+        out[k0] = m;
+      }
+      wrote = true;
+      done = true;
+    } else if (!done) {
+      // all four (or fewer) rejected: move on among the known keys, or re-scan above the horizon, or give up
+      uint32_t last = prev;
+#pragma unroll
+      for (int r = 0; r < kStereoSegs; ++r) last = sel[r] != kNoKey ? sel[r] : last;
+      prev = last;
+      if (sel[kStereoSegs - 1] == kNoKey) {  // the known keys are used up
+        if (horizon == kNoKey) {
+          done = true;  // every segment exhausted: no match
+        } else {
+          floor_key = horizon;
+          need_scan = true;
+        }
+      }
+    }
+    if (!__any(!done)) break;  // block-uniform (identical state in the four waves)
+  }
+  if (seg == 0 && active && !wrote) {
+    okvfe_stereo_match m;
+    m.k1 = -1; m.dist = threshold; m.initialisable = 0; m.pad = 0;
+    m.hp_W[0] = 0.0; m.hp_W[1] = 0.0; m.hp_W[2] = 0.0; m.hp_W[3] = 0.0;
+    out[k0] = m;
+  }
+}
+
+__device__ __forceinline__ void match_stereo_rows(const PairParams& P, const BlockView& I0, const BlockView& I1,
+                                                  int threshold, okvfe_stereo_match* __restrict__ out) {
+#if OKVFE_MATCH_MERGED == 3
+  match_stereo_rows_pooled(P, I0, I1, threshold, out);
+#elif OKVFE_MATCH_MERGED == 2
+  match_stereo_rows_bound(P, I0, I1, threshold, out);
+#elif OKVFE_MATCH_MERGED
+  match_stereo_rows_merged(P, I0, I1, threshold, out);
+#else
+  match_stereo_rows_r5(P, I0, I1, threshold, out);  // (A/B: the per-segment form of rounds 2-5)
+#endif
+}
+
+__global__ __launch_bounds__(64 * kStereoSegs) __attribute__((amdgpu_waves_per_eu(OKVFE_MATCH_WAVES, 8))) void match_stereo_kernel(
     const PairParams* __restrict__ pairs, const okvfe_keypoint* __restrict__ kps,
     const uint8_t* __restrict__ desc, const double* __restrict__ bp,
     const uint8_t* __restrict__ bpv, const int32_t* __restrict__ counts, int kp_cap,

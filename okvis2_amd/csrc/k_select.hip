@@ -1372,8 +1372,8 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
   while (ws_stride < cand_cap) ws_stride <<= 1;
   const LazyPlan lp = lazy_plan(radius, max_kpts, kp_cap, occupancy, occ_image_bytes, occ_rows, occ_cols);
   if (lp.list) {
-    static std::once_flag attr_once_l;
-    std::call_once(attr_once_l, [] {
+    static PerDeviceOnce attr_once_l;
+    attr_once_l.run([] {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_list_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
         (void)hipGetLastError();
@@ -1394,8 +1394,8 @@ bool launch_select(const int32_t* score, ScoreLayout layout, int w, int h, int n
       const int v = e ? atoi(e) : kLazyBlockMax;
       return v < 4 ? 4 : (v > kLazyBlockMax ? kLazyBlockMax : v);
     }();
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [] {
+    static PerDeviceOnce attr_once;
+    attr_once.run([] {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(select_lazy_kernel<true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLazyMaxLds) != hipSuccess)
         (void)hipGetLastError();  // launches above 64 KiB will then fail loudly on their own

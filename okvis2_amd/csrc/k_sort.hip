@@ -315,8 +315,8 @@ void launch_sort(const Candidate* cand, int cand_cap, const int32_t* cand_count,
   }
   if (two) {  // second launch: 8193..16384 keys in 136 KiB, larger sets in the HBM workspace
     const size_t big_lds = (size_t)rb_slot(2 * kLdsSortKeys) * 8;  // >= the classic 128 KiB
-    static std::once_flag attr_once;  // (several host threads may launch through several contexts)
-    std::call_once(attr_once, [&] {
+    static PerDeviceOnce attr_once;  // (several host threads may launch through several contexts, on several devices)
+    attr_once.run([&] {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)big_lds) != hipSuccess)
         (void)hipGetLastError();

@@ -1,6 +1,7 @@
 // okvfe_internal.h -- shared declarations of the libokvfe.so runtime (host + HIP kernels).
 // Product code; never includes or links anything under oracle/.
 #pragma once
+#include <atomic>
 #include <cstdlib>
 
 #include <hip/hip_runtime.h>
@@ -22,6 +23,30 @@ inline const char* lab_env(const char* name) { return std::getenv(name); }
 #else
 inline const char* lab_env(const char*) { return nullptr; }
 #endif
+
+// A function attribute (opt-in to > 64 KiB of dynamic LDS) belongs to the function ON THE CURRENT DEVICE: one process may
+// hold contexts on several GPUs, so the one-shot is kept per device ordinal, thread-safe.
+constexpr int kMaxAttrDevices = 64;
+struct PerDeviceOnce {
+  std::atomic<int> state[kMaxAttrDevices];  // 0 = not yet, 1 = being set, 2 = set
+  template <typename F>
+  void run(F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxAttrDevices) {
+      f();  // (unknown ordinal: set it every time)
+      return;
+    }
+    int expect = 0;
+    if (state[dev].load(std::memory_order_acquire) == 2) return;
+    if (state[dev].compare_exchange_strong(expect, 1)) {
+      f();
+      state[dev].store(2, std::memory_order_release);
+    } else {
+      while (state[dev].load(std::memory_order_acquire) != 2) {}  // another host thread is setting it right now
+    }
+  }
+};
+
 
 
 constexpr int kPatternPoints = 72;  // capacity (lane i and, past 64, a second sample on lane i - 64); built-in: 66
