@@ -54,6 +54,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
   ctx->wide_patches = false;
   ctx->aware_fast = true;
   ctx->all_aware = n_images > 0;
+  ctx->none_aware = true;
   for (int i = 0; i < n_images; ++i) {
     ImageParams& p = prm[i];
     p.cam = cam_ids ? cam_ids[i] : -1;
@@ -65,6 +66,7 @@ static okvfe_status upload_image_params(okvfe_ctx* ctx, int n_images, const int3
         return fail(ctx, OKVFE_ERR_NOT_READY,
                     "camera-aware extraction requested for camera %d before okvfe_set_camera[_maps]", p.cam);
       p.mode = kCameraAware;
+      ctx->none_aware = false;
       p.dir[0] = gravity[3 * i];
       p.dir[1] = gravity[3 * i + 1];
       p.dir[2] = gravity[3 * i + 2];
@@ -114,6 +116,28 @@ static int pattern_box_class(const okvfe::Pattern& P) {
     if (!(s >= 0.5f)) cls = 2;
   }
   return cls;
+}
+
+// describe_rot_kernel (upright / gradient modes on the fast box sums) takes the installed pattern when its circle fits a
+// 64-byte row pitch, its samples beyond 64 lanes fit the kernel's table and its long-pair weights fit 16 bits
+static bool pattern_rot_ok(const okvfe::Pattern& P) {
+  const int extra = P.n_points > 64 ? P.n_points - 64 : 0;
+  if (P.border > 29 || extra > okvfe::kAwareMaxExtra || P.n_long > okvfe::kMaxLongPairs) return false;
+  for (int l = 0; l < P.n_long; ++l)
+    if (P.long_wdx[l] < -32768 || P.long_wdx[l] > 32767 || P.long_wdy[l] < -32768 || P.long_wdy[l] > 32767) return false;
+  // the rotation tables must follow the quarter-wave rule exactly (they do for the tables build_pattern computes)
+  static const bool sym = [&P] {
+    for (int k = 0; k < okvfe::kRot; ++k) {
+      if (okvfe::quarter_sin(P.rot_sin, k) != P.rot_sin[k] || okvfe::quarter_cos(P.rot_sin, k) != P.rot_cos[k]) return false;
+      // (float tables: sin(pi) and cos(pi / 2) are 1e-16, not 0, in double -- entries sin[512], cos[256], cos[768] are
+      // read from the global table by the kernel and exempt here)
+      const float fs = okvfe::quarter_sin(P.rot_sinf, k), fc = okvfe::quarter_cos(P.rot_sinf, k);
+      if (k != 512 && std::memcmp(&fs, &P.rot_sinf[k], 4) != 0) return false;
+      if (k != 256 && k != 768 && std::memcmp(&fc, &P.rot_cosf[k], 4) != 0) return false;
+    }
+    return true;
+  }();
+  return sym;
 }
 
 extern "C" int32_t okvfe_pattern_kernel_class(const okvfe_ctx* ctx) { return ctx ? pattern_box_class(ctx->host_pattern) : -1; }
@@ -413,7 +437,8 @@ okvfe_status describe_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_ima
                     ctx->d_rays_ptrs, ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count,
                     ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, setup_done,
                     ctx->all_aware, ctx->lane_view ? ctx->box_class_call : pattern_box_class(ctx->host_pattern),
-                    ctx->lane_view || setup_done ? ctx->aware_extra_box : aware_box_for_call(ctx, images_dev));
+                    ctx->lane_view || setup_done ? ctx->aware_extra_box : aware_box_for_call(ctx, images_dev),
+                    ctx->none_aware && (ctx->lane_view ? ctx->rot_fast_call : pattern_rot_ok(ctx->host_pattern)));
   }
   if ((st = heavy_end(ctx, s, 1, &token)) != OKVFE_OK) return st;
   {
@@ -514,6 +539,7 @@ void bind_lane(okvfe_ctx* v, okvfe_ctx* p, int first, int n) {
   v->d_cams = p->d_cams; v->d_rays_ptrs = p->d_rays_ptrs; v->d_jac_ptrs = p->d_jac_ptrs;
   v->wide_patches = p->wide_patches; v->all_aware = p->all_aware; v->aware_fast = p->aware_fast;
   v->aware_extra_box = p->aware_extra_box; v->box_class_call = p->box_class_call;
+  v->none_aware = p->none_aware; v->rot_fast_call = p->rot_fast_call;
   v->fuse_setup = p->fuse_setup;
   v->counters_cleared = p->counters_cleared;
   v->prof_mask = p->prof_mask;
@@ -541,6 +567,7 @@ okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, in
   chunk = (chunk + 7) & ~7;
   const size_t P = (size_t)ctx->w * ctx->h;
   ctx->box_class_call = pattern_box_class(ctx->host_pattern);
+  ctx->rot_fast_call = pattern_rot_ok(ctx->host_pattern);
   ctx->aware_extra_box = aware_box_for_call(ctx, images_dev);
   HIP_TRY(ctx, hipEventRecord(ctx->lane_fork, s));  // behind the parameter upload (and whatever the caller queued)
   okvfe_status first_err = OKVFE_OK;
@@ -983,7 +1010,8 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
   launch_describe(ctx->d_img_stage, w, h, 1, ctx->d_pattern, ctx->d_prm, ctx->d_rays_ptrs,
                   ctx->d_jac_ptrs, ctx->d_kps_det, ctx->kp_cap, ctx->d_det_count, ctx->d_kps_tmp,
                   ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_scales, ctx->wide_patches, s, false,
-                  ctx->all_aware, pattern_box_class(ctx->host_pattern), aware_box_for_call(ctx, ctx->d_img_stage));
+                  ctx->all_aware, pattern_box_class(ctx->host_pattern), aware_box_for_call(ctx, ctx->d_img_stage),
+                  ctx->none_aware && pattern_rot_ok(ctx->host_pattern));
   launch_compact(1, ctx->d_cams, ctx->d_prm, ctx->d_kps_tmp, ctx->d_desc_tmp, ctx->d_valid_tmp, ctx->d_det_count,
                  ctx->kp_cap, ctx->d_kps, ctx->d_desc, ctx->d_bp, ctx->d_bpv, ctx->d_count, s);
   HIP_TRY(ctx, hipGetLastError());

@@ -841,7 +841,7 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in,
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done,
-                     bool all_camera_aware, int box_class, int aware_extra_box) {
+                     bool all_camera_aware, int box_class, int aware_extra_box, bool rot_fast) {
   if (n_images <= 0) return;
   static const char* force = lab_env("OKVFE_DESC_WAVES");  // A/B knob: 5 / 6
   if (force) wide_patches = force[0] == '5';
@@ -869,6 +869,14 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
     launch_describe_aware(img, w, h, n_images, pat, kps_in, kp_cap, kp_count_in, desc_tmp, valid_tmp, box_class == 1,
                           stream, aware_extra_box > 0 && !aware_extras_in_setup() ? (aware_extra_box >> 8) : 0,
                           aware_extra_box & 0xFF);
+    return;
+  }
+  // round 6: upright / gradient-orientation calls (the BRISK scale-space path, callers without a camera) on the same box
+  // sums: describe_rot_kernel (k_describe_aware.hip)
+  static const bool no_rot = lab_env("OKVFE_DESC_NO_ROT") != nullptr;  // A/B knob
+  if (rot_fast && !no_rot && !no_aware && box_class == 0 && scales == nullptr && w % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(img) & 3) == 0) {
+    launch_describe_rot(img, w, h, n_images, pat, prm, kps_in, kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, stream);
     return;
   }
   // box_class (capi_detect.cpp: pattern_box_class): 0 = every box fits the 11 x 11 / 5 x 5 slots, 1 = the 21 x 21 /

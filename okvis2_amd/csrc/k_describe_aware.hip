@@ -497,6 +497,234 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(W
 #endif
 }
 
+
+// ---- upright / gradient-orientation extraction on the same box sums (round 6) ----------------------------------------
+// The modes the BRISK scale-space path (brisk::BriskFeatureDetector + extractor, okvis_cv/test/TestFrame.cpp:71-77) and
+// cv::Feature2D-style callers without a camera use: rotationInvariant = false (upright) or true with the published
+// gradient orientation -- the pattern sampled UPRIGHT, the 968 long pairs summed into a gradient, the best of 1024
+// tabulated directions, the pattern sampled again under that rotation.  Until round 6 these ran on describe_kernel's
+// all-modes form (128 registers, row loops with computed addresses: 4.3 ms per 512 images x 2780 keypoints); here they
+// get the camera-aware kernel's box sum: a fixed 64-byte row pitch (the pattern's circle, 2 * border + 2 <= 64 pixels,
+// always fits), aligned 8-byte row windows, exec-masked rows.  The patch is staged ONCE per keypoint and serves both
+// samplings.  The samples beyond the 64 lanes are a second, exec-masked call of the small-box form on lanes 0 .. extra-1
+// (their M is not known to any set-up thread in gradient mode).  Bit-exact to describe_kernel and the oracle.
+constexpr int kRotBufBytes = 64 * kAwPitch0 + 32;
+__global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(5, 8))) void describe_rot_kernel(
+    const uint8_t* __restrict__ images, int w, int h, const Pattern* __restrict__ pat, const ImageParams* __restrict__ prm,
+    const okvfe_keypoint* __restrict__ kps_in, int kp_cap, const int32_t* __restrict__ kp_count_in,
+    okvfe_keypoint* __restrict__ kps_tmp, uint8_t* __restrict__ desc_tmp, uint8_t* __restrict__ valid_tmp, int n_images,
+    int tiles, uint32_t inv_tiles) {
+  using T = AwCfg<false>;
+  __shared__ __attribute__((aligned(16))) uint8_t patches[kAwWaves][kRotBufBytes];
+  __shared__ int values[kAwWaves][kPatternPoints];
+  __shared__ __attribute__((aligned(16))) uint32_t box_masks[T::kAlign * T::kCounts * T::kRowDw];
+  __shared__ uint2 long_tab[kMaxLongPairs];  // {i | j << 8, wdx (16 bit) | wdy << 16}: the host checked the ranges
+  __shared__ float ex_f[3][kAwareMaxExtra];
+  __shared__ int ex_i[2][kAwareMaxExtra];
+  // quarter waves of the rotation tables (okvfe_internal.h: quarter_sin; the host verified the rule for this pattern):
+  // no gather from global memory inside a keypoint's chain
+  __shared__ int32_t q_sin_i[257];
+  __shared__ float q_sin_f[257];
+  int img, tile;
+  {
+    const uint32_t L = blockIdx.x, n8 = (uint32_t)n_images & ~7u, full = n8 * (uint32_t)tiles;
+    const uint32_t slot = L < full ? L >> 3 : L - full;
+    uint32_t g = (uint32_t)(((uint64_t)slot * inv_tiles) >> 32);  // slot / tiles, off by <= 1
+    if (g * (uint32_t)tiles > slot) --g;
+    if ((g + 1) * (uint32_t)tiles <= slot) ++g;
+    img = L < full ? (int)(g * 8u + (L & 7u)) : (int)(n8 + g);  // an image's blocks on one XCD
+    tile = (int)(slot - g * (uint32_t)tiles);
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  const int k_first = tile * kAwWaves + wv, k_step = tiles * kAwWaves;
+  const size_t slot0 = (size_t)img * kp_cap;
+  const int n_raw = kp_count_in[img];
+  const int n_points = pat->n_points;
+  const int4 lc0 = *reinterpret_cast<const int4*>(&pat->aware_lane[lane][0]);
+  const int4 lc1 = *reinterpret_cast<const int4*>(&pat->aware_lane[lane][4]);
+  const int mode = __builtin_amdgcn_readfirstlane(prm[img].mode);
+  const int border = __builtin_amdgcn_readfirstlane(pat->border);
+  fill_box_masks<false>(box_masks, threadIdx.x, 64 * kAwWaves);
+  for (int t = threadIdx.x; t < pat->n_long; t += 64 * kAwWaves)
+    long_tab[t] = make_uint2((uint32_t)pat->long_i[t] | ((uint32_t)pat->long_j[t] << 8),
+                             ((uint32_t)pat->long_wdx[t] & 0xFFFFu) | ((uint32_t)pat->long_wdy[t] << 16));
+  for (int t = threadIdx.x; t < 257; t += 64 * kAwWaves) {
+    q_sin_i[t] = pat->rot_sin[t];
+    q_sin_f[t] = pat->rot_sinf[t];
+  }
+  // the three float entries the rule does not reproduce (sin(pi), cos(pi / 2), cos(3 pi / 2) are 1e-16 in double, not 0)
+  const float f_s512 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pat->rot_sinf[512])));
+  const float f_c256 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pat->rot_cosf[256])));
+  const float f_c768 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pat->rot_cosf[768])));
+  if (threadIdx.x < kAwareMaxExtra) {
+    ex_f[0][threadIdx.x] = pat->px[threadIdx.x];
+    ex_f[1][threadIdx.x] = pat->py[threadIdx.x];
+    ex_f[2][threadIdx.x] = pat->sigma_half[threadIdx.x];
+    ex_i[0][threadIdx.x] = pat->box_scaling[threadIdx.x];
+    ex_i[1][threadIdx.x] = pat->box_scaling2[threadIdx.x];
+  }
+  typedef const float __attribute__((address_space(4))) * cfloat_p;
+  typedef const uint8_t __attribute__((address_space(4))) * cbyte_p;
+  float nxt_x = 0.f, nxt_y = 0.f;
+  int nxt_valid = 0;
+  auto fetch = [&](int kk) {  // scalar loads: the next keypoint waits in SGPRs (see describe_aware_kernel)
+    const size_t sl = slot0 + kk;
+    const cfloat_p pxy = (cfloat_p)(uintptr_t)(&kps_in[sl].x);
+    nxt_x = pxy[0];
+    nxt_y = pxy[1];
+    nxt_valid = (int)((cbyte_p)(uintptr_t)valid_tmp)[sl];
+  };
+  fetch(k_first < kp_cap ? k_first : kp_cap - 1);
+  __syncthreads();
+  const int n = __builtin_amdgcn_readfirstlane(n_raw);
+  if (k_first >= n) return;  // whole wave exits; no block-wide barriers below
+  const uint8_t* im = images + (size_t)img * w * h;
+  const int extra = __builtin_amdgcn_readfirstlane(n_points > 64 ? n_points - 64 : 0);
+  const bool active = extra + lane < n_points;
+  const bool active2 = lane < extra;
+  float px = __int_as_float(lc0.x), py = __int_as_float(lc0.y), sg = __int_as_float(lc0.z);
+  int bsc = lc0.w, bsc2 = lc1.x;
+  const uint32_t my_pairs[3] = {(uint32_t)lc1.y, (uint32_t)lc1.z, (uint32_t)lc1.w};
+  int* vals = values[wv];
+  uint8_t* patch = patches[wv];
+  const __amdgpu_buffer_rsrc_t img_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(im), 0, w * h, 0x00027000);
+  const int src_lane0 = (lane >> 2) * w + (lane & 3) * 16;  // pitch 64: 16 rows per trip
+  const int nl = pat->n_long;
+  for (int k = k_first; k < n; k += k_step) {  // (k: wave-uniform)
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(sg), "+v"(bsc), "+v"(bsc2), "+v"(lane));  // (no hoisting: registers)
+    const size_t slot = slot0 + k;
+    auto unif = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    const float kx = unif(nxt_x), ky = unif(nxt_y);
+    bool valid = (__builtin_amdgcn_readfirstlane(nxt_valid) & 1) != 0;  // the set-up kernel's rim test
+    if (k + k_step < n) fetch(k + k_step);
+    bool new_angle = false;
+    float angle = 0.0f;
+    if (valid) {
+      // the pattern's circle, clipped to the image: covers every rotation
+      const int cx = (int)kx, cy = (int)ky;
+      int bx0 = cx - border, bx1 = cx + border + 1, by0 = cy - border, by1 = cy + border + 1;
+      bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+      bx1 = bx1 > w - 1 ? w - 1 : bx1; by1 = by1 > h - 1 ? h - 1 : by1;
+      const int x0 = bx0 & ~3, y0 = by0, ph = by1 - by0 + 1;  // (bx1 - x0 + 1 <= 2 * border + 5 <= 64: launch_describe)
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int trips = (ph + 15) >> 4;
+        const int g0 = y0 * w + x0;
+        for (int it = 0; it < trips; ++it)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rsrc, (__attribute__((address_space(3))) void*)(patch + it * 1024),
+                                                   16, src_lane0, g0 + it * 16 * w, 0, 0);
+      }
+      const LdsReader<kAwPitch0> rd{patch};
+      bool staged = false;
+      // all samples under M -> vals[]; false: a box leaves the image
+      auto sample_all = [&](float M0, float M1, float M2, float M3) -> bool {
+        float xf, yf;
+        const bool ok = sample_pos(M0, M1, M2, M3, kx, ky, px, py, sg, w, h, &xf, &yf);
+        const int l2 = active2 ? lane : 0;
+        float xf2 = 0.f, yf2 = 0.f;
+        const float sg2 = ex_f[2][l2];
+        bool ok2 = true;
+        if (extra > 0) ok2 = sample_pos(M0, M1, M2, M3, kx, ky, ex_f[0][l2], ex_f[1][l2], sg2, w, h, &xf2, &yf2) || !active2;
+        const bool all_ok = __all((ok || !active) && ok2);
+        if (!staged) {  // (the loads are waited for even when the keypoint is dropped: the next one's may not overtake them)
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the staged rows have landed in LDS
+          __builtin_amdgcn_wave_barrier();
+          staged = true;
+        }
+        if (!all_ok) return false;
+        const int v = box_mean<T::kMaxB, false>(rd, box_masks, x0, y0, xf, yf, sg, bsc, bsc2,
+                                                __builtin_amdgcn_rcpf((float)bsc2));
+        int v2 = 0;
+        if (active2) {  // (exec-masked second call: the samples beyond the 64 lanes, 5 x 5 row slots)
+          const int b1 = ex_i[0][l2], b2 = ex_i[1][l2];
+          v2 = box_mean<T::kMaxB2, false>(rd, box_masks, x0, y0, xf2, yf2, sg2, b1, b2, __builtin_amdgcn_rcpf((float)b2));
+        }
+        __builtin_amdgcn_wave_barrier();
+        vals[extra + lane] = v;  // extra + 63 < kPatternPoints
+        if (active2) vals[lane] = v2;
+        __builtin_amdgcn_wave_barrier();
+        return true;
+      };
+      valid = sample_all(1.0f, 0.0f, 0.0f, 1.0f);
+      if (valid && mode == kGradient) {
+        int d0 = 0, d1 = 0;
+        // four long pairs per lane and trip: the table reads, then the eight value gathers, are issued together (one at
+        // a time the loop was 15 x two dependent LDS round trips); slots past n_long carry weight 0
+        for (int l0 = 0; l0 < nl; l0 += 256) {  // wave-uniform
+          uint2 e[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int l = l0 + 64 * u + lane;
+            e[u] = long_tab[l < kMaxLongPairs ? l : 0];
+            if (l >= nl) e[u] = make_uint2(0u, 0u);
+          }
+          int dt[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dt[u] = vals[e[u].x & 255u] - vals[(e[u].x >> 8) & 255u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            d0 += dt[u] * (int)(short)(e[u].y & 0xFFFFu) / 1024;
+            d1 += dt[u] * ((int)e[u].y >> 16) / 1024;
+          }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          d0 += __shfl_xor(d0, d);
+          d1 += __shfl_xor(d1, d);
+        }
+        int best_k = 0;
+        if (d0 != 0 || d1 != 0) {
+          // exact arg-max over the 1024 directions in a 64-step window around the float estimate (k_describe.hip)
+          const float ang = atan2f((float)d1, (float)d0);
+          const int k_est = (int)lrintf(ang * (1024.0f / 6.2831853071795864769f));
+          int bk = (k_est - 32 + lane) & 1023;
+          long long best = (long long)d0 * quarter_cos(q_sin_i, bk) + (long long)d1 * quarter_sin(q_sin_i, bk);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) {
+            const long long ob = __shfl_xor(best, d);
+            const int ok2 = __shfl_xor(bk, d);
+            if (ob > best || (ob == best && ok2 < bk)) {
+              best = ob;
+              bk = ok2;
+            }
+          }
+          best_k = bk;
+        }
+        best_k = __builtin_amdgcn_readfirstlane(best_k);
+        angle = (float)best_k * 0.3515625f;
+        new_angle = true;
+        float c = quarter_cos(q_sin_f, best_k), sn = quarter_sin(q_sin_f, best_k);
+        sn = best_k == 512 ? f_s512 : sn;
+        c = best_k == 256 ? f_c256 : (best_k == 768 ? f_c768 : c);
+        valid = sample_all(c, -sn, sn, c);
+      }
+      if (valid) {
+        unsigned long long words[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const uint32_t pr = (j & 1) ? my_pairs[j >> 1] >> 16 : my_pairs[j >> 1] & 0xFFFFu;  // slots past n_short: 0 | 0
+          const bool bit = vals[pr & 255u] > vals[pr >> 8];
+          words[j] = __ballot(bit);
+        }
+        if (lane < 6) {
+          unsigned long long wsel = words[0];
+#pragma unroll
+          for (int j = 1; j < 6; ++j)
+            if (lane == j) wsel = words[j];
+          reinterpret_cast<unsigned long long*>(desc_tmp + slot * OKVFE_DESC_BYTES)[lane] = wsel;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (new_angle) kps_tmp[slot].angle = angle;  // the rest of the record: describe_setup_kernel
+      valid_tmp[slot] = valid ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();  // vals[] / the patch are rewritten for the next keypoint
+  }
+}
+
 }  // namespace
 
 // Patch class of a camera-aware keypoint (describe_setup_dev.h computes the same on the device): 0 / 1 = LDS patch of
@@ -526,6 +754,19 @@ bool aware_extras_in_setup() {
   // kernel's tail takes 0.085 for the same work -- 688 k vs 705 k stereo-frames/s)
   static const bool own_kernel = lab_env("OKVFE_EXTRAS_KERNEL") != nullptr;
   return !own_kernel;
+}
+
+// upright / gradient modes of a whole call on describe_rot_kernel (launch_describe decides: no camera-aware image, boxes
+// of class 0, pattern circle within 64 pixels, long-pair weights within 16 bits)
+void launch_describe_rot(const uint8_t* img, int w, int h, int n_images, const Pattern* pat, const ImageParams* prm,
+                         const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in, okvfe_keypoint* kps_tmp,
+                         uint8_t* desc_tmp, uint8_t* valid_tmp, hipStream_t stream) {
+  if (n_images <= 0) return;
+  int tiles = (kp_cap + kAwWaves - 1) / kAwWaves;
+  if (tiles > 16) tiles = 16;
+  const uint32_t inv_tiles = (uint32_t)((0x100000000ull + (uint64_t)tiles - 1) / (uint64_t)tiles);
+  hipLaunchKernelGGL(describe_rot_kernel, dim3(tiles * n_images), dim3(64 * kAwWaves), 0, stream, img, w, h, pat, prm, kps_in,
+                     kp_cap, kp_count_in, kps_tmp, desc_tmp, valid_tmp, n_images, tiles, inv_tiles);
 }
 
 void launch_describe_aware(const uint8_t* img, int w, int h, int n_images, const Pattern* pat,

@@ -136,6 +136,8 @@ struct okvfe_ctx {
   std::vector<std::vector<float>> cam_norms;
   std::vector<uint8_t> cam_aware_slow;
   bool aware_fast = false;        // of the images of the current batch: none from a cam_aware_slow camera
+  bool none_aware = false;        // no image of the last parameter upload is camera-aware (describe_rot_kernel's call)
+  bool rot_fast_call = false;     // lane view: pattern_rot_ok of the owner's pattern
   int box_class_call = 0;         // lane view: pattern_box_class of the owner's pattern
   int aware_extra_box = -1;       // of the running call (aware_box_for_call): >= 0 = describe_aware_kernel serves it
   bool wide_patches = false;      // of the images of the current batch

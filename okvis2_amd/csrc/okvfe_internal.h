@@ -295,7 +295,8 @@ void launch_describe(const uint8_t* img, int w, int h, int n_images, const Patte
                      okvfe_keypoint* kps_tmp, uint8_t* desc_tmp, uint8_t* valid_tmp,
                      const PatternScales* scales, bool wide_patches, hipStream_t stream, bool setup_done = false,
                      bool all_camera_aware = false, int box_class = 0,  // (every image of the call has mode kCameraAware)
-                     int aware_extra_box = -1);  // >= 0: describe_aware_kernel serves the call (capi_detect.cpp: aware_box_for_call)
+                     int aware_extra_box = -1,  // >= 0: describe_aware_kernel serves the call (capi_detect.cpp: aware_box_for_call)
+                     bool rot_fast = false);    // no image of the call is camera-aware and the pattern suits describe_rot_kernel
 bool describe_patch_fits(float nx, float ny, int border);
 // k_describe_aware.hip: the camera-aware-only extractor with batched extra samples (round 6)
 int describe_aware_patch_class(float nx, float ny, float reach);
@@ -305,6 +306,23 @@ void launch_describe_aware(const uint8_t* img, int w, int h, int n_images, const
 // true: the set-up threads (selection kernel's tail / describe_setup_kernel) evaluate the extra samples; false: a
 // kernel of their own does (describe_extras_kernel)
 bool aware_extras_in_setup();
+// Quarter-wave lookup of the pattern's 1024-step rotation tables: sin(k) = +-Q[r or 256 - r] with Q = the first 257
+// entries of the sine table, cos(k) = sin(k + 256).  describe_rot_kernel keeps Q (ints and floats, 2 KB) in LDS instead
+// of gathering from the 16 KB of global tables inside every keypoint's chain; the host verifies once per pattern that the
+// rule reproduces all 4096 table entries bit for bit (pattern_rot_ok, capi_detect.cpp) and keeps the all-modes kernel
+// otherwise.
+template <typename V>
+__host__ __device__ inline V quarter_sin(const V* Q, int k) {
+  k &= 1023;
+  const int r = k & 255, q = k >> 8;
+  const V v = (q & 1) ? Q[256 - r] : Q[r];
+  return (q & 2) ? -v : v;
+}
+template <typename V>
+__host__ __device__ inline V quarter_cos(const V* Q, int k) { return quarter_sin(Q, k + 256); }
+void launch_describe_rot(const uint8_t* img, int w, int h, int n_images, const Pattern* pat, const ImageParams* prm,
+                         const okvfe_keypoint* kps_in, int kp_cap, const int32_t* kp_count_in, okvfe_keypoint* kps_tmp,
+                         uint8_t* desc_tmp, uint8_t* valid_tmp, hipStream_t stream);
 void launch_compact(int n_images, const DeviceCamera* cams, const ImageParams* prm,
                     const okvfe_keypoint* kps_tmp, const uint8_t* desc_tmp,
                     const uint8_t* valid_tmp, const int32_t* kp_count_in, int kp_cap,

@@ -6,6 +6,6 @@ tail -1 /tmp/ss.log
 python - <<'PY'
 import csv,glob
 f=glob.glob("/tmp/ss/**/*kernel_stats.csv",recursive=True)[0]
-for x in list(csv.DictReader(open(f)))[:4]:
+for x in list(csv.DictReader(open(f)))[:14]:
     print("%-50s calls %4s avg %9.1f us"%(x["Name"].replace("okvfe::(anonymous namespace)::","")[:50], x["Calls"], float(x["AverageNs"])/1e3))
 PY
