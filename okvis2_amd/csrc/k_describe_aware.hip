@@ -647,58 +647,64 @@ __global__ __launch_bounds__(64 * kAwWaves) __attribute__((amdgpu_waves_per_eu(5
         __builtin_amdgcn_wave_barrier();
         return true;
       };
-      valid = sample_all(1.0f, 0.0f, 0.0f, 1.0f);
-      if (valid && mode == kGradient) {
-        int d0 = 0, d1 = 0;
-        // four long pairs per lane and trip: the table reads, then the eight value gathers, are issued together (one at
-        // a time the loop was 15 x two dependent LDS round trips); slots past n_long carry weight 0
-        for (int l0 = 0; l0 < nl; l0 += 256) {  // wave-uniform
-          uint2 e[4];
+      // one or two samplings through ONE copy of the box-sum code (a loop the compiler must not unroll: two inlined
+      // copies of the row groups do not fit the instruction cache next to each other)
+      float M0 = 1.0f, M1 = 0.0f, M2 = 0.0f, M3 = 1.0f;
+      int passes = mode == kGradient ? 2 : 1;
+      asm volatile("" : "+s"(passes));
+      for (int pass = 0; pass < passes && valid; ++pass) {
+        valid = sample_all(M0, M1, M2, M3);
+        if (!valid || pass + 1 >= passes) break;
+          int d0 = 0, d1 = 0;
+          // four long pairs per lane and trip: the table reads, then the eight value gathers, are issued together (one at
+          // a time the loop was 15 x two dependent LDS round trips); slots past n_long carry weight 0
+          for (int l0 = 0; l0 < nl; l0 += 256) {  // wave-uniform
+            uint2 e[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int l = l0 + 64 * u + lane;
-            e[u] = long_tab[l < kMaxLongPairs ? l : 0];
-            if (l >= nl) e[u] = make_uint2(0u, 0u);
-          }
-          int dt[4];
+            for (int u = 0; u < 4; ++u) {
+              const int l = l0 + 64 * u + lane;
+              e[u] = long_tab[l < kMaxLongPairs ? l : 0];
+              if (l >= nl) e[u] = make_uint2(0u, 0u);
+            }
+            int dt[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) dt[u] = vals[e[u].x & 255u] - vals[(e[u].x >> 8) & 255u];
+            for (int u = 0; u < 4; ++u) dt[u] = vals[e[u].x & 255u] - vals[(e[u].x >> 8) & 255u];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            d0 += dt[u] * (int)(short)(e[u].y & 0xFFFFu) / 1024;
-            d1 += dt[u] * ((int)e[u].y >> 16) / 1024;
-          }
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-          d0 += __shfl_xor(d0, d);
-          d1 += __shfl_xor(d1, d);
-        }
-        int best_k = 0;
-        if (d0 != 0 || d1 != 0) {
-          // exact arg-max over the 1024 directions in a 64-step window around the float estimate (k_describe.hip)
-          const float ang = atan2f((float)d1, (float)d0);
-          const int k_est = (int)lrintf(ang * (1024.0f / 6.2831853071795864769f));
-          int bk = (k_est - 32 + lane) & 1023;
-          long long best = (long long)d0 * quarter_cos(q_sin_i, bk) + (long long)d1 * quarter_sin(q_sin_i, bk);
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) {
-            const long long ob = __shfl_xor(best, d);
-            const int ok2 = __shfl_xor(bk, d);
-            if (ob > best || (ob == best && ok2 < bk)) {
-              best = ob;
-              bk = ok2;
+            for (int u = 0; u < 4; ++u) {
+              d0 += dt[u] * (int)(short)(e[u].y & 0xFFFFu) / 1024;
+              d1 += dt[u] * ((int)e[u].y >> 16) / 1024;
             }
           }
-          best_k = bk;
-        }
-        best_k = __builtin_amdgcn_readfirstlane(best_k);
-        angle = (float)best_k * 0.3515625f;
-        new_angle = true;
-        float c = quarter_cos(q_sin_f, best_k), sn = quarter_sin(q_sin_f, best_k);
-        sn = best_k == 512 ? f_s512 : sn;
-        c = best_k == 256 ? f_c256 : (best_k == 768 ? f_c768 : c);
-        valid = sample_all(c, -sn, sn, c);
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) {
+            d0 += __shfl_xor(d0, d);
+            d1 += __shfl_xor(d1, d);
+          }
+          int best_k = 0;
+          if (d0 != 0 || d1 != 0) {
+            // exact arg-max over the 1024 directions in a 64-step window around the float estimate (k_describe.hip)
+            const float ang = atan2f((float)d1, (float)d0);
+            const int k_est = (int)lrintf(ang * (1024.0f / 6.2831853071795864769f));
+            int bk = (k_est - 32 + lane) & 1023;
+            long long best = (long long)d0 * quarter_cos(q_sin_i, bk) + (long long)d1 * quarter_sin(q_sin_i, bk);
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+              const long long ob = __shfl_xor(best, d);
+              const int ok2 = __shfl_xor(bk, d);
+              if (ob > best || (ob == best && ok2 < bk)) {
+                best = ob;
+                bk = ok2;
+              }
+            }
+            best_k = bk;
+          }
+          best_k = __builtin_amdgcn_readfirstlane(best_k);
+          angle = (float)best_k * 0.3515625f;
+          new_angle = true;
+          float c = quarter_cos(q_sin_f, best_k), sn = quarter_sin(q_sin_f, best_k);
+          sn = best_k == 512 ? f_s512 : sn;
+          c = best_k == 256 ? f_c256 : (best_k == 768 ? f_c768 : c);
+          M0 = c; M1 = -sn; M2 = sn; M3 = c;
       }
       if (valid) {
         unsigned long long words[6];
