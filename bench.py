@@ -770,6 +770,8 @@ def main():
                     help="informational: install the built-in pattern with every smoothing box widened by this factor "
                          "(1.73 = what the vocabulary's statistics favour, tools/pattern/README.md); the oracle of the "
                          "cpu_baseline leg gets the same pattern")
+    ap.add_argument("--pipelined-lanes", type=int, default=4,
+                    help="lanes of the `pipelined_lanes` leg (okvfe_set_internal_lanes(-K) on the one context of `value`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-fed / dense-content legs")
     ap.add_argument("--exact-steps", action="store_true",
@@ -1179,6 +1181,42 @@ def main():
             for lane in lanes4:
                 lane[0].close()
             del lanes4
+        # (1c') the same on ONE context: okvfe_set_internal_lanes(-4), pipelined lanes -- the call does not join its four
+        # slices onto the caller's stream and the matcher runs on the lane streams too, so lane l starts the next step
+        # behind its own previous work (what the four contexts above get from being separate); joined at the end
+        if S == 1 and C == 2 and B % 4 == 0 and B // 4 >= distinct:
+            try:
+                fe.set_internal_lanes(-args.pipelined_lanes)
+                for _ in range(3):
+                    step("device")
+                n_p = max(3, min(args.steps, 40))
+                el_p, _ = timed(n_p, "device")  # (torch.cuda.synchronize() inside covers the lane streams: device-wide)
+                fe.lanes_join(lanes[0][1])
+                torch.cuda.synchronize()
+                fe.check_capacity(n_lane_img)
+                mp_ = d_match[:distinct].cpu().numpy().copy()
+                outp = [fe.download(i) for i in range(C * distinct)]
+                fe.set_internal_lanes(0)
+                state["step"] -= 1
+                step("device")
+                torch.cuda.synchronize()
+                m1 = d_match[:distinct].cpu().numpy()
+                same = all(np.array_equal(p.view(np.uint8), q.view(np.uint8))
+                           for i in range(C * distinct) for p, q in zip(outp[i], fe.download(i)))
+                same = same and all(np.array_equal(mp_[f, :len(outp[C * f][0])], m1[f, :len(outp[C * f][0])])
+                                    for f in range(distinct))
+                extras["pipelined_lanes"] = {
+                    "value": world * B * n_p / el_p, "steps": n_p, "ms_per_step": 1e3 * el_p / n_p, "internal_lanes": -args.pipelined_lanes,
+                    "outputs_equal_unsplit_call": bool(same),
+                    "note": "ONE context, one caller stream, okvfe_set_internal_lanes(-K): K slices per call on the "
+                            "context's own streams without a join per call (include/okvfe.h states the contract)"}
+            except Exception as e:  # (an informational leg must not take the line down)
+                extras["pipelined_lanes"] = {"error": str(e)[:300]}
+            finally:
+                try:
+                    fe.set_internal_lanes(0)
+                except Exception:
+                    pass
         # (1d) the content of rounds 1-5: 16 distinct stereo pairs tiled over the batch (selection and matcher then see
         # 32 different images per step instead of 2 x --distinct)
         if args.content == "corners" and n_content > 16:
@@ -1325,6 +1363,7 @@ def main():
         result["value_score_map_kept"] = extras.get("score_map_kept", {}).get("value")
         result["value_host_fed"] = extras.get("host_fed", {}).get("value")
         result["value_four_lanes"] = extras.get("four_lanes", {}).get("value")
+        result["value_pipelined_lanes"] = extras.get("pipelined_lanes", {}).get("value")
         if cpu is not None:
             result["cpu_baseline"] = cpu
         print(json.dumps(result), flush=True)

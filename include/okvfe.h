@@ -276,8 +276,19 @@ okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep);
  * call, byte for byte (every kernel works per image).  lanes = 0: the library's choice -- at present not to cut: with
  * ONE caller stream every call ends in a join, the slices run in phase and measure 1-5 % slower than the unsplit call,
  * while several contexts on several streams (lanes that drift out of phase across calls) gain 8 %: DESIGN.md (e); 1: off;
- * 2..8: that many.  Single-scale contexts only; others ignore it. */
+ * 2..8: that many.  Single-scale contexts only; others ignore it.
+ * NEGATIVE, -2 .. -8: PIPELINED lanes.  The call does not join its lanes onto the caller's stream at all, and an
+ * okvfe_match_stereo_batch_device that follows matches each slice's pairs on that slice's lane stream (every pair inside
+ * one slice, the slices' pairs in contiguous runs -- what a batch of stereo pairs (2i, 2i + 1) is).  Lane l then starts
+ * the NEXT call's score kernel behind its own previous work instead of behind everybody's: the lanes drift out of phase
+ * and stay there, which is what makes several contexts on several streams faster than one.  The price is the contract:
+ * after such a call returns, work the CALLER queues on its stream is NOT ordered behind the results.  Any other entry
+ * point of the context joins first (stream-taking ones make their stream wait, host-side readers synchronise), and
+ * okvfe_lanes_join(ctx, stream) does it explicitly; the caller must join before it overwrites the input images or reads
+ * okvfe_device_outputs / the match rows with kernels of its own.  Results are the unsplit call's, byte for byte. */
 okvfe_status okvfe_set_internal_lanes(okvfe_ctx* ctx, int32_t lanes);
+/* Makes `stream` (NULL: the context's own) wait for every pipelined lane of the context; no-op when none is pending. */
+okvfe_status okvfe_lanes_join(okvfe_ctx* ctx, void* stream);
 
 /* Order of every 3-term FP64 sum in the matchers' gate chain (dot products, norms, C * v and C^T * v:
  * stereo_triangulation.cpp:62-76, Frontend.cpp:2027-2073 evaluate them through Eigen):

@@ -82,7 +82,7 @@ EXPORTS = [
     "okvfe_create", "okvfe_destroy", "okvfe_last_error", "okvfe_abi_version",
     "okvfe_set_camera_maps", "okvfe_set_camera", "okvfe_build_awareness_maps",
     "okvfe_detect_describe", "okvfe_detect", "okvfe_detect_ahead", "okvfe_detect_describe_batch_device",
-    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_set_heavy_kernel_chaining", "okvfe_set_keep_score_map", "okvfe_set_internal_lanes", "okvfe_set_fp64_reduction", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device", "okvfe_harris_byte_mover_device",
+    "okvfe_get_device_outputs", "okvfe_score_column", "okvfe_set_heavy_kernel_chaining", "okvfe_set_keep_score_map", "okvfe_set_internal_lanes", "okvfe_lanes_join", "okvfe_set_fp64_reduction", "okvfe_scale_index", "okvfe_download_image_result", "okvfe_harris_score_device", "okvfe_harris_byte_mover_device",
     "okvfe_match_stereo_batch_device", "okvfe_match_stereo", "okvfe_hamming_candidates",
     "okvfe_hamming_argmin", "okvfe_popcnt_xor", "okvfe_gather_block_bytes",
     "okvfe_pack_gather_block_device", "okvfe_match_stereo_blocks_device",
@@ -500,6 +500,10 @@ class Frontend:
         """okvfe_set_internal_lanes: slices a batch call is cut into, each on a stream of the context's own
         (0 = automatic, 1 = off)."""
         self._check(lib().okvfe_set_internal_lanes(self._h, int(lanes)))
+
+    def lanes_join(self, stream=None):
+        """okvfe_lanes_join: `stream` (None: the context's own) waits for every pipelined lane (set_internal_lanes(-k))"""
+        self._check(lib().okvfe_lanes_join(self._h, _s(stream)))
 
     def set_fp64_reduction(self, eigen_tree: bool = True):
         """okvfe_set_fp64_reduction: order of the 3-term FP64 sums of the gate chain -- Eigen's x0 + (x1 + x2)

@@ -229,10 +229,28 @@ okvfe_status check_size_classes(okvfe_ctx* ctx, const okvfe_keypoint* kp, int n,
 // NULL = the context's own non-blocking stream; OKVFE_STREAM_LEGACY_DEFAULT = the HIP legacy
 // default (null) stream, which is what torch.cuda.default_stream() is: its handle is 0 and could
 // not be told apart from "no stream given" otherwise.
-hipStream_t pick_stream(okvfe_ctx* ctx, void* stream) {
+hipStream_t pick_stream_raw(okvfe_ctx* ctx, void* stream) {
   if (!stream) return ctx->stream;
   if (stream == OKVFE_STREAM_LEGACY_DEFAULT) return static_cast<hipStream_t>(nullptr);
   return static_cast<hipStream_t>(stream);
+}
+hipStream_t pick_stream(okvfe_ctx* ctx, void* stream) {
+  hipStream_t s = pick_stream_raw(ctx, stream);
+  if (ctx->lanes_pending && ctx->join_done) {  // pipelined lanes: whatever this call queues on s sees their results
+    if (hipStreamWaitEvent(s, ctx->join_done, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+    }
+    ctx->lanes_pending = false;
+  }
+  return s;
+}
+okvfe_status lanes_join_host(okvfe_ctx* ctx) {
+  if (!ctx->lanes_pending) return OKVFE_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (ctx->join_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->join_stream));
+  ctx->lanes_pending = false;
+  return OKVFE_OK;
 }
 
 void layer_size(int w, int h, int l, int* lw, int* lh) {  // oracle: orc_layer_size
@@ -284,8 +302,18 @@ okvfe_status okvfe_set_keep_score_map(okvfe_ctx* ctx, int32_t keep) {
 
 okvfe_status okvfe_set_internal_lanes(okvfe_ctx* ctx, int32_t lanes) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
-  if (lanes < 0 || lanes > 8) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_internal_lanes: %d (0 .. 8)", lanes);
-  ctx->internal_lanes = lanes;
+  if (lanes < -8 || lanes > 8) return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_set_internal_lanes: %d (-8 .. 8)", lanes);
+  okvfe_status st = lanes_join_host(ctx);
+  if (st != OKVFE_OK) return st;
+  ctx->internal_lanes = lanes < 0 ? -lanes : lanes;
+  ctx->lanes_pipelined = lanes < -1;
+  return OKVFE_OK;
+}
+
+okvfe_status okvfe_lanes_join(okvfe_ctx* ctx, void* stream) {
+  if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  (void)pick_stream(ctx, stream);
   return OKVFE_OK;
 }
 
@@ -533,6 +561,11 @@ void okvfe_destroy(okvfe_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->cfg.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->join_stream) {
+    (void)hipStreamSynchronize(ctx->join_stream);
+    (void)hipStreamDestroy(ctx->join_stream);
+  }
+  if (ctx->join_done) (void)hipEventDestroy(ctx->join_done);
   if (ctx->last_stream) (void)hipStreamSynchronize(ctx->last_stream);
   for (okvfe_ctx* ch : ctx->layers) okvfe_destroy(ch);
   for (okvfe_ctx* v : ctx->lane_ctx) {  // views: a stream and two chaining events each, no memory
@@ -670,6 +703,7 @@ okvfe_status okvfe_set_camera(okvfe_ctx* ctx, int32_t cam, const okvfe_camera* c
 okvfe_status okvfe_profile_enable(okvfe_ctx* ctx, int32_t enable) {
   if (!ctx) return OKVFE_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  { const okvfe_status js = lanes_join_host(ctx); if (js != OKVFE_OK) return js; }
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& e : ctx->prof_events) {
@@ -685,6 +719,7 @@ okvfe_status okvfe_profile_read(okvfe_ctx* ctx, double total_ms[OKVFE_STAGE_COUN
                                 int32_t launches[OKVFE_STAGE_COUNT]) {
   if (!ctx || !total_ms || !launches) return OKVFE_ERR_INVALID_ARGUMENT;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  { const okvfe_status js = lanes_join_host(ctx); if (js != OKVFE_OK) return js; }
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < OKVFE_STAGE_COUNT; ++i) {
@@ -772,6 +807,7 @@ okvfe_status okvfe_set_pattern(okvfe_ctx* ctx, const okvfe_pattern* p) {
   }
   fill_aware_lanes(&P);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  { const okvfe_status js = lanes_join_host(ctx); if (js != OKVFE_OK) return js; }
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipMemcpy(ctx->d_pattern, &P, sizeof(Pattern), hipMemcpyHostToDevice));

@@ -405,6 +405,7 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
 // synchronises the last stream
 okvfe_status find_overflow(okvfe_ctx* ctx, int first, int n_images, int* bad, int* count, int* cap) {
   *bad = -1;
+  { const okvfe_status js = lanes_join_host(ctx); if (js != OKVFE_OK) return js; }
   if (ctx->last_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->last_stream));
   std::vector<int32_t> counts(n_images);
   const int L = ctx->n_layers;
@@ -469,6 +470,15 @@ int lanes_for_call(const okvfe_ctx* ctx, int n_images) {
   if (k > 8) k = 8;
   while (k > 1 && n_images / k < 64) --k;
   return k < 1 ? 1 : k;
+}
+
+okvfe_status ensure_join(okvfe_ctx* ctx) {
+  if (!ctx->join_stream) {
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->join_stream, hipStreamNonBlocking));
+  }
+  if (!ctx->join_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->join_done, hipEventDisableTiming));
+  return OKVFE_OK;
 }
 
 okvfe_status ensure_lanes(okvfe_ctx* ctx, int k) {
@@ -547,8 +557,10 @@ void bind_lane(okvfe_ctx* v, okvfe_ctx* p, int first, int n) {
 }
 
 // detect + describe of a device-resident batch, in lanes when the call is large enough
-okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
-  const int k = lanes_for_call(ctx, n_images);
+okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s,
+                                   bool pipelined = false) {
+  // (a context set to pipelined lanes splits only the calls that can stay un-joined; everything else runs unsplit)
+  const int k = ctx->lanes_pipelined && !pipelined ? 1 : lanes_for_call(ctx, n_images);
   okvfe_status st;
   if (k <= 1) {
     st = detect_stage(ctx, images_dev, n_images, s);
@@ -579,7 +591,8 @@ okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, in
     okvfe_ctx* v = ctx->lane_ctx[l];
     bind_lane(v, ctx, first, n);
     static const bool no_chain = lab_env("OKVFE_LANES_NOCHAIN") != nullptr;  // A/B knob
-    v->k1_wait = l > 0 && !no_chain ? ctx->lane_ctx[l - 1]->k1_done : nullptr;
+    // (pipelined lanes are never chained: each follows its own previous call, like separate contexts)
+    v->k1_wait = l > 0 && !no_chain && !pipelined ? ctx->lane_ctx[l - 1]->k1_done : nullptr;
     v->score_stream = ctx->score_stream;
     HIP_TRY(ctx, hipStreamWaitEvent(v->stream, ctx->lane_fork, 0));
     if (ctx->score_stream && l == 0) HIP_TRY(ctx, hipStreamWaitEvent(ctx->score_stream, ctx->lane_fork, 0));
@@ -593,7 +606,17 @@ okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, in
     HIP_TRY(ctx, hipEventRecord(ctx->lane_done[l], v->stream));
     used = l + 1;
   }
-  for (int l = 0; l < used; ++l) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lane_done[l], 0));
+  if (pipelined) {
+    // no join onto the caller's stream: the join stream waits for every lane (it is what releases the parameter slot)
+    // and `join_done` is what a later consumer waits for (pick_stream / lanes_join_host)
+    if ((st = ensure_join(ctx)) != OKVFE_OK) return st;
+    for (int l = 0; l < used; ++l) HIP_TRY(ctx, hipStreamWaitEvent(ctx->join_stream, ctx->lane_done[l], 0));
+    ctx->lanes_pending = true;
+    ctx->lanes_used = used;
+    ctx->lane_chunk = chunk;
+  } else {
+    for (int l = 0; l < used; ++l) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->lane_done[l], 0));
+  }
   ctx->fuse_setup = false;
   ctx->setup_done = false;
   ctx->counters_cleared = false;
@@ -605,7 +628,8 @@ okvfe_status detect_describe_split(okvfe_ctx* ctx, const uint8_t* images_dev, in
   ctx->last_n_images = n_images;
   const int slot = ctx->prm_slot;
   ctx->prm_slot = -1;
-  st = ring_release(ctx, &ctx->prm_ring, slot, s);  // behind the join: every lane has read its parameters
+  st = ring_release(ctx, &ctx->prm_ring, slot, pipelined ? ctx->join_stream : s);  // behind the join: every lane has read its parameters
+  if (pipelined && st == OKVFE_OK) HIP_TRY(ctx, hipEventRecord(ctx->join_done, ctx->join_stream));
   if (first_err != OKVFE_OK) {
     ctx->detected_images = 0;
     return first_err;
@@ -650,12 +674,22 @@ okvfe_status okvfe_detect_describe_batch_device(okvfe_ctx* ctx, const uint8_t* i
     return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_detect_describe_batch_device: n_images=%d (max_batch %d)",
                 n_images, ctx->B);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  hipStream_t s = pick_stream(ctx, stream);
-  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, true);
+  // pipelined lanes (okvfe_set_internal_lanes(-k)): no join onto the caller's stream, neither before nor after the call,
+  // as long as the slices stay what they were (a lane only ever follows ITS OWN previous work)
+  bool piped = false;
+  if (ctx->lanes_pipelined) {
+    const int k = lanes_for_call(ctx, n_images);
+    const int chunk = (((n_images + k - 1) / k) + 7) & ~7;
+    piped = k > 1 && (!ctx->lanes_pending || ctx->lane_chunk == chunk);
+  }
+  hipStream_t s = piped ? pick_stream_raw(ctx, stream) : pick_stream(ctx, stream);
+  // (pipelined: the candidate counters are cleared by every lane on its own stream, not by the parameter upload on the
+  // caller's -- a lane may still be reading last call's)
+  okvfe_status st = upload_image_params(ctx, n_images, cam_ids, gravity_C, s, !piped);
   if (st != OKVFE_OK) return st;
   static const bool no_fuse = lab_env("OKVFE_NO_FUSED_SETUP") != nullptr;  // A/B knob
   ctx->fuse_setup = !no_fuse;
-  return detect_describe_split(ctx, images_dev, n_images, s);
+  return detect_describe_split(ctx, images_dev, n_images, s, piped);
 }
 
 okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* images_host, int32_t n_images,
@@ -714,6 +748,7 @@ okvfe_status okvfe_detect_describe_batch_host(okvfe_ctx* ctx, const uint8_t* ima
 
 okvfe_status okvfe_get_device_outputs(okvfe_ctx* ctx, okvfe_device_outputs* out) {
   if (!ctx || !out) return OKVFE_ERR_INVALID_ARGUMENT;
+  { const okvfe_status js = lanes_join_host(ctx); if (js != OKVFE_OK) return js; }  // (pipelined lanes: the caller is about to read)
   out->max_keypoints = ctx->kp_cap;
   out->counts = ctx->d_count;
   out->keypoints = ctx->d_kps;
@@ -892,7 +927,9 @@ okvfe_status okvfe_download_image_result(okvfe_ctx* ctx, int32_t index, okvfe_ke
                 ctx->last_n_images);
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   ctx->ahead.valid = false;  // h_result is reused
-  okvfe_status st = export_and_wait(ctx, index, true, ctx->last_stream ? ctx->last_stream : ctx->stream);
+  okvfe_status st = lanes_join_host(ctx);  // (pipelined lanes: the results are read on the host next)
+  if (st != OKVFE_OK) return st;
+  st = export_and_wait(ctx, index, true, ctx->last_stream ? ctx->last_stream : ctx->stream);
   if (st != OKVFE_OK) return st;
   return copy_results_out(ctx, keypoints, descriptors, backproj, backproj_valid, cap, n_out);
 }

@@ -14,7 +14,6 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
   if (!pairs || !matches_dev || n_pairs < 1)
     return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "okvfe_match_stereo_batch_device: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-  hipStream_t s = pick_stream(ctx, stream);
   std::vector<PairParams> pp(n_pairs);
   for (int i = 0; i < n_pairs; ++i) {
     if (pairs[i].image0 < 0 || pairs[i].image0 >= ctx->B || pairs[i].image1 < 0 || pairs[i].image1 >= ctx->B ||
@@ -22,6 +21,22 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
       return fail(ctx, OKVFE_ERR_INVALID_ARGUMENT, "pair %d: image index or focal length out of range", i);
     pp[i] = to_pair_params(pairs[i]);
   }
+  // pipelined lanes (okvfe_set_internal_lanes(-k)): the pairs of a slice are matched on the slice's lane stream, behind
+  // its detect + describe chain, when every pair lies inside one slice and the slices' pairs are contiguous runs
+  std::vector<int> lane_first;
+  bool piped = ctx->lanes_pipelined && ctx->lanes_pending && ctx->n_layers == 1 && ctx->lane_chunk > 0 &&
+               ctx->lanes_used > 1 && (int)ctx->lane_ctx.size() >= ctx->lanes_used && ctx->join_stream;
+  if (piped) {
+    lane_first.assign(ctx->lanes_used + 1, n_pairs);
+    int cur = -1;
+    for (int i = 0; i < n_pairs && piped; ++i) {
+      const int l0 = pairs[i].image0 / ctx->lane_chunk, l1 = pairs[i].image1 / ctx->lane_chunk;
+      if (l0 != l1 || l0 < cur || l0 >= ctx->lanes_used) piped = false;
+      while (piped && cur < l0) lane_first[++cur] = i;
+    }
+    while (piped && cur < ctx->lanes_used - 1) lane_first[++cur] = n_pairs;
+  }
+  hipStream_t s = piped ? pick_stream_raw(ctx, stream) : pick_stream(ctx, stream);
   okvfe_status st;
   int cls_slot = -1;
   if (ctx->n_layers > 1) {
@@ -51,6 +66,27 @@ okvfe_status okvfe_match_stereo_batch_device(okvfe_ctx* ctx, const okvfe_stereo_
   int slot = -1;
   st = ring_upload(ctx, &ctx->pair_ring, pp.data(), (size_t)n_pairs * sizeof(PairParams), s, &d_pairs, &slot);
   if (st != OKVFE_OK) return st;
+  if (piped) {
+    HIP_TRY(ctx, hipEventRecord(ctx->lane_fork, s));  // behind the pair upload
+    for (int l = 0; l < ctx->lanes_used; ++l) {
+      const int first = lane_first[l], n = lane_first[l + 1] - first;
+      hipStream_t ls = ctx->lane_ctx[l]->stream;
+      HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->lane_fork, 0));
+      if (n > 0) {
+        StageTimer t(ctx, OKVFE_STAGE_MATCH, ls);
+        launch_match_stereo(static_cast<const PairParams*>(d_pairs) + first, n, ctx->d_kps, ctx->d_desc, ctx->d_bp,
+                            ctx->d_bpv, ctx->d_count, ctx->kp_cap, ctx->cfg.match_threshold,
+                            matches_dev + (size_t)first * ctx->kp_cap, ls);
+      }
+      HIP_TRY(ctx, hipEventRecord(ctx->lane_done[l], ls));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->join_stream, ctx->lane_done[l], 0));
+    }
+    if ((st = ring_release(ctx, &ctx->pair_ring, slot, ctx->join_stream)) != OKVFE_OK) return st;
+    HIP_TRY(ctx, hipEventRecord(ctx->join_done, ctx->join_stream));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_stream = s;
+    return OKVFE_OK;
+  }
   {
     StageTimer t(ctx, OKVFE_STAGE_MATCH, s);
     launch_match_stereo(static_cast<const PairParams*>(d_pairs), n_pairs, ctx->d_kps, ctx->d_desc, ctx->d_bp,

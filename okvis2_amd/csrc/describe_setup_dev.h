@@ -209,7 +209,10 @@ __device__ __forceinline__ void describe_setup_one(const DescribeSetup& ds, int 
         bx1 = bx1 > w - 1 ? w - 1 : bx1;
         by1 = by1 > h - 1 ? h - 1 : by1;
         const int px0 = bx0 & ~3, pw = bx1 - px0 + 1, ph = by1 - by0 + 1;
-        const int cls = (pw <= 64 && ph <= 64) ? 0 : ((pw <= 80 && ph <= 72) ? 1 : 3);
+#ifndef OKVFE_AWARE_PITCH80
+#define OKVFE_AWARE_PITCH80 0  // A/B: every patch in the 80-byte-pitch class (rows step through 16 bank phases instead of 4)
+#endif
+        const int cls = (!OKVFE_AWARE_PITCH80 && pw <= 64 && ph <= 64) ? 0 : ((pw <= 80 && ph <= 72) ? 1 : 3);
         if (pw >= 1 && ph >= 1 && px0 < 4096 && by0 < 4096) {
           g0 = by0 * w + px0;
           g1 = (px0 >> 2) | (by0 << 10) | ((cls == 3 ? 0 : ph) << 22) | (cls << 29);

@@ -110,6 +110,17 @@ struct okvfe_ctx {
   // score kernels of all slices back to back, the slices' tails (fix-up .. compaction) run on high-priority lane streams
   hipStream_t score_stream = nullptr;  // owner: the low-priority stream; lane view: where its score kernel goes (or null)
   bool lanes_prio = false;             // owner: lane streams were created with priorities
+  // PIPELINED lanes (okvfe_set_internal_lanes(ctx, -k)): the call does not join its lanes onto the caller's stream; the
+  // slices' chains -- and those of the okvfe_match_stereo_batch_device call that follows -- stay on the lane streams, so
+  // lane l starts the next call's score kernel behind ITS OWN previous work and the lanes drift out of phase, as separate
+  // contexts do.  The join happens when something needs the results: any other entry point of this context (the stream
+  // it is given waits for `join_done`; host-side readers synchronise), or okvfe_lanes_join.
+  bool lanes_pipelined = false;        // owner: internal_lanes was set negative
+  bool lanes_pending = false;          // owner: lane work has been issued that the caller's streams have not waited for
+  int lanes_used = 0;                  // owner: lanes of the pending call
+  int lane_chunk = 0;                  // owner: images per lane of the pending call
+  hipStream_t join_stream = nullptr;   // owner: waits for every lane, releases the parameter slots, records join_done
+  hipEvent_t join_done = nullptr;
 
   // scale space (octaves > 0): one detect-only child context per layer (K1..K4 at the layer's
   // size), layer images for l >= 1 owned here; this (parent) context keeps the merged keypoints
@@ -221,7 +232,9 @@ double layer_keypoint_size(int l);
 void fill_class_table(double* t, double f0, double f1, bool motion);
 constexpr size_t kClassTableDoubles = 2 * kSizeClasses * kSizeClasses;
 okvfe_status check_size_classes(okvfe_ctx* ctx, const okvfe_keypoint* kp, int n, bool* multi);
-hipStream_t pick_stream(okvfe_ctx* ctx, void* stream);
+hipStream_t pick_stream(okvfe_ctx* ctx, void* stream);      // joins pending pipelined lanes onto the stream it returns
+hipStream_t pick_stream_raw(okvfe_ctx* ctx, void* stream);  // no join (the lane-aware entry points)
+okvfe_status lanes_join_host(okvfe_ctx* ctx);               // host-side join of pending pipelined lanes
 void layer_size(int w, int h, int l, int* lw, int* lh);
 void layer_scale(int l, int* num, int* den);
 

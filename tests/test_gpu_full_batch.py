@@ -135,6 +135,26 @@ def test_full_size_batch_replicas_permutation_idempotence(oracle, workload, FRAM
             assert _digest(res3, matches3) == first, lanes
             del res3, matches3
         fe.set_internal_lanes(0)
+        # ---- pipelined lanes (okvfe_set_internal_lanes(-k)): no join onto the caller's stream, the matcher on the lane
+        # streams too; three steps queued back to back on alternating content (lane l starts step n + 1 behind its own
+        # step n only), then the join through the host-side readers: same bytes as the unsplit call
+        d_img_b = torch.flip(d_img, dims=[2]).contiguous()  # other content in the same buffers' slices
+        cam_ids = np.array([0, 1] * FRAMES, dtype=np.int32)
+        sptr = torch.cuda.current_stream().cuda_stream
+        for lanes in (-4, -3):
+            fe.set_internal_lanes(lanes)
+            for img_t in (d_img, d_img_b, d_img):
+                fe.detect_describe_batch_device(img_t.data_ptr(), 2 * FRAMES, cam_ids, grav, sptr)
+                fe.match_stereo_batch_device(pairs, d_match.data_ptr(), sptr)
+            fe.lanes_join(sptr)
+            torch.cuda.synchronize()
+            fe.check_capacity(2 * FRAMES)
+            res4 = [fe.download(i) for i in range(2 * FRAMES)]
+            rows = d_match.cpu().numpy().view(capi.STEREO_MATCH_DTYPE).reshape(FRAMES, -1)
+            matches4 = [rows[f, :len(res4[2 * f][0])].copy() for f in range(FRAMES)]
+            assert _digest(res4, matches4) == first, lanes
+            del res4, matches4
+        fe.set_internal_lanes(0)
 
     # ---- permutation: multiframes in reversed order
     order = np.arange(FRAMES)[::-1].copy()
