@@ -590,6 +590,9 @@ void okvfe_destroy(okvfe_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->score_stream);
     (void)hipStreamDestroy(ctx->score_stream);
   }
+  for (hipEvent_t ev : ctx->layer_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->layer_fork) (void)hipEventDestroy(ctx->layer_fork);
   for (uint8_t* p : ctx->d_layer_img)
     if (p) (void)hipFree(p);
   if (ctx->d_virtual) (void)hipFree(ctx->d_virtual);

@@ -240,6 +240,128 @@ void layer_select(okvfe_ctx* L, int n_images, hipStream_t s) {
                                 L->d_sort_ws, s, fuse ? &setup : nullptr, L->map_free_live ? L->live_images : nullptr);
 }
 
+static bool scale_space_serial() {
+  static const bool serial = lab_env("OKVFE_SS_SERIAL") != nullptr;  // A/B knob: the layers one after the other on one stream
+  return serial;
+}
+
+// scale of layer l relative to layer m, reduced (oracle: the layer ratios of detect_scale_space)
+static void layer_ratio(int l, int m, int out[2]) {
+  int sn, sd, mn, md;
+  layer_scale(l, &sn, &sd);
+  layer_scale(m, &mn, &md);
+  int rn = sn * md, rd = sd * mn;
+  for (int g = 2; g <= 3; ++g)
+    while (rn % g == 0 && rd % g == 0) { rn /= g; rd /= g; }
+  out[0] = rn; out[1] = rd;
+}
+
+// The scale space of one call with its layers SIDE BY SIDE (round 6): the kernels of the small layers are a few hundred
+// workgroups each -- one after the other on one stream they left most of the GPU idle (scale filter 4 x 0.1 ms,
+// refinement 4 x 0.05, NMS of the upper layers ...).  Layer l runs on the stream of its own layer context:
+//   sampler (behind the image it samples) -> score map -> NMS            | event "map l"
+//   (behind the maps of l - 1 and l + 1) scale filter -> sort -> selection / refinement | event "done l"
+// and the caller's stream picks up behind all "done" events for the merge.  Same kernels, same results.
+static okvfe_status detect_layers_concurrent(okvfe_ctx* ctx, const uint8_t* images_dev, int n_images, hipStream_t s) {
+  const int L = ctx->n_layers;
+  HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+  if (!ctx->layer_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->layer_fork, hipEventDisableTiming));
+  while ((int)ctx->layer_ev.size() < 3 * L) {
+    hipEvent_t ev = nullptr;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->layer_ev.push_back(ev);
+  }
+  static const int own_mask = lab_env("OKVFE_SS_OWN") ? atoi(lab_env("OKVFE_SS_OWN")) : 0xFF;  // bisecting knob: layers on streams of their own
+  auto ev_img = [&](int l) { return ctx->layer_ev[3 * l]; };
+  auto ev_map = [&](int l) { return ctx->layer_ev[3 * l + 1]; };
+  auto ev_done = [&](int l) { return ctx->layer_ev[3 * l + 2]; };
+  std::vector<const uint8_t*> img(L);
+  img[0] = images_dev;
+  for (int l = 1; l < L; ++l) img[l] = ctx->d_layer_img[l];
+  const bool brisk_ss = ctx->cfg.score_type == OKVFE_SCORE_BRISK_SCALESPACE;
+  HIP_TRY(ctx, hipEventRecord(ctx->layer_fork, s));
+  // ---- per layer: image, score map, 2-D maxima
+  for (int l = 0; l < L; ++l) {
+    okvfe_ctx* ch = ctx->layers[l];
+    hipStream_t ls = ((own_mask >> l) & 1) ? ch->stream : s;
+    HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->layer_fork, 0));
+    if (l == 1) {
+      launch_twothird(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_layer_img[1], ls);
+    } else if (l >= 2) {
+      if (l - 2 >= 1) HIP_TRY(ctx, hipStreamWaitEvent(ls, ev_img(l - 2), 0));  // (layer 0 is the caller's image)
+      launch_halfsample(img[l - 2], ctx->layer_w[l - 2], ctx->layer_h[l - 2], n_images, ctx->d_layer_img[l], ls);
+    }
+    if (l >= 1) HIP_TRY(ctx, hipEventRecord(ev_img(l), ls));
+    static const int dbg_l1 = lab_env("OKVFE_SS_DBG_L1") ? atoi(lab_env("OKVFE_SS_DBG_L1")) : 0;  // bisecting knob
+    if (l == 1 && dbg_l1 == 1) (void)hipDeviceSynchronize();
+    static const bool dbg_memset = lab_env("OKVFE_SS_DBG_MEMSET") != nullptr;  // bisecting knob: the runtime's memset
+    if (dbg_memset)
+      HIP_TRY(ctx, hipMemsetAsync(ch->d_cand_count, 0, 2 * (size_t)ch->B * sizeof(int32_t), ls));
+    else  // counters cleared by a kernel of our own (stays in the layer's compute queue)
+      launch_param_copy(nullptr, nullptr, 0, ch->d_cand_count, 2 * ch->B, ls, nullptr, 0);
+    bool f;
+    layer_score_nms(ch, img[l], n_images, ls, &f);
+    if (l == 1 && dbg_l1 == 2) (void)hipDeviceSynchronize();
+    if (l == 0 && ctx->d_virtual) launch_fast58_score(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_virtual, ls);
+    layer_nms_finish(ch, n_images, ls, f);
+    HIP_TRY(ctx, hipEventRecord(ev_map(l), ls));
+    if (const char* m = lab_env("OKVFE_SS_DBG_A"))  // bisecting knob: device sync behind the layers of this bit mask
+      if ((atoi(m) >> l) & 1) (void)hipDeviceSynchronize();
+  }
+  static const char* dbg = lab_env("OKVFE_SS_DBG");  // bisecting knob: 1 = device sync between the phases, 2 = after every layer too
+  if (dbg) (void)hipDeviceSynchronize();
+  // ---- per layer: scale-space maxima against the finished maps below and above, order, selection / refinement
+  for (int l = 0; l < L; ++l) {
+    okvfe_ctx* ch = ctx->layers[l];
+    hipStream_t ls = ((own_mask >> l) & 1) ? ch->stream : s;
+    if (dbg && dbg[0] == '2') (void)hipDeviceSynchronize();
+    if (l > 0) HIP_TRY(ctx, hipStreamWaitEvent(ls, ev_map(l - 1), 0));
+    if (l + 1 < L) HIP_TRY(ctx, hipStreamWaitEvent(ls, ev_map(l + 1), 0));
+    const int32_t *below = nullptr, *above = nullptr;
+    ScoreLayout lb{0, 0}, la{0, 0};
+    int rb[2] = {1, 1}, ra[2] = {1, 1};
+    if (l > 0) { below = ctx->layers[l - 1]->d_scores; lb = ctx->layers[l - 1]->live_layout; layer_ratio(l, l - 1, rb); }
+    if (l == 0 && ctx->d_virtual) { below = ctx->d_virtual; lb = ScoreLayout{ctx->layer_w[0], 0}; }  // same grid: ratio 1
+    if (l + 1 < L) { above = ctx->layers[l + 1]->d_scores; la = ctx->layers[l + 1]->live_layout; layer_ratio(l, l + 1, ra); }
+    launch_scale_filter(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, below, lb,
+                        l > 0 ? ctx->layer_w[l - 1] : (below ? ctx->layer_w[0] : 0),
+                        l > 0 ? ctx->layer_h[l - 1] : (below ? ctx->layer_h[0] : 0), rb[0], rb[1], above, la,
+                        l + 1 < L ? ctx->layer_w[l + 1] : 0, l + 1 < L ? ctx->layer_h[l + 1] : 0, ra[0], ra[1], ls);
+    if (brisk_ss) {
+      launch_sort(ch->d_cand, ch->cand_cap, ch->d_cand_count, n_images, 1.0f, ch->d_sort_ws, ls);
+      const int32_t* rbelow = l == 0 ? ctx->d_virtual : ctx->layers[l - 1]->d_scores;
+      const int wb = l == 0 ? ctx->layer_w[0] : ctx->layer_w[l - 1], hb = l == 0 ? ctx->layer_h[0] : ctx->layer_h[l - 1];
+      const int32_t* rabove = l + 1 < L ? ctx->layers[l + 1]->d_scores : nullptr;
+      // c_0: the virtual FAST 5-8 layer sits at 2/3 and the result is clamped to [0.7, 1.5] (published refine1D_2)
+      const double rel_b = (l & 1) || l == 0 ? 2.0 / 3.0 : 0.75, rel_a = (l & 1) ? 4.0 / 3.0 : 1.5;
+      const double rel_lo = l == 0 ? 0.7 : rel_b;
+      launch_brisk_refine(ch->d_scores, ch->w, ch->h, n_images, ch->cand_cap, ch->d_cand_count, ch->d_sort_ws,
+                          ch->cfg.max_keypoints, rbelow, wb, hb, rb[0], rb[1], rabove,
+                          rabove ? ctx->layer_w[l + 1] : 0, rabove ? ctx->layer_h[l + 1] : 0, ra[0], ra[1], rel_b, rel_a,
+                          rel_lo, ch->d_kps_det, ch->kp_cap, ch->d_det_count, ls);
+    } else {
+      layer_sort(ch, n_images, ls);
+      layer_select(ch, n_images, ls);
+    }
+    HIP_TRY(ctx, hipEventRecord(ev_done(l), ls));
+  }
+  // ---- join and merge into image coordinates
+  for (int l = 0; l < L; ++l) HIP_TRY(ctx, hipStreamWaitEvent(s, ev_done(l), 0));
+  const okvfe_keypoint* kps[8];
+  const int32_t* counts[8];
+  float scale[8];
+  for (int l = 0; l < L; ++l) {
+    kps[l] = ctx->layers[l]->d_kps_det;
+    counts[l] = ctx->layers[l]->d_det_count;
+    int sn, sd;
+    layer_scale(l, &sn, &sd);
+    scale[l] = (float)sn / (float)sd;
+  }
+  launch_merge_layers(kps, counts, scale, L, ctx->cfg.max_keypoints, n_images, ctx->d_kps_det, ctx->kp_cap,
+                      ctx->d_det_count, s);
+  return OKVFE_OK;
+}
+
 // K1..K4: score map + NMS, sort, uniformity selection, sub-pixel -> d_kps_det / d_det_count.
 // octaves > 0: the same per layer of the scale space (k_pyramid.hip), with the cross-layer maximum
 // test between NMS and selection and the merge into image coordinates at the end.
@@ -284,6 +406,9 @@ okvfe_status detect_stage(okvfe_ctx* ctx, const uint8_t* images_dev, int n_image
       StageTimer t(ctx, OKVFE_STAGE_SELECT, s);
       layer_select(ctx, n_images, s);
     }
+  } else if (ctx->prof_mask == 0 && score_token_mode() == 0 && !scale_space_serial()) {  // (stage timers and the
+    // cross-context chaining of the heavy kernels belong to the one-stream form below)
+    if ((st = detect_layers_concurrent(ctx, images_dev, n_images, s)) != OKVFE_OK) return st;
   } else {
     const int L = ctx->n_layers;
     std::vector<const uint8_t*> img(L);
@@ -1064,3 +1189,22 @@ okvfe_status okvfe_compute(okvfe_ctx* ctx, const uint8_t* image, size_t stride, 
 }
 
 }  // extern "C"
+
+#ifdef OKVFE_LAB
+// lab build only: buffers of one scale-space layer after the last call (what: 0 = score map, 1 = layer image,
+// 2 = candidate records, 3 = candidate counts); returns the bytes the buffer holds (copies min(bytes, that))
+extern "C" long long okvfe_lab_dump_layer(okvfe_ctx* ctx, int layer, int what, void* host, size_t bytes) {
+  if (!ctx || layer < 0 || layer >= (int)ctx->layers.size()) return -1;
+  (void)hipDeviceSynchronize();
+  okvfe_ctx* ch = ctx->layers[layer];
+  const void* src = nullptr;
+  size_t n = 0;
+  if (what == 0) { src = ch->d_scores; n = (size_t)ch->live_layout.pitch * ch->h * ch->B * 4; }
+  if (what == 1) { src = layer == 0 ? nullptr : ctx->d_layer_img[layer]; n = (size_t)ch->w * ch->h * ch->B; }
+  if (what == 2) { src = ch->d_cand; n = (size_t)ch->cand_cap * ch->B * sizeof(okvfe::Candidate); }
+  if (what == 3) { src = ch->d_cand_count; n = (size_t)ch->B * 4; }
+  if (!src) return 0;
+  if (host && hipMemcpy(host, src, bytes < n ? bytes : n, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return (long long)n;
+}
+#endif

@@ -248,6 +248,20 @@ __device__ __forceinline__ void dpp_fence4(int& a, int& b, int& c, int& d) {
 __device__ __forceinline__ void dpp_fence2(int& a, int& b) {
   asm volatile("s_nop 1" : "+v"(a), "+v"(b));
 }
+// Neighbour reads with their wait states INSIDE the asm (round 6).  A DPP read of a VGPR needs two wait states behind the
+// VALU write of that VGPR; the compiler keeps them by counting instructions, and it counts a v_mfma scheduled in between
+// as one -- but on gfx950 the matrix instruction issues BESIDE the vector ALU when its pipe is free, so "v_xor; s_...;
+// v_mfma; v_mov_dpp" can reach the DPP one state early.  Whether it does depends on what else runs on the SIMD: the
+// map-writing PACK instantiation did it beside the generic score kernel of another scale-space layer (lanes 12..15 of
+// every 16 -- DPP bank 3, the last quarter of a row to be written -- read the stale register: ~50 wrong score-map
+// entries per call, tools/lab/ss_dump.py), never alone.  l = `a` of lane - 1, r = `b` of lane + 1, 0 beyond the wave.
+__device__ __forceinline__ void lane_neighbours(int a, int b, int& l, int& r) {
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(l), "=&v"(r)
+      : "v"(a), "v"(b));
+}
 __device__ __forceinline__ int from_left(int v) {   // value of lane-1
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
 }
@@ -473,7 +487,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
   asm volatile("" : "+v"(A_above), "+v"(A_centre), "+v"(A_below));
   auto make_windows = [&](uint32_t dw, int wn[2]) {
     const int x = (int)(dw ^ 0x80808080u);
-    const int l = from_left(x), r = from_right(x);
+    int l, r;
+    lane_neighbours(x, x, l, r);
     wn[0] = (int)__builtin_amdgcn_alignbyte((uint32_t)x, (uint32_t)l, 3);  // l.b3 x.b0 x.b1 x.b2
     wn[1] = (int)__builtin_amdgcn_alignbyte((uint32_t)r, (uint32_t)x, 1);  // x.b1 x.b2 x.b3 r.b0
   };
@@ -552,7 +567,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     // instruction that reads its result: without it the shifts below read stale registers on
     // gfx950 (tools/ubench/mfma_grad_test.hip is correct stand-alone; in this kernel the schedule
     // is tighter).  Measured with 1 .. 16 wait states: results exact from 1 on.
-    asm volatile("s_nop 1" : "+v"(acc1), "+v"(acc2));
+    // Round 6: TWO wait states are not enough when another kernel shares the SIMD.  The map-writing PACK instantiation
+    // (scale-space layers, okvfe_set_keep_score_map) read acc1 four wait states behind its MFMA (next MFMA, s_nop 1, a
+    // scalar branch) and -- with the layers of a scale space on streams of their own -- delivered stale gradients in
+    // lanes 12..15 of every 16 (tools/lab/ss_dump.py: ~50 wrong map entries per call, element 0 of a quad); alone, or
+    // beside kernels of its own kind, it never did.  The operands being inline-asm outputs ("+v") hides the MFMA from
+    // the compiler's hazard recogniser, so the distance is ours to keep: eight wait states (the table of the ISA guide
+    // asks for at most seven behind a 4 x 4 MFMA).
+#ifndef OKVFE_K1_MFMA_NOPS
+#define OKVFE_K1_MFMA_NOPS 7
+#endif
+#define OKVFE_STR2(x) #x
+#define OKVFE_STR(x) OKVFE_STR2(x)
+    asm volatile("s_nop " OKVFE_STR(OKVFE_K1_MFMA_NOPS) : "+v"(acc1), "+v"(acc2));
+    // The B operands stay LIVE past the matrix instructions: a window that dies at its MFMA (the first pixel rows of a
+    // tile, in the prologue) was given a register INSIDE the MFMA's destination quad ("v_mfma v[8:11], v34, v8, ...") --
+    // legal for the assembler, and exact alone, but beside another kernel the last quarter of every 16 lanes (DPP bank
+    // 3) came back wrong for the tile's first row (tools/lab/ss_dump.py).  Live operands cannot share the destination.
+    asm volatile("" ::"v"(wa[0]), "v"(wa[1]), "v"(wb[0]), "v"(wb[1]), "v"(wc[0]), "v"(wc[1]), "v"(A_above), "v"(A_centre),
+                 "v"(A_below));
     if (__builtin_expect(!inner, 0)) {  // covariance rows 0 / h-1 are rim: scalar branch, two steps per strip
       asm volatile("" ::: "memory");
       acc1 = v4i_t{0, 0, 0, 0};
@@ -585,7 +618,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     dpp_fence4(G[0][0], G[0][3], G[1][0], G[1][3]);
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const int gl = from_left(G[ch][3]), gr = from_right(G[ch][0]);
+      int gl, gr;
+      lane_neighbours(G[ch][3], G[ch][0], gl, gr);
       const int pm = gl + G[ch][0];
       const int p0 = G[ch][0] + G[ch][1];
       const int p1 = G[ch][1] + G[ch][2];
@@ -624,11 +658,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i v = {sc[0], sc[1], sc[2], sc[3]};
     __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, st_off, y * pitch * 4, 0);
+    // Round 6: a 16-byte store reads its data registers AFTER it has issued, and a vector instruction that overwrites one
+    // of them needs wait states behind it (the 12-dword-store hazard of the ISA).  The compiler keeps them inside a basic
+    // block; here the store ends the block of the `y < h` branch and the next block began with "v_sub v0, ..." -- the first
+    // data register -- zero states later.  With the GPU to itself the store always won; beside another kernel's memory
+    // traffic the last quarter of every 16 lanes stored the NEW v0 (element 0 of the tile's first row = a score of the
+    // row above: tools/lab/ss_analyse.py).  The data stay live, and untouched, for two states behind the store.
+    asm volatile("s_nop 1" ::"v"(v));
   };
   // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc): optionally test centre row y-1, then
   // roll the state
   auto nms_row = [&](const int sc[4], int q, bool test, int r) {  // r = the centre row (scalar)
-    const int l = from_left(sc[3]), r2 = from_right(sc[0]);
+    int l, r2;
+    lane_neighbours(sc[3], sc[0], l, r2);
     const int hn[4] = {max3i(l, sc[0], sc[1]), max3i(sc[0], sc[1], sc[2]),
                        max3i(sc[1], sc[2], sc[3]), max3i(sc[2], sc[3], r2)};
 #ifndef OKVFE_K1_SKIP

@@ -63,55 +63,130 @@ __device__ __forceinline__ bool accepted_slow(const int32_t* __restrict__ s, int
   return accepted_slow(DenseMap{s, w}, w, x, y, thr);
 }
 
+// The raster rule over ONE WAVE'S consecutive pixels, in registers.  Lane l holds the pass bits of its four pixels
+// (bit i = pixel 4 l + i passes); accepted[p] = pass[p] & !accepted[p - 1] (the scan skips the pixel after a hit), which
+// is the parity rule of accepted_slow.  A lane's nibble is a map carry-in -> carry-out (two bits); the maps are composed
+// by a six-step wave prefix, then every lane evaluates its nibble with its carry-in.  `carry0` = accepted state of the
+// pixel left of lane 0's first one (0 at the image's left edge).  AGAST / FAST score maps are small integers: runs of
+// equal maxima are the rule there, and walking them pixel by pixel through global memory (accepted_slow) was most of
+// the stand-alone NMS on those maps.
+__device__ __forceinline__ uint32_t nibble_accept(uint32_t p, uint32_t c, uint32_t* carry_out) {
+  const uint32_t a0 = p & ~c & 1u;
+  const uint32_t a1 = (p >> 1) & ~a0 & 1u;
+  const uint32_t a2 = (p >> 2) & ~a1 & 1u;
+  const uint32_t a3 = (p >> 3) & ~a2 & 1u;
+  *carry_out = a3;
+  return a0 | (a1 << 1) | (a2 << 2) | (a3 << 3);
+}
+__device__ __forceinline__ uint32_t raster_accept_wave(uint32_t p, int lane, uint32_t carry0) {
+  uint32_t t0, t1;
+  (void)nibble_accept(p, 0u, &t0);
+  (void)nibble_accept(p, 1u, &t1);
+  uint32_t inc = t0 | (t1 << 1);  // this lane's map; after the scan: the map of lanes 0 .. l together
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const uint32_t prev = (uint32_t)__shfl_up((int)inc, dd);  // lanes l - 2 dd + 1 .. l - dd, applied first
+    if (lane >= dd) inc = ((inc >> (prev & 1u)) & 1u) | (((inc >> ((prev >> 1) & 1u)) & 1u) << 1);
+  }
+  const uint32_t before = (uint32_t)__shfl_up((int)inc, 1);
+  const uint32_t cin = lane == 0 ? carry0 : ((before >> carry0) & 1u);
+  uint32_t unused;
+  return nibble_accept(p, cin, &unused);
+}
+
 // ---- generic kernel (any width): one lane = 4 pixels of one row ---------------------------------
+// A block = 64 lanes x 4 waves walks kGenIters groups of four rows (wave = row), keeps the accepted pixels as one nibble
+// per group in a register, and reserves its slots in the image's list with ONE atomic: an image's rows run on all eight
+// XCDs, so a returning atomic on its counter is a round trip to memory -- one per ROW (round 5: 156 per 250 x 160 layer)
+// made this kernel 0.24 ms on a layer whose arithmetic takes 0.01 ms.
+constexpr int kGenIters = 8;
 __global__ __launch_bounds__(256) void nms_generic_kernel(const int32_t* __restrict__ scores, int w,
                                                           int h, int thr,
                                                           Candidate* __restrict__ cand,
                                                           int cand_cap,
                                                           int32_t* __restrict__ cand_count) {
+  __shared__ int wtot[4];
+  __shared__ int base_s;
   const int img = blockIdx.z;
   const int32_t* s = scores + (size_t)img * w * h;
-  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  bool acc[4] = {false, false, false, false};
-  int val[4] = {0, 0, 0, 0};
-  if (y >= 2 && y < h - 2 && x0 < w) {
+  const int lane = threadIdx.x, wave = threadIdx.y;
+  const int x0 = (blockIdx.x * 64 + lane) * 4;
+  uint32_t bits = 0u;  // nibble `it` = accepted pixels of row (blockIdx.y * kGenIters + it) * 4 + wave
+  int cnt = 0;
+#pragma unroll 1
+  for (int it = 0; it < kGenIters; ++it) {
+    const int y = (blockIdx.y * kGenIters + it) * 4 + wave;
+    bool acc[4] = {false, false, false, false};
+    if (y >= 2 && y < h - 2 && x0 < w) {
+      // the 3 x 6 window of this lane's four pixels, loaded up front (clamped columns only ever stand in for the
+      // neighbours of pixels that cannot be maxima): one memory round trip instead of a dependent chain per pixel
+      int v[3][6];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = x0 + i;
-      if (x >= 2 && x < w - 2) {
-        val[i] = s[(size_t)y * w + x];
-        if (val[i] >= thr) acc[i] = accepted_slow(s, w, x, y, thr);
+      for (int r = 0; r < 3; ++r) {
+        const int32_t* row = s + (size_t)(y - 1 + r) * w;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          int x = x0 - 1 + c;
+          x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+          v[r][c] = row[x];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = x0 + i;
+        int nb = thr;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            if (r != 1 || c != 1) nb = max(nb, v[r][i + c]);
+        acc[i] = x >= 2 && x < w - 2 && v[1][i + 1] >= nb;  // >= thr and no strictly greater neighbour = passes()
+      }
+      if (blockIdx.x != 0) {  // further right than 256 pixels the run to the left is walked through memory
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (acc[i]) acc[i] = accepted_slow(s, w, x0 + i, y, thr);
       }
     }
+    uint32_t a = (acc[0] ? 1u : 0u) | (acc[1] ? 2u : 0u) | (acc[2] ? 4u : 0u) | (acc[3] ? 8u : 0u);
+    if (blockIdx.x == 0) a = raster_accept_wave(a, lane, 0u);  // block-uniform: the leftmost 256 pixels, in registers
+    bits |= a << (4 * it);
+    cnt += __popc(a);
   }
-  unsigned long long b[4];
-  int total = 0;
+  int incl = cnt;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    b[i] = __ballot(acc[i]);
-    total += __popcll(b[i]);
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const int t = __shfl_up(incl, dd);
+    if (lane >= dd) incl += t;
   }
-  if (total == 0) return;
-  const int lane = threadIdx.x;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(&cand_count[img], total);
-  base = __shfl(base, 0);
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int off = base;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (acc[i]) {
-      const int pos = off + __popcll(b[i] & lt);
-      if (pos < cand_cap) {
-        Candidate c;
-        c.x = x0 + i;
-        c.y = y;
-        c.score = val[i];
-        cand[(size_t)img * cand_cap + pos] = c;
-      }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  if (lane == 0 && wave == 0) {
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    base_s = total > 0 ? atomicAdd(&cand_count[img], total) : 0;
+  }
+  __syncthreads();
+  int pos = base_s + incl - cnt;
+  for (int w2 = 0; w2 < wave; ++w2) pos += wtot[w2];
+  if (cnt == 0) return;
+#ifdef OKVFE_NMS_TIMING_NOWRITE  // (timing experiment only: wrong results)
+  return;
+#endif
+  Candidate* out = cand + (size_t)img * cand_cap;
+#pragma unroll 1
+  for (int it = 0; it < kGenIters; ++it) {
+    const int y = (blockIdx.y * kGenIters + it) * 4 + wave;
+    uint32_t a = (bits >> (4 * it)) & 15u;
+    while (a) {
+      const int i = __ffs((int)a) - 1;
+      a &= a - 1u;
+      Candidate c;
+      c.x = x0 + i;
+      c.y = y;
+      c.score = s[(size_t)y * w + x0 + i];
+      if (pos < cand_cap) out[pos] = c;
+      ++pos;
     }
-    off += __popcll(b[i]);
   }
 }
 
@@ -212,6 +287,18 @@ __global__ __launch_bounds__(64 * kWaves) void nms_kernel(const int32_t* __restr
     while (rows_adj) {
       const int k = __ffs((int)rows_adj) - 1;
       rows_adj &= rows_adj - 1;
+      // the row's pass bits of this wave's 256 pixels (lanes past the row end repeat the last dword: no pixels)
+      uint32_t p = ((m[0] >> k) & 1u) | (((m[1] >> k) & 1u) << 1) | (((m[2] >> k) & 1u) << 2) | (((m[3] >> k) & 1u) << 3);
+      if (d >= nd) p = 0u;
+      // a strip that does not start at the image's edge knows the state left of its halo lane only if that lane holds
+      // a pixel that does not pass (the run then starts inside it); four passing halo pixels: walk the runs in memory
+      const bool ambiguous = strip > 0 && (uint32_t)__shfl((int)p, 0) == 15u;  // wave-uniform
+      if (!ambiguous) {
+        const uint32_t a = raster_accept_wave(p, lane, 0u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = (m[i] & ~(1u << k)) | (((a >> i) & 1u) << k);
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if ((m[i] >> k) & 1u)
@@ -475,7 +562,7 @@ void launch_nms(const int32_t* score, int w, int h, int n_images, int abs_thresh
                        score, w, h, abs_threshold, cand, cand_cap, cand_count, strips, ytiles,
                        n_images);
   } else {
-    const dim3 grid((w + 255) / 256, (h + 3) / 4, n_images);
+    const dim3 grid((w + 255) / 256, (h + 4 * kGenIters - 1) / (4 * kGenIters), n_images);
     hipLaunchKernelGGL(nms_generic_kernel, grid, dim3(64, 4, 1), 0, stream, score, w, h,
                        abs_threshold, cand, cand_cap, cand_count);
   }

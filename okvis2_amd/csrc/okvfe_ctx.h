@@ -129,6 +129,10 @@ struct okvfe_ctx {
   int n_layers = 1;
   std::vector<okvfe_ctx*> layers;
   std::vector<uint8_t*> d_layer_img;
+  // scale-space parent: the layers of a call run concurrently on the layer contexts' own streams (round 6) -- per layer
+  // {image ready, score map + candidates ready, keypoints ready} and the fork of the call
+  std::vector<hipEvent_t> layer_ev;
+  hipEvent_t layer_fork = nullptr;
   std::vector<int> layer_w, layer_h;
 
   // host-fed batches (okvfe_detect_describe_batch_host): two device image buffers filled by an
