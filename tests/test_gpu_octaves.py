@@ -96,3 +96,27 @@ def test_scale_space_stereo_match_uses_size_classes(oracle):
     assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
     matched = want["k1"] >= 0
     assert matched.sum() > 30 and len(np.unique(k0["octave"][matched])) >= 2
+
+
+def test_scale_space_layers_side_by_side_stay_exact(oracle):
+    """The layers of a scale-space call run on streams of their own (round 6), so the map-writing score kernel of one layer
+    shares the GPU with the kernels of the others.  That exposed a store-data hazard of the score kernel (a 16-byte store at
+    the end of a basic block, its first data register overwritten by the next block: LAB_NOTES "Round 6") which made about
+    every second call of this configuration store a few wrong score-map entries -- and move sub-pixel positions in layer 2.
+    Ten calls on fresh contexts, each against the oracle."""
+    w, h, octaves, B = 1024, 1024, 3, 3
+    imgs = np.stack([synth.corners_image(w, h, 7 + 10 * i) for i in range(B)])
+    want = [oracle.detect_describe(imgs[i], 30.0, octaves, 100, 300, oracle.MODE_GRADIENT) for i in range(B)]
+    d_img = torch.from_numpy(imgs).cuda()
+    for _ in range(10):
+        fe = capi.Frontend(w, h, 30.0, octaves, 100, 300, max_batch=B, max_candidates=0)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        fe.detect_describe_batch_device(d_img.data_ptr(), B, None, None, st)
+        st.synchronize()
+        fe.check_capacity(B)
+        for i in range(B):
+            k, d, _, _ = fe.download(i)
+            G.assert_keypoints_equal(k, want[i][0])
+            assert np.array_equal(d, want[i][1])
+        fe.close()
