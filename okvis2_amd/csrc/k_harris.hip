@@ -664,7 +664,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) OKVFE_K1_WAVES void harris_ker
     // data register -- zero states later.  With the GPU to itself the store always won; beside another kernel's memory
     // traffic the last quarter of every 16 lanes stored the NEW v0 (element 0 of the tile's first row = a score of the
     // row above: tools/lab/ss_analyse.py).  The data stay live, and untouched, for two states behind the store.
+#ifndef OKVFE_K1_NO_STORE_NOP  // (A/B: the binary before the fix, to check that the stress tools still catch it)
     asm volatile("s_nop 1" ::"v"(v));
+#endif
   };
   // rows y-2 (nh[q]), y-1 (nc, nl, nr; nh[q^1]) and y (sc): optionally test centre row y-1, then
   // roll the state
