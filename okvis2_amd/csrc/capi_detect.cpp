@@ -266,7 +266,7 @@ static okvfe_status detect_layers_concurrent(okvfe_ctx* ctx, const uint8_t* imag
   const int L = ctx->n_layers;
   HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
   if (!ctx->layer_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->layer_fork, hipEventDisableTiming));
-  while ((int)ctx->layer_ev.size() < 3 * L) {
+  while ((int)ctx->layer_ev.size() < 3 * L + 1) {  // (+ 1: the virtual layer's map)
     hipEvent_t ev = nullptr;
     HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     ctx->layer_ev.push_back(ev);
@@ -302,11 +302,18 @@ static okvfe_status detect_layers_concurrent(okvfe_ctx* ctx, const uint8_t* imag
     bool f;
     layer_score_nms(ch, img[l], n_images, ls, &f);
     if (l == 1 && dbg_l1 == 2) (void)hipDeviceSynchronize();
-    if (l == 0 && ctx->d_virtual) launch_fast58_score(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_virtual, ls);
     layer_nms_finish(ch, n_images, ls, f);
     HIP_TRY(ctx, hipEventRecord(ev_map(l), ls));
     if (const char* m = lab_env("OKVFE_SS_DBG_A"))  // bisecting knob: device sync behind the layers of this bit mask
       if ((atoi(m) >> l) & 1) (void)hipDeviceSynchronize();
+  }
+  // the FAST 5-8 map of c0 (the virtual layer below the first octave) is as large as c0's own score map: it runs on the
+  // LAST layer's stream, whose own chain is the shortest, instead of behind c0's score kernel on the longest one
+  hipEvent_t ev_virtual = ctx->layer_ev[3 * L];
+  if (ctx->d_virtual) {
+    hipStream_t vs = ((own_mask >> (L - 1)) & 1) ? ctx->layers[L - 1]->stream : s;
+    launch_fast58_score(img[0], ctx->layer_w[0], ctx->layer_h[0], n_images, ctx->d_virtual, vs);
+    HIP_TRY(ctx, hipEventRecord(ev_virtual, vs));
   }
   static const char* dbg = lab_env("OKVFE_SS_DBG");  // bisecting knob: 1 = device sync between the phases, 2 = after every layer too
   if (dbg) (void)hipDeviceSynchronize();
@@ -317,6 +324,7 @@ static okvfe_status detect_layers_concurrent(okvfe_ctx* ctx, const uint8_t* imag
     if (dbg && dbg[0] == '2') (void)hipDeviceSynchronize();
     if (l > 0) HIP_TRY(ctx, hipStreamWaitEvent(ls, ev_map(l - 1), 0));
     if (l + 1 < L) HIP_TRY(ctx, hipStreamWaitEvent(ls, ev_map(l + 1), 0));
+    if (l == 0 && ctx->d_virtual) HIP_TRY(ctx, hipStreamWaitEvent(ls, ev_virtual, 0));
     const int32_t *below = nullptr, *above = nullptr;
     ScoreLayout lb{0, 0}, la{0, 0};
     int rb[2] = {1, 1}, ra[2] = {1, 1};
